@@ -1,0 +1,744 @@
+/*
+ * fss_oracle.c -- TEST INFRASTRUCTURE ONLY (see fss_oracle.h for the pinning statement).
+ *
+ * Plain-C restatement of the reference's CPU algorithms.  All file:line citations
+ * are into /root/reference.  Nothing here is used by the shipped HIP path.
+ */
+#include "fss_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef FO_HAVE_OPENSSL
+#include <openssl/evp.h>
+#endif
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ util */
+/* include/fss/util.cuh:16-38 */
+static inline fo_i4 xor4(fo_i4 a, fo_i4 b) {
+  fo_i4 r = {a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w};
+  return r;
+}
+static inline fo_i4 set_lsb(fo_i4 v, int bit) {
+  if (bit) v.w |= 1;
+  else v.w &= ~1;
+  return v;
+}
+static inline int get_lsb(fo_i4 v) { return (v.w & 1) != 0; }
+static const fo_i4 kZero4 = {0, 0, 0, 0};
+
+static inline u128 mk128(uint64_t lo, uint64_t hi) { return ((u128)hi << 64) | lo; }
+static inline int bit_of(u128 v, int pos) { return (int)((v >> pos) & 1); }
+
+/* ------------------------------------------------------------------ AES-128 (FIPS-197) */
+static uint8_t g_sbox[256];
+static uint32_t g_te[4][256]; /* little-endian T-tables: byte r of the word = row r */
+static int g_aes_ready = 0;
+
+static uint8_t xtime(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1b)); }
+
+static void aes_tables_init(void) {
+  if (g_aes_ready) return;
+  /* S-box from the multiplicative inverse + affine map (FIPS-197 5.1.1). */
+  uint8_t p = 1, q = 1;
+  do {
+    p = (uint8_t)(p ^ (p << 1) ^ ((p & 0x80) ? 0x1b : 0));
+    q ^= (uint8_t)(q << 1);
+    q ^= (uint8_t)(q << 2);
+    q ^= (uint8_t)(q << 4);
+    if (q & 0x80) q ^= 0x09;
+    uint8_t x = (uint8_t)(q ^ ((q << 1) | (q >> 7)) ^ ((q << 2) | (q >> 6)) ^ ((q << 3) | (q >> 5)) ^
+                          ((q << 4) | (q >> 4)));
+    g_sbox[p] = (uint8_t)(x ^ 0x63);
+  } while (p != 1);
+  g_sbox[0] = 0x63;
+  for (int i = 0; i < 256; ++i) {
+    uint8_t s = g_sbox[i], s2 = xtime(s), s3 = (uint8_t)(s2 ^ s);
+    /* column (2,1,1,3)*s, row 0 in the low byte */
+    uint32_t t0 = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
+    g_te[0][i] = t0;
+    g_te[1][i] = (t0 << 8) | (t0 >> 24);
+    g_te[2][i] = (t0 << 16) | (t0 >> 16);
+    g_te[3][i] = (t0 << 24) | (t0 >> 8);
+  }
+  g_aes_ready = 1;
+}
+
+static void aes_expand(const uint8_t key[16], uint32_t rk[44]) {
+  aes_tables_init();
+  uint8_t w[176];
+  memcpy(w, key, 16);
+  uint8_t rcon = 1;
+  for (int i = 16; i < 176; i += 4) {
+    uint8_t t[4] = {w[i - 4], w[i - 3], w[i - 2], w[i - 1]};
+    if (i % 16 == 0) {
+      uint8_t t0 = t[0];
+      t[0] = (uint8_t)(g_sbox[t[1]] ^ rcon);
+      t[1] = g_sbox[t[2]];
+      t[2] = g_sbox[t[3]];
+      t[3] = g_sbox[t0];
+      rcon = xtime(rcon);
+    }
+    for (int j = 0; j < 4; ++j) w[i + j] = (uint8_t)(w[i - 16 + j] ^ t[j]);
+  }
+  for (int i = 0; i < 44; ++i)
+    rk[i] = (uint32_t)w[4 * i] | ((uint32_t)w[4 * i + 1] << 8) | ((uint32_t)w[4 * i + 2] << 16) |
+            ((uint32_t)w[4 * i + 3] << 24);
+}
+
+/* state columns as little-endian words c[0..3] (= the int4's x,y,z,w) */
+static void aes_encrypt_words(const uint32_t rk[44], const uint32_t in[4], uint32_t out[4]) {
+  uint32_t s0 = in[0] ^ rk[0], s1 = in[1] ^ rk[1], s2 = in[2] ^ rk[2], s3 = in[3] ^ rk[3];
+  for (int r = 1; r < 10; ++r) {
+    uint32_t t0 = g_te[0][s0 & 0xff] ^ g_te[1][(s1 >> 8) & 0xff] ^ g_te[2][(s2 >> 16) & 0xff] ^ g_te[3][s3 >> 24] ^
+                  rk[4 * r + 0];
+    uint32_t t1 = g_te[0][s1 & 0xff] ^ g_te[1][(s2 >> 8) & 0xff] ^ g_te[2][(s3 >> 16) & 0xff] ^ g_te[3][s0 >> 24] ^
+                  rk[4 * r + 1];
+    uint32_t t2 = g_te[0][s2 & 0xff] ^ g_te[1][(s3 >> 8) & 0xff] ^ g_te[2][(s0 >> 16) & 0xff] ^ g_te[3][s1 >> 24] ^
+                  rk[4 * r + 2];
+    uint32_t t3 = g_te[0][s3 & 0xff] ^ g_te[1][(s0 >> 8) & 0xff] ^ g_te[2][(s1 >> 16) & 0xff] ^ g_te[3][s2 >> 24] ^
+                  rk[4 * r + 3];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
+#define SB(x) ((uint32_t)g_sbox[(x) & 0xff])
+  out[0] = (SB(s0) | (SB(s1 >> 8) << 8) | (SB(s2 >> 16) << 16) | (SB(s3 >> 24) << 24)) ^ rk[40];
+  out[1] = (SB(s1) | (SB(s2 >> 8) << 8) | (SB(s3 >> 16) << 16) | (SB(s0 >> 24) << 24)) ^ rk[41];
+  out[2] = (SB(s2) | (SB(s3 >> 8) << 8) | (SB(s0 >> 16) << 16) | (SB(s1 >> 24) << 24)) ^ rk[42];
+  out[3] = (SB(s3) | (SB(s0 >> 8) << 8) | (SB(s1 >> 16) << 16) | (SB(s2 >> 24) << 24)) ^ rk[43];
+#undef SB
+}
+
+void fo_aes128_encrypt(const uint8_t key[16], const uint8_t in[16], uint8_t out[16]) {
+  uint32_t rk[44], a[4], b[4];
+  aes_expand(key, rk);
+  memcpy(a, in, 16); /* little-endian host */
+  aes_encrypt_words(rk, a, b);
+  memcpy(out, b, 16);
+}
+
+/* ------------------------------------------------------------------ PRG */
+/* include/fss/prg/aes128_mmo.cuh:49-64 (CreateCtxs), :72-93 (Gen) */
+static int evp_make(fo_prg *p) {
+#ifdef FO_HAVE_OPENSSL
+  for (int i = 0; i < p->mul; ++i) {
+    EVP_CIPHER_CTX *c = EVP_CIPHER_CTX_new();
+    if (!c) return -1;
+    if (EVP_EncryptInit_ex2(c, EVP_aes_128_ecb(), p->key[i], NULL, NULL) != 1) return -1;
+    if (EVP_CIPHER_CTX_set_padding(c, 0) != 1) return -1;
+    p->evp[i] = c;
+  }
+  return 0;
+#else
+  (void)p;
+  return -1;
+#endif
+}
+
+int fo_prg_init(fo_prg *p, const uint8_t *keys, int mul, int use_evp) {
+  memset(p, 0, sizeof(*p));
+  if (mul < 1 || mul > 4) return -1;
+  p->mul = mul;
+  p->use_evp = use_evp;
+  for (int i = 0; i < mul; ++i) {
+    memcpy(p->key[i], keys + 16 * i, 16);
+    aes_expand(p->key[i], p->rk[i]);
+  }
+  if (use_evp) return evp_make(p);
+  return 0;
+}
+
+void fo_prg_free(fo_prg *p) {
+#ifdef FO_HAVE_OPENSSL
+  for (int i = 0; i < 4; ++i)
+    if (p->evp[i]) EVP_CIPHER_CTX_free((EVP_CIPHER_CTX *)p->evp[i]);
+#endif
+  memset(p->evp, 0, sizeof(p->evp));
+}
+
+/* out[i] = AES128-ECB_{key_i}(seed) ^ seed -- aes128_mmo.cuh:79-89 */
+void fo_prg_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) {
+  for (int i = 0; i < p->mul; ++i) {
+#ifdef FO_HAVE_OPENSSL
+    if (p->use_evp) {
+      int len = 0;
+      EVP_EncryptUpdate((EVP_CIPHER_CTX *)p->evp[i], (unsigned char *)&out[i], &len, (const unsigned char *)&seed, 16);
+      out[i] = xor4(out[i], seed);
+      continue;
+    }
+#endif
+    uint32_t a[4], b[4];
+    memcpy(a, &seed, 16);
+    aes_encrypt_words(p->rk[i], a, b);
+    memcpy(&out[i], b, 16);
+    out[i] = xor4(out[i], seed);
+  }
+}
+
+/* ------------------------------------------------------------------ groups */
+/* include/fss/group/bytes.cuh:19-43, include/fss/group/uint.cuh:27-88 */
+typedef struct {
+  u128 v;
+} gel;
+#define M127 (((u128)1) << 127)
+
+static inline u128 gmask(int g) {
+  switch (g) {
+    case FO_GROUP_U8: return 0xff;
+    case FO_GROUP_U16: return 0xffff;
+    case FO_GROUP_U32: return 0xffffffffu;
+    case FO_GROUP_U64: return ~(uint64_t)0;
+    default: return ~(u128)0;
+  }
+}
+
+static gel g_from(int g, fo_i4 b) {
+  gel r;
+  u128 x = (uint32_t)b.x, y = (uint32_t)b.y, z = (uint32_t)b.z, w = (uint32_t)b.w;
+  switch (g) {
+    case FO_GROUP_BYTES: r.v = x | (y << 32) | (z << 64) | (w << 96); break;
+    case FO_GROUP_U8: r.v = x & 0xff; break;      /* uint.cuh:53 */
+    case FO_GROUP_U16: r.v = x & 0xffff; break;   /* uint.cuh:53 */
+    case FO_GROUP_U32: r.v = x; break;            /* uint.cuh:55 */
+    case FO_GROUP_U64: r.v = x | (y << 32); break; /* uint.cuh:56-57 */
+    default:                                      /* uint.cuh:58-62: clamp bit dropped from w */
+      r.v = (x | (y << 32) | (z << 64) | ((w >> 1) << 96)) % M127;
+      break;
+  }
+  return r;
+}
+
+static gel g_add(int g, gel a, gel b) {
+  gel r;
+  if (g == FO_GROUP_BYTES) r.v = a.v ^ b.v;
+  else if (g == FO_GROUP_U128_M127) { /* uint.cuh:33-35 */
+    if (a.v >= M127 - b.v) r.v = a.v + b.v - M127;
+    else r.v = a.v + b.v;
+  } else r.v = (a.v + b.v) & gmask(g);
+  return r;
+}
+
+static gel g_neg(int g, gel a) {
+  gel r;
+  if (g == FO_GROUP_BYTES) r.v = a.v;
+  else if (g == FO_GROUP_U128_M127) r.v = a.v == 0 ? 0 : M127 - a.v; /* uint.cuh:41-42 */
+  else r.v = (0 - a.v) & gmask(g);
+  return r;
+}
+
+static fo_i4 g_into(int g, gel a) {
+  fo_i4 b = {0, 0, 0, 0};
+  switch (g) {
+    case FO_GROUP_BYTES:
+      b.x = (int32_t)(uint32_t)a.v; b.y = (int32_t)(uint32_t)(a.v >> 32);
+      b.z = (int32_t)(uint32_t)(a.v >> 64); b.w = (int32_t)(uint32_t)(a.v >> 96);
+      break;
+    case FO_GROUP_U8: case FO_GROUP_U16: case FO_GROUP_U32: b.x = (int32_t)(uint32_t)a.v; break; /* uint.cuh:72 */
+    case FO_GROUP_U64: b.x = (int32_t)(uint32_t)a.v; b.y = (int32_t)(uint32_t)(a.v >> 32); break; /* :73-75 */
+    default: /* uint.cuh:76-82 */
+      b.x = (int32_t)(uint32_t)a.v; b.y = (int32_t)(uint32_t)(a.v >> 32);
+      b.z = (int32_t)(uint32_t)(a.v >> 64); b.w = (int32_t)(((uint32_t)(a.v >> 96)) << 1);
+      break;
+  }
+  return b;
+}
+static gel g_zero(void) { gel r; r.v = 0; return r; }
+
+/* ------------------------------------------------------------------ DPF */
+static inline fo_cw mk_cw(fo_i4 s, int flag) {
+  fo_cw c;
+  c.s = s;
+  c.v = kZero4;
+  c.v.x = flag ? 1 : 0; /* dpf.cuh:151-153: cw_slot[1] = make_int4(tr_cw,0,0,0) */
+  return c;
+}
+static inline int cw_flag(const fo_cw *c) { return (c->v.x & 0xff) != 0; } /* bool at byte 16 */
+
+/* dpf.cuh:93-159 */
+void fo_dpf_gen(const fo_prg *p, int in_bits, int group, fo_cw *cws, const fo_i4 s0s[2], uint64_t a_lo, uint64_t a_hi,
+                fo_i4 beta) {
+  u128 a = mk128(a_lo, a_hi);
+  fo_i4 s0 = set_lsb(s0s[0], 0), s1 = set_lsb(s0s[1], 0);
+  int t0 = 0, t1 = 1;
+  beta = set_lsb(beta, 0);
+  for (int i = 0; i < in_bits; ++i) {
+    fo_i4 g0[2], g1[2];
+    fo_prg_gen(p, s0, g0);
+    fo_prg_gen(p, s1, g1);
+    int t0l = get_lsb(g0[0]), t0r = get_lsb(g0[1]), t1l = get_lsb(g1[0]), t1r = get_lsb(g1[1]);
+    fo_i4 s0l = set_lsb(g0[0], 0), s0r = set_lsb(g0[1], 0), s1l = set_lsb(g1[0], 0), s1r = set_lsb(g1[1], 0);
+    int a_bit = bit_of(a, in_bits - 1 - i);
+    fo_i4 s_cw = !a_bit ? xor4(s0r, s1r) : xor4(s0l, s1l);
+    int tl_cw = t0l ^ t1l ^ a_bit ^ 1;
+    int tr_cw = t0r ^ t1r ^ a_bit;
+    if (!a_bit) {
+      s0 = s0l; if (t0) s0 = xor4(s0, s_cw);
+      s1 = s1l; if (t1) s1 = xor4(s1, s_cw);
+      t0 = t0 ? (t0l ^ tl_cw) : t0l;
+      t1 = t1 ? (t1l ^ tl_cw) : t1l;
+    } else {
+      s0 = s0r; if (t0) s0 = xor4(s0, s_cw);
+      s1 = s1r; if (t1) s1 = xor4(s1, s_cw);
+      t0 = t0 ? (t0r ^ tr_cw) : t0r;
+      t1 = t1 ? (t1r ^ tr_cw) : t1r;
+    }
+    cws[i] = mk_cw(set_lsb(s_cw, tl_cw), tr_cw);
+  }
+  gel v = g_add(group, g_add(group, g_from(group, beta), g_neg(group, g_from(group, s0))), g_from(group, s1));
+  if (t1) v = g_neg(group, v);
+  cws[in_bits] = mk_cw(g_into(group, v), 0);
+}
+
+/* one level of dpf.cuh:175-205 / 266-289: node (s, t) -> both children (s, t) */
+static inline void dpf_expand(const fo_prg *p, fo_i4 s, int t, const fo_cw *cw, fo_i4 *sl, int *tl, fo_i4 *sr,
+                              int *tr) {
+  fo_i4 s_cw = cw->s;
+  int tl_cw = get_lsb(s_cw);
+  s_cw = set_lsb(s_cw, 0);
+  int tr_cw = cw_flag(cw);
+  fo_i4 g[2];
+  fo_prg_gen(p, s, g);
+  *tl = get_lsb(g[0]); *sl = set_lsb(g[0], 0);
+  *tr = get_lsb(g[1]); *sr = set_lsb(g[1], 0);
+  if (t) {
+    *sl = xor4(*sl, s_cw); *sr = xor4(*sr, s_cw);
+    *tl ^= tl_cw; *tr ^= tr_cw;
+  }
+}
+
+static inline fo_i4 dpf_leaf(int group, int b, fo_i4 s, int t, const fo_cw *cw_last) {
+  gel y = g_from(group, s); /* dpf.cuh:207-213 */
+  if (t) y = g_add(group, y, g_from(group, cw_last->s));
+  if (b) y = g_neg(group, y);
+  return g_into(group, y);
+}
+
+/* dpf.cuh:170-214 */
+fo_i4 fo_dpf_eval(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, uint64_t x_lo,
+                  uint64_t x_hi) {
+  u128 x = mk128(x_lo, x_hi);
+  fo_i4 s = set_lsb(s0, 0);
+  int t = b;
+  for (int i = 0; i < in_bits; ++i) {
+    fo_i4 sl, sr; int tl, tr;
+    dpf_expand(p, s, t, &cws[i], &sl, &tl, &sr, &tr);
+    if (!bit_of(x, in_bits - 1 - i)) { s = sl; t = tl; } else { s = sr; t = tr; }
+  }
+  return dpf_leaf(group, b, s, t, &cws[in_bits]);
+}
+
+/* dpf.cuh:232-303; the recursion is flattened to an in-place breadth-first
+ * expansion (children of node j at level i land at 2j, 2j+1), which visits the
+ * same nodes and writes the same leaves in the same index order. */
+void fo_dpf_eval_all(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys) {
+  ys[0] = set_lsb(s0, b); /* dpf.cuh:233-235: t packed into the control bit */
+  for (int i = 0; i < in_bits; ++i) {
+    size_t cnt = (size_t)1 << i;
+    for (size_t j = cnt; j-- > 0;) {
+      fo_i4 st = ys[j], sl, sr; int tl, tr;
+      dpf_expand(p, set_lsb(st, 0), get_lsb(st), &cws[i], &sl, &tl, &sr, &tr);
+      ys[2 * j] = set_lsb(sl, tl);
+      ys[2 * j + 1] = set_lsb(sr, tr);
+    }
+  }
+  size_t n = (size_t)1 << in_bits;
+  for (size_t j = 0; j < n; ++j) ys[j] = dpf_leaf(group, b, set_lsb(ys[j], 0), get_lsb(ys[j]), &cws[in_bits]);
+}
+
+/* ------------------------------------------------------------------ DCF */
+/* dcf.cuh:108-194 */
+void fo_dcf_gen(const fo_prg *p, int in_bits, int group, int pred, fo_cw *cws, const fo_i4 s0s[2], uint64_t a_lo,
+                uint64_t a_hi, fo_i4 beta) {
+  u128 a = mk128(a_lo, a_hi);
+  fo_i4 s0 = set_lsb(s0s[0], 0), s1 = set_lsb(s0s[1], 0);
+  int t0 = 0, t1 = 1;
+  gel v = g_zero();
+  beta = set_lsb(beta, 0);
+  gel gb = g_from(group, beta);
+  for (int i = 0; i < in_bits; ++i) {
+    fo_i4 g0[4], g1[4];
+    fo_prg_gen(p, s0, g0); /* [sl, vl, sr, vr] dcf.cuh:119 */
+    fo_prg_gen(p, s1, g1);
+    int t0l = get_lsb(g0[0]), t0r = get_lsb(g0[2]), t1l = get_lsb(g1[0]), t1r = get_lsb(g1[2]);
+    fo_i4 s0l = set_lsb(g0[0], 0), s0r = set_lsb(g0[2], 0), s1l = set_lsb(g1[0], 0), s1r = set_lsb(g1[2], 0);
+    gel v0l = g_from(group, set_lsb(g0[1], 0)), v0r = g_from(group, set_lsb(g0[3], 0));
+    gel v1l = g_from(group, set_lsb(g1[1], 0)), v1r = g_from(group, set_lsb(g1[3], 0));
+    int a_bit = bit_of(a, in_bits - 1 - i);
+    fo_i4 s_cw = !a_bit ? xor4(s0r, s1r) : xor4(s0l, s1l);
+
+    gel v_cw = g_neg(group, v); /* dcf.cuh:146-154 */
+    if (!a_bit) {
+      v_cw = g_add(group, g_add(group, v_cw, v1r), g_neg(group, v0r));
+      if (pred == FO_PRED_GT) v_cw = g_add(group, v_cw, gb);
+    } else {
+      v_cw = g_add(group, g_add(group, v_cw, v1l), g_neg(group, v0l));
+      if (pred == FO_PRED_LT) v_cw = g_add(group, v_cw, gb);
+    }
+    if (t1) v_cw = g_neg(group, v_cw);
+
+    if (!a_bit) v = g_add(group, g_add(group, v, g_neg(group, v1l)), v0l); /* dcf.cuh:156-159 */
+    else v = g_add(group, g_add(group, v, g_neg(group, v1r)), v0r);
+    if (t1) v = g_add(group, v, g_neg(group, v_cw));
+    else v = g_add(group, v, v_cw);
+
+    int tl_cw = t0l ^ t1l ^ a_bit ^ 1;
+    int tr_cw = t0r ^ t1r ^ a_bit;
+    if (!a_bit) {
+      s0 = s0l; if (t0) s0 = xor4(s0, s_cw);
+      s1 = s1l; if (t1) s1 = xor4(s1, s_cw);
+      t0 = t0 ? (t0l ^ tl_cw) : t0l;
+      t1 = t1 ? (t1l ^ tl_cw) : t1l;
+    } else {
+      s0 = s0r; if (t0) s0 = xor4(s0, s_cw);
+      s1 = s1r; if (t1) s1 = xor4(s1, s_cw);
+      t0 = t0 ? (t0r ^ tr_cw) : t0r;
+      t1 = t1 ? (t1r ^ tr_cw) : t1r;
+    }
+    cws[i].s = set_lsb(s_cw, tl_cw); /* dcf.cuh:185-188 */
+    cws[i].v = set_lsb(g_into(group, v_cw), tr_cw);
+  }
+  gel vn = g_add(group, g_add(group, g_from(group, s1), g_neg(group, g_from(group, s0))), g_neg(group, v));
+  if (t1) vn = g_neg(group, vn);
+  cws[in_bits].s = kZero4; /* dcf.cuh:193 */
+  cws[in_bits].v = g_into(group, vn);
+}
+
+typedef struct {
+  fo_i4 sl, sr;
+  int tl, tr;
+  gel vl, vr, v_cw;
+} dcf_step;
+
+/* dcf.cuh:211-242: one PRG call and the correction of s/t (v handled by callers) */
+static inline void dcf_expand(const fo_prg *p, int group, fo_i4 s, int t, const fo_cw *cw, dcf_step *o) {
+  fo_i4 s_cw = cw->s;
+  int tl_cw = get_lsb(s_cw);
+  s_cw = set_lsb(s_cw, 0);
+  fo_i4 v_cw_buf = cw->v;
+  int tr_cw = get_lsb(v_cw_buf);
+  v_cw_buf = set_lsb(v_cw_buf, 0);
+  o->v_cw = g_from(group, v_cw_buf);
+  fo_i4 g[4];
+  fo_prg_gen(p, s, g);
+  o->tl = get_lsb(g[0]); o->sl = set_lsb(g[0], 0); o->vl = g_from(group, set_lsb(g[1], 0));
+  o->tr = get_lsb(g[2]); o->sr = set_lsb(g[2], 0); o->vr = g_from(group, set_lsb(g[3], 0));
+  if (t) {
+    o->sl = xor4(o->sl, s_cw); o->sr = xor4(o->sr, s_cw);
+    o->tl ^= tl_cw; o->tr ^= tr_cw;
+  }
+}
+
+/* dcf.cuh:205-276 */
+fo_i4 fo_dcf_eval(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, uint64_t x_lo,
+                  uint64_t x_hi) {
+  u128 x = mk128(x_lo, x_hi);
+  fo_i4 s = set_lsb(s0, 0);
+  gel v = g_zero();
+  int t = b;
+  for (int i = 0; i < in_bits; ++i) {
+    dcf_step o;
+    dcf_expand(p, group, s, t, &cws[i], &o);
+    int x_bit = bit_of(x, in_bits - 1 - i);
+    if (b) { /* dcf.cuh:244-252 */
+      v = g_add(group, v, g_neg(group, x_bit ? o.vr : o.vl));
+      if (t) v = g_add(group, v, g_neg(group, o.v_cw));
+    } else {
+      v = g_add(group, v, x_bit ? o.vr : o.vl);
+      if (t) v = g_add(group, v, o.v_cw);
+    }
+    if (!x_bit) { s = o.sl; t = o.tl; } else { s = o.sr; t = o.tr; }
+  }
+  gel vn = g_from(group, cws[in_bits].v); /* dcf.cuh:263-273 */
+  if (b) {
+    v = g_add(group, v, g_neg(group, g_from(group, s)));
+    if (t) v = g_add(group, v, g_neg(group, vn));
+  } else {
+    v = g_add(group, v, g_from(group, s));
+    if (t) v = g_add(group, v, vn);
+  }
+  return g_into(group, v);
+}
+
+/* dcf.cuh:294-385, flattened breadth-first like fo_dpf_eval_all; the running
+ * group value of every node is kept in a side array. */
+void fo_dcf_eval_all(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys) {
+  size_t n = (size_t)1 << in_bits;
+  gel *vs = (gel *)malloc(n * sizeof(gel));
+  ys[0] = set_lsb(s0, b);
+  vs[0] = g_zero();
+  for (int i = 0; i < in_bits; ++i) {
+    size_t cnt = (size_t)1 << i;
+    for (size_t j = cnt; j-- > 0;) {
+      fo_i4 st = ys[j];
+      int t = get_lsb(st);
+      gel v = vs[j];
+      dcf_step o;
+      dcf_expand(p, group, set_lsb(st, 0), t, &cws[i], &o);
+      gel vl = o.vl, vr = o.vr;
+      if (t) { vl = g_add(group, vl, o.v_cw); vr = g_add(group, vr, o.v_cw); } /* dcf.cuh:348-355 */
+      if (b) { vl = g_neg(group, vl); vr = g_neg(group, vr); }
+      vl = g_add(group, vl, v);
+      vr = g_add(group, vr, v);
+      ys[2 * j] = set_lsb(o.sl, o.tl); vs[2 * j] = vl;
+      ys[2 * j + 1] = set_lsb(o.sr, o.tr); vs[2 * j + 1] = vr;
+    }
+  }
+  gel vn = g_from(group, cws[in_bits].v);
+  for (size_t j = 0; j < n; ++j) { /* dcf.cuh:318-329 */
+    gel term = g_from(group, set_lsb(ys[j], 0));
+    if (get_lsb(ys[j])) term = g_add(group, term, vn);
+    if (b) term = g_neg(group, term);
+    ys[j] = g_into(group, g_add(group, vs[j], term));
+  }
+  free(vs);
+}
+
+/* ------------------------------------------------------------------ Half-Tree DPF */
+static inline fo_i4 ht_hash(const fo_prg *p, fo_i4 hash_key, fo_i4 node) {
+  fo_i4 out[4]; /* only output 0 is used: prg.Gen(hash_key ^ node)[0] */
+  fo_prg_gen(p, xor4(hash_key, node), out);
+  return out[0];
+}
+
+/* half_tree_dpf.cuh:68-175 */
+void fo_ht_gen(const fo_prg *p, fo_i4 hash_key, int in_bits, int group, fo_cw *cws, fo_i4 *ocw, const fo_i4 s0s[2],
+               uint64_t a_lo, uint64_t a_hi, fo_i4 beta) {
+  u128 a = mk128(a_lo, a_hi);
+  beta = set_lsb(beta, 0);
+  fo_i4 node0 = set_lsb(s0s[0], 0), node1 = set_lsb(s0s[1], 1);
+  fo_i4 delta = xor4(node0, node1);
+  for (int i = 0; i < in_bits - 1; ++i) {
+    fo_i4 h0 = ht_hash(p, hash_key, node0), h1 = ht_hash(p, hash_key, node1);
+    int a_bit = bit_of(a, in_bits - 1 - i);
+    fo_i4 cw = xor4(h0, h1);
+    if (!a_bit) cw = xor4(cw, delta);
+    cws[i] = mk_cw(cw, 0);
+    int t0 = get_lsb(node0), t1 = get_lsb(node1);
+    fo_i4 n0 = xor4(xor4(h0, a_bit ? node0 : kZero4), t0 ? cw : kZero4);
+    fo_i4 n1 = xor4(xor4(h1, a_bit ? node1 : kZero4), t1 ? cw : kZero4);
+    node0 = n0; node1 = n1;
+    delta = xor4(node0, node1);
+  }
+  {
+    int a_n = bit_of(a, 0);
+    int t0 = get_lsb(node0), t1 = get_lsb(node1);
+    fo_i4 h0_0 = ht_hash(p, hash_key, set_lsb(node0, 0)), h0_1 = ht_hash(p, hash_key, set_lsb(node0, 1));
+    fo_i4 h1_0 = ht_hash(p, hash_key, set_lsb(node1, 0)), h1_1 = ht_hash(p, hash_key, set_lsb(node1, 1));
+    fo_i4 high0_0 = set_lsb(h0_0, 0), high0_1 = set_lsb(h0_1, 0), high1_0 = set_lsb(h1_0, 0),
+          high1_1 = set_lsb(h1_1, 0);
+    int low0_0 = get_lsb(h0_0), low0_1 = get_lsb(h0_1), low1_0 = get_lsb(h1_0), low1_1 = get_lsb(h1_1);
+    fo_i4 HCW = a_n ? xor4(high0_0, high1_0) : xor4(high0_1, high1_1); /* :123-125 */
+    int LCW_0 = low0_0 ^ low1_0 ^ !a_n;                                  /* :132-133 */
+    int LCW_1 = low0_1 ^ low1_1 ^ a_n;
+    cws[in_bits - 1] = mk_cw(set_lsb(HCW, LCW_0), LCW_1); /* :139-141 */
+    fo_i4 leaf0, leaf1;
+    if (a_n) { leaf0 = set_lsb(high0_1, low0_1); leaf1 = set_lsb(high1_1, low1_1); }
+    else { leaf0 = set_lsb(high0_0, low0_0); leaf1 = set_lsb(high1_0, low1_0); }
+    int lcw_an = a_n ? LCW_1 : LCW_0;
+    fo_i4 leaf_cw = set_lsb(HCW, lcw_an);
+    if (t0) leaf0 = xor4(leaf0, leaf_cw);
+    if (t1) leaf1 = xor4(leaf1, leaf_cw);
+    gel v = g_add(group, g_add(group, g_from(group, beta), g_neg(group, g_from(group, set_lsb(leaf0, 0)))),
+                  g_from(group, set_lsb(leaf1, 0)));
+    if (get_lsb(leaf1)) v = g_neg(group, v);
+    *ocw = g_into(group, v);
+  }
+}
+
+/* half_tree_dpf.cuh:205-229 / 325-354: last level + output conversion for sigma */
+static inline fo_i4 ht_convert(const fo_prg *p, fo_i4 hash_key, int group, int b, fo_i4 parent, int sigma,
+                               const fo_cw *cw_last, fo_i4 ocw) {
+  int t = get_lsb(parent);
+  fo_i4 h = ht_hash(p, hash_key, set_lsb(parent, sigma));
+  fo_i4 hcw = set_lsb(cw_last->s, 0);
+  int lcw = sigma ? cw_flag(cw_last) : get_lsb(cw_last->s);
+  fo_i4 high = set_lsb(h, 0);
+  int low = get_lsb(h);
+  if (t) { high = xor4(high, hcw); low ^= lcw; }
+  gel y = g_from(group, high);
+  if (low) y = g_add(group, y, g_from(group, ocw));
+  if (b) y = g_neg(group, y);
+  return g_into(group, y);
+}
+
+/* half_tree_dpf.cuh:187-231 */
+fo_i4 fo_ht_eval(const fo_prg *p, fo_i4 hash_key, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws,
+                 fo_i4 ocw, uint64_t x_lo, uint64_t x_hi) {
+  u128 x = mk128(x_lo, x_hi);
+  fo_i4 node = set_lsb(s0, b);
+  for (int i = 0; i < in_bits - 1; ++i) {
+    int x_bit = bit_of(x, in_bits - 1 - i);
+    int t = get_lsb(node);
+    fo_i4 h = ht_hash(p, hash_key, node);
+    node = xor4(xor4(h, x_bit ? node : kZero4), t ? cws[i].s : kZero4);
+  }
+  return ht_convert(p, hash_key, group, b, node, bit_of(x, 0), &cws[in_bits - 1], ocw);
+}
+
+/* half_tree_dpf.cuh:246-316 (EvalTree flattened breadth-first, then the backward
+ * in-place last level :277-280) */
+void fo_ht_eval_all(const fo_prg *p, fo_i4 hash_key, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws,
+                    fo_i4 ocw, fo_i4 *ys) {
+  ys[0] = set_lsb(s0, b);
+  for (int i = 0; i < in_bits - 1; ++i) {
+    size_t cnt = (size_t)1 << i;
+    for (size_t j = cnt; j-- > 0;) {
+      fo_i4 node = ys[j];
+      fo_i4 h = ht_hash(p, hash_key, node);
+      fo_i4 left = xor4(h, get_lsb(node) ? cws[i].s : kZero4); /* :299 */
+      fo_i4 right = xor4(left, node);                          /* :301 */
+      ys[2 * j] = left;
+      ys[2 * j + 1] = right;
+    }
+  }
+  size_t half = (size_t)1 << (in_bits - 1);
+  for (size_t j = half; j-- > 0;) {
+    fo_i4 parent = ys[j];
+    ys[2 * j] = ht_convert(p, hash_key, group, b, parent, 0, &cws[in_bits - 1], ocw);
+    ys[2 * j + 1] = ht_convert(p, hash_key, group, b, parent, 1, &cws[in_bits - 1], ocw);
+  }
+}
+
+/* ------------------------------------------------------------------ Grotto DCF */
+/* grotto_dcf.cuh:63-67 */
+void fo_grotto_gen(const fo_prg *p, int in_bits, fo_cw *cws, const fo_i4 s0s[2], uint64_t a_lo, uint64_t a_hi) {
+  fo_dpf_gen(p, in_bits, FO_GROUP_BYTES, cws, s0s, a_lo, a_hi, kZero4);
+}
+
+/* grotto_dcf.cuh:175-238 (ExpandTree): leaf control bits, in index order */
+static void grotto_expand(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_cw *cws, uint8_t *t) {
+  size_t n = (size_t)1 << in_bits;
+  fo_i4 *nodes = (fo_i4 *)malloc(n * sizeof(fo_i4));
+  nodes[0] = set_lsb(s0, b);
+  for (int i = 0; i < in_bits; ++i) {
+    size_t cnt = (size_t)1 << i;
+    for (size_t j = cnt; j-- > 0;) {
+      fo_i4 st = nodes[j], sl, sr; int tl, tr;
+      dpf_expand(p, set_lsb(st, 0), get_lsb(st), &cws[i], &sl, &tl, &sr, &tr);
+      nodes[2 * j] = set_lsb(sl, tl);
+      nodes[2 * j + 1] = set_lsb(sr, tr);
+    }
+  }
+  for (size_t j = 0; j < n; ++j) t[j] = (uint8_t)get_lsb(nodes[j]);
+  free(nodes);
+}
+
+/* grotto_dcf.cuh:94-104 */
+void fo_grotto_preprocess(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_cw *cws, uint8_t *pt) {
+  size_t N = (size_t)1 << in_bits;
+  grotto_expand(p, in_bits, b, s0, cws, pt + (N - 1));
+  for (size_t j = N - 2; j < N - 1; --j) pt[j] = pt[2 * j + 1] ^ pt[2 * j + 2];
+}
+
+/* grotto_dcf.cuh:116-135 */
+int fo_grotto_eval(int in_bits, const uint8_t *pt, uint64_t x) {
+  u128 N = (u128)1 << in_bits;
+  u128 e = (u128)x + 1;
+  if (e == N) return pt[0]; /* :121 (e == 0 is the same case when in_bits is the width of In) */
+  int pi = 0;
+  size_t cur = 0;
+  for (int i = 0; i < in_bits; ++i) {
+    if (bit_of(e, in_bits - 1 - i)) { pi ^= pt[2 * cur + 1]; cur = 2 * cur + 2; }
+    else cur = 2 * cur + 1;
+  }
+  return pi;
+}
+
+/* grotto_dcf.cuh:151-163 */
+void fo_grotto_eval_all(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_cw *cws, uint8_t *ys) {
+  size_t N = (size_t)1 << in_bits;
+  grotto_expand(p, in_bits, b, s0, cws, ys);
+  for (size_t x = 1; x < N; ++x) ys[x] ^= ys[x - 1];
+}
+
+/* Path walk (not in the reference). */
+int fo_grotto_eval_walk(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_cw *cws, uint64_t x) {
+  u128 N = (u128)1 << in_bits; /* in_bits <= 64 */
+  u128 e = (u128)x + 1;
+  if (e == N) return b; /* whole domain: the root's control bit */
+  fo_i4 s = set_lsb(s0, 0);
+  int t = b, pi = 0;
+  for (int i = 0; i < in_bits; ++i) {
+    fo_i4 sl, sr; int tl, tr;
+    dpf_expand(p, s, t, &cws[i], &sl, &tl, &sr, &tr);
+    if (bit_of(e, in_bits - 1 - i)) { pi ^= tl; s = sr; t = tr; }
+    else { s = sl; t = tl; }
+  }
+  return pi;
+}
+
+/* ------------------------------------------------------------------ batched drivers */
+static void prg_thread_copy(const fo_prg *src, fo_prg *dst) {
+  *dst = *src;
+  memset(dst->evp, 0, sizeof(dst->evp));
+  if (src->use_evp) evp_make(dst); /* one EVP ctx set per thread */
+}
+
+static fo_i4 eval_one(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, fo_i4 s0,
+                      const fo_cw *cws, fo_i4 ocw, uint64_t x) {
+  switch (scheme) {
+    case FO_DPF: return fo_dpf_eval(p, in_bits, group, b, s0, cws, x, 0);
+    case FO_DCF: return fo_dcf_eval(p, in_bits, group, b, s0, cws, x, 0);
+    case FO_HT: return fo_ht_eval(p, hk, in_bits, group, b, s0, cws, ocw, x, 0);
+    default: {
+      fo_i4 r = {fo_grotto_eval_walk(p, in_bits, b, s0, cws, x), 0, 0, 0};
+      return r;
+    }
+  }
+}
+
+void fo_eval_points(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws,
+                    fo_i4 ocw, const uint64_t *xs, size_t n, fo_i4 *ys, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    fo_prg tp;
+    prg_thread_copy(p, &tp);
+#pragma omp for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) ys[i] = eval_one(&tp, hk, scheme, in_bits, group, b, s0, cws, ocw, xs[i]);
+    fo_prg_free(&tp);
+  }
+}
+
+void fo_eval_keys(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, const fo_i4 *s0s,
+                  const fo_cw *cws, size_t stride, const fo_i4 *ocws, const uint64_t *xs, size_t n, fo_i4 *ys,
+                  int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    fo_prg tp;
+    prg_thread_copy(p, &tp);
+#pragma omp for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i)
+      ys[i] = eval_one(&tp, hk, scheme, in_bits, group, b, s0s[i], cws + (size_t)i * stride, ocws ? ocws[i] : kZero4,
+                       xs[i]);
+    fo_prg_free(&tp);
+  }
+}
+
+void fo_gen_keys(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int pred, const fo_i4 *s0s,
+                 const uint64_t *alphas, const fo_i4 *betas, size_t n, fo_cw *cws, size_t stride, fo_i4 *ocws,
+                 int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+  {
+    fo_prg tp;
+    prg_thread_copy(p, &tp);
+#pragma omp for schedule(static)
+    for (long long i = 0; i < (long long)n; ++i) {
+      fo_cw *c = cws + (size_t)i * stride;
+      const fo_i4 *ss = s0s + 2 * (size_t)i;
+      switch (scheme) {
+        case FO_DPF: fo_dpf_gen(&tp, in_bits, group, c, ss, alphas[i], 0, betas[i]); break;
+        case FO_DCF: fo_dcf_gen(&tp, in_bits, group, pred, c, ss, alphas[i], 0, betas[i]); break;
+        case FO_HT: fo_ht_gen(&tp, hk, in_bits, group, c, &ocws[i], ss, alphas[i], 0, betas[i]); break;
+        default: fo_grotto_gen(&tp, in_bits, c, ss, alphas[i], 0); break;
+      }
+    }
+    fo_prg_free(&tp);
+  }
+}

@@ -1,0 +1,296 @@
+"""ctypes/numpy front end of the CPU oracle (oracle/fss_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (fss_amd) never imports this.
+
+Shapes follow the reference's Python binding (fss_crypto/_csrc/dpf_binding_impl.cuh:27-131):
+seeds are int32[4], correction words int32[n_slots, 8] (raw 32-byte Cw slots),
+outputs int32[..., 4].
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfss_oracle.so")
+
+BYTES, U8, U16, U32, U64, U128M127 = 0, 1, 2, 3, 4, 5
+LT, GT = 0, 1
+DPF, DCF, HT, GROTTO = 0, 1, 2, 3
+
+# AES keys and Half-Tree hash key of the reference's benches/samples
+# (src/bench_cpu.cu:37-40, :509; samples/dpf_dcf_cpu.cu:96-103).
+KEYS = [
+    bytes(range(1, 17)),
+    bytes(range(16, 0, -1)),
+    bytes([1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8]),
+    bytes([8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1]),
+]
+HASH_KEY = np.array([0x12345678, 0x9ABCDEF0, 0x13572468, 0x2468ACE0], dtype=np.uint32).view(np.int32)
+
+
+def build(force=False):
+    """Compile oracle/libfss_oracle.so with gcc (no-op when up to date)."""
+    src = os.path.join(_HERE, "fss_oracle.c")
+    hdr = os.path.join(_HERE, "fss_oracle.h")
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libfss_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class _I4(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32), ("w", C.c_int32)]
+
+
+class _Prg(C.Structure):
+    _fields_ = [("mul", C.c_int), ("use_evp", C.c_int), ("key", (C.c_uint8 * 16) * 4),
+                ("rk", (C.c_uint32 * 44) * 4), ("evp", C.c_void_p * 4)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, i, u64, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
+        P = C.POINTER(_Prg)
+        L.fo_prg_init.argtypes = [P, vp, i, i]
+        L.fo_prg_init.restype = i
+        L.fo_prg_free.argtypes = [P]
+        L.fo_prg_gen.argtypes = [P, _I4, vp]
+        L.fo_aes128_encrypt.argtypes = [vp, vp, vp]
+        L.fo_dpf_gen.argtypes = [P, i, i, vp, vp, u64, u64, _I4]
+        L.fo_dpf_eval.argtypes = [P, i, i, i, _I4, vp, u64, u64]
+        L.fo_dpf_eval.restype = _I4
+        L.fo_dpf_eval_all.argtypes = [P, i, i, i, _I4, vp, vp]
+        L.fo_dcf_gen.argtypes = [P, i, i, i, vp, vp, u64, u64, _I4]
+        L.fo_dcf_eval.argtypes = [P, i, i, i, _I4, vp, u64, u64]
+        L.fo_dcf_eval.restype = _I4
+        L.fo_dcf_eval_all.argtypes = [P, i, i, i, _I4, vp, vp]
+        L.fo_ht_gen.argtypes = [P, _I4, i, i, vp, vp, vp, u64, u64, _I4]
+        L.fo_ht_eval.argtypes = [P, _I4, i, i, i, _I4, vp, _I4, u64, u64]
+        L.fo_ht_eval.restype = _I4
+        L.fo_ht_eval_all.argtypes = [P, _I4, i, i, i, _I4, vp, _I4, vp]
+        L.fo_grotto_gen.argtypes = [P, i, vp, vp, u64, u64]
+        L.fo_grotto_preprocess.argtypes = [P, i, i, _I4, vp, vp]
+        L.fo_grotto_eval.argtypes = [i, vp, u64]
+        L.fo_grotto_eval.restype = i
+        L.fo_grotto_eval_all.argtypes = [P, i, i, _I4, vp, vp]
+        L.fo_grotto_eval_walk.argtypes = [P, i, i, _I4, vp, u64]
+        L.fo_grotto_eval_walk.restype = i
+        L.fo_eval_points.argtypes = [P, _I4, i, i, i, i, _I4, vp, _I4, vp, sz, vp, i]
+        L.fo_eval_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, sz, vp, vp, sz, vp, i]
+        L.fo_gen_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, vp, sz, vp, sz, vp, i]
+        _lib = L
+    return _lib
+
+
+def _i4(a):
+    a = np.asarray(a).astype(np.int64)
+    a = (a & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    return _I4(int(a[0]), int(a[1]), int(a[2]), int(a[3]))
+
+
+def _arr(v):
+    return np.array([v.x, v.y, v.z, v.w], dtype=np.int32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _split(v):
+    v = int(v)
+    return v & ((1 << 64) - 1), (v >> 64) & ((1 << 64) - 1)
+
+
+def aes128_encrypt(key: bytes, block: bytes) -> bytes:
+    out = (C.c_uint8 * 16)()
+    lib().fo_aes128_encrypt(C.c_char_p(key), C.c_char_p(block), out)
+    return bytes(out)
+
+
+class Prg:
+    """fss::prg::Aes128Mmo<mul> (include/fss/prg/aes128_mmo.cuh:27-95)."""
+
+    def __init__(self, mul, keys=None, use_evp=False):
+        keys = KEYS[:mul] if keys is None else keys
+        assert len(keys) == mul
+        self.mul = mul
+        self._p = _Prg()
+        buf = b"".join(keys)
+        rc = lib().fo_prg_init(C.byref(self._p), C.c_char_p(buf), mul, 1 if use_evp else 0)
+        if rc != 0:
+            raise RuntimeError("fo_prg_init failed (OpenSSL missing?)")
+
+    def __del__(self):
+        try:
+            lib().fo_prg_free(C.byref(self._p))
+        except Exception:
+            pass
+
+    @property
+    def ref(self):
+        return C.byref(self._p)
+
+    def gen(self, seed):
+        out = np.zeros((self.mul, 4), dtype=np.int32)
+        lib().fo_prg_gen(self.ref, _i4(seed), _ptr(out))
+        return out
+
+
+def _cws_buf(n):
+    return np.zeros((n, 8), dtype=np.int32)
+
+
+def _seeds2(s0s):
+    return np.ascontiguousarray(np.asarray(s0s, dtype=np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(2, 4)
+
+
+# ---------------------------------------------------------------- DPF
+def dpf_gen(prg, in_bits, group, s0s, alpha, beta):
+    cws = _cws_buf(in_bits + 1)
+    s = _seeds2(s0s)
+    lo, hi = _split(alpha)
+    lib().fo_dpf_gen(prg.ref, in_bits, group, _ptr(cws), _ptr(s), lo, hi, _i4(beta))
+    return cws
+
+
+def dpf_eval(prg, in_bits, group, b, s0, cws, x):
+    lo, hi = _split(x)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    return _arr(lib().fo_dpf_eval(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), lo, hi))
+
+
+def dpf_eval_all(prg, in_bits, group, b, s0, cws):
+    ys = np.zeros((1 << in_bits, 4), dtype=np.int32)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    lib().fo_dpf_eval_all(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(ys))
+    return ys
+
+
+# ---------------------------------------------------------------- DCF
+def dcf_gen(prg, in_bits, group, pred, s0s, alpha, beta):
+    cws = _cws_buf(in_bits + 1)
+    s = _seeds2(s0s)
+    lo, hi = _split(alpha)
+    lib().fo_dcf_gen(prg.ref, in_bits, group, pred, _ptr(cws), _ptr(s), lo, hi, _i4(beta))
+    return cws
+
+
+def dcf_eval(prg, in_bits, group, b, s0, cws, x):
+    lo, hi = _split(x)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    return _arr(lib().fo_dcf_eval(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), lo, hi))
+
+
+def dcf_eval_all(prg, in_bits, group, b, s0, cws):
+    ys = np.zeros((1 << in_bits, 4), dtype=np.int32)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    lib().fo_dcf_eval_all(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(ys))
+    return ys
+
+
+# ---------------------------------------------------------------- Half-Tree
+def ht_gen(prg, in_bits, group, s0s, alpha, beta, hash_key=HASH_KEY):
+    cws = _cws_buf(in_bits)
+    ocw = np.zeros(4, dtype=np.int32)
+    s = _seeds2(s0s)
+    lo, hi = _split(alpha)
+    lib().fo_ht_gen(prg.ref, _i4(hash_key), in_bits, group, _ptr(cws), _ptr(ocw), _ptr(s), lo, hi, _i4(beta))
+    return cws, ocw
+
+
+def ht_eval(prg, in_bits, group, b, s0, cws, ocw, x, hash_key=HASH_KEY):
+    lo, hi = _split(x)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    return _arr(lib().fo_ht_eval(prg.ref, _i4(hash_key), in_bits, group, int(b), _i4(s0), _ptr(cws), _i4(ocw), lo, hi))
+
+
+def ht_eval_all(prg, in_bits, group, b, s0, cws, ocw, hash_key=HASH_KEY):
+    ys = np.zeros((1 << in_bits, 4), dtype=np.int32)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    lib().fo_ht_eval_all(prg.ref, _i4(hash_key), in_bits, group, int(b), _i4(s0), _ptr(cws), _i4(ocw), _ptr(ys))
+    return ys
+
+
+# ---------------------------------------------------------------- Grotto
+def grotto_gen(prg, in_bits, s0s, alpha):
+    cws = _cws_buf(in_bits + 1)
+    s = _seeds2(s0s)
+    lo, hi = _split(alpha)
+    lib().fo_grotto_gen(prg.ref, in_bits, _ptr(cws), _ptr(s), lo, hi)
+    return cws
+
+
+def grotto_preprocess(prg, in_bits, b, s0, cws):
+    pt = np.zeros(2 * (1 << in_bits) - 1, dtype=np.uint8)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    lib().fo_grotto_preprocess(prg.ref, in_bits, int(b), _i4(s0), _ptr(cws), _ptr(pt))
+    return pt
+
+
+def grotto_eval(in_bits, pt, x):
+    return lib().fo_grotto_eval(in_bits, _ptr(pt), int(x))
+
+
+def grotto_eval_all(prg, in_bits, b, s0, cws):
+    ys = np.zeros(1 << in_bits, dtype=np.uint8)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    lib().fo_grotto_eval_all(prg.ref, in_bits, int(b), _i4(s0), _ptr(cws), _ptr(ys))
+    return ys
+
+
+def grotto_eval_walk(prg, in_bits, b, s0, cws, x):
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    return lib().fo_grotto_eval_walk(prg.ref, in_bits, int(b), _i4(s0), _ptr(cws), int(x))
+
+
+# ---------------------------------------------------------------- batched
+def eval_points(prg, scheme, in_bits, group, b, s0, cws, xs, ocw=None, hash_key=HASH_KEY, nthreads=1):
+    """One key, many points.  xs: uint64[n].  Returns int32[n,4]."""
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    ys = np.zeros((xs.size, 4), dtype=np.int32)
+    oc = _i4(ocw if ocw is not None else [0, 0, 0, 0])
+    lib().fo_eval_points(prg.ref, _i4(hash_key), scheme, in_bits, group, int(b), _i4(s0), _ptr(cws), oc, _ptr(xs),
+                         xs.size, _ptr(ys), nthreads)
+    return ys
+
+
+def eval_keys(prg, scheme, in_bits, group, b, s0s, cws, xs, ocws=None, hash_key=HASH_KEY, nthreads=1):
+    """Many keys x one point each.  s0s int32[n,4]; cws int32[n,stride,8]; xs uint64[n]."""
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    s0s = np.ascontiguousarray(s0s, dtype=np.int32)
+    n, stride = cws.shape[0], cws.shape[1]
+    ys = np.zeros((n, 4), dtype=np.int32)
+    op = None
+    if ocws is not None:
+        ocws = np.ascontiguousarray(ocws, dtype=np.int32)
+        op = _ptr(ocws)
+    lib().fo_eval_keys(prg.ref, _i4(hash_key), scheme, in_bits, group, int(b), _ptr(s0s), _ptr(cws), stride, op,
+                       _ptr(xs), n, _ptr(ys), nthreads)
+    return ys
+
+
+def gen_keys(prg, scheme, in_bits, group, s0s, alphas, betas, pred=LT, hash_key=HASH_KEY, nthreads=1):
+    """Many keys.  s0s int32[n,2,4]; alphas uint64[n]; betas int32[n,4].
+    Returns (cws int32[n,stride,8], ocws int32[n,4] or None)."""
+    s0s = np.ascontiguousarray(s0s, dtype=np.int32)
+    alphas = np.ascontiguousarray(alphas, dtype=np.uint64)
+    betas = np.ascontiguousarray(betas, dtype=np.int32)
+    n = alphas.size
+    stride = in_bits if scheme == HT else in_bits + 1
+    cws = np.zeros((n, stride, 8), dtype=np.int32)
+    ocws = np.zeros((n, 4), dtype=np.int32)
+    lib().fo_gen_keys(prg.ref, _i4(hash_key), scheme, in_bits, group, pred, _ptr(s0s), _ptr(alphas), _ptr(betas), n,
+                      _ptr(cws), stride, _ptr(ocws), nthreads)
+    return cws, (ocws if scheme == HT else None)
