@@ -1,0 +1,73 @@
+"""ctypes binding of libfss_amd.so (include/fss_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable the
+calls raise (ImportError / RuntimeError).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(_HERE, "libfss_amd.so")
+
+OK, EINVAL, EHIP, EUNSUPPORTED = 0, -1, -2, -3
+
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol include/fss_amd.h declares.
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+PROTOTYPES = {
+    "fss_amd_ctx_create": (_i, [C.POINTER(_vp), _i, _vp, _vp]),
+    "fss_amd_ctx_destroy": (None, [_vp]),
+    "fss_amd_ctx_device": (_i, [_vp]),
+    "fss_amd_strerror": (C.c_char_p, [_i]),
+    "fss_amd_last_hip_error": (_i, []),
+    "fss_amd_prg_gen": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),
+    "fss_amd_dpf_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_dcf_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_ht_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_dpf_relayout": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fss_amd_dcf_relayout": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fss_amd_ht_relayout": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_dpf_eval_keys": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_dcf_eval_keys": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_ht_eval_keys": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_eval_all_workspace": (_sz, [_i, _i, _i64]),
+    "fss_amd_dpf_eval_all": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "fss_amd_dcf_eval_all": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "fss_amd_ht_eval_all": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "fss_amd_grotto_eval_all": (_i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "fss_amd_grotto_eval_keys": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_dpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
+    "fss_amd_dcf_gen": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
+    "fss_amd_ht_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_last_kernel": (C.c_char_p, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+}
+
+
+def lib():
+    """Load libfss_amd.so; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise ImportError(
+                f"{SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). fss_amd has no CPU fallback.")
+        L = C.CDLL(SO)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class FssAmdError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != OK:
+        L = lib()
+        msg = L.fss_amd_strerror(rc).decode()
+        extra = f" (hipError_t {L.fss_amd_last_hip_error()})" if rc == EHIP else ""
+        raise FssAmdError(f"{what}: {msg}{extra}")

@@ -1,0 +1,364 @@
+// libfss_amd.so -- C ABI (include/fss_amd.h) over the gfx950 kernels.
+// Host side: context (AES key schedule, Te0 table), argument checks, launches.
+#include "../../include/fss_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "fss_dev.hpp"
+#include "fss_evalall.hpp"
+#include "fss_gen.hpp"
+#include "fss_point.hpp"
+
+using namespace fssamd;
+
+// ------------------------------------------------------------------ context
+struct fss_amd_ctx {
+  int device;
+  int num_cu;
+  uint32_t* te0;  // device: Te0 table, 1 KiB
+  DevCtx host;    // round keys etc., passed to kernels by value
+  const char* last_kernel;
+  int last_grid, last_block;
+};
+
+static thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                    \
+  do {                                   \
+    hipError_t e_ = (expr);              \
+    if (e_ != hipSuccess) {              \
+      g_last_hip = (int)e_;              \
+      return FSS_AMD_EHIP;               \
+    }                                    \
+  } while (0)
+
+namespace {
+
+// FIPS-197 S-box from the field inverse and the affine map.
+void make_sbox(uint8_t sbox[256]) {
+  uint8_t p = 1, q = 1;
+  do {
+    p = (uint8_t)(p ^ (p << 1) ^ ((p & 0x80) ? 0x1b : 0));
+    q ^= (uint8_t)(q << 1);
+    q ^= (uint8_t)(q << 2);
+    q ^= (uint8_t)(q << 4);
+    if (q & 0x80) q ^= 0x09;
+    auto rl = [](uint8_t v, int n) { return (uint8_t)((v << n) | (v >> (8 - n))); };
+    sbox[p] = (uint8_t)(q ^ rl(q, 1) ^ rl(q, 2) ^ rl(q, 3) ^ rl(q, 4) ^ 0x63);
+  } while (p != 1);
+  sbox[0] = 0x63;
+}
+
+inline uint8_t xtime(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1b)); }
+
+void expand_key(const uint8_t sbox[256], const uint8_t key[16], uint32_t rk[44]) {
+  uint8_t w[176];
+  memcpy(w, key, 16);
+  uint8_t rcon = 1;
+  for (int i = 16; i < 176; i += 4) {
+    uint8_t t[4] = {w[i - 4], w[i - 3], w[i - 2], w[i - 1]};
+    if (i % 16 == 0) {
+      uint8_t t0 = t[0];
+      t[0] = (uint8_t)(sbox[t[1]] ^ rcon);
+      t[1] = sbox[t[2]];
+      t[2] = sbox[t[3]];
+      t[3] = sbox[t0];
+      rcon = xtime(rcon);
+    }
+    for (int j = 0; j < 4; ++j) w[i + j] = (uint8_t)(w[i - 16 + j] ^ t[j]);
+  }
+  for (int i = 0; i < 44; ++i)
+    rk[i] = (uint32_t)w[4 * i] | ((uint32_t)w[4 * i + 1] << 8) | ((uint32_t)w[4 * i + 2] << 16) |
+            ((uint32_t)w[4 * i + 3] << 24);
+}
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+bool group_ok(int g) { return g >= 0 && g <= 5; }
+bool x_ok(int in_bits, int x_bytes) {
+  if (in_bits < 1) return false;
+  if (x_bytes == 4) return in_bits <= 32;
+  if (x_bytes == 8) return in_bits <= 64;
+  return false;
+}
+
+// Tunables (env, read once): FSS_AMD_ILP in {1,2}, FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU.
+struct Tune {
+  int ilp = 1, bs = 1024, wgs_per_cu = 0;
+  Tune() {
+    if (const char* e = getenv("FSS_AMD_ILP")) ilp = atoi(e);
+    if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
+    if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
+    if (ilp != 1 && ilp != 2) ilp = 1;
+    if (bs != 256 && bs != 512 && bs != 1024) bs = 1024;
+  }
+};
+const Tune& tune() {
+  static Tune t;
+  return t;
+}
+
+template <typename K, typename... Args>
+int launch_persistent(fss_amd_ctx* ctx, K kernel, const char* name, int bs, int64_t threads_needed, hipStream_t st,
+                      Args... args) {
+  int occ = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, bs, 0));
+  if (occ < 1) occ = 1;
+  if (tune().wgs_per_cu > 0 && tune().wgs_per_cu < occ) occ = tune().wgs_per_cu;
+  int64_t want = (threads_needed + bs - 1) / bs;
+  int64_t cap = (int64_t)ctx->num_cu * occ;
+  int grid = (int)(want < cap ? want : cap);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bs), 0, st, args...);
+  HIP_TRY(hipGetLastError());
+  ctx->last_kernel = name;
+  ctx->last_grid = grid;
+  ctx->last_block = bs;
+  return FSS_AMD_OK;
+}
+
+struct SharedKey {
+  const uint32_t *seed = nullptr, *cws = nullptr, *ocw = nullptr;
+};
+
+template <int SCHEME, bool SHARED>
+int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
+  if (a.n == 0) return FSS_AMD_OK;
+  const int ilp = tune().ilp, bs = tune().bs;
+  int64_t thr = (a.n + ilp - 1) / ilp;
+#define FSS_L(I, B) \
+  if (ilp == I && bs == B)                                                                                    \
+  return launch_persistent(ctx, eval_points_kernel<SCHEME, SHARED, I, B>, name, B, thr, st, ctx->host, ctx->te0, \
+                           k.seed, k.cws, k.ocw, a)
+  FSS_L(1, 1024);
+  FSS_L(2, 1024);
+  FSS_L(1, 512);
+  FSS_L(2, 512);
+  FSS_L(1, 256);
+  FSS_L(2, 256);
+#undef FSS_L
+  return FSS_AMD_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64], const int32_t hash_key[4]) {
+  if (!out || !aes_keys) return FSS_AMD_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return FSS_AMD_EINVAL;
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+
+  fss_amd_ctx* c = new (std::nothrow) fss_amd_ctx();
+  if (!c) return FSS_AMD_EINVAL;
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  c->last_kernel = "";
+  c->last_grid = c->last_block = 0;
+
+  uint8_t sbox[256];
+  uint32_t te0[256];
+  make_sbox(sbox);
+  for (int i = 0; i < 256; ++i) {
+    uint8_t s = sbox[i], s2 = xtime(s), s3 = (uint8_t)(s2 ^ s);
+    te0[i] = (uint32_t)s2 | ((uint32_t)s << 8) | ((uint32_t)s << 16) | ((uint32_t)s3 << 24);
+  }
+  for (int k = 0; k < 4; ++k) expand_key(sbox, aes_keys + 16 * k, c->host.rk[k]);
+  for (int r = 0; r < 11; ++r)
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t *k0 = c->host.rk[0], *k1 = c->host.rk[1], *k2 = c->host.rk[2], *k3 = c->host.rk[3];
+      c->host.sel01[r][j] = k0[4 * r + j]; c->host.sel01[r][4 + j] = k0[4 * r + j] ^ k1[4 * r + j];
+      c->host.sel02[r][j] = k0[4 * r + j]; c->host.sel02[r][4 + j] = k0[4 * r + j] ^ k2[4 * r + j];
+      c->host.sel13[r][j] = k1[4 * r + j]; c->host.sel13[r][4 + j] = k1[4 * r + j] ^ k3[4 * r + j];
+    }
+  for (int i = 0; i < 4; ++i) c->host.hash_key[i] = hash_key ? (uint32_t)hash_key[i] : 0u;
+
+  c->te0 = nullptr;
+  hipError_t e = hipMalloc(&c->te0, sizeof(te0));
+  if (e == hipSuccess) e = hipMemcpy(c->te0, te0, sizeof(te0), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    g_last_hip = (int)e;
+    if (c->te0) (void)hipFree(c->te0);
+    delete c;
+    return FSS_AMD_EHIP;
+  }
+  *out = c;
+  return FSS_AMD_OK;
+}
+
+void fss_amd_ctx_destroy(fss_amd_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->te0) (void)hipFree(ctx->te0);
+  delete ctx;
+}
+
+int fss_amd_ctx_device(const fss_amd_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+const char* fss_amd_strerror(int code) {
+  switch (code) {
+    case FSS_AMD_OK: return "ok";
+    case FSS_AMD_EINVAL: return "invalid argument";
+    case FSS_AMD_EHIP: return "HIP runtime error";
+    case FSS_AMD_EUNSUPPORTED: return "not supported by this build";
+    default: return "unknown error";
+  }
+}
+
+int fss_amd_last_hip_error(void) { return g_last_hip; }
+
+const char* fss_amd_last_kernel(const fss_amd_ctx* ctx, int* grid, int* block) {
+  if (!ctx) return "";
+  if (grid) *grid = ctx->last_grid;
+  if (block) *block = ctx->last_block;
+  return ctx->last_kernel;
+}
+
+// ------------------------------------------------------------------ raw PRG
+int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, void* out, void* stream) {
+  if (!ctx || !seeds || !out || n < 0 || (mul != 1 && mul != 2 && mul != 4)) return FSS_AMD_EINVAL;
+  if (n == 0) return FSS_AMD_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  int bs = 256;
+  int64_t want = (n + bs - 1) / bs;
+  int grid = (int)(want < (int64_t)ctx->num_cu * 2 ? want : (int64_t)ctx->num_cu * 2);
+  hipLaunchKernelGGL(prg_gen_kernel, dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, mul,
+                     reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out));
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+
+// ------------------------------------------------------------------ point eval, shared key
+static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seed,
+                         const void* cws, const void* ocw, const void* xs, int x_bytes, int64_t n, void* ys,
+                         void* stream) {
+  if (!ctx || !seed || !cws || n < 0 || !group_ok(group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes))
+    return FSS_AMD_EINVAL;
+  if (n > 0 && (!xs || !ys)) return FSS_AMD_EINVAL;
+  if (scheme == S_HT && !ocw) return FSS_AMD_EINVAL;
+  HIP_TRY(hipSetDevice(ctx->device));
+  EvalArgs a{};
+  a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;
+  a.xs = xs; a.ys = ys;
+  SharedKey k;
+  k.seed = reinterpret_cast<const uint32_t*>(seed);
+  k.cws = reinterpret_cast<const uint32_t*>(cws);
+  k.ocw = reinterpret_cast<const uint32_t*>(ocw);
+  switch (scheme) {
+    case S_DPF: return launch_points<S_DPF, true>(ctx, "dpf_eval_points", k, a, S(stream));
+    case S_DCF: return launch_points<S_DCF, true>(ctx, "dcf_eval_points", k, a, S(stream));
+    default: return launch_points<S_HT, true>(ctx, "ht_eval_points", k, a, S(stream));
+  }
+}
+
+int fss_amd_dpf_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
+                            const void* xs, int x_bytes, int64_t npoints, void* ys, void* stream) {
+  return points_common(ctx, S_DPF, in_bits, group, party, seed, cws, nullptr, xs, x_bytes, npoints, ys, stream);
+}
+int fss_amd_dcf_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
+                            const void* xs, int x_bytes, int64_t npoints, void* ys, void* stream) {
+  return points_common(ctx, S_DCF, in_bits, group, party, seed, cws, nullptr, xs, x_bytes, npoints, ys, stream);
+}
+int fss_amd_ht_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
+                           const void* ocw, const void* xs, int x_bytes, int64_t npoints, void* ys, void* stream) {
+  return points_common(ctx, S_HT, in_bits, group, party, seed, cws, ocw, xs, x_bytes, npoints, ys, stream);
+}
+
+// ------------------------------------------------------------------ relayout
+int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
+                         void* out_cw, void* stream) {
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 64) return FSS_AMD_EINVAL;
+  if (nkeys == 0) return FSS_AMD_OK;
+  if (!cws || !cw_s || !tr_bits || !out_cw) return FSS_AMD_EINVAL;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(relayout_kernel<S_DPF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+                     in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
+                     (uint4*)nullptr, reinterpret_cast<uint64_t*>(tr_bits), reinterpret_cast<uint4*>(out_cw),
+                     (uint32_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* cw_v,
+                         void* out_cw, void* stream) {
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 64) return FSS_AMD_EINVAL;
+  if (nkeys == 0) return FSS_AMD_OK;
+  if (!cws || !cw_s || !cw_v || !out_cw) return FSS_AMD_EINVAL;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(relayout_kernel<S_DCF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+                     in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
+                     reinterpret_cast<uint4*>(cw_v), (uint64_t*)nullptr, reinterpret_cast<uint4*>(out_cw),
+                     (uint32_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* extra,
+                        void* stream) {
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 64) return FSS_AMD_EINVAL;
+  if (nkeys == 0) return FSS_AMD_OK;
+  if (!cws || !cw_s || !extra) return FSS_AMD_EINVAL;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(relayout_kernel<S_HT>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+                     in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
+                     (uint4*)nullptr, (uint64_t*)nullptr, (uint4*)nullptr, reinterpret_cast<uint32_t*>(extra));
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+
+// ------------------------------------------------------------------ point eval, independent keys
+static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seeds,
+                       const void* cw_s, const void* cw_v, const void* tr_bits, const void* out_cw, const void* extra,
+                       const void* xs, int x_bytes, int64_t n, void* ys, void* stream) {
+  if (!ctx || n < 0 || !group_ok(group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
+  if (n == 0) return FSS_AMD_OK;
+  if (!seeds || !cw_s || !xs || !ys || !out_cw) return FSS_AMD_EINVAL;
+  if (scheme == S_DPF && !tr_bits) return FSS_AMD_EINVAL;
+  if (scheme == S_DCF && !cw_v) return FSS_AMD_EINVAL;
+  if (scheme == S_HT && !extra) return FSS_AMD_EINVAL;
+  HIP_TRY(hipSetDevice(ctx->device));
+  EvalArgs a{};
+  a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;
+  a.xs = xs; a.ys = ys;
+  a.seeds = reinterpret_cast<const uint4*>(seeds);
+  a.cw_s = reinterpret_cast<const uint4*>(cw_s);
+  a.cw_v = reinterpret_cast<const uint4*>(cw_v);
+  a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
+  a.out_cw = reinterpret_cast<const uint4*>(out_cw);
+  a.extra = reinterpret_cast<const uint32_t*>(extra);
+  switch (scheme) {
+    case S_DPF: return launch_points<S_DPF, false>(ctx, "dpf_eval_keys", SharedKey{}, a, S(stream));
+    case S_DCF: return launch_points<S_DCF, false>(ctx, "dcf_eval_keys", SharedKey{}, a, S(stream));
+    default: return launch_points<S_HT, false>(ctx, "ht_eval_keys", SharedKey{}, a, S(stream));
+  }
+}
+
+int fss_amd_dpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                          const void* tr_bits, const void* out_cw, const void* xs, int x_bytes, int64_t nkeys, void* ys,
+                          void* stream) {
+  return keys_common(ctx, S_DPF, in_bits, group, party, seeds, cw_s, nullptr, tr_bits, out_cw, nullptr, xs, x_bytes,
+                     nkeys, ys, stream);
+}
+int fss_amd_dcf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                          const void* cw_v, const void* out_cw, const void* xs, int x_bytes, int64_t nkeys, void* ys,
+                          void* stream) {
+  return keys_common(ctx, S_DCF, in_bits, group, party, seeds, cw_s, cw_v, nullptr, out_cw, nullptr, xs, x_bytes,
+                     nkeys, ys, stream);
+}
+int fss_amd_ht_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                         const void* extra, const void* ocws, const void* xs, int x_bytes, int64_t nkeys, void* ys,
+                         void* stream) {
+  return keys_common(ctx, S_HT, in_bits, group, party, seeds, cw_s, nullptr, nullptr, ocws, extra, xs, x_bytes, nkeys,
+                     ys, stream);
+}
+
+}  // extern "C"
+
+#include "fss_abi_rest.inc"

@@ -1,0 +1,336 @@
+// Full-domain evaluation (EvalAll) as a short chain of expansion stages.
+//
+// The evaluated block [first_leaf, first_leaf + 2^r) is the subtree under the
+// depth-p node whose path is `prefix` (p = in_bits - r): this is the unit a GPU
+// owns when the domain is sharded.  walk_kernel walks the p prefix levels once
+// (point-eval style), then every stage lets one lane take one node and expand it
+// D levels in registers into 2^D children (each node is expanded exactly once:
+// 2 AES per DPF node, 4 per DCF node, 1 per Half-Tree node, as the reference's
+// EvalTree).  The last stage converts leaves to group outputs and writes them in
+// index order with 64-bit indexing.  Intermediate frontiers live in the caller's
+// workspace (nodes of 16 B; 1/16 of the leaves for the last frontier).
+//
+// Follows: fss::Dpf::EvalTree (include/fss/dpf.cuh:250-303), fss::Dcf::EvalTree
+// (include/fss/dcf.cuh:315-385), fss::HalfTreeDpf::EvalTree / ConvertLastLevel
+// (include/fss/half_tree_dpf.cuh:284-354), GrottoDcf::ExpandTreeRec
+// (include/fss/grotto_dcf.cuh:190-238); replaces the kernels of
+// include/fss/eval_all_gpu.cuh:207-268, :62-150.
+#pragma once
+#include "fss_dev.hpp"
+#include "fss_point.hpp"
+
+namespace fssamd {
+
+struct ExpandArgs {
+  int scheme;
+  int in_bits;
+  int party;
+  int group;
+  int level0;         // tree level of the input nodes
+  int64_t n_in;       // number of input nodes
+  uint64_t prefix;      // walk_kernel: path of the subtree root (level0 bits)
+  const uint4* in_nodes;
+  const uint4* in_v;    // DCF: running group value per node
+  uint4* out_nodes;
+  uint4* out_v;
+  void* ys;             // leaf stage: uint4 per leaf (Grotto: uint8 control bit per leaf)
+};
+
+// -- one-node expansions ------------------------------------------------------
+// DPF / Grotto node -> both children, control bits packed (dpf.cuh:266-289).
+__device__ __forceinline__ void dpf_expand(const Lds& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
+                                           const uint32_t st[4], uint32_t left[4], uint32_t right[4]) {
+  uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+  uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
+  aes_mmo<false>(L, c->rk[0], 0, in, left);
+  aes_mmo<false>(L, c->rk[1], 0, in, right);
+  uint32_t wl = cw[3], wr = (cw[3] & ~1u) | (cw[4] & 1u);
+  left[0] = and_xor(tm, cw[0], left[0]);   right[0] = and_xor(tm, cw[0], right[0]);
+  left[1] = and_xor(tm, cw[1], left[1]);   right[1] = and_xor(tm, cw[1], right[1]);
+  left[2] = and_xor(tm, cw[2], left[2]);   right[2] = and_xor(tm, cw[2], right[2]);
+  left[3] = and_xor(tm, wl, left[3]);      right[3] = and_xor(tm, wr, right[3]);
+}
+
+// DCF node (dcf.cuh:331-366): children plus their running values (positive terms;
+// the party sign is applied at the leaf).
+__device__ __forceinline__ void dcf_expand(const Lds& L, const DevCtx* __restrict__ c, int g,
+                                           const uint32_t* __restrict__ cw, const uint32_t st[4], const Acc& v,
+                                           uint32_t left[4], Acc& vl, uint32_t right[4], Acc& vr) {
+  uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+  uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
+  uint32_t bl[4], br[4];
+  aes_mmo<false>(L, c->rk[0], 0, in, left);
+  aes_mmo<false>(L, c->rk[1], 0, in, bl);
+  aes_mmo<false>(L, c->rk[2], 0, in, right);
+  aes_mmo<false>(L, c->rk[3], 0, in, br);
+  bl[3] &= ~1u; br[3] &= ~1u;
+  uint32_t vcw[4] = {cw[4], cw[5], cw[6], cw[7] & ~1u};
+  vl = v; vl.add(g, bl); vl.add_if(g, tm, vcw);
+  vr = v; vr.add(g, br); vr.add_if(g, tm, vcw);
+  uint32_t wl = cw[3], wr = (cw[3] & ~1u) | (cw[7] & 1u);
+  left[0] = and_xor(tm, cw[0], left[0]);   right[0] = and_xor(tm, cw[0], right[0]);
+  left[1] = and_xor(tm, cw[1], left[1]);   right[1] = and_xor(tm, cw[1], right[1]);
+  left[2] = and_xor(tm, cw[2], left[2]);   right[2] = and_xor(tm, cw[2], right[2]);
+  left[3] = and_xor(tm, wl, left[3]);      right[3] = and_xor(tm, wr, right[3]);
+}
+
+// Half-Tree inner node (half_tree_dpf.cuh:293-302): one hash, right = left ^ parent.
+__device__ __forceinline__ void ht_expand(const Lds& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
+                                          const uint32_t node[4], uint32_t left[4], uint32_t right[4]) {
+  uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(node[3], 0, 1);
+  uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
+                    node[3] ^ c->hash_key[3]};
+  uint32_t h[4];
+  aes_mmo<false>(L, c->rk[0], 0, in, h);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    left[j] = and_xor(tm, cw[j], h[j]);
+    right[j] = left[j] ^ node[j];
+  }
+}
+
+// Half-Tree last level for one sigma (half_tree_dpf.cuh:325-354).
+__device__ __forceinline__ uint4 ht_convert(const Lds& L, const DevCtx* __restrict__ c, int g, int party,
+                                            const uint32_t* __restrict__ cw, const uint32_t* __restrict__ ocw,
+                                            const uint32_t parent[4], uint32_t sigma) {
+  uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(parent[3], 0, 1);
+  uint32_t in[4] = {parent[0] ^ c->hash_key[0], parent[1] ^ c->hash_key[1], parent[2] ^ c->hash_key[2],
+                    ((parent[3] & ~1u) | sigma) ^ c->hash_key[3]};
+  uint32_t h[4];
+  aes_mmo<false>(L, c->rk[0], 0, in, h);
+  uint32_t lcw = sigma ? (cw[4] & 1u) : (cw[3] & 1u);
+  uint32_t low = (h[3] ^ (tm & lcw)) & 1u;
+  uint32_t high[4] = {and_xor(tm, cw[0], h[0]), and_xor(tm, cw[1], h[1]), and_xor(tm, cw[2], h[2]),
+                      and_xor(tm, cw[3], h[3]) & ~1u};
+  uint32_t oc[4] = {ocw[0], ocw[1], ocw[2], ocw[3]};
+  Acc y;
+  y.add(g, high);
+  y.add_if(g, 0u - low, oc);
+  return y.finish(g, party != 0);
+}
+
+// -- frontier: lane j walks prefix . j from the root (taken child only) ----------
+// Produces the 2^top nodes at depth level0 = p + top under the subtree root whose
+// path is `prefix` (p bits).  Same walk as point evaluation, but the node (and the
+// DCF running value) is stored instead of converted.
+template <int SCHEME>
+__global__ __launch_bounds__(256) void frontier_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                       const uint32_t* __restrict__ k_seed,
+                                                       const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  const int depth = a.level0;  // p + top
+  const int64_t nout = (int64_t)1 << top;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nout; j += (int64_t)gridDim.x * 256) {
+    const uint64_t path = (top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j;
+    uint32_t s0[4] = {k_seed[0], k_seed[1], k_seed[2], k_seed[3]};
+    if constexpr (SCHEME == S_DCF) {
+      DcfWalk w;
+      w.init(s0, a.party, path);
+      for (int i = 0; i < depth; ++i) {
+        const uint32_t* p = k_cws + 8 * i;
+        CwDcf cw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cw.s[q] = p[q]; cw.v[q] = p[4 + q]; }
+        w.level(L, c, a.group, depth, i, cw);
+      }
+      a.out_nodes[j] = make_uint4(w.st[0], w.st[1], w.st[2], w.st[3]);
+      a.out_v[j] = make_uint4(w.v.v[0], w.v.v[1], w.v.v[2], w.v.v[3]);
+    } else if constexpr (SCHEME == S_HT) {
+      HtWalk w;
+      w.init(s0, a.party, path);
+      for (int i = 0; i < depth; ++i) {
+        const uint32_t* p = k_cws + 8 * i;
+        uint32_t cw[4] = {p[0], p[1], p[2], p[3]};
+        w.level(L, c, depth, i, cw);
+      }
+      a.out_nodes[j] = make_uint4(w.node[0], w.node[1], w.node[2], w.node[3]);
+    } else {
+      DpfWalk w;
+      w.init(s0, a.party, path);
+      for (int i = 0; i < depth; ++i) {
+        const uint32_t* p = k_cws + 8 * i;
+        CwDpf cw{p[0], p[1], p[2], p[3], p[4]};
+        w.level(L, c, depth, i, cw);
+      }
+      a.out_nodes[j] = make_uint4(w.st[0], w.st[1], w.st[2], w.st[3]);
+    }
+  }
+}
+
+// -- expansion stage ------------------------------------------------------------
+// Lane j takes input node j at level `level0`, expands D levels in registers and
+// writes children (j << D) + k.  LEAF: the outputs are the tree's leaves and are
+// converted (dpf.cuh:255-263, dcf.cuh:318-329, half_tree_dpf.cuh ConvertLastLevel,
+// grotto_dcf.cuh:194-198) instead of stored as nodes.
+template <int SCHEME, int D, bool LEAF, int BS>
+__global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                    const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
+                                                    const uint32_t* __restrict__ k_ocw,  // Half-Tree
+                                                    ExpandArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  const int g = a.group, party = a.party;
+
+  constexpr int NN = 1 << D;
+  for (int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x; j < a.n_in; j += (int64_t)gridDim.x * BS) {
+    uint32_t nodes[NN][4];
+    Acc vs[SCHEME == S_DCF ? NN : 1];
+    {
+      uint4 t = a.in_nodes[j];
+      nodes[0][0] = t.x; nodes[0][1] = t.y; nodes[0][2] = t.z; nodes[0][3] = t.w;
+      if constexpr (SCHEME == S_DCF) {
+        uint4 u = a.in_v[j];
+        vs[0].v[0] = u.x; vs[0].v[1] = u.y; vs[0].v[2] = u.z; vs[0].v[3] = u.w;
+      }
+    }
+    // Half-Tree: the tree's last level is the conversion, not an expansion.
+    constexpr int DE = (SCHEME == S_HT && LEAF) ? D - 1 : D;
+#pragma unroll
+    for (int lev = 0; lev < DE; ++lev) {
+      const uint32_t* cw = k_cws + 8 * (a.level0 + lev);
+#pragma unroll
+      for (int k = (1 << lev) - 1; k >= 0; --k) {
+        uint32_t l[4], r[4];
+        if constexpr (SCHEME == S_DCF) {
+          Acc vl, vr;
+          dcf_expand(L, c, g, cw, nodes[k], vs[k], l, vl, r, vr);
+          vs[2 * k] = vl; vs[2 * k + 1] = vr;
+        } else if constexpr (SCHEME == S_HT) {
+          ht_expand(L, c, cw, nodes[k], l, r);
+        } else {
+          dpf_expand(L, c, cw, nodes[k], l, r);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { nodes[2 * k][q] = l[q]; nodes[2 * k + 1][q] = r[q]; }
+      }
+    }
+    const int64_t ob = j << D;
+    if constexpr (!LEAF) {
+#pragma unroll
+      for (int k = 0; k < NN; ++k) {
+        a.out_nodes[ob + k] = make_uint4(nodes[k][0], nodes[k][1], nodes[k][2], nodes[k][3]);
+        if constexpr (SCHEME == S_DCF) a.out_v[ob + k] = make_uint4(vs[k].v[0], vs[k].v[1], vs[k].v[2], vs[k].v[3]);
+      }
+    } else if constexpr (SCHEME == S_HT) {
+      const uint32_t* cw = k_cws + 8 * (a.in_bits - 1);
+      uint4* ys = reinterpret_cast<uint4*>(a.ys);
+#pragma unroll
+      for (int k = 0; k < (1 << DE); ++k) {
+        ys[ob + 2 * k] = ht_convert(L, c, g, party, cw, k_ocw, nodes[k], 0u);
+        ys[ob + 2 * k + 1] = ht_convert(L, c, g, party, cw, k_ocw, nodes[k], 1u);
+      }
+    } else if constexpr (SCHEME == S_GROTTO) {
+      uint8_t* ys = reinterpret_cast<uint8_t*>(a.ys);
+      if constexpr (NN >= 4) {
+#pragma unroll
+        for (int k = 0; k < NN; k += 4) {
+          uint32_t w = (nodes[k][3] & 1u) | ((nodes[k + 1][3] & 1u) << 8) | ((nodes[k + 2][3] & 1u) << 16) |
+                       ((nodes[k + 3][3] & 1u) << 24);
+          *reinterpret_cast<uint32_t*>(ys + ob + k) = w;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NN; ++k) ys[ob + k] = (uint8_t)(nodes[k][3] & 1u);
+      }
+    } else {
+      const uint32_t* ocp = k_cws + 8 * a.in_bits + (SCHEME == S_DCF ? 4 : 0);
+      uint32_t oc[4] = {ocp[0], ocp[1], ocp[2], ocp[3]};
+      uint4* ys = reinterpret_cast<uint4*>(a.ys);
+#pragma unroll
+      for (int k = 0; k < NN; ++k) {
+        uint32_t s[4] = {nodes[k][0], nodes[k][1], nodes[k][2], nodes[k][3] & ~1u};
+        uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(nodes[k][3], 0, 1);
+        Acc y;
+        if constexpr (SCHEME == S_DCF) y = vs[k];
+        y.add(g, s);
+        y.add_if(g, tm, oc);
+        ys[ob + k] = y.finish(g, party != 0);
+      }
+    }
+  }
+}
+
+// Grotto EvalAll phase 2 (grotto_dcf.cuh:158-162): in-place running XOR over the
+// leaf control bits.  Three passes: per-chunk parity, scan of the chunk parities,
+// per-chunk running XOR seeded with the carry.
+constexpr int kScanChunk = 4096;  // bytes per lane-chunk group: one workgroup of 256 lanes x 16 B
+
+__global__ __launch_bounds__(256) void grotto_chunk_parity_kernel(const uint8_t* __restrict__ t, int64_t n,
+                                                                 uint8_t* __restrict__ parity) {
+  __shared__ uint32_t red[4];
+  int64_t base = (int64_t)blockIdx.x * kScanChunk + threadIdx.x * 16;
+  uint32_t x = 0;
+  if (base + 16 <= n) {
+    uint4 v = *reinterpret_cast<const uint4*>(t + base);
+    x = v.x ^ v.y ^ v.z ^ v.w;
+  } else {
+    for (int q = 0; q < 16; ++q)
+      if (base + q < n) x ^= t[base + q];
+  }
+  x ^= x >> 16; x ^= x >> 8; x &= 1u;
+  uint64_t b = __ballot(x != 0);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = __popcll(b) & 1;
+  __syncthreads();
+  if (threadIdx.x == 0) parity[blockIdx.x] = (uint8_t)((red[0] ^ red[1] ^ red[2] ^ red[3]) & 1u);
+}
+
+// Serial exclusive scan of chunk parities by one wave (nchunks is small: n / 4096).
+__global__ __launch_bounds__(64) void grotto_carry_kernel(uint8_t* parity, int64_t nchunks) {
+  // lane-strided blocks of the parity array; wave-level exclusive XOR scan of block parities.
+  int64_t per = (nchunks + 63) / 64;
+  int64_t b0 = (int64_t)threadIdx.x * per, b1 = b0 + per < nchunks ? b0 + per : nchunks;
+  uint32_t p = 0;
+  for (int64_t i = b0; i < b1; ++i) p ^= parity[i];
+  uint64_t ball = __ballot(p & 1u);
+  uint64_t below = threadIdx.x == 0 ? 0ull : (ball & ((~0ull) >> (64 - threadIdx.x)));
+  uint32_t carry = __popcll(below) & 1;
+  for (int64_t i = b0; i < b1; ++i) {
+    uint32_t v = parity[i];
+    parity[i] = (uint8_t)carry;  // exclusive: parity of everything before chunk i
+    carry ^= v;
+  }
+}
+
+__global__ __launch_bounds__(256) void grotto_chunk_scan_kernel(uint8_t* __restrict__ t, int64_t n,
+                                                               const uint8_t* __restrict__ carry_in) {
+  __shared__ uint32_t wsum[4];
+  int64_t base = (int64_t)blockIdx.x * kScanChunk + threadIdx.x * 16;
+  alignas(16) uint8_t b[16];
+  if (base + 16 <= n) {
+    *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(t + base);
+  } else {
+    for (int q = 0; q < 16; ++q) b[q] = base + q < n ? t[base + q] : 0;
+  }
+  uint32_t run = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { run ^= b[q] & 1u; b[q] = (uint8_t)run; }
+  // exclusive prefix of lane totals inside the wave, then across the 4 waves
+  uint64_t ball = __ballot(run != 0);
+  uint32_t lane = threadIdx.x & 63;
+  uint64_t below = lane == 0 ? 0ull : (ball & ((~0ull) >> (64 - lane)));
+  uint32_t pre = __popcll(below) & 1;
+  if (lane == 0) wsum[threadIdx.x >> 6] = __popcll(ball) & 1;
+  __syncthreads();
+  uint32_t w = threadIdx.x >> 6;
+  for (uint32_t q = 0; q < w; ++q) pre ^= wsum[q];
+  pre ^= carry_in[blockIdx.x] & 1u;
+  if (pre) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] ^= 1;
+  }
+  if (base + 16 <= n) {
+    *reinterpret_cast<uint4*>(t + base) = *reinterpret_cast<uint4*>(b);
+  } else {
+    for (int q = 0; q < 16; ++q)
+      if (base + q < n) t[base + q] = b[q];
+  }
+}
+
+}  // namespace fssamd

@@ -1,0 +1,252 @@
+// Dealer-side kernels: raw PRG, key relayout, key generation (one key per lane).
+#pragma once
+#include "fss_dev.hpp"
+#include "fss_point.hpp"
+
+namespace fssamd {
+
+// out[i*mul + j] = AES_{key j}(seeds[i]) ^ seeds[i]   (include/fss/prg/aes128_mmo.cuh:79-89)
+__global__ __launch_bounds__(256) void prg_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, int mul,
+                                                      const uint4* __restrict__ seeds, int64_t n,
+                                                      uint4* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    uint4 s = seeds[i];
+    uint32_t in[4] = {s.x, s.y, s.z, s.w};
+    for (int j = 0; j < mul; ++j) {
+      uint32_t o[4];
+      aes_mmo<false>(L, c->rk[j], 0, in, o);
+      out[i * mul + j] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// Key-major raw Cw slots -> level-major arrays (include/fss/point_eval_gpu.cuh:39-91).
+// A 256-lane workgroup owns 64 keys; its four waves take levels i = w, w+4, ... so
+// the 128-byte lines (4 consecutive slots of one key) are shared through L1.
+template <int SCHEME>
+__global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, const uint4* __restrict__ cws,
+                                                       int64_t nkeys, uint4* __restrict__ cw_s,
+                                                       uint4* __restrict__ cw_v, uint64_t* __restrict__ tr_bits,
+                                                       uint4* __restrict__ out_cw, uint32_t* __restrict__ extra) {
+  __shared__ unsigned long long bits[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t k = (int64_t)blockIdx.x * 64 + lane;
+  if (wave == 0) bits[lane] = 0ull;
+  __syncthreads();
+  if (k < nkeys) {
+    const uint4* slot = cws + k * (int64_t)stride * 2;
+    unsigned long long mine = 0ull;
+    for (int i = wave; i < in_bits; i += 4) {
+      uint4 s = slot[2 * i], v = slot[2 * i + 1];
+      cw_s[(int64_t)i * nkeys + k] = s;
+      if (SCHEME == S_DCF) cw_v[(int64_t)i * nkeys + k] = v;
+      if (SCHEME == S_DPF) mine |= (unsigned long long)(v.x & 1u) << i;
+    }
+    if (SCHEME == S_DPF && mine) atomicOr(&bits[lane], mine);
+  }
+  __syncthreads();
+  if (wave == 0 && k < nkeys) {
+    const uint4* slot = cws + k * (int64_t)stride * 2;
+    if (SCHEME == S_DPF) {
+      tr_bits[k] = bits[lane];
+      out_cw[k] = slot[2 * in_bits];
+    } else if (SCHEME == S_DCF) {
+      out_cw[k] = slot[2 * in_bits + 1];
+    } else {
+      extra[k] = slot[2 * (in_bits - 1) + 1].x & 1u;
+    }
+  }
+}
+
+struct GenArgs {
+  int in_bits, group, pred, x_bytes;
+  int64_t nkeys;
+  const uint4* s0s;     // [nkeys][2]
+  const void* alphas;
+  const uint4* betas;
+  uint4* cws;           // key-major raw slots
+  uint4* ocws;          // Half-Tree
+};
+
+__device__ __forceinline__ void ld4(uint32_t d[4], uint4 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
+__device__ __forceinline__ uint4 mk4(const uint32_t d[4]) { return make_uint4(d[0], d[1], d[2], d[3]); }
+
+// fss::Dpf::Gen (include/fss/dpf.cuh:93-159) and fss::Dcf::Gen (include/fss/dcf.cuh:108-194).
+template <int SCHEME>
+__global__ __launch_bounds__(256) void gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  const int n = a.in_bits, g = a.group;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * 256) {
+    uint32_t s0[4], s1[4], beta[4];
+    ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
+    s0[3] &= ~1u; s1[3] &= ~1u; beta[3] &= ~1u;
+    uint32_t t0 = 0u, t1 = ~0u;  // masks
+    const uint64_t alpha = load_x(a.alphas, a.x_bytes, k);
+    uint4* slot = a.cws + k * (int64_t)(n + 1) * 2;
+    Acc v;  // DCF running value (dcf.cuh:115)
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+      const uint32_t am = bit_mask(alpha, n - 1 - i);  // ~0 when a_bit
+      uint32_t s0l[4], s0r[4], s1l[4], s1r[4];
+      uint32_t v0l[4], v0r[4], v1l[4], v1r[4];
+      if (SCHEME == S_DCF) {
+        aes_mmo<false>(L, c->rk[0], 0, s0, s0l); aes_mmo<false>(L, c->rk[1], 0, s0, v0l);
+        aes_mmo<false>(L, c->rk[2], 0, s0, s0r); aes_mmo<false>(L, c->rk[3], 0, s0, v0r);
+        aes_mmo<false>(L, c->rk[0], 0, s1, s1l); aes_mmo<false>(L, c->rk[1], 0, s1, v1l);
+        aes_mmo<false>(L, c->rk[2], 0, s1, s1r); aes_mmo<false>(L, c->rk[3], 0, s1, v1r);
+        v0l[3] &= ~1u; v0r[3] &= ~1u; v1l[3] &= ~1u; v1r[3] &= ~1u;
+      } else {
+        aes_mmo<false>(L, c->rk[0], 0, s0, s0l); aes_mmo<false>(L, c->rk[1], 0, s0, s0r);
+        aes_mmo<false>(L, c->rk[0], 0, s1, s1l); aes_mmo<false>(L, c->rk[1], 0, s1, s1r);
+      }
+      const uint32_t t0l = s0l[3] & 1u, t0r = s0r[3] & 1u, t1l = s1l[3] & 1u, t1r = s1r[3] & 1u;
+      s0l[3] &= ~1u; s0r[3] &= ~1u; s1l[3] &= ~1u; s1r[3] &= ~1u;
+      const uint32_t ab = am & 1u;
+      uint32_t scw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) scw[q] = am ? (s0l[q] ^ s1l[q]) : (s0r[q] ^ s1r[q]);  // lose side
+      const uint32_t tl_cw = t0l ^ t1l ^ ab ^ 1u, tr_cw = t0r ^ t1r ^ ab;
+
+      uint32_t vcw_buf[4] = {tr_cw, 0, 0, 0};
+      if (SCHEME == S_DCF) {
+        // v_cw = -v + (v1_lose - v0_lose) [+ beta]   (dcf.cuh:146-154); negated when t1
+        Acc vc;
+        uint32_t lose1[4], lose0[4], keep1[4], keep0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          lose1[q] = am ? v1l[q] : v1r[q]; lose0[q] = am ? v0l[q] : v0r[q];
+          keep1[q] = am ? v1r[q] : v1l[q]; keep0[q] = am ? v0r[q] : v0l[q];
+        }
+        vc.add(g, lose1); vc.sub(g, lose0);
+        const bool add_beta = am ? (a.pred == 0) : (a.pred == 1);
+        if (add_beta) vc.add(g, beta);
+        // vc -= v
+        {
+          uint4 vb = v.finish(g, false);
+          uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
+          vc.sub(g, vbuf);
+        }
+        uint4 vcw4 = vc.finish(g, t1 != 0u);
+        uint32_t vcw[4] = {vcw4.x, vcw4.y, vcw4.z, vcw4.w};
+        // v = v - v1_keep + v0_keep + (t1 ? -v_cw : v_cw)   (dcf.cuh:156-159)
+        v.sub(g, keep1); v.add(g, keep0);
+        if (t1) v.sub(g, vcw); else v.add(g, vcw);
+        vcw_buf[0] = vcw[0]; vcw_buf[1] = vcw[1]; vcw_buf[2] = vcw[2]; vcw_buf[3] = (vcw[3] & ~1u) | tr_cw;
+      }
+      // keep side, corrected (dpf.cuh:124-144)
+      const uint32_t keep_cw = am ? tr_cw : tl_cw;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t k0 = am ? s0r[q] : s0l[q], k1 = am ? s1r[q] : s1l[q];
+        s0[q] = k0 ^ (t0 & scw[q]);
+        s1[q] = k1 ^ (t1 & scw[q]);
+      }
+      {
+        uint32_t k0 = am ? t0r : t0l, k1 = am ? t1r : t1l;
+        t0 = 0u - ((k0 ^ ((t0 & 1u) & keep_cw)) & 1u);
+        t1 = 0u - ((k1 ^ ((t1 & 1u) & keep_cw)) & 1u);
+      }
+      slot[2 * i] = make_uint4(scw[0], scw[1], scw[2], (scw[3] & ~1u) | tl_cw);
+      slot[2 * i + 1] = mk4(vcw_buf);
+    }
+    Acc y;
+    if (SCHEME == S_DCF) {
+      // v_cw_np1 = s1 - s0 - v, negated when t1 (dcf.cuh:191-193)
+      uint4 vb = v.finish(g, false);
+      uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
+      y.add(g, s1); y.sub(g, s0); y.sub(g, vbuf);
+      slot[2 * n] = make_uint4(0, 0, 0, 0);
+      slot[2 * n + 1] = y.finish(g, t1 != 0u);
+    } else {
+      // beta - s0 + s1, negated when t1 (dpf.cuh:156-158)
+      y.add(g, beta); y.sub(g, s0); y.add(g, s1);
+      slot[2 * n] = y.finish(g, t1 != 0u);
+      slot[2 * n + 1] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+// fss::HalfTreeDpf::Gen (include/fss/half_tree_dpf.cuh:68-175).
+__global__ __launch_bounds__(256) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  const int n = a.in_bits, g = a.group;
+  auto hash = [&](const uint32_t node[4], uint32_t h[4]) {
+    uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
+                      node[3] ^ c->hash_key[3]};
+    aes_mmo<false>(L, c->rk[0], 0, in, h);
+  };
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * 256) {
+    uint32_t n0[4], n1[4], beta[4];
+    ld4(n0, a.s0s[2 * k]); ld4(n1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
+    n0[3] &= ~1u; n1[3] |= 1u; beta[3] &= ~1u;
+    const uint64_t alpha = load_x(a.alphas, a.x_bytes, k);
+    uint4* slot = a.cws + k * (int64_t)n * 2;
+#pragma unroll 1
+    for (int i = 0; i < n - 1; ++i) {
+      const uint32_t am = bit_mask(alpha, n - 1 - i);
+      uint32_t h0[4], h1[4], cw[4];
+      hash(n0, h0); hash(n1, h1);
+      const uint32_t t0 = lsb_mask(n0[3]), t1 = lsb_mask(n1[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        cw[q] = h0[q] ^ h1[q] ^ (~am & (n0[q] ^ n1[q]));  // :84-85
+        uint32_t a0 = h0[q] ^ (am & n0[q]) ^ (t0 & cw[q]);   // :93-101
+        uint32_t a1 = h1[q] ^ (am & n1[q]) ^ (t1 & cw[q]);
+        n0[q] = a0; n1[q] = a1;
+      }
+      slot[2 * i] = mk4(cw);
+      slot[2 * i + 1] = make_uint4(0, 0, 0, 0);
+    }
+    {
+      const uint32_t an = (uint32_t)alpha & 1u;
+      const uint32_t t0 = lsb_mask(n0[3]), t1 = lsb_mask(n1[3]);
+      uint32_t p[4], h00[4], h01[4], h10[4], h11[4];
+      p[0] = n0[0]; p[1] = n0[1]; p[2] = n0[2];
+      p[3] = n0[3] & ~1u; hash(p, h00);
+      p[3] = n0[3] | 1u; hash(p, h01);
+      p[0] = n1[0]; p[1] = n1[1]; p[2] = n1[2];
+      p[3] = n1[3] & ~1u; hash(p, h10);
+      p[3] = n1[3] | 1u; hash(p, h11);
+      const uint32_t l00 = h00[3] & 1u, l01 = h01[3] & 1u, l10 = h10[3] & 1u, l11 = h11[3] & 1u;
+      h00[3] &= ~1u; h01[3] &= ~1u; h10[3] &= ~1u; h11[3] &= ~1u;
+      uint32_t hcw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hcw[q] = an ? (h00[q] ^ h10[q]) : (h01[q] ^ h11[q]);  // :123-125
+      const uint32_t lcw0 = l00 ^ l10 ^ (an ^ 1u), lcw1 = l01 ^ l11 ^ an;                // :132-133
+      slot[2 * (n - 1)] = make_uint4(hcw[0], hcw[1], hcw[2], (hcw[3] & ~1u) | lcw0);
+      slot[2 * (n - 1) + 1] = make_uint4(lcw1, 0, 0, 0);
+      uint32_t leaf0[4], leaf1[4];
+      const uint32_t lcw_an = an ? lcw1 : lcw0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        leaf0[q] = an ? h01[q] : h00[q];
+        leaf1[q] = an ? h11[q] : h10[q];
+      }
+      leaf0[3] |= an ? l01 : l00;
+      leaf1[3] |= an ? l11 : l10;
+      uint32_t lc[4] = {hcw[0], hcw[1], hcw[2], (hcw[3] & ~1u) | lcw_an};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { leaf0[q] ^= t0 & lc[q]; leaf1[q] ^= t1 & lc[q]; }
+      const bool neg = (leaf1[3] & 1u) != 0;
+      leaf0[3] &= ~1u; leaf1[3] &= ~1u;
+      Acc y;  // beta - leaf0 + leaf1, negated when leaf1's control bit (:168-172)
+      y.add(g, beta); y.sub(g, leaf0); y.add(g, leaf1);
+      a.ocws[k] = y.finish(g, neg);
+    }
+  }
+}
+
+}  // namespace fssamd

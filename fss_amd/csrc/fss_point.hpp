@@ -1,0 +1,352 @@
+// Per-point PRG-tree walks (one evaluation per lane, ILP evaluations per thread).
+//
+// Only the child the walk takes is computed: Aes128Mmo output i is
+// AES_{key_i}(s) ^ s independently per key (include/fss/prg/aes128_mmo.cuh:79-89),
+// and Eval keeps only (sl,tl) or (sr,tr) (include/fss/dpf.cuh:198-204), so the
+// per-lane round-key choice halves the AES work with bit-identical outputs.
+#pragma once
+#include "fss_dev.hpp"
+
+namespace fssamd {
+
+struct EvalArgs {
+  int in_bits;
+  int party;
+  int group;
+  int x_bytes;
+  int64_t n;        // evaluations
+  const void* xs;   // uint32 or uint64 per evaluation
+  void* ys;         // uint4 per evaluation (Grotto: uint8)
+  // independent keys, level-major
+  const uint4* seeds;
+  const uint4* cw_s;
+  const uint4* cw_v;        // DCF
+  const uint64_t* tr_bits;  // DPF / Grotto
+  const uint4* out_cw;      // DPF / DCF: cws[in_bits]; Half-Tree: ocw per key
+  const uint32_t* extra;    // Half-Tree
+};
+
+__device__ __forceinline__ uint32_t bit_mask(uint64_t x, int pos) {  // 0 or ~0
+  uint32_t w = pos >= 32 ? (uint32_t)(x >> 32) : (uint32_t)x;
+  return (uint32_t)__builtin_amdgcn_sbfe(w, pos & 31, 1);
+}
+__device__ __forceinline__ uint32_t lsb_mask(uint32_t w) { return (uint32_t)__builtin_amdgcn_sbfe(w, 0, 1); }
+
+__device__ __forceinline__ uint64_t load_x(const void* xs, int x_bytes, int64_t i) {
+  return x_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t*>(xs)[i] : reinterpret_cast<const uint64_t*>(xs)[i];
+}
+
+// Correction word of one level as the walk consumes it.
+struct CwDpf {
+  uint32_t x, y, z;
+  uint32_t wl;  // s.w with tl_cw in bit 0
+  uint32_t tr;  // tr_cw in bit 0
+};
+
+// ---------------------------------------------------------------- DPF (dpf.cuh:170-214)
+struct DpfWalk {
+  uint32_t st[4];  // seed with the control bit t packed into bit 0 of w (dpf.cuh:233-235)
+  uint64_t x;
+
+  __device__ __forceinline__ void init(const uint32_t s0[4], int party, uint64_t x_) {
+    st[0] = s0[0]; st[1] = s0[1]; st[2] = s0[2];
+    st[3] = (s0[3] & ~1u) | (uint32_t)party;  // dpf.cuh:171-173
+    x = x_;
+  }
+  __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i, const CwDpf& cw) {
+    uint32_t m = bit_mask(x, in_bits - 1 - i);  // dpf.cuh:196
+    uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+    uint32_t o[4];
+    aes_mmo<true>(L, &c->sel01[0][0], m, in, o);  // dpf.cuh:182, taken child only
+    uint32_t tm = lsb_mask(st[3]);
+    // bit 0 of o[3] is tl/tr; bit 0 of the word below is tl_cw/tr_cw: one XOR does
+    // both the seed and the control-bit correction (dpf.cuh:189-194).
+    uint32_t cww = cw.wl ^ (m & ((cw.wl ^ cw.tr) & 1u));
+    st[0] = and_xor(tm, cw.x, o[0]);
+    st[1] = and_xor(tm, cw.y, o[1]);
+    st[2] = and_xor(tm, cw.z, o[2]);
+    st[3] = and_xor(tm, cww, o[3]);
+  }
+  __device__ __forceinline__ uint4 finish(int g, int party, const uint32_t out_cw[4]) const {
+    Acc y;  // dpf.cuh:207-213
+    uint32_t s[4] = {st[0], st[1], st[2], st[3] & ~1u};
+    y.add(g, s);
+    y.add_if(g, lsb_mask(st[3]), out_cw);
+    return y.finish(g, party != 0);
+  }
+};
+
+// ---------------------------------------------------------------- DCF (dcf.cuh:205-276)
+struct CwDcf {
+  uint32_t s[4];  // s.w has tl_cw in bit 0
+  uint32_t v[4];  // v.w has tr_cw in bit 0
+};
+
+struct DcfWalk {
+  uint32_t st[4];
+  uint64_t x;
+  Acc v;  // dcf.cuh:208, zero
+
+  __device__ __forceinline__ void init(const uint32_t s0[4], int party, uint64_t x_) {
+    st[0] = s0[0]; st[1] = s0[1]; st[2] = s0[2];
+    st[3] = (s0[3] & ~1u) | (uint32_t)party;
+    x = x_;
+  }
+  __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int g, int in_bits, int i,
+                                        const CwDcf& cw) {
+    uint32_t m = bit_mask(x, in_bits - 1 - i);
+    uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+    uint32_t os[4], ov[4];
+    aes_mmo<true>(L, &c->sel02[0][0], m, in, os);  // sl (key 0) or sr (key 2), dcf.cuh:223
+    aes_mmo<true>(L, &c->sel13[0][0], m, in, ov);  // vl (key 1) or vr (key 3)
+    uint32_t tm = lsb_mask(st[3]);
+    ov[3] &= ~1u;  // dcf.cuh:227,232
+    v.add(g, ov);  // dcf.cuh:244-252 (signs applied once in finish)
+    uint32_t vcw[4] = {cw.v[0], cw.v[1], cw.v[2], cw.v[3] & ~1u};
+    v.add_if(g, tm, vcw);
+    uint32_t cww = cw.s[3] ^ (m & ((cw.s[3] ^ cw.v[3]) & 1u));
+    st[0] = and_xor(tm, cw.s[0], os[0]);
+    st[1] = and_xor(tm, cw.s[1], os[1]);
+    st[2] = and_xor(tm, cw.s[2], os[2]);
+    st[3] = and_xor(tm, cww, os[3]);
+  }
+  __device__ __forceinline__ uint4 finish(int g, int party, const uint32_t out_cw[4]) {
+    uint32_t s[4] = {st[0], st[1], st[2], st[3] & ~1u};  // dcf.cuh:263-273
+    v.add(g, s);
+    v.add_if(g, lsb_mask(st[3]), out_cw);
+    return v.finish(g, party != 0);
+  }
+};
+
+// ---------------------------------------------------------------- Half-Tree DPF (half_tree_dpf.cuh:187-231)
+struct HtWalk {
+  uint32_t node[4];  // control bit kept in bit 0 of w (half_tree_dpf.cuh:188)
+  uint64_t x;
+
+  __device__ __forceinline__ void init(const uint32_t s0[4], int party, uint64_t x_) {
+    node[0] = s0[0]; node[1] = s0[1]; node[2] = s0[2];
+    node[3] = (s0[3] & ~1u) | (uint32_t)party;
+    x = x_;
+  }
+  // levels 0 .. in_bits-2
+  __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i, const uint32_t cw[4]) {
+    uint32_t m = bit_mask(x, in_bits - 1 - i);
+    uint32_t tm = lsb_mask(node[3]);
+    uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
+                      node[3] ^ c->hash_key[3]};
+    uint32_t h[4];
+    aes_mmo<false>(L, c->rk[0], 0, in, h);  // prg.Gen(hash_key ^ node)[0], :195
+#pragma unroll
+    for (int j = 0; j < 4; ++j) node[j] = and_xor(m, node[j], and_xor(tm, cw[j], h[j]));  // :197-201
+  }
+  // last level + output conversion, :205-229
+  __device__ __forceinline__ uint4 finish(const Lds& L, const DevCtx* __restrict__ c, int g, int party, const uint32_t cw[4],
+                                          uint32_t extra, const uint32_t ocw[4]) const {
+    uint32_t xn = (uint32_t)x & 1u;
+    uint32_t tm = lsb_mask(node[3]);
+    uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
+                      ((node[3] & ~1u) | xn) ^ c->hash_key[3]};
+    uint32_t h[4];
+    aes_mmo<false>(L, c->rk[0], 0, in, h);
+    uint32_t lcw = xn ? (extra & 1u) : (cw[3] & 1u);
+    uint32_t low = (h[3] ^ (tm & lcw)) & 1u;
+    uint32_t high[4] = {and_xor(tm, cw[0], h[0]), and_xor(tm, cw[1], h[1]), and_xor(tm, cw[2], h[2]),
+                        and_xor(tm, cw[3], h[3]) & ~1u};
+    Acc y;
+    y.add(g, high);
+    y.add_if(g, 0u - low, ocw);
+    return y.finish(g, party != 0);
+  }
+};
+
+// ---------------------------------------------------------------- kernels
+// SHARED: every evaluation uses the same key (correction words are wave-uniform,
+// fetched with scalar loads from the raw key-major slots).  Otherwise evaluation k
+// uses key k from the level-major arrays (one coalesced 16-byte load per lane and
+// level, as include/fss/point_eval_gpu.cuh:144).
+//
+// K (by value), and the shared key's seed / cws / ocw as __restrict__ kernel
+// arguments, are wave-uniform and provably not clobbered by the ys stores, so they
+// are read with scalar loads.
+template <int SCHEME, bool SHARED, int ILP, int BS>
+__global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                         const uint32_t* __restrict__ k_seed,  // uint32[4]
+                                                         const uint32_t* __restrict__ k_cws,   // raw Cw slots
+                                                         const uint32_t* __restrict__ k_ocw,   // Half-Tree
+                                                         EvalArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+
+  const int in_bits = a.in_bits, party = a.party, g = a.group;
+  const int64_t T = (int64_t)gridDim.x * BS;
+  const int64_t n = a.n;
+  uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
+
+  for (int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x; base < n; base += T * ILP) {
+    int64_t idx[ILP];
+#pragma unroll
+    for (int j = 0; j < ILP; ++j) {
+      int64_t e = base + (int64_t)j * T;
+      idx[j] = e < n ? e : n - 1;  // clamp: keeps the tail lanes converged, the store is masked
+    }
+
+    if constexpr (SCHEME == S_DPF) {
+      DpfWalk w[ILP];
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        uint32_t s0[4];
+        if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
+        else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+        w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+      }
+      uint64_t trb[ILP];
+      if constexpr (!SHARED) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) trb[j] = a.tr_bits[idx[j]];
+      }
+#pragma unroll 1
+      for (int i = 0; i < in_bits; ++i) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+          CwDpf cw;
+          if constexpr (SHARED) {
+            const uint32_t* p = k_cws + 8 * i;
+            cw.x = p[0]; cw.y = p[1]; cw.z = p[2]; cw.wl = p[3]; cw.tr = p[4];
+          } else {
+            uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
+            cw.x = t.x; cw.y = t.y; cw.z = t.z; cw.wl = t.w;
+            cw.tr = (uint32_t)(trb[j] >> i);
+          }
+          w[j].level(L, c, in_bits, i, cw);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        uint32_t oc[4];
+        if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * in_bits; oc[0] = p[0]; oc[1] = p[1]; oc[2] = p[2]; oc[3] = p[3]; }
+        else { uint4 t = a.out_cw[idx[j]]; oc[0] = t.x; oc[1] = t.y; oc[2] = t.z; oc[3] = t.w; }
+        uint4 y = w[j].finish(g, party, oc);
+        if (base + (int64_t)j * T < n) ys[idx[j]] = y;
+      }
+    } else if constexpr (SCHEME == S_DCF) {
+      DcfWalk w[ILP];
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        uint32_t s0[4];
+        if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
+        else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+        w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+      }
+#pragma unroll 1
+      for (int i = 0; i < in_bits; ++i) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+          CwDcf cw;
+          if constexpr (SHARED) {
+            const uint32_t* p = k_cws + 8 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { cw.s[q] = p[q]; cw.v[q] = p[4 + q]; }
+          } else {
+            uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
+            uint4 u = a.cw_v[(int64_t)i * n + idx[j]];
+            cw.s[0] = t.x; cw.s[1] = t.y; cw.s[2] = t.z; cw.s[3] = t.w;
+            cw.v[0] = u.x; cw.v[1] = u.y; cw.v[2] = u.z; cw.v[3] = u.w;
+          }
+          w[j].level(L, c, g, in_bits, i, cw);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        uint32_t oc[4];
+        if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * in_bits + 4; oc[0] = p[0]; oc[1] = p[1]; oc[2] = p[2]; oc[3] = p[3]; }
+        else { uint4 t = a.out_cw[idx[j]]; oc[0] = t.x; oc[1] = t.y; oc[2] = t.z; oc[3] = t.w; }
+        uint4 y = w[j].finish(g, party, oc);
+        if (base + (int64_t)j * T < n) ys[idx[j]] = y;
+      }
+    } else if constexpr (SCHEME == S_HT) {
+      HtWalk w[ILP];
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        uint32_t s0[4];
+        if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
+        else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+        w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+      }
+#pragma unroll 1
+      for (int i = 0; i < in_bits - 1; ++i) {
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) {
+          uint32_t cw[4];
+          if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * i; cw[0] = p[0]; cw[1] = p[1]; cw[2] = p[2]; cw[3] = p[3]; }
+          else { uint4 t = a.cw_s[(int64_t)i * n + idx[j]]; cw[0] = t.x; cw[1] = t.y; cw[2] = t.z; cw[3] = t.w; }
+          w[j].level(L, c, in_bits, i, cw);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        uint32_t cw[4], oc[4], extra;
+        if constexpr (SHARED) {
+          const uint32_t* p = k_cws + 8 * (in_bits - 1);
+          cw[0] = p[0]; cw[1] = p[1]; cw[2] = p[2]; cw[3] = p[3]; extra = p[4];
+          oc[0] = k_ocw[0]; oc[1] = k_ocw[1]; oc[2] = k_ocw[2]; oc[3] = k_ocw[3];
+        } else {
+          uint4 t = a.cw_s[(int64_t)(in_bits - 1) * n + idx[j]];
+          cw[0] = t.x; cw[1] = t.y; cw[2] = t.z; cw[3] = t.w;
+          extra = a.extra[idx[j]];
+          uint4 u = a.out_cw[idx[j]];
+          oc[0] = u.x; oc[1] = u.y; oc[2] = u.z; oc[3] = u.w;
+        }
+        uint4 y = w[j].finish(L, c, g, party, cw, extra, oc);
+        if (base + (int64_t)j * T < n) ys[idx[j]] = y;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- Grotto DCF, path walk
+// Share of 1[alpha <= x] for domains with no parity table (in_bits up to 64):
+// XOR of the control bits of the left siblings where e = x + 1 has a 1 bit
+// (the whole-domain case e = 2^n is the root's control bit).  Keys are DPF keys
+// over Bytes (include/fss/grotto_dcf.cuh:63-67); the per-level expansion is
+// ExpandTreeRec's (grotto_dcf.cuh:201-222).  Independent keys, level-major.
+template <int BS>
+__global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+  const DevCtx* c = &K;
+  lds_table_fill(lds_te, te0);
+  __syncthreads();
+  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  const int n = a.in_bits;
+  uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
+  for (int64_t k = (int64_t)blockIdx.x * BS + threadIdx.x; k < a.n; k += (int64_t)gridDim.x * BS) {
+    const uint64_t x = load_x(a.xs, a.x_bytes, k);
+    const uint64_t e = x + 1;
+    const bool whole = n == 64 ? (e == 0) : (e == (1ull << n));
+    uint4 s4 = a.seeds[k];
+    uint32_t st[4] = {s4.x, s4.y, s4.z, (s4.w & ~1u) | (uint32_t)a.party};
+    const uint64_t trb = a.tr_bits[k];
+    uint32_t pi = 0;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+      uint4 t = a.cw_s[(int64_t)i * a.n + k];
+      const uint32_t m = bit_mask(e, n - 1 - i);
+      uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+      const uint32_t tm = lsb_mask(st[3]);
+      uint32_t l[4], r[4];
+      aes_mmo<false>(L, c->rk[0], 0, in, l);
+      aes_mmo<false>(L, c->rk[1], 0, in, r);
+      const uint32_t wl = t.w, wr = (t.w & ~1u) | ((uint32_t)(trb >> i) & 1u);
+      l[0] = and_xor(tm, t.x, l[0]); l[1] = and_xor(tm, t.y, l[1]); l[2] = and_xor(tm, t.z, l[2]); l[3] = and_xor(tm, wl, l[3]);
+      r[0] = and_xor(tm, t.x, r[0]); r[1] = and_xor(tm, t.y, r[1]); r[2] = and_xor(tm, t.z, r[2]); r[3] = and_xor(tm, wr, r[3]);
+      pi ^= m & l[3] & 1u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) st[q] = m ? r[q] : l[q];
+    }
+    ys[k] = (uint8_t)(whole ? (uint32_t)a.party : pi);
+  }
+}
+
+}  // namespace fssamd

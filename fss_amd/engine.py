@@ -1,0 +1,237 @@
+"""Engine: one libfss_amd context (AES keys + Half-Tree hash key) on one GPU, with
+torch tensors as device memory.  Everything here is plumbing around the C ABI
+(include/fss_amd.h); the arithmetic runs in the HIP kernels only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# Output groups (enum fss_amd_group).
+BYTES, U8, U16, U32, U64, U128 = 0, 1, 2, 3, 4, 5
+GROUP_IDS = {"bytes": BYTES, "u8": U8, "u16": U16, "u32": U32, "u64": U64, "u128": U128}
+DPF, DCF, HT, GROTTO = 0, 1, 2, 3
+
+# AES keys / hash key of the reference's benches and samples (src/bench_cpu.cu:37-40, :509).
+DEFAULT_AES_KEYS = (
+    bytes(range(1, 17)),
+    bytes(range(16, 0, -1)),
+    bytes([1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8]),
+    bytes([8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1]),
+)
+DEFAULT_HASH_KEY = (0x12345678, 0x9ABCDEF0, 0x13572468, 0x2468ACE0)
+
+
+def resolve_group(group, in_bits):
+    """'bytes' | 'uint' (sized by in_bits as fss_crypto/_jit.py:76-87) | 'u8'..'u128' | int id."""
+    if isinstance(group, int):
+        return group
+    if group == "uint":
+        return U32 if in_bits <= 32 else (U64 if in_bits <= 64 else U128)
+    return GROUP_IDS[group]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class LevelMajorKeys:
+    """Level-major device layout of a batch of keys (include/fss_amd.h, relayout)."""
+
+    def __init__(self, scheme, in_bits, nkeys, cw_s, cw_v=None, tr_bits=None, out_cw=None, extra=None):
+        self.scheme, self.in_bits, self.nkeys = scheme, in_bits, nkeys
+        self.cw_s, self.cw_v, self.tr_bits, self.out_cw, self.extra = cw_s, cw_v, tr_bits, out_cw, extra
+
+
+class Engine:
+    def __init__(self, device=None, aes_keys=DEFAULT_AES_KEYS, hash_key=DEFAULT_HASH_KEY):
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("fss_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        keys = b"".join(bytes(k) for k in aes_keys)
+        if len(keys) != 64:
+            raise ValueError("aes_keys must be four 16-byte keys")
+        hk = (C.c_int32 * 4)(*[int(np.uint32(v).astype(np.int32)) for v in hash_key])
+        h = C.c_void_p()
+        _lib.check(L.fss_amd_ctx_create(C.byref(h), self.device.index, C.c_char_p(keys), hk), "fss_amd_ctx_create")
+        self._h, self._L = h, L
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.fss_amd_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype=None):
+        t = t if dtype is None or t.dtype == dtype else t.to(dtype)
+        return t.to(self.device).contiguous()
+
+    @staticmethod
+    def _xbytes(xs, in_bits):
+        if xs.dtype == torch.int32:
+            if in_bits > 32:
+                raise ValueError("int32 xs only cover in_bits <= 32; pass int64")
+            return 4
+        if xs.dtype == torch.int64:
+            return 8
+        raise TypeError(f"xs must be int32 (uint32 bit pattern) or int64 (uint64 bit pattern), got {xs.dtype}")
+
+    def last_kernel(self):
+        g, b = C.c_int(0), C.c_int(0)
+        name = self._L.fss_amd_last_kernel(self._h, C.byref(g), C.byref(b)).decode()
+        return name, g.value, b.value
+
+    # ------------------------------------------------------------ PRG
+    def prg_gen(self, mul, seeds):
+        seeds = self._dev(seeds, torch.int32).view(-1, 4)
+        out = torch.empty((seeds.shape[0], mul, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.fss_amd_prg_gen(self._h, mul, _ptr(seeds), seeds.shape[0], _ptr(out), self._stream()),
+                   "fss_amd_prg_gen")
+        return out
+
+    # ------------------------------------------------------------ one key, many points
+    def eval_points(self, scheme, in_bits, group, party, seed, cws, xs, ocw=None, out=None):
+        seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
+        n = xs.numel()
+        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        xb = self._xbytes(xs, in_bits)
+        L, st = self._L, self._stream()
+        if scheme == DPF:
+            rc = L.fss_amd_dpf_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
+                                           _ptr(ys), st)
+        elif scheme == DCF:
+            rc = L.fss_amd_dcf_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
+                                           _ptr(ys), st)
+        elif scheme == HT:
+            ocw = self._dev(ocw, torch.int32)
+            rc = L.fss_amd_ht_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(ocw), _ptr(xs),
+                                          xb, n, _ptr(ys), st)
+        else:
+            raise ValueError("scheme")
+        _lib.check(rc, "eval_points")
+        return ys
+
+    # ------------------------------------------------------------ relayout + independent keys
+    def relayout(self, scheme, in_bits, cws):
+        """cws: int32[nkeys, slots, 8] key-major raw Cw slots -> LevelMajorKeys."""
+        cws = self._dev(cws, torch.int32)
+        nkeys = cws.shape[0]
+        dev, L, st = self.device, self._L, self._stream()
+        cw_s = torch.empty((in_bits, nkeys, 4), dtype=torch.int32, device=dev)
+        if scheme in (DPF, GROTTO):
+            tr = torch.empty((nkeys,), dtype=torch.int64, device=dev)
+            oc = torch.empty((nkeys, 4), dtype=torch.int32, device=dev)
+            _lib.check(L.fss_amd_dpf_relayout(self._h, in_bits, _ptr(cws), nkeys, _ptr(cw_s), _ptr(tr), _ptr(oc), st),
+                       "dpf_relayout")
+            return LevelMajorKeys(scheme, in_bits, nkeys, cw_s, tr_bits=tr, out_cw=oc)
+        if scheme == DCF:
+            cw_v = torch.empty((in_bits, nkeys, 4), dtype=torch.int32, device=dev)
+            oc = torch.empty((nkeys, 4), dtype=torch.int32, device=dev)
+            _lib.check(L.fss_amd_dcf_relayout(self._h, in_bits, _ptr(cws), nkeys, _ptr(cw_s), _ptr(cw_v), _ptr(oc), st),
+                       "dcf_relayout")
+            return LevelMajorKeys(scheme, in_bits, nkeys, cw_s, cw_v=cw_v, out_cw=oc)
+        ex = torch.empty((nkeys,), dtype=torch.int32, device=dev)
+        _lib.check(L.fss_amd_ht_relayout(self._h, in_bits, _ptr(cws), nkeys, _ptr(cw_s), _ptr(ex), st), "ht_relayout")
+        return LevelMajorKeys(scheme, in_bits, nkeys, cw_s, extra=ex)
+
+    def eval_keys(self, keys, group, party, seeds, xs, ocws=None, out=None):
+        """ys[k] = Eval(party, seeds[k], key k, xs[k]) on a LevelMajorKeys batch."""
+        seeds, xs = self._dev(seeds, torch.int32), self._dev(xs)
+        n, nb = keys.nkeys, keys.in_bits
+        xb = self._xbytes(xs, nb)
+        L, st = self._L, self._stream()
+        if keys.scheme == GROTTO:
+            ys = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=self.device)
+            rc = L.fss_amd_grotto_eval_keys(self._h, nb, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.tr_bits),
+                                            _ptr(xs), xb, n, _ptr(ys), st)
+            _lib.check(rc, "grotto_eval_keys")
+            return ys
+        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        if keys.scheme == DPF:
+            rc = L.fss_amd_dpf_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.tr_bits),
+                                         _ptr(keys.out_cw), _ptr(xs), xb, n, _ptr(ys), st)
+        elif keys.scheme == DCF:
+            rc = L.fss_amd_dcf_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.cw_v),
+                                         _ptr(keys.out_cw), _ptr(xs), xb, n, _ptr(ys), st)
+        else:
+            ocws = self._dev(ocws, torch.int32)
+            rc = L.fss_amd_ht_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.extra),
+                                        _ptr(ocws), _ptr(xs), xb, n, _ptr(ys), st)
+        _lib.check(rc, "eval_keys")
+        return ys
+
+    # ------------------------------------------------------------ full domain
+    def eval_all(self, scheme, in_bits, group, party, seed, cws, ocw=None, first_leaf=0, nleaves=None, out=None):
+        seed, cws = self._dev(seed, torch.int32), self._dev(cws, torch.int32)
+        if nleaves is None:
+            nleaves = 1 << in_bits
+        L, st = self._L, self._stream()
+        ws_bytes = L.fss_amd_eval_all_workspace(scheme, in_bits, nleaves)
+        if ws_bytes == 0:
+            raise ValueError(f"eval_all: unsupported block (in_bits={in_bits}, nleaves={nleaves})")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
+        if scheme == GROTTO:
+            ys = out if out is not None else torch.empty((nleaves,), dtype=torch.uint8, device=self.device)
+            rc = L.fss_amd_grotto_eval_all(self._h, in_bits, party, _ptr(seed), _ptr(cws), first_leaf, nleaves,
+                                           _ptr(ys), _ptr(ws), ws_bytes, st)
+        else:
+            ys = out if out is not None else torch.empty((nleaves, 4), dtype=torch.int32, device=self.device)
+            if scheme == DPF:
+                rc = L.fss_amd_dpf_eval_all(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), first_leaf, nleaves,
+                                            _ptr(ys), _ptr(ws), ws_bytes, st)
+            elif scheme == DCF:
+                rc = L.fss_amd_dcf_eval_all(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), first_leaf, nleaves,
+                                            _ptr(ys), _ptr(ws), ws_bytes, st)
+            else:
+                ocw = self._dev(ocw, torch.int32)
+                rc = L.fss_amd_ht_eval_all(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(ocw),
+                                           first_leaf, nleaves, _ptr(ys), _ptr(ws), ws_bytes, st)
+        _lib.check(rc, "eval_all")
+        # the workspace must outlive the enqueued kernels
+        ws.record_stream(torch.cuda.current_stream(self.device))
+        return ys
+
+    # ------------------------------------------------------------ key generation
+    def gen(self, scheme, in_bits, group, s0s, alphas, betas, pred=0):
+        """s0s int32[n,2,4], alphas int32/int64[n], betas int32[n,4] -> (cws int32[n,slots,8], ocws|None)."""
+        s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)
+        n = alphas.numel()
+        xb = self._xbytes(alphas, in_bits)
+        slots = in_bits if scheme == HT else in_bits + 1
+        cws = torch.empty((n, slots, 8), dtype=torch.int32, device=self.device)
+        L, st = self._L, self._stream()
+        ocws = None
+        if scheme in (DPF, GROTTO):
+            rc = L.fss_amd_dpf_gen(self._h, in_bits, group, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n, _ptr(cws), st)
+        elif scheme == DCF:
+            rc = L.fss_amd_dcf_gen(self._h, in_bits, group, pred, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n,
+                                   _ptr(cws), st)
+        else:
+            ocws = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+            rc = L.fss_amd_ht_gen(self._h, in_bits, group, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n, _ptr(cws),
+                                  _ptr(ocws), st)
+        _lib.check(rc, "gen")
+        return cws, ocws
+
+
+_default = {}
+
+
+def default_engine(device=None):
+    """Process-wide engine per device with the reference's bench AES keys."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("fss_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+    idx = torch.cuda.current_device() if device is None else (device if isinstance(device, int) else torch.device(device).index or 0)
+    if idx not in _default:
+        _default[idx] = Engine(idx)
+    return _default[idx]

@@ -1,0 +1,180 @@
+/*
+ * fss_amd.h -- C ABI of libfss_amd.so, the MI355X (gfx950) batched DPF/DCF
+ * evaluation engine.  This is the drop-in boundary for the reference's GPU
+ * evaluation path: every entry point names the myl7/fss interface it replaces
+ * (paths relative to the reference checkout).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - int4 = 16 bytes = four little-endian int32 {x,y,z,w}; the control bit is
+ *    bit 0 of w (include/fss/util.cuh:30-38).
+ *  - "Cw slot" = the reference's 32-byte correction word, raw bytes:
+ *      Dpf::Cw         {int4 s; bool tr;  pad}  include/fss/dpf.cuh:76-81
+ *      Dcf::Cw         {int4 s; int4 v}         include/fss/dcf.cuh:91-96
+ *      HalfTreeDpf::Cw {int4 s; bool extra;pad} include/fss/half_tree_dpf.cuh:53-57
+ *    Only byte 16 of a Dpf/HalfTree slot's second half is read.
+ *  - Every `*_dev` / unnamed data pointer is a DEVICE pointer owned by the
+ *    caller; nothing is allocated, freed or synchronised by the eval calls:
+ *    they enqueue kernels on `stream` (a hipStream_t passed as void*, NULL =
+ *    default stream) and return, like the reference launchers
+ *    (include/fss/point_eval_gpu.cuh:448-460).
+ *  - Return value: 0 on success, a negative FSS_AMD_E* code otherwise.  No
+ *    exceptions cross the ABI.  There is no CPU fallback: without a usable HIP
+ *    device fss_amd_ctx_create fails with FSS_AMD_EHIP.
+ *  - x values: `x_bytes` = 4 (uint32_t, in_bits <= 32) or 8 (uint64_t,
+ *    in_bits <= 64).  Bits are consumed MSB-first (dpf.cuh:196).
+ */
+#ifndef FSS_AMD_H_
+#define FSS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSS_AMD_OK 0
+#define FSS_AMD_EINVAL (-1)       /* bad argument (range, NULL, unsupported combination) */
+#define FSS_AMD_EHIP (-2)         /* HIP runtime error; see fss_amd_last_hip_error() */
+#define FSS_AMD_EUNSUPPORTED (-3) /* valid in the reference but not built here yet */
+
+/* Output groups: fss::group::Bytes, fss::group::Uint<uint8_t|uint16_t|uint32_t|uint64_t>,
+ * fss::group::Uint<__uint128_t, 1 << 127> (include/fss/group/bytes.cuh, uint.cuh). */
+enum fss_amd_group {
+  FSS_AMD_GROUP_BYTES = 0,
+  FSS_AMD_GROUP_U8 = 1,
+  FSS_AMD_GROUP_U16 = 2,
+  FSS_AMD_GROUP_U32 = 3,
+  FSS_AMD_GROUP_U64 = 4,
+  FSS_AMD_GROUP_U128_M127 = 5
+};
+
+/* fss::DcfPred (include/fss/dcf.cuh:58-61); only matters to key generation. */
+enum fss_amd_pred { FSS_AMD_PRED_LT = 0, FSS_AMD_PRED_GT = 1 };
+
+typedef struct fss_amd_ctx fss_amd_ctx;
+
+/* ---- context: the PRG hook -------------------------------------------------
+ * Replaces fss::prg::Aes128Mmo<mul>::CreateCtxs / FreeCtxs
+ * (include/fss/prg/aes128_mmo.cuh:49-70) and the HalfTreeDpf::hash_key member
+ * (include/fss/half_tree_dpf.cuh:45): four AES-128 keys (key i produces PRG
+ * output i; DPF/Grotto use 0-1, DCF 0-3, Half-Tree 0) and the Half-Tree hash
+ * key, expanded once and kept resident on `device`. */
+int fss_amd_ctx_create(fss_amd_ctx **out, int device, const uint8_t aes_keys[64], const int32_t hash_key[4]);
+void fss_amd_ctx_destroy(fss_amd_ctx *ctx);
+int fss_amd_ctx_device(const fss_amd_ctx *ctx);
+const char *fss_amd_strerror(int code);
+/* Last hipError_t seen by this library on the calling thread (0 = hipSuccess). */
+int fss_amd_last_hip_error(void);
+
+/* ---- raw PRG (for KATs): out[i*mul + j] = AES_{key j}(seeds[i]) ^ seeds[i], j < mul.
+ * fss::prg::Aes128Mmo<mul>::Gen, include/fss/prg/aes128_mmo.cuh:72-93. */
+int fss_amd_prg_gen(fss_amd_ctx *ctx, int mul, const void *seeds, int64_t n, void *out, void *stream);
+
+/* ---- point evaluation, ONE key shared by all points --------------------------
+ * ys[i] = Scheme::Eval(party, *seed, cws, xs[i]).
+ * Replaces a user kernel calling fss::Dpf::Eval / fss::Dcf::Eval /
+ * fss::HalfTreeDpf::Eval per thread on one key (include/fss/dpf.cuh:170-214,
+ * include/fss/dcf.cuh:205-276, include/fss/half_tree_dpf.cuh:187-231;
+ * samples/dpf_dcf_gpu.cu:51-59) and the Python binding's single-point
+ * dpf_eval / dcf_eval (fss_crypto/_csrc/dpf_binding_impl.cuh:58-101).
+ * seed: device int4.  cws: device, in_bits+1 raw Cw slots (in_bits for Half-Tree).
+ * ocw (Half-Tree): device int4.  ys: device int4[npoints]. */
+int fss_amd_dpf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                            const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
+int fss_amd_dcf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                            const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
+int fss_amd_ht_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                           const void *ocw, const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
+
+/* ---- key relayout: key-major Cw slots -> level-major arrays --------------------
+ * Replaces fss::gpu::{Dpf,Dcf,HalfTreeDpf}RelayoutGpu
+ * (include/fss/point_eval_gpu.cuh:324-375).  cws: device, key-major, stride
+ * in_bits+1 slots per key (in_bits for Half-Tree).  Outputs (device):
+ *   cw_s  int4[in_bits][nkeys]          cw_s[i*nkeys + k] = cws[k][i].s
+ *   cw_v  int4[in_bits][nkeys]          (DCF)
+ *   tr_bits uint64[nkeys]               (DPF) bit i = cws[k][i].tr  -- 64 bits, the
+ *                                        reference packs 32 (point_eval_gpu.cuh:57-62)
+ *   out_cw int4[nkeys]                  cws[k][in_bits].s (DPF) / .v (DCF)
+ *   extra uint32[nkeys]                 (Half-Tree) bit 0 = cws[k][in_bits-1].extra */
+int fss_amd_dpf_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *tr_bits,
+                         void *out_cw, void *stream);
+int fss_amd_dcf_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *cw_v,
+                         void *out_cw, void *stream);
+int fss_amd_ht_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *extra,
+                        void *stream);
+
+/* ---- point evaluation, independent keys: ys[k] = Eval(party, seeds[k], key k, xs[k]) --
+ * Replaces fss::gpu::{Dpf,Dcf,HalfTreeDpf}EvalPointGpu
+ * (include/fss/point_eval_gpu.cuh:416-491) on the level-major arrays above. */
+int fss_amd_dpf_eval_keys(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
+                          const void *tr_bits, const void *out_cw, const void *xs, int x_bytes, int64_t nkeys,
+                          void *ys, void *stream);
+int fss_amd_dcf_eval_keys(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
+                          const void *cw_v, const void *out_cw, const void *xs, int x_bytes, int64_t nkeys, void *ys,
+                          void *stream);
+int fss_amd_ht_eval_keys(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
+                         const void *extra, const void *ocws, const void *xs, int x_bytes, int64_t nkeys, void *ys,
+                         void *stream);
+
+/* ---- full-domain evaluation ----------------------------------------------------
+ * ys[j] = Eval(party, *seed, cws, first_leaf + j) for j < nleaves, leaves in index
+ * order.  Replaces fss::gpu::{Dpf,HalfTreeDpf}EvalAllGpu (include/fss/eval_all_gpu.cuh:451-488),
+ * host fss::Dpf::EvalAll / fss::Dcf::EvalAll / fss::HalfTreeDpf::EvalAll
+ * (dpf.cuh:232-303, dcf.cuh:294-385, half_tree_dpf.cuh:246-316) and the binding's
+ * dpf_eval_all (fss_crypto/_csrc/dpf_binding_impl.cuh:107-131).
+ * [first_leaf, first_leaf + nleaves) must be an aligned power-of-two block of the
+ * domain (a subtree): this is how the domain is sharded across GPUs.  `workspace`:
+ * device scratch of at least fss_amd_eval_all_workspace(scheme, in_bits, nleaves)
+ * bytes.  64-bit indexing throughout (the reference's int indices overflow at
+ * in_bits >= 31, eval_all_gpu.cuh:257,287). */
+enum fss_amd_scheme { FSS_AMD_DPF = 0, FSS_AMD_DCF = 1, FSS_AMD_HT = 2, FSS_AMD_GROTTO = 3 };
+size_t fss_amd_eval_all_workspace(int scheme, int in_bits, int64_t nleaves);
+int fss_amd_dpf_eval_all(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                         int64_t first_leaf, int64_t nleaves, void *ys, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int fss_amd_dcf_eval_all(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                         int64_t first_leaf, int64_t nleaves, void *ys, void *workspace, size_t workspace_bytes,
+                         void *stream);
+int fss_amd_ht_eval_all(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                        const void *ocw, int64_t first_leaf, int64_t nleaves, void *ys, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* ---- Grotto DCF (include/fss/grotto_dcf.cuh) -------------------------------------
+ * Keys are DPF keys over Bytes with beta = 0 (grotto_dcf.cuh:63-67).
+ * eval_all: ys[x] = share of 1[alpha <= x], one byte per point, = GrottoDcf::EvalAll
+ * (grotto_dcf.cuh:151-163) -- bit-exact per party.
+ * eval_keys: path-walk evaluator for domains with no table (in_bits up to 64):
+ * XOR of the control bits of the left siblings along the path of x+1.  It
+ * reconstructs the same predicate; its per-party share is NOT the table-based
+ * GrottoDcf::Eval share (grotto_dcf.cuh:116-135), see DESIGN.md. */
+int fss_amd_grotto_eval_all(fss_amd_ctx *ctx, int in_bits, int party, const void *seed, const void *cws,
+                            int64_t first_leaf, int64_t nleaves, void *ys_bytes, void *workspace,
+                            size_t workspace_bytes, void *stream);
+int fss_amd_grotto_eval_keys(fss_amd_ctx *ctx, int in_bits, int party, const void *seeds, const void *cw_s,
+                             const void *tr_bits, const void *xs, int x_bytes, int64_t nkeys, void *ys_bytes,
+                             void *stream);
+
+/* ---- key generation on the device (dealer side) ------------------------------------
+ * One key per lane; writes key-major raw Cw slots, identical to the reference's Gen
+ * for the same seeds / alpha / beta: fss::Dpf::Gen (dpf.cuh:93-159), fss::Dcf::Gen
+ * (dcf.cuh:108-194), fss::HalfTreeDpf::Gen (half_tree_dpf.cuh:68-175).
+ * s0s: int4[nkeys][2]; alphas: x_bytes-wide; betas: int4[nkeys];
+ * cws: (in_bits+1)*nkeys slots (in_bits for Half-Tree), padding bytes zero;
+ * ocws (Half-Tree): int4[nkeys]. */
+int fss_amd_dpf_gen(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas, int x_bytes,
+                    const void *betas, int64_t nkeys, void *cws, void *stream);
+int fss_amd_dcf_gen(fss_amd_ctx *ctx, int in_bits, int group, int pred, const void *s0s, const void *alphas,
+                    int x_bytes, const void *betas, int64_t nkeys, void *cws, void *stream);
+int fss_amd_ht_gen(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas, int x_bytes,
+                   const void *betas, int64_t nkeys, void *cws, void *ocws, void *stream);
+
+/* ---- tuning / introspection -------------------------------------------------------- */
+/* Name and launch geometry of the kernel the last eval call on this ctx launched
+ * (for bench.py / profiles). */
+const char *fss_amd_last_kernel(const fss_amd_ctx *ctx, int *grid, int *block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

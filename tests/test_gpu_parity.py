@@ -1,0 +1,352 @@
+"""Parity of the HIP path (through the C ABI, libfss_amd.so) with the CPU oracle and
+with the reference's known answers.  Bit-exact: everything on this path is integer /
+XOR arithmetic."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import groups as G
+from conftest import SplitMix64
+from kat import load, words
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+GROUPS = [G.BYTES, G.U8, G.U16, G.U32, G.U64, G.U128]
+DPF, DCF, HT, GROTTO = 0, 1, 2, 3
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def xs_tensor(xs, n):
+    a = np.array(xs, dtype=np.uint64)
+    return T(a.astype(np.uint32).view(np.int32)) if n <= 32 else T(a.view(np.int64))
+
+
+def edge_xs(rng, n, alpha, extra):
+    top = (1 << n) - 1
+    xs = [0, top, alpha, max(alpha - 1, 0), min(alpha + 1, top)] + [rng.below(n) for _ in range(extra)]
+    return xs
+
+
+def beta_for(rng):
+    return rng.i4()
+
+
+# ---------------------------------------------------------------- PRG
+def test_prg_matches_reference_kat(engine):
+    K = load()
+    out = engine.prg_gen(4, T(words(K["s0"])).view(1, 4)).cpu().numpy()[0]
+    for i in range(4):
+        assert (out[i] == words(K["prg4"][i])).all()
+
+
+@pytest.mark.parametrize("mul", [1, 2, 4])
+def test_prg_matches_oracle(engine, O, mul):
+    rng = SplitMix64(11)
+    seeds = np.stack([rng.i4(clear_lsb=False) for _ in range(1000)])
+    got = engine.prg_gen(mul, T(seeds)).cpu().numpy()
+    p = O.Prg(mul)
+    for i in range(0, 1000, 7):
+        assert (got[i] == p.gen(seeds[i])).all()
+
+
+# ---------------------------------------------------------------- reference KATs on the GPU
+def test_reference_kats_on_gpu(engine):
+    import fss_amd
+    K = load()
+    s0, s1, beta = T(words(K["s0"])), T(words(K["s1"])), T(words(K["beta"]))
+    s0s = torch.stack([s0, s1])
+
+    k = K["dpf8_bytes"]
+    d = fss_amd.Dpf(8, "bytes")
+    cws = d.gen(s0s, k["alpha"], beta)
+    assert (cws[0, :4].numpy() == words(k["cw0_s"])).all() and int(cws[0, 4]) == k["cw0_tr"]
+    assert (cws[8, :4].numpy() == words(k["cw8_s"])).all()
+    assert (d.eval(0, s0, cws, 42).numpy() == words(k["y0_42"])).all()
+    assert (d.eval(1, s1, cws, 42).numpy() == words(k["y1_42"])).all()
+    assert (d.eval(0, s0, cws, 100).numpy() == words(k["y0_100"])).all()
+    assert hashlib.sha256(d.eval_all(0, s0, cws).numpy().tobytes()).hexdigest() == k["evalall_sha256_p0"]
+    assert hashlib.sha256(d.eval_all(1, s1, cws).numpy().tobytes()).hexdigest() == k["evalall_sha256_p1"]
+
+    k = K["dcf8_bytes_lt"]
+    d = fss_amd.Dcf(8, "bytes", pred="lt")
+    cws = d.gen(s0s, k["alpha"], beta)
+    assert hashlib.sha256(cws.numpy().tobytes()).hexdigest() == k["cws_sha256"]
+    assert (d.eval(0, s0, cws, 10).numpy() == words(k["y0_10"])).all()
+    assert (d.eval(1, s1, cws, 10).numpy() == words(k["y1_10"])).all()
+    assert hashlib.sha256(d.eval_all(0, s0, cws).numpy().tobytes()).hexdigest() == k["evalall_sha256_p0"]
+
+    k = K["dpf32_u64"]
+    d = fss_amd.Dpf(32, "uint")  # uint -> Uint<uint32_t> at in_bits 32 in the binding; the KAT is Uint<uint64_t>
+    d64 = fss_amd.Dpf(32, "u64")
+    cws = d64.gen(s0s, k["alpha"], beta)
+    assert (cws[32, :4].numpy() == words(k["cw32_s"])).all()
+    assert (d64.eval(0, s0, cws, k["alpha"]).numpy() == words(k["y0_alpha"])).all()
+    assert (d64.eval(1, s1, cws, k["alpha"]).numpy() == words(k["y1_alpha"])).all()
+    assert (d64.eval(0, s0, cws, k["x_other"]).numpy() == words(k["y0_other"])).all()
+    assert d._g == G.U32
+
+    k = K["ht64_u64"]
+    h = fss_amd.HalfTreeDpf(64, "u64")
+    cws, ocw = h.gen(s0s, k["alpha"], beta)
+    assert (cws[0, :4].numpy() == words(k["cw0_s"])).all() and int(cws[63, 4]) == k["cw63_extra"]
+    assert (ocw.numpy() == words(k["ocw"])).all()
+    assert (h.eval(0, s0, cws, ocw, k["alpha"]).numpy() == words(k["y0_alpha"])).all()
+    assert (h.eval(1, s1, cws, ocw, k["alpha"]).numpy() == words(k["y1_alpha"])).all()
+    assert (h.eval(0, s0, cws, ocw, k["x_other"]).numpy() == words(k["y0_other"])).all()
+
+
+# ---------------------------------------------------------------- one key, many points
+@pytest.mark.parametrize("g", GROUPS)
+@pytest.mark.parametrize("n", [1, 7, 16, 32, 33, 64])
+@pytest.mark.parametrize("scheme", [DPF, DCF, HT])
+def test_eval_points_vs_oracle(engine, O, scheme, n, g):
+    rng = SplitMix64(1000 * scheme + 10 * n + g)
+    mul = {DPF: 2, DCF: 4, HT: 1}[scheme]
+    p = O.Prg(mul)
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), beta_for(rng)
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, rng.next() & 1, s, alpha, beta)
+    else:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    xs = edge_xs(rng, n, alpha, 300)  # ragged: not a multiple of the wave or block size
+    for b in (0, 1):
+        want = O.eval_points(p, scheme, n, g, b, s[b], cws, np.array(xs, dtype=np.uint64), ocw=ocw)
+        got = engine.eval_points(scheme, n, g, b, T(s[b]), T(cws), xs_tensor(xs, n),
+                                 ocw=None if ocw is None else T(ocw)).cpu().numpy()
+        assert (got == want).all(), (scheme, n, g, b, np.argwhere(got != want)[:4])
+
+
+def test_eval_points_empty(engine):
+    out = engine.eval_points(DPF, 16, G.BYTES, 0, torch.zeros(4, dtype=torch.int32),
+                             torch.zeros((17, 8), dtype=torch.int32), torch.zeros(0, dtype=torch.int32))
+    assert out.shape == (0, 4)
+
+
+# ---------------------------------------------------------------- independent keys (relayout + eval_keys)
+@pytest.mark.parametrize("scheme,n,g", [(DPF, 32, G.U64), (DPF, 64, G.BYTES), (DPF, 5, G.U8), (DCF, 32, G.U64),
+                                        (DCF, 64, G.U128), (DCF, 9, G.BYTES), (HT, 64, G.U64), (HT, 32, G.BYTES),
+                                        (HT, 1, G.U16), (HT, 2, G.U64)])
+def test_eval_keys_vs_oracle(engine, O, scheme, n, g):
+    rng = SplitMix64(77 + 1000 * scheme + n)
+    nkeys = 333
+    mul = {DPF: 2, DCF: 4, HT: 1}[scheme]
+    p = O.Prg(mul)
+    s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    betas = np.stack([rng.i4() for _ in range(nkeys)])
+    cws, ocws = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=O.GT if n == 9 else O.LT, nthreads=4)
+    xs = np.array([alphas[i] if i % 3 == 0 else rng.below(n) for i in range(nkeys)], dtype=np.uint64)
+    keys = engine.relayout(scheme, n, T(cws))
+    # the relayout itself, against a numpy transposition (point_eval_gpu.cuh:53-91)
+    assert (keys.cw_s.cpu().numpy() == np.transpose(cws[:, :n, :4], (1, 0, 2))).all()
+    if scheme == DPF:
+        tr = np.zeros(nkeys, dtype=np.uint64)
+        for i in range(n):
+            tr |= (cws[:, i, 4].astype(np.uint64) & np.uint64(1)) << np.uint64(i)
+        assert (keys.tr_bits.cpu().numpy().view(np.uint64) == tr).all()
+        assert (keys.out_cw.cpu().numpy() == cws[:, n, :4]).all()
+    elif scheme == DCF:
+        assert (keys.cw_v.cpu().numpy() == np.transpose(cws[:, :n, 4:], (1, 0, 2))).all()
+        assert (keys.out_cw.cpu().numpy() == cws[:, n, 4:]).all()
+    else:
+        assert (keys.extra.cpu().numpy() == (cws[:, n - 1, 4] & 1)).all()
+    for b in (0, 1):
+        want = O.eval_keys(p, scheme, n, g, b, s0s[:, b], cws, xs, ocws=ocws, nthreads=4)
+        got = engine.eval_keys(keys, g, b, T(s0s[:, b].copy()), xs_tensor(xs, n),
+                               ocws=None if ocws is None else T(ocws)).cpu().numpy()
+        assert (got == want).all(), (scheme, n, g, b)
+
+
+# ---------------------------------------------------------------- key generation on the device
+@pytest.mark.parametrize("scheme,n,g,pred", [(DPF, 32, G.U64, 0), (DPF, 64, G.U128, 0), (DPF, 1, G.BYTES, 0),
+                                             (DCF, 32, G.U64, 0), (DCF, 16, G.BYTES, 1), (DCF, 64, G.U128, 1),
+                                             (DCF, 8, G.U8, 0), (HT, 64, G.U64, 0), (HT, 1, G.BYTES, 0),
+                                             (HT, 17, G.U128, 0), (HT, 8, G.U16, 0)])
+def test_gen_vs_oracle(engine, O, scheme, n, g, pred):
+    rng = SplitMix64(5 + 100 * scheme + n)
+    nkeys = 130
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s0s = np.stack([np.stack([rng.i4(clear_lsb=False), rng.i4(clear_lsb=False)]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    betas = np.stack([rng.i4(clear_lsb=False) for _ in range(nkeys)])
+    want, want_ocw = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=pred, nthreads=4)
+    got, got_ocw = engine.gen(scheme, n, g, T(s0s), xs_tensor(alphas, n), T(betas), pred=pred)
+    assert (got.cpu().numpy() == want).all()
+    if scheme == HT:
+        assert (got_ocw.cpu().numpy() == want_ocw).all()
+
+
+# ---------------------------------------------------------------- full domain
+@pytest.mark.parametrize("g", [G.BYTES, G.U32, G.U64, G.U128])
+@pytest.mark.parametrize("n", [1, 2, 5, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize("scheme", [DPF, DCF, HT])
+def test_eval_all_vs_oracle(engine, O, scheme, n, g):
+    if g in (G.U32, G.U128) and n not in (5, 14):
+        pytest.skip("group coverage on two sizes is enough")
+    rng = SplitMix64(31337 + 100 * scheme + n)
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), beta_for(rng)
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+        ref = lambda b: O.dpf_eval_all(p, n, g, b, s[b], cws)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 0, s, alpha, beta)
+        ref = lambda b: O.dcf_eval_all(p, n, g, b, s[b], cws)
+    else:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+        ref = lambda b: O.ht_eval_all(p, n, g, b, s[b], cws, ocw)
+    for b in (0, 1):
+        got = engine.eval_all(scheme, n, g, b, T(s[b]), T(cws), ocw=None if ocw is None else T(ocw)).cpu().numpy()
+        assert (got == ref(b)).all(), (scheme, n, g, b)
+
+
+@pytest.mark.parametrize("scheme", [DPF, DCF, HT])
+def test_eval_all_subblocks(engine, O, scheme):
+    """Domain sharding: aligned power-of-two blocks reproduce the slices of the whole."""
+    n, g = 15, G.U64
+    rng = SplitMix64(4242 + scheme)
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s = [rng.i4(), rng.i4()]
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, rng.below(n), beta_for(rng))
+        whole = O.dpf_eval_all(p, n, g, 1, s[1], cws)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 1, s, rng.below(n), beta_for(rng))
+        whole = O.dcf_eval_all(p, n, g, 1, s[1], cws)
+    else:
+        cws, ocw = O.ht_gen(p, n, g, s, rng.below(n), beta_for(rng))
+        whole = O.ht_eval_all(p, n, g, 1, s[1], cws, ocw)
+    for nl, first in [(1 << 12, 3 << 12), (1 << 14, 1 << 14), (1 << 5, 17 << 5), (2, 2 * 777),
+                      (1 if scheme != HT else 2, 4 * 100)]:
+        got = engine.eval_all(scheme, n, g, 1, T(s[1]), T(cws), ocw=None if ocw is None else T(ocw),
+                              first_leaf=first, nleaves=nl).cpu().numpy()
+        assert (got == whole[first:first + nl]).all(), (scheme, nl, first)
+
+
+# ---------------------------------------------------------------- Grotto
+@pytest.mark.parametrize("n", [1, 3, 10, 13, 16])
+def test_grotto_eval_all_vs_oracle(engine, O, n):
+    rng = SplitMix64(900 + n)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    for alpha in {0, (1 << n) - 1, rng.below(n)}:
+        cws = O.grotto_gen(p, n, s, alpha)
+        got = []
+        for b in (0, 1):
+            y = engine.eval_all(GROTTO, n, G.BYTES, b, T(s[b]), T(cws)).cpu().numpy()
+            assert (y == O.grotto_eval_all(p, n, b, s[b], cws)).all(), (n, alpha, b)
+            got.append(y)
+        assert ((got[0] ^ got[1]) == (np.arange(1 << n) >= alpha)).all()
+
+
+@pytest.mark.parametrize("n", [1, 16, 32, 64])
+def test_grotto_eval_keys_vs_oracle_walk(engine, O, n):
+    rng = SplitMix64(901 + n)
+    nkeys = 200
+    p = O.Prg(2)
+    s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    cws, _ = O.gen_keys(p, GROTTO, n, G.BYTES, s0s, alphas, np.zeros((nkeys, 4), np.int32), nthreads=4)
+    top = (1 << n) - 1
+    xs = np.array([[alphas[i], top, 0, rng.below(n)][i % 4] for i in range(nkeys)], dtype=np.uint64)
+    keys = engine.relayout(GROTTO, n, T(cws))
+    sh = []
+    for b in (0, 1):
+        want = O.eval_keys(p, GROTTO, n, G.BYTES, b, s0s[:, b], cws, xs, nthreads=4)[:, 0].astype(np.uint8)
+        got = engine.eval_keys(keys, G.BYTES, b, T(s0s[:, b].copy()), xs_tensor(xs, n)).cpu().numpy()
+        assert (got == want).all()
+        sh.append(got)
+    assert ((sh[0] ^ sh[1]) == (alphas <= xs)).all()
+
+
+# ---------------------------------------------------------------- BASELINE sizes: size-independent properties
+@pytest.mark.parametrize("scheme,n", [(DPF, 32), (DCF, 32)])
+def test_full_size_points_reconstruct(engine, O, scheme, n):
+    """configs[1]/[2]: one key, 2^20 random points, both parties on the GPU; the sum of
+    shares is beta exactly where the predicate holds; a strided sample equals the oracle."""
+    g = G.U64
+    rng = SplitMix64(0x5EED0000 + 2 + scheme)
+    p = O.Prg(2 if scheme == DPF else 4)
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), rng.i4()
+    cws = O.dpf_gen(p, n, g, s, alpha, beta) if scheme == DPF else O.dcf_gen(p, n, g, 0, s, alpha, beta)
+    N = 1 << 20
+    gen = torch.Generator().manual_seed(1234)
+    xs = torch.randint(-2**31, 2**31, (N,), dtype=torch.int32, generator=gen)
+    xs[:3] = torch.tensor([alpha - (1 << 32) if alpha >= 2**31 else alpha, 0, -1], dtype=torch.int32)
+    xd = xs.cuda()
+    y = [engine.eval_points(scheme, n, g, b, T(s[b]), T(cws), xd) for b in (0, 1)]
+    v = [(t[:, 0].to(torch.int64) & 0xFFFFFFFF) | (t[:, 1].to(torch.int64) << 32) for t in y]
+    total = v[0] + v[1]  # wraps mod 2^64
+    xu = xd.to(torch.int64) & 0xFFFFFFFF
+    hit = (xu == alpha) if scheme == DPF else (xu < alpha)
+    bv = (int(beta[0]) & 0xFFFFFFFF) | ((int(beta[1]) & 0xFFFFFFFF) << 32)
+    bv = bv - (1 << 64) if bv >= (1 << 63) else bv
+    want = torch.where(hit, torch.tensor(bv, dtype=torch.int64, device=xd.device), torch.zeros_like(total))
+    assert bool((total == want).all())
+    assert bool((y[0][:, 2:] == 0).all())
+    idx = np.arange(0, N, 4099)
+    xs_np = xs.numpy().view(np.uint32).astype(np.uint64)[idx]
+    want0 = O.eval_points(p, scheme, n, g, 0, s[0], cws, xs_np, nthreads=4)
+    assert (y[0].cpu().numpy()[idx] == want0).all()
+
+
+def test_full_size_eval_all_properties(engine, O):
+    """configs[3] shape at a size that fits the test budget (2^24 leaves): exactly one
+    non-zero reconstructed leaf (= beta at alpha), and random leaves equal Eval."""
+    n, g = 24, G.U64
+    rng = SplitMix64(0x5EED0004)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), rng.i4()
+    cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    y = [engine.eval_all(DPF, n, g, b, T(s[b]), T(cws)) for b in (0, 1)]
+    v = [(t[:, 0].to(torch.int64) & 0xFFFFFFFF) | (t[:, 1].to(torch.int64) << 32) for t in y]
+    total = v[0] + v[1]
+    nz = torch.nonzero(total).flatten()
+    assert nz.numel() == 1 and int(nz[0]) == alpha
+    bv = (int(beta[0]) & 0xFFFFFFFF) | ((int(beta[1]) & 0xFFFFFFFF) << 32)
+    assert (int(total[alpha]) & 0xFFFFFFFFFFFFFFFF) == bv
+    y0 = y[0].cpu().numpy()
+    for x in [0, (1 << n) - 1, alpha] + [rng.below(n) for _ in range(50)]:
+        assert (y0[x] == O.dpf_eval(p, n, g, 0, s[0], cws, x)).all()
+
+
+def test_full_size_half_tree_keys_reconstruct(engine, O):
+    """configs[4] shape (Half-Tree n=64, independent keys) at 2^18 keys generated on the
+    device: shares reconstruct beta at alpha and 0 elsewhere; a sample equals the oracle."""
+    import fss_amd
+    n, g, nkeys = 64, G.U64, 1 << 18
+    gen = torch.Generator().manual_seed(99)
+    s0s = torch.randint(-2**31, 2**31, (nkeys, 2, 4), dtype=torch.int32, generator=gen)
+    alphas = torch.randint(-2**63, 2**63 - 1, (nkeys,), dtype=torch.int64, generator=gen)
+    betas = torch.randint(-2**31, 2**31, (nkeys, 4), dtype=torch.int32, generator=gen)
+    h = fss_amd.HalfTreeDpf(n, "u64", engine=engine)
+    cws, ocws = h.gen_batch(s0s, alphas, betas)
+    keys = h.relayout(cws)
+    xs = alphas.clone()
+    xs[1::2] = torch.randint(-2**63, 2**63 - 1, (nkeys // 2,), dtype=torch.int64, generator=gen)
+    y = [h.eval_keys(b, s0s[:, b].contiguous(), keys, ocws, xs) for b in (0, 1)]
+    v = [(t[:, 0].to(torch.int64) & 0xFFFFFFFF) | (t[:, 1].to(torch.int64) << 32) for t in y]
+    total = (v[0] + v[1]).cpu()
+    bl = (betas[:, 0].to(torch.int64) & 0xFFFFFFFF) | (betas[:, 1].to(torch.int64) << 32)
+    want = torch.where(xs == alphas, bl, torch.zeros_like(bl))
+    assert bool((total == want).all())
+    p = O.Prg(1)
+    idx = np.arange(0, nkeys, 1031)
+    want0 = O.eval_keys(p, HT, n, g, 0, s0s[:, 0].numpy()[idx], cws.cpu().numpy()[idx],
+                        xs.numpy().view(np.uint64)[idx], ocws=ocws.cpu().numpy()[idx], nthreads=4)
+    assert (y[0].cpu().numpy()[idx] == want0).all()

@@ -1,0 +1,78 @@
+"""Pins the CPU oracle (oracle/fss_oracle.c): FIPS-197, OpenSSL EVP (the reference's
+PRG dependency), and the reference's own outputs recorded in SURVEY.md 8(c)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from kat import load, words
+
+K = load()
+S0, S1, BETA = words(K["s0"]), words(K["s1"]), words(K["beta"])
+
+
+def test_fips197_appendix_c1(O):
+    key = bytes(range(16))
+    pt = bytes.fromhex("00112233445566778899aabbccddeeff")
+    assert O.aes128_encrypt(key, pt).hex() == "69c4e0d86a7b0430d8cdb78070b4c55a"
+
+
+def test_fips197_appendix_b(O):
+    key = bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c")
+    pt = bytes.fromhex("3243f6a8885a308d313198a2e0370734")
+    assert O.aes128_encrypt(key, pt).hex() == "3925841d02dc09fbdc118597196a0b32"
+
+
+def test_prg_kat(O):
+    out = O.Prg(4).gen(S0)
+    for i in range(4):
+        assert (out[i] == words(K["prg4"][i])).all()
+
+
+@pytest.mark.parametrize("mul", [1, 2, 4])
+def test_prg_matches_openssl_evp(O, mul, rng):
+    own, evp = O.Prg(mul), O.Prg(mul, use_evp=True)
+    for _ in range(200):
+        s = rng.i4(clear_lsb=False)
+        assert (own.gen(s) == evp.gen(s)).all()
+
+
+def test_dpf8_bytes(O):
+    k, p = K["dpf8_bytes"], O.Prg(2)
+    cws = O.dpf_gen(p, 8, O.BYTES, [S0, S1], k["alpha"], BETA)
+    assert (cws[0, :4] == words(k["cw0_s"])).all() and cws[0, 4] == k["cw0_tr"]
+    assert (cws[8, :4] == words(k["cw8_s"])).all()
+    assert (O.dpf_eval(p, 8, O.BYTES, 0, S0, cws, 42) == words(k["y0_42"])).all()
+    assert (O.dpf_eval(p, 8, O.BYTES, 1, S1, cws, 42) == words(k["y1_42"])).all()
+    assert (O.dpf_eval(p, 8, O.BYTES, 0, S0, cws, 100) == words(k["y0_100"])).all()
+    assert hashlib.sha256(O.dpf_eval_all(p, 8, O.BYTES, 0, S0, cws).tobytes()).hexdigest() == k["evalall_sha256_p0"]
+    assert hashlib.sha256(O.dpf_eval_all(p, 8, O.BYTES, 1, S1, cws).tobytes()).hexdigest() == k["evalall_sha256_p1"]
+
+
+def test_dcf8_bytes(O):
+    k, p = K["dcf8_bytes_lt"], O.Prg(4)
+    cws = O.dcf_gen(p, 8, O.BYTES, O.LT, [S0, S1], k["alpha"], BETA)
+    assert (cws[0, :4] == words(k["cw0_s"])).all() and (cws[0, 4:] == words(k["cw0_v"])).all()
+    assert hashlib.sha256(cws.tobytes()).hexdigest() == k["cws_sha256"]
+    assert (O.dcf_eval(p, 8, O.BYTES, 0, S0, cws, 10) == words(k["y0_10"])).all()
+    assert (O.dcf_eval(p, 8, O.BYTES, 1, S1, cws, 10) == words(k["y1_10"])).all()
+    assert hashlib.sha256(O.dcf_eval_all(p, 8, O.BYTES, 0, S0, cws).tobytes()).hexdigest() == k["evalall_sha256_p0"]
+
+
+def test_dpf32_u64(O):
+    k, p = K["dpf32_u64"], O.Prg(2)
+    cws = O.dpf_gen(p, 32, O.U64, [S0, S1], k["alpha"], BETA)
+    assert (cws[32, :4] == words(k["cw32_s"])).all()
+    assert (O.dpf_eval(p, 32, O.U64, 0, S0, cws, k["alpha"]) == words(k["y0_alpha"])).all()
+    assert (O.dpf_eval(p, 32, O.U64, 1, S1, cws, k["alpha"]) == words(k["y1_alpha"])).all()
+    assert (O.dpf_eval(p, 32, O.U64, 0, S0, cws, k["x_other"]) == words(k["y0_other"])).all()
+
+
+def test_ht64_u64(O):
+    k, p = K["ht64_u64"], O.Prg(1)
+    cws, ocw = O.ht_gen(p, 64, O.U64, [S0, S1], k["alpha"], BETA)
+    assert (cws[0, :4] == words(k["cw0_s"])).all() and cws[63, 4] == k["cw63_extra"]
+    assert (ocw == words(k["ocw"])).all()
+    assert (O.ht_eval(p, 64, O.U64, 0, S0, cws, ocw, k["alpha"]) == words(k["y0_alpha"])).all()
+    assert (O.ht_eval(p, 64, O.U64, 1, S1, cws, ocw, k["alpha"]) == words(k["y1_alpha"])).all()
+    assert (O.ht_eval(p, 64, O.U64, 0, S0, cws, ocw, k["x_other"]) == words(k["y0_other"])).all()

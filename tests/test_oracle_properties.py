@@ -1,0 +1,129 @@
+"""The reference's own correctness tests restated against the oracle: they pin the
+FSS property (share reconstruction), with the constants of src/dpf_test.cu:30-32
+(alpha = 107, beta = 604) and per-run random seeds made deterministic here.
+Follows src/dpf_test.cu:58-139,189-266, src/dcf_test.cu:58-135,187-252,
+src/half_tree_dpf_test.cu:64-140,205-289,327-451, src/grotto_dcf_test.cu:39-137."""
+import numpy as np
+import pytest
+
+import groups as G
+
+ALPHA, BETA_X = 107, 604
+GROUPS = [G.BYTES, G.U8, G.U16, G.U32, G.U64, G.U128]
+
+
+def beta_for(g):
+    if g in (G.BYTES, G.U128):
+        return np.array([BETA_X, 5, 6, 8], dtype=np.int32)
+    return np.array([BETA_X, 0, 0, 0], dtype=np.int32)
+
+
+@pytest.mark.parametrize("g", GROUPS)
+@pytest.mark.parametrize("n", [1, 8, 16, 33, 64])
+def test_dpf_eval_reconstructs(O, rng, g, n):
+    p = O.Prg(2)
+    alpha = ALPHA & ((1 << n) - 1)
+    s = [rng.i4(), rng.i4()]
+    beta = beta_for(g)
+    cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    xs = {0, alpha, (1 << n) - 1, max(alpha - 1, 0), min(alpha + 1, (1 << n) - 1)} | {rng.below(n) for _ in range(8)}
+    for x in xs:
+        y = G.add(g, O.dpf_eval(p, n, g, 0, s[0], cws, x), O.dpf_eval(p, n, g, 1, s[1], cws, x))
+        want = G.canon(g, beta) if x == alpha else np.zeros(4, np.int32)
+        assert (y == want).all(), (g, n, x)
+
+
+@pytest.mark.parametrize("g", [G.BYTES, G.U32, G.U64])
+def test_dpf_eval_all_matches_eval_and_reconstructs(O, rng, g):
+    n, p = 10, O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    beta = beta_for(g)
+    cws = O.dpf_gen(p, n, g, s, ALPHA, beta)
+    y0, y1 = O.dpf_eval_all(p, n, g, 0, s[0], cws), O.dpf_eval_all(p, n, g, 1, s[1], cws)
+    for x in range(0, 1 << n, 37):
+        assert (y0[x] == O.dpf_eval(p, n, g, 0, s[0], cws, x)).all()
+    r = G.add_rows(g, y0, y1)
+    want = np.zeros_like(r)
+    want[ALPHA] = G.canon(g, beta)
+    assert (r == want).all()
+
+
+@pytest.mark.parametrize("pred", [0, 1])
+@pytest.mark.parametrize("g", GROUPS)
+@pytest.mark.parametrize("n", [1, 8, 16, 64])
+def test_dcf_eval_reconstructs(O, rng, g, n, pred):
+    p = O.Prg(4)
+    alpha = ALPHA & ((1 << n) - 1)
+    s = [rng.i4(), rng.i4()]
+    beta = beta_for(g)
+    cws = O.dcf_gen(p, n, g, pred, s, alpha, beta)
+    xs = {0, alpha, (1 << n) - 1, max(alpha - 1, 0), min(alpha + 1, (1 << n) - 1)} | {rng.below(n) for _ in range(8)}
+    for x in xs:
+        y = G.add(g, O.dcf_eval(p, n, g, 0, s[0], cws, x), O.dcf_eval(p, n, g, 1, s[1], cws, x))
+        hit = x < alpha if pred == 0 else x > alpha
+        want = G.canon(g, beta) if hit else np.zeros(4, np.int32)
+        assert (y == want).all(), (g, n, x, pred)
+
+
+@pytest.mark.parametrize("g", [G.BYTES, G.U64])
+def test_dcf_eval_all_matches_eval(O, rng, g):
+    n, p = 9, O.Prg(4)
+    s = [rng.i4(), rng.i4()]
+    cws = O.dcf_gen(p, n, g, 0, s, ALPHA, beta_for(g))
+    for b in (0, 1):
+        ys = O.dcf_eval_all(p, n, g, b, s[b], cws)
+        for x in range(0, 1 << n, 13):
+            assert (ys[x] == O.dcf_eval(p, n, g, b, s[b], cws, x)).all()
+
+
+@pytest.mark.parametrize("g", GROUPS)
+@pytest.mark.parametrize("n", [1, 2, 8, 16, 64])
+def test_half_tree_reconstructs(O, rng, g, n):
+    p = O.Prg(1)
+    alpha = ALPHA & ((1 << n) - 1)
+    s = [rng.i4(), rng.i4()]
+    beta = beta_for(g)
+    cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    xs = {0, alpha, (1 << n) - 1} | {rng.below(n) for _ in range(8)}
+    for x in xs:
+        y = G.add(g, O.ht_eval(p, n, g, 0, s[0], cws, ocw, x), O.ht_eval(p, n, g, 1, s[1], cws, ocw, x))
+        want = G.canon(g, beta) if x == alpha else np.zeros(4, np.int32)
+        assert (y == want).all(), (g, n, x)
+
+
+@pytest.mark.parametrize("n", [1, 2, 9])
+def test_half_tree_eval_all_matches_eval(O, rng, n):
+    p, g = O.Prg(1), G.U64
+    s = [rng.i4(), rng.i4()]
+    cws, ocw = O.ht_gen(p, n, g, s, ALPHA & ((1 << n) - 1), beta_for(g))
+    for b in (0, 1):
+        ys = O.ht_eval_all(p, n, g, b, s[b], cws, ocw)
+        for x in range(1 << n):
+            assert (ys[x] == O.ht_eval(p, n, g, b, s[b], cws, ocw, x)).all()
+
+
+@pytest.mark.parametrize("alpha", [0, 107, (1 << 10) - 1])
+def test_grotto(O, rng, alpha):
+    n, p = 10, O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    cws = O.grotto_gen(p, n, s, alpha)
+    ea = [O.grotto_eval_all(p, n, b, s[b], cws) for b in (0, 1)]
+    want = (np.arange(1 << n) >= alpha).astype(np.uint8)
+    assert ((ea[0] ^ ea[1]) == want).all()  # src/grotto_dcf_test.cu:39-77
+    for b in (0, 1):  # Preprocess + Eval == EvalAll, :79-96
+        pt = O.grotto_preprocess(p, n, b, s[b], cws)
+        got = np.array([O.grotto_eval(n, pt, x) for x in range(1 << n)], dtype=np.uint8)
+        assert (got == ea[b]).all()
+    walk = [np.array([O.grotto_eval_walk(p, n, b, s[b], cws, x) for x in range(1 << n)], dtype=np.uint8)
+            for b in (0, 1)]
+    assert ((walk[0] ^ walk[1]) == want).all()  # the path walk reconstructs the same predicate
+
+
+def test_grotto_walk_64(O, rng):
+    n, p = 64, O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    alpha = 0x0123456789ABCDEF
+    cws = O.grotto_gen(p, n, s, alpha)
+    for x in [0, alpha - 1, alpha, alpha + 1, (1 << 64) - 1, rng.below(64), rng.below(64)]:
+        r = O.grotto_eval_walk(p, n, 0, s[0], cws, x) ^ O.grotto_eval_walk(p, n, 1, s[1], cws, x)
+        assert r == int(alpha <= x)
