@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(_HERE, "libfss_amd.so")
+SO = os.environ.get("FSS_AMD_LIB") or os.path.join(_HERE, "libfss_amd.so")  # FSS_AMD_LIB: A/B builds while tuning
 
 OK, EINVAL, EHIP, EUNSUPPORTED = 0, -1, -2, -3
 

@@ -20,7 +20,7 @@ using namespace fssamd;
 struct fss_amd_ctx {
   int device;
   int num_cu;
-  uint32_t* te0;  // device: Te0 table, 1 KiB
+  uint32_t* te0;  // device: Te0 table, 1 KiB, followed by the device copy of `host`
   DevCtx host;    // round keys etc., passed to kernels by value
   const char* last_kernel;
   int last_grid, last_block;
@@ -184,8 +184,12 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   for (int i = 0; i < 4; ++i) c->host.hash_key[i] = hash_key ? (uint32_t)hash_key[i] : 0u;
 
   c->te0 = nullptr;
-  hipError_t e = hipMalloc(&c->te0, sizeof(te0));
+  hipError_t e = hipMalloc(&c->te0, sizeof(te0) + sizeof(DevCtx));
   if (e == hipSuccess) e = hipMemcpy(c->te0, te0, sizeof(te0), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    c->host.self_dev = c->te0 + 256;
+    e = hipMemcpy(c->te0 + 256, &c->host, sizeof(DevCtx), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     g_last_hip = (int)e;
     if (c->te0) (void)hipFree(c->te0);
@@ -228,9 +232,10 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
   if (!ctx || !seeds || !out || n < 0 || (mul != 1 && mul != 2 && mul != 4)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
   HIP_TRY(hipSetDevice(ctx->device));
-  int bs = 256;
+  // one wave per workgroup for tiny batches (the LDS fill is per workgroup), 1024 lanes otherwise
+  int bs = n <= 64 ? 64 : (n <= 256 ? 256 : 1024);
   int64_t want = (n + bs - 1) / bs;
-  int grid = (int)(want < (int64_t)ctx->num_cu * 2 ? want : (int64_t)ctx->num_cu * 2);
+  int grid = (int)(want < (int64_t)ctx->num_cu ? want : (int64_t)ctx->num_cu);
   hipLaunchKernelGGL(prg_gen_kernel, dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, mul,
                      reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out));
   HIP_TRY(hipGetLastError());

@@ -42,6 +42,7 @@ struct DevCtx {
   uint32_t sel02[11][8];  // A = key 0, B = key 2   DCF seed:  left / right
   uint32_t sel13[11][8];  // A = key 1, B = key 3   DCF value: left / right
   uint32_t hash_key[4];
+  const uint32_t* self_dev;  // device-memory copy of this struct (for per-lane vector loads of round keys)
 };
 
 constexpr int kLdsTableBytes = 256 * 256;  // 64 KiB: 256 indices x 64 lane copies x 4 B
@@ -60,23 +61,109 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) {
   return __builtin_amdgcn_alignbit(x, x, 32 - n);
 }
 
-struct Lds {
-  const uint8_t* tab;  // LDS table base
-  uint32_t lo;         // (lane & 63) * 4
-};
+// ---- LDS table layouts --------------------------------------------------------
+// FSS_T4 = 1 (default): four tables T0..T3 (T_t = Te0 rotated left by 8t bits), each
+// replicated 32x so that lane l always reads bank l % 32 (conflict-free for any 64
+// indices); 128 KiB, one 1024-thread workgroup per CU.  Rows are 256 B:
+//   region A (first 64 KiB):  row idx = [T0[idx] x 32 lanes | T1[idx] x 32 lanes]
+//   region B (second 64 KiB): row idx = [T2[idx] x 32 lanes | T3[idx] x 32 lanes]
+// so a lookup address is  region << 16 | idx << 8 | half << 7 | (lane & 31) << 2  and
+// the round needs no rotate instructions.  On gfx950 v_perm_b32 / v_alignbit_b32 /
+// anything with an SGPR operand issue at 4 cycles per wave while v_bitop3_b32, shifts
+// and 2-input logic on VGPRs issue at 2 (tools/ubench/valu_rate.hip), and the walk is
+// VALU-issue bound, so dropping the 12 rotates per round is worth ~1.4x.
+// FSS_T4 = 0: one table Te0 x 64 lanes (64 KiB, two workgroups per CU), rotates in VALU.
+#ifndef FSS_T4
+#define FSS_T4 1
+#endif
 
-// Fill the workgroup's LDS table.  Call from every thread, then __syncthreads().
-__device__ __forceinline__ void lds_table_fill(uint32_t* lds, const uint32_t* __restrict__ te0) {
-  for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) lds[i] = te0[i >> 6];
+constexpr int kLdsWords = FSS_T4 ? 32768 : 16384;
+
+// a ? b : c bitwise  (a = 0xF0, b = 0xCC, c = 0xAA)
+constexpr uint32_t kSelect = (0xF0 & 0xCC) | (~0xF0 & 0xAA & 0xFF);
+constexpr uint32_t kAndOr = (0xF0 & 0xCC) | 0xAA;  // (a & b) | c
+
+// A constant the compiler must keep in a VGPR (an SGPR or literal operand would put
+// the consuming VALU op on the 4-cycle path).
+__device__ __forceinline__ uint32_t vconst(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
-// One table lookup: Te0[byte K of w].
-template <int K>
-__device__ __forceinline__ uint32_t te(const Lds& L, uint32_t w) {
-  // result bytes: [0] = lane offset, [1] = byte K of w, [2], [3] = 0
+// FSS_VKEYS = 1 (experiment, measured 11 % SLOWER than scalar keys on MI355X: the 2 x 1 KiB of
+// return data per round saturate the L1 -> VGPR path): round keys are fetched with vector loads (global_load_dwordx4, every lane
+// the same address, L1-resident) into VGPRs instead of scalar loads into SGPRs: a VALU op with
+// an SGPR operand issues at 4 cycles per wave, with VGPR operands at 2, and vector loads use
+// vmcnt, leaving lgkmcnt to the LDS lookups alone (counted waits instead of full drains).
+#ifndef FSS_VKEYS
+#define FSS_VKEYS 0
+#endif
+
+struct Lds {
+  const uint8_t* tab;  // LDS table base
+  const uint32_t* kbase;  // &K (kernel-argument copy of DevCtx), as words
+  const uint32_t* gk;     // K.self_dev + an opaque per-lane zero
+#if FSS_T4
+  uint32_t lo[4];      // per table: region << 16 | half << 7 | (lane & 31) << 2
+  uint32_t m_ff00, m_00ff, m_ff0000, m_ffff;
+#else
+  uint32_t lo;         // (lane & 63) * 4
+#endif
+};
+
+__device__ __forceinline__ Lds make_lds(const uint32_t* lds, const DevCtx& K) {
+  Lds L;
+  L.tab = reinterpret_cast<const uint8_t*>(lds);
+  L.kbase = reinterpret_cast<const uint32_t*>(&K);
+  L.gk = K.self_dev + vconst(0u);
+#if FSS_T4
+  const uint32_t l4 = (threadIdx.x & 31u) << 2;
+  L.lo[0] = l4; L.lo[1] = l4 | 0x80u; L.lo[2] = l4 | 0x10000u; L.lo[3] = l4 | 0x10080u;
+  L.m_ff00 = vconst(0xff00u); L.m_00ff = vconst(0xffu); L.m_ff0000 = vconst(0xff0000u); L.m_ffff = vconst(0xffffu);
+#else
+  L.lo = (threadIdx.x & 63u) * 4u;
+#endif
+  return L;
+}
+
+// Fill the workgroup's LDS tables.  Call from every thread, then __syncthreads().
+__device__ __forceinline__ void lds_table_fill(uint32_t* lds, const uint32_t* __restrict__ te0) {
+#if FSS_T4
+  for (int i = threadIdx.x; i < 32768; i += blockDim.x) {
+    uint32_t t = te0[(i >> 6) & 255];
+    int tbl = ((i >> 14) << 1) | ((i >> 5) & 1);
+    lds[i] = tbl ? __builtin_amdgcn_alignbit(t, t, 32 - 8 * tbl) : t;
+  }
+#else
+  for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) lds[i] = te0[i >> 6];
+#endif
+}
+
+#define FSS_LDS_PROLOGUE(te0)                                              \
+  __shared__ __attribute__((aligned(16))) uint32_t lds_te[kLdsWords];     \
+  lds_table_fill(lds_te, te0);                                            \
+  __syncthreads();                                                        \
+  const Lds L = make_lds(lds_te, K)
+
+// One table lookup: T_T[byte K of w]  (T_T = Te0 rotated left by 8T bits).
+template <int K, int T>
+__device__ __forceinline__ uint32_t lk(const Lds& L, uint32_t w) {
+#if FSS_T4
+  uint32_t addr;
+  if (K == 1) {
+    addr = __builtin_amdgcn_bitop3_b32(w, L.m_ff00, L.lo[T], kAndOr);  // byte 1 is already at idx << 8
+  } else {
+    // result bytes: [0] = lo byte 0, [1] = byte K of w, [2] = lo byte 2 (region), [3] = 0
+    constexpr uint32_t sel = 0x0c020000u | ((4u + K) << 8);
+    addr = __builtin_amdgcn_perm(w, L.lo[T], sel);
+  }
+  return *reinterpret_cast<const uint32_t*>(L.tab + addr);
+#else
   constexpr uint32_t sel = 0x0c0c0000u | ((4u + K) << 8);
   uint32_t addr = __builtin_amdgcn_perm(w, L.lo, sel);
-  return *reinterpret_cast<const uint32_t*>(L.tab + addr);
+  uint32_t v = *reinterpret_cast<const uint32_t*>(L.tab + addr);
+  return T ? __builtin_amdgcn_alignbit(v, v, 32 - 8 * T) : v;
+#endif
 }
 
 // Opaque zero in an SGPR that depends on a lane value: placed at the head of an
@@ -95,13 +182,32 @@ __device__ __forceinline__ uint32_t round_anchor(uint32_t dep) {
 // SEL = false: `key` = 44 round-key words of one wave-uniform key.
 // SEL = true:  `key` = DevCtx::selXY, per lane k = key A where mask == 0 and key B
 // where mask == ~0.
+// Opaque per-lane zero that depends on a lane value (same purpose as round_anchor, for
+// vector-loaded keys).
+__device__ __forceinline__ uint32_t lane_anchor(uint32_t dep) {
+  uint32_t z = 0;
+  asm volatile("" : "+v"(z) : "v"(dep));
+  return z;
+}
+
+// Pointer to the key words of round r, readable one round at a time.
+__device__ __forceinline__ const uint32_t* round_key(const Lds& L, const uint32_t* key, int word, uint32_t dep) {
+#if FSS_VKEYS
+  return L.gk + (key - L.kbase) + word + lane_anchor(dep);
+#else
+  return key + word + round_anchor(dep);
+#endif
+}
+
 template <bool SEL>
 __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict__ key, uint32_t mask,
                                         const uint32_t in[4], uint32_t out[4]) {
   constexpr int RS = SEL ? 8 : 4;  // key words per round
   uint32_t s0, s1, s2, s3;
+  uint32_t kc[RS];  // key words of the round being computed, fetched one phase ahead
   {
-    const uint32_t* k = key + round_anchor(in[0]);
+    const uint32_t* k = round_key(L, key, 0, in[0]);
+    const uint32_t* k1 = round_key(L, key, RS, in[1]);
     if (SEL) {
       s0 = xor3(in[0], k[0], mask & k[4]);
       s1 = xor3(in[1], k[1], mask & k[5]);
@@ -110,53 +216,80 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
     } else {
       s0 = in[0] ^ k[0]; s1 = in[1] ^ k[1]; s2 = in[2] ^ k[2]; s3 = in[3] ^ k[3];
     }
+#pragma unroll
+    for (int j = 0; j < RS; ++j) kc[j] = k1[j];
   }
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
-    const uint32_t* k = key + RS * r + round_anchor(s0);
-    uint32_t a0 = te<0>(L, s0), a1 = te<0>(L, s1), a2 = te<0>(L, s2), a3 = te<0>(L, s3);
-    uint32_t b0 = te<1>(L, s1), b1 = te<1>(L, s2), b2 = te<1>(L, s3), b3 = te<1>(L, s0);
-    uint32_t c0 = te<2>(L, s2), c1 = te<2>(L, s3), c2 = te<2>(L, s0), c3 = te<2>(L, s1);
-    uint32_t d0 = te<3>(L, s3), d1 = te<3>(L, s0), d2 = te<3>(L, s1), d3 = te<3>(L, s2);
-    uint32_t x0 = xor3(a0, rotl32(b0, 8), rotl32(c0, 16));
-    uint32_t x1 = xor3(a1, rotl32(b1, 8), rotl32(c1, 16));
-    uint32_t x2 = xor3(a2, rotl32(b2, 8), rotl32(c2, 16));
-    uint32_t x3 = xor3(a3, rotl32(b3, 8), rotl32(c3, 16));
+    uint32_t a0 = lk<0, 0>(L, s0), a1 = lk<0, 0>(L, s1), a2 = lk<0, 0>(L, s2), a3 = lk<0, 0>(L, s3);
+    uint32_t b0 = lk<1, 1>(L, s1), b1 = lk<1, 1>(L, s2), b2 = lk<1, 1>(L, s3), b3 = lk<1, 1>(L, s0);
+    uint32_t c0 = lk<2, 2>(L, s2), c1 = lk<2, 2>(L, s3), c2 = lk<2, 2>(L, s0), c3 = lk<2, 2>(L, s1);
+    uint32_t d0 = lk<3, 3>(L, s3), d1 = lk<3, 3>(L, s0), d2 = lk<3, 3>(L, s1), d3 = lk<3, 3>(L, s2);
+    // The next round's key load is anchored on a looked-up value: it is issued right after
+    // this round's LDS wait, and has the whole VALU phase plus the next LDS phase to land.
+    const uint32_t* kn = round_key(L, key, RS * (r + 1), a0);
+    uint32_t knx[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) knx[j] = kn[j];
+    uint32_t x0 = xor3(a0, b0, c0);
+    uint32_t x1 = xor3(a1, b1, c1);
+    uint32_t x2 = xor3(a2, b2, c2);
+    uint32_t x3 = xor3(a3, b3, c3);
     if (SEL) {
-      s0 = xor3(x0, and_xor(mask, k[4], rotl32(d0, 24)), k[0]);
-      s1 = xor3(x1, and_xor(mask, k[5], rotl32(d1, 24)), k[1]);
-      s2 = xor3(x2, and_xor(mask, k[6], rotl32(d2, 24)), k[2]);
-      s3 = xor3(x3, and_xor(mask, k[7], rotl32(d3, 24)), k[3]);
+      s0 = xor3(x0, and_xor(mask, kc[4], d0), kc[0]);
+      s1 = xor3(x1, and_xor(mask, kc[5], d1), kc[1]);
+      s2 = xor3(x2, and_xor(mask, kc[6], d2), kc[2]);
+      s3 = xor3(x3, and_xor(mask, kc[7], d3), kc[3]);
     } else {
-      s0 = xor3(x0, rotl32(d0, 24), k[0]);
-      s1 = xor3(x1, rotl32(d1, 24), k[1]);
-      s2 = xor3(x2, rotl32(d2, 24), k[2]);
-      s3 = xor3(x3, rotl32(d3, 24), k[3]);
+      s0 = xor3(x0, d0, kc[0]);
+      s1 = xor3(x1, d1, kc[1]);
+      s2 = xor3(x2, d2, kc[2]);
+      s3 = xor3(x3, d3, kc[3]);
     }
+#pragma unroll
+    for (int j = 0; j < RS; ++j) kc[j] = knx[j];
   }
-  // Last round: S-box only (byte 1 of a Te0 entry is S), ShiftRows, AddRoundKey, then ^ in.
+  // Last round: S-box only, ShiftRows, AddRoundKey, then ^ in.
   {
-    const uint32_t* k = key + RS * 10 + round_anchor(s0);
-    uint32_t a0 = te<0>(L, s0), a1 = te<0>(L, s1), a2 = te<0>(L, s2), a3 = te<0>(L, s3);
-    uint32_t b0 = te<1>(L, s1), b1 = te<1>(L, s2), b2 = te<1>(L, s3), b3 = te<1>(L, s0);
-    uint32_t c0 = te<2>(L, s2), c1 = te<2>(L, s3), c2 = te<2>(L, s0), c3 = te<2>(L, s1);
-    uint32_t d0 = te<3>(L, s3), d1 = te<3>(L, s0), d2 = te<3>(L, s1), d3 = te<3>(L, s2);
-    // p = S(a) | S(b) << 8 ; q = S(c) << 16 | S(d) << 24   (perm: bytes 4-7 = src0, 0-3 = src1)
+    const uint32_t* k = kc;
+#if FSS_T4
+    // T2 has S in byte 0, T3 in byte 1, T0 in byte 2, T1 in byte 3: each lookup already
+    // holds its S-box byte in place; three bitwise selects assemble the column.
+    uint32_t a0 = lk<0, 2>(L, s0), a1 = lk<0, 2>(L, s1), a2 = lk<0, 2>(L, s2), a3 = lk<0, 2>(L, s3);
+    uint32_t b0 = lk<1, 3>(L, s1), b1 = lk<1, 3>(L, s2), b2 = lk<1, 3>(L, s3), b3 = lk<1, 3>(L, s0);
+    uint32_t c0 = lk<2, 0>(L, s2), c1 = lk<2, 0>(L, s3), c2 = lk<2, 0>(L, s0), c3 = lk<2, 0>(L, s1);
+    uint32_t d0 = lk<3, 1>(L, s3), d1 = lk<3, 1>(L, s0), d2 = lk<3, 1>(L, s1), d3 = lk<3, 1>(L, s2);
+#define FSS_COL(a, b, c, d)                                                           \
+  __builtin_amdgcn_bitop3_b32(L.m_ffff, __builtin_amdgcn_bitop3_b32(L.m_00ff, a, b, kSelect), \
+                              __builtin_amdgcn_bitop3_b32(L.m_ff0000, c, d, kSelect), kSelect)
+    uint32_t p0 = FSS_COL(a0, b0, c0, d0), p1 = FSS_COL(a1, b1, c1, d1), p2 = FSS_COL(a2, b2, c2, d2),
+             p3 = FSS_COL(a3, b3, c3, d3);
+#undef FSS_COL
+#else
+    uint32_t a0 = lk<0, 0>(L, s0), a1 = lk<0, 0>(L, s1), a2 = lk<0, 0>(L, s2), a3 = lk<0, 0>(L, s3);
+    uint32_t b0 = lk<1, 0>(L, s1), b1 = lk<1, 0>(L, s2), b2 = lk<1, 0>(L, s3), b3 = lk<1, 0>(L, s0);
+    uint32_t c0 = lk<2, 0>(L, s2), c1 = lk<2, 0>(L, s3), c2 = lk<2, 0>(L, s0), c3 = lk<2, 0>(L, s1);
+    uint32_t d0 = lk<3, 0>(L, s3), d1 = lk<3, 0>(L, s0), d2 = lk<3, 0>(L, s1), d3 = lk<3, 0>(L, s2);
+    // byte 1 of a Te0 entry is S: p = S(a) | S(b) << 8 ; q = S(c) << 16 | S(d) << 24
     constexpr uint32_t selp = 0x0c0c0501u, selq = 0x05010c0cu;
     uint32_t p0 = __builtin_amdgcn_perm(b0, a0, selp), q0 = __builtin_amdgcn_perm(d0, c0, selq);
     uint32_t p1 = __builtin_amdgcn_perm(b1, a1, selp), q1 = __builtin_amdgcn_perm(d1, c1, selq);
     uint32_t p2 = __builtin_amdgcn_perm(b2, a2, selp), q2 = __builtin_amdgcn_perm(d2, c2, selq);
     uint32_t p3 = __builtin_amdgcn_perm(b3, a3, selp), q3 = __builtin_amdgcn_perm(d3, c3, selq);
+#endif
+#if !FSS_T4
+    p0 ^= q0; p1 ^= q1; p2 ^= q2; p3 ^= q3;
+#endif
     if (SEL) {
-      out[0] = xor3(xor3(p0, q0, in[0]), mask & k[4], k[0]);
-      out[1] = xor3(xor3(p1, q1, in[1]), mask & k[5], k[1]);
-      out[2] = xor3(xor3(p2, q2, in[2]), mask & k[6], k[2]);
-      out[3] = xor3(xor3(p3, q3, in[3]), mask & k[7], k[3]);
+      out[0] = xor3(and_xor(mask, k[4], p0), in[0], k[0]);
+      out[1] = xor3(and_xor(mask, k[5], p1), in[1], k[1]);
+      out[2] = xor3(and_xor(mask, k[6], p2), in[2], k[2]);
+      out[3] = xor3(and_xor(mask, k[7], p3), in[3], k[3]);
     } else {
-      out[0] = xor3(p0, q0, in[0]) ^ k[0];
-      out[1] = xor3(p1, q1, in[1]) ^ k[1];
-      out[2] = xor3(p2, q2, in[2]) ^ k[2];
-      out[3] = xor3(p3, q3, in[3]) ^ k[3];
+      out[0] = xor3(p0, in[0], k[0]);
+      out[1] = xor3(p1, in[1], k[1]);
+      out[2] = xor3(p2, in[2], k[2]);
+      out[3] = xor3(p3, in[3], k[3]);
     }
   }
 }

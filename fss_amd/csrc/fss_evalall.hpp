@@ -114,17 +114,14 @@ __device__ __forceinline__ uint4 ht_convert(const Lds& L, const DevCtx* __restri
 // path is `prefix` (p bits).  Same walk as point evaluation, but the node (and the
 // DCF running value) is stored instead of converted.
 template <int SCHEME>
-__global__ __launch_bounds__(256) void frontier_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+__global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                        const uint32_t* __restrict__ k_seed,
                                                        const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  FSS_LDS_PROLOGUE(te0);
   const int depth = a.level0;  // p + top
   const int64_t nout = (int64_t)1 << top;
-  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nout; j += (int64_t)gridDim.x * 256) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t path = (top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j;
     uint32_t s0[4] = {k_seed[0], k_seed[1], k_seed[2], k_seed[3]};
     if constexpr (SCHEME == S_DCF) {
@@ -171,11 +168,8 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
                                                     const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
                                                     const uint32_t* __restrict__ k_ocw,  // Half-Tree
                                                     ExpandArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  FSS_LDS_PROLOGUE(te0);
   const int g = a.group, party = a.party;
 
   constexpr int NN = 1 << D;

@@ -6,15 +6,12 @@
 namespace fssamd {
 
 // out[i*mul + j] = AES_{key j}(seeds[i]) ^ seeds[i]   (include/fss/prg/aes128_mmo.cuh:79-89)
-__global__ __launch_bounds__(256) void prg_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, int mul,
+__global__ __launch_bounds__(1024) void prg_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, int mul,
                                                       const uint4* __restrict__ seeds, int64_t n,
                                                       uint4* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+  FSS_LDS_PROLOGUE(te0);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint4 s = seeds[i];
     uint32_t in[4] = {s.x, s.y, s.z, s.w};
     for (int j = 0; j < mul; ++j) {
@@ -78,14 +75,11 @@ __device__ __forceinline__ uint4 mk4(const uint32_t d[4]) { return make_uint4(d[
 
 // fss::Dpf::Gen (include/fss/dpf.cuh:93-159) and fss::Dcf::Gen (include/fss/dcf.cuh:108-194).
 template <int SCHEME>
-__global__ __launch_bounds__(256) void gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+__global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  FSS_LDS_PROLOGUE(te0);
   const int n = a.in_bits, g = a.group;
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * 256) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t s0[4], s1[4], beta[4];
     ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
     s0[3] &= ~1u; s1[3] &= ~1u; beta[3] &= ~1u;
@@ -99,10 +93,15 @@ __global__ __launch_bounds__(256) void gen_kernel(const DevCtx K, const uint32_t
       uint32_t s0l[4], s0r[4], s1l[4], s1r[4];
       uint32_t v0l[4], v0r[4], v1l[4], v1r[4];
       if (SCHEME == S_DCF) {
+        // two blocks at a time: eight interleaved AES states do not fit 128 VGPRs
         aes_mmo<false>(L, c->rk[0], 0, s0, s0l); aes_mmo<false>(L, c->rk[1], 0, s0, v0l);
+        __builtin_amdgcn_sched_barrier(0);
         aes_mmo<false>(L, c->rk[2], 0, s0, s0r); aes_mmo<false>(L, c->rk[3], 0, s0, v0r);
+        __builtin_amdgcn_sched_barrier(0);
         aes_mmo<false>(L, c->rk[0], 0, s1, s1l); aes_mmo<false>(L, c->rk[1], 0, s1, v1l);
+        __builtin_amdgcn_sched_barrier(0);
         aes_mmo<false>(L, c->rk[2], 0, s1, s1r); aes_mmo<false>(L, c->rk[3], 0, s1, v1r);
+        __builtin_amdgcn_sched_barrier(0);
         v0l[3] &= ~1u; v0r[3] &= ~1u; v1l[3] &= ~1u; v1r[3] &= ~1u;
       } else {
         aes_mmo<false>(L, c->rk[0], 0, s0, s0l); aes_mmo<false>(L, c->rk[1], 0, s0, s0r);
@@ -176,19 +175,16 @@ __global__ __launch_bounds__(256) void gen_kernel(const DevCtx K, const uint32_t
 }
 
 // fss::HalfTreeDpf::Gen (include/fss/half_tree_dpf.cuh:68-175).
-__global__ __launch_bounds__(256) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
+__global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  FSS_LDS_PROLOGUE(te0);
   const int n = a.in_bits, g = a.group;
   auto hash = [&](const uint32_t node[4], uint32_t h[4]) {
     uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                       node[3] ^ c->hash_key[3]};
     aes_mmo<false>(L, c->rk[0], 0, in, h);
   };
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * 256) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t n0[4], n1[4], beta[4];
     ld4(n0, a.s0s[2 * k]); ld4(n1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
     n0[3] &= ~1u; n1[3] |= 1u; beta[3] &= ~1u;

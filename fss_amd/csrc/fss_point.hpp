@@ -174,11 +174,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_cws,   // raw Cw slots
                                                          const uint32_t* __restrict__ k_ocw,   // Half-Tree
                                                          EvalArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  FSS_LDS_PROLOGUE(te0);
 
   const int in_bits = a.in_bits, party = a.party, g = a.group;
   const int64_t T = (int64_t)gridDim.x * BS;
@@ -314,11 +311,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 // ExpandTreeRec's (grotto_dcf.cuh:201-222).  Independent keys, level-major.
 template <int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_te[256 * 64];
   const DevCtx* c = &K;
-  lds_table_fill(lds_te, te0);
-  __syncthreads();
-  Lds L{reinterpret_cast<const uint8_t*>(lds_te), (threadIdx.x & 63u) * 4u};
+  FSS_LDS_PROLOGUE(te0);
   const int n = a.in_bits;
   uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
   for (int64_t k = (int64_t)blockIdx.x * BS + threadIdx.x; k < a.n; k += (int64_t)gridDim.x * BS) {

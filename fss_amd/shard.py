@@ -1,0 +1,54 @@
+"""Sharding of an evaluation job across the GPUs of one node.
+
+The points x keys batch and the EvalAll sub-domains are independent, so the data path
+has no collective: rank r evaluates its slice and keeps the outputs on its GPU.  The
+only exchange on this path is Grotto's EvalAll, whose running XOR crosses shard
+boundaries: each rank needs the parity of all leaves before its block -- one byte per
+rank, all-gathered (torch.distributed; RCCL on GPUs, gloo in the CPU tests).
+"""
+
+
+def batch_slice(n, rank, world):
+    """Contiguous [lo, hi) of an n-element batch for `rank`; sizes differ by at most 1."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def domain_block(in_bits, rank, world):
+    """(first_leaf, nleaves) of rank's EvalAll block: world must be a power of two no larger
+    than the domain; rank owns the subtree whose path is its log2(world)-bit prefix."""
+    if world < 1 or world & (world - 1) or not (0 <= rank < world):
+        raise ValueError("world must be a power of two")
+    if world > (1 << in_bits):
+        raise ValueError("more ranks than leaves")
+    nleaves = (1 << in_bits) // world
+    return rank * nleaves, nleaves
+
+
+def grotto_carries(last_bits):
+    """Exclusive XOR scan of the per-shard parities (the last running-XOR byte of each
+    shard computed with carry-in 0) -> carry-in of every shard."""
+    out, acc = [], 0
+    for b in last_bits:
+        out.append(acc)
+        acc ^= int(b) & 1
+    return out
+
+
+def grotto_fix_shard(ys_local, dist=None):
+    """ys_local: this rank's EvalAll block (uint8 running XOR with carry-in 0).  All-gathers the
+    shard parities and applies this rank's carry in place.  With dist=None it is a no-op."""
+    import torch
+    if dist is None or dist.get_world_size() == 1:
+        return ys_local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = ys_local[-1:].to(torch.uint8).clone()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    carry = grotto_carries([int(p.item()) for p in parts])[rank]
+    if carry:
+        ys_local ^= 1
+    return ys_local
