@@ -89,12 +89,12 @@ bool x_ok(int in_bits, int x_bytes) {
 
 // Tunables (env, read once): FSS_AMD_ILP in {1,2}, FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU.
 struct Tune {
-  int ilp = 1, bs = 1024, wgs_per_cu = 0;
+  int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
   Tune() {
     if (const char* e = getenv("FSS_AMD_ILP")) ilp = atoi(e);
     if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
     if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
-    if (ilp != 1 && ilp != 2) ilp = 1;
+    if (ilp != 1 && ilp != 2) ilp = 2;
     if (bs != 256 && bs != 512 && bs != 1024) bs = 1024;
   }
 };

@@ -157,6 +157,9 @@ __device__ __forceinline__ uint32_t lk(const Lds& L, uint32_t w) {
     constexpr uint32_t sel = 0x0c020000u | ((4u + K) << 8);
     addr = __builtin_amdgcn_perm(w, L.lo[T], sel);
   }
+#if defined(FSS_EXP_NOLDS)
+  return addr;
+#endif
   return *reinterpret_cast<const uint32_t*>(L.tab + addr);
 #else
   constexpr uint32_t sel = 0x0c0c0000u | ((4u + K) << 8);
@@ -192,7 +195,9 @@ __device__ __forceinline__ uint32_t lane_anchor(uint32_t dep) {
 
 // Pointer to the key words of round r, readable one round at a time.
 __device__ __forceinline__ const uint32_t* round_key(const Lds& L, const uint32_t* key, int word, uint32_t dep) {
-#if FSS_VKEYS
+#if defined(FSS_EXP_NOKEYLOAD)
+  return key;  // timing experiment only (wrong results): every round uses round 0's key, loaded once
+#elif FSS_VKEYS
   return L.gk + (key - L.kbase) + word + lane_anchor(dep);
 #else
   return key + word + round_anchor(dep);
@@ -292,6 +297,158 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
       out[3] = xor3(p3, in[3], k[3]);
     }
   }
+}
+
+// ---- two interleaved AES streams ------------------------------------------------
+// A single stream alternates "16 lookups in flight" and "VALU on the 16 results": within a wave
+// the LDS latency is dead time, and with the 128 KiB tables only 4 waves share a SIMD.  aes_mmo2
+// runs two independent blocks A and B half a round apart:
+//     load A | VALU(B) + next addresses(B) | wait | load B | VALU(A) + next addresses(A) | wait | ...
+// so each stream's lookups fly while the other stream's ~96 issue cycles of VALU run.  At every
+// wait exactly one stream (and its round-key scalar load) is outstanding, so `lgkmcnt(0)` is the
+// exact wait; the waits are explicit and fenced with sched_barrier so the compiler keeps the
+// order (its own waitcnt pass then has nothing left to insert).
+template <int K, int T>
+__device__ __forceinline__ uint32_t lk_addr(const Lds& L, uint32_t w) {
+#if FSS_T4
+  if (K == 1) return __builtin_amdgcn_bitop3_b32(w, L.m_ff00, L.lo[T], kAndOr);
+  constexpr uint32_t sel = 0x0c020000u | ((4u + K) << 8);
+  return __builtin_amdgcn_perm(w, L.lo[T], sel);
+#else
+  constexpr uint32_t sel = 0x0c0c0000u | ((4u + K) << 8);
+  return __builtin_amdgcn_perm(w, L.lo, sel);
+#endif
+}
+
+// Addresses of the 16 lookups of one round: [0..3] byte 0 of s0..s3, [4..7] byte 1 of s1,s2,s3,s0,
+// [8..11] byte 2 of s2,s3,s0,s1, [12..15] byte 3 of s3,s0,s1,s2.  LAST picks the tables that hold
+// S in the output byte position.
+template <bool LAST>
+__device__ __forceinline__ void aes_addr16(const Lds& L, const uint32_t s[4], uint32_t ad[16]) {
+#if FSS_T4
+  constexpr int T0 = LAST ? 2 : 0, T1 = LAST ? 3 : 1, T2 = LAST ? 0 : 2, T3 = LAST ? 1 : 3;
+#else
+  constexpr int T0 = 0, T1 = 0, T2 = 0, T3 = 0;
+#endif
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ad[j] = lk_addr<0, T0>(L, s[j]);
+    ad[4 + j] = lk_addr<1, T1>(L, s[(j + 1) & 3]);
+    ad[8 + j] = lk_addr<2, T2>(L, s[(j + 2) & 3]);
+    ad[12 + j] = lk_addr<3, T3>(L, s[(j + 3) & 3]);
+  }
+}
+
+__device__ __forceinline__ void aes_load16(const Lds& L, const uint32_t ad[16], uint32_t v[16]) {
+#pragma unroll
+#if defined(FSS_EXP_NOLDS)
+  for (int j = 0; j < 16; ++j) v[j] = ad[j];  // timing experiment only: no lookups
+#else
+  for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const uint32_t*>(L.tab + ad[j]);
+#endif
+}
+
+template <bool SEL>
+__device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k, uint32_t mask, uint32_t s[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#if FSS_T4
+    uint32_t x = xor3(v[j], v[4 + j], v[8 + j]), d = v[12 + j];
+#else
+    uint32_t x = xor3(v[j], rotl32(v[4 + j], 8), rotl32(v[8 + j], 16)), d = rotl32(v[12 + j], 24);
+#endif
+    s[j] = SEL ? xor3(x, and_xor(mask, k[4 + j], d), k[j]) : xor3(x, d, k[j]);
+  }
+}
+
+template <bool SEL>
+__device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], const uint32_t* k, uint32_t mask,
+                                        const uint32_t in[4], uint32_t out[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#if FSS_T4
+    uint32_t p = __builtin_amdgcn_bitop3_b32(L.m_ffff, __builtin_amdgcn_bitop3_b32(L.m_00ff, v[j], v[4 + j], kSelect),
+                                             __builtin_amdgcn_bitop3_b32(L.m_ff0000, v[8 + j], v[12 + j], kSelect),
+                                             kSelect);
+#else
+    uint32_t p = __builtin_amdgcn_perm(v[4 + j], v[j], 0x0c0c0501u) ^ __builtin_amdgcn_perm(v[12 + j], v[8 + j], 0x05010c0cu);
+#endif
+    out[j] = SEL ? xor3(and_xor(mask, k[4 + j], p), in[j], k[j]) : xor3(p, in[j], k[j]);
+  }
+}
+
+#define FSS_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define FSS_DRAIN_LGKM()                  \
+  do {                                    \
+    FSS_FENCE();                          \
+    __builtin_amdgcn_s_waitcnt(0xC07F);   \
+    FSS_FENCE();                          \
+  } while (0)
+
+// outA = AES_{keyA}(inA) ^ inA and outB = AES_{keyB}(inB) ^ inB, interleaved.  keyA / keyB and
+// maskA / maskB as for aes_mmo<SEL>; they may be the same or different key schedules.
+template <bool SEL>
+__device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restrict__ keyA,
+                                         const uint32_t* __restrict__ keyB, uint32_t maskA, uint32_t maskB,
+                                         const uint32_t inA[4], const uint32_t inB[4], uint32_t outA[4],
+                                         uint32_t outB[4]) {
+  constexpr int RS = SEL ? 8 : 4;
+  uint32_t sA[4], sB[4], vA[16], vB[16], kA[RS], kB[RS];
+  {
+    const uint32_t* k0 = round_key(L, keyA, 0, inA[0]);
+    const uint32_t* k1 = round_key(L, keyB, 0, inB[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sA[j] = SEL ? xor3(inA[j], k0[j], maskA & k0[4 + j]) : (inA[j] ^ k0[j]);
+      sB[j] = SEL ? xor3(inB[j], k1[j], maskB & k1[4 + j]) : (inB[j] ^ k1[j]);
+    }
+  }
+  aes_addr16<false>(L, sA, vA);
+  FSS_FENCE();
+  {
+    const uint32_t* kn = round_key(L, keyA, RS, sA[0]);
+    aes_load16(L, vA, vA);
+#pragma unroll
+    for (int j = 0; j < RS; ++j) kA[j] = kn[j];
+  }
+  FSS_FENCE();
+  aes_addr16<false>(L, sB, vB);
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    FSS_DRAIN_LGKM();  // A's round-r lookups and keys have landed; nothing else is outstanding
+    {
+      const uint32_t* kn = round_key(L, keyB, RS * r, sB[0]);
+      aes_load16(L, vB, vB);
+#pragma unroll
+      for (int j = 0; j < RS; ++j) kB[j] = kn[j];
+    }
+    FSS_FENCE();
+    aes_mix<SEL>(vA, kA, maskA, sA);  // B's lookups fly during A's VALU
+    if (r < 9) aes_addr16<false>(L, sA, vA);
+    else aes_addr16<true>(L, sA, vA);
+    FSS_DRAIN_LGKM();  // B's round-r lookups and keys
+    {
+      const uint32_t* kn = round_key(L, keyA, RS * (r + 1), sA[0]);
+      aes_load16(L, vA, vA);
+#pragma unroll
+      for (int j = 0; j < RS; ++j) kA[j] = kn[j];
+    }
+    FSS_FENCE();
+    aes_mix<SEL>(vB, kB, maskB, sB);
+    if (r < 9) aes_addr16<false>(L, sB, vB);
+    else aes_addr16<true>(L, sB, vB);
+  }
+  FSS_DRAIN_LGKM();  // A's last-round lookups
+  {
+    const uint32_t* kn = round_key(L, keyB, RS * 10, sB[0]);
+    aes_load16(L, vB, vB);
+#pragma unroll
+    for (int j = 0; j < RS; ++j) kB[j] = kn[j];
+  }
+  FSS_FENCE();
+  aes_fin<SEL>(L, vA, kA, maskA, inA, outA);
+  FSS_DRAIN_LGKM();
+  aes_fin<SEL>(L, vB, kB, maskB, inB, outB);
 }
 
 // ------------------------------------------------------------------ output groups

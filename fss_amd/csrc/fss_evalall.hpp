@@ -42,8 +42,7 @@ __device__ __forceinline__ void dpf_expand(const Lds& L, const DevCtx* __restric
                                            const uint32_t st[4], uint32_t left[4], uint32_t right[4]) {
   uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
-  aes_mmo<false>(L, c->rk[0], 0, in, left);
-  aes_mmo<false>(L, c->rk[1], 0, in, right);
+  aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, in, in, left, right);  // both children, interleaved
   uint32_t wl = cw[3], wr = (cw[3] & ~1u) | (cw[4] & 1u);
   left[0] = and_xor(tm, cw[0], left[0]);   right[0] = and_xor(tm, cw[0], right[0]);
   left[1] = and_xor(tm, cw[1], left[1]);   right[1] = and_xor(tm, cw[1], right[1]);
@@ -59,10 +58,8 @@ __device__ __forceinline__ void dcf_expand(const Lds& L, const DevCtx* __restric
   uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
   uint32_t bl[4], br[4];
-  aes_mmo<false>(L, c->rk[0], 0, in, left);
-  aes_mmo<false>(L, c->rk[1], 0, in, bl);
-  aes_mmo<false>(L, c->rk[2], 0, in, right);
-  aes_mmo<false>(L, c->rk[3], 0, in, br);
+  aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, in, in, left, bl);
+  aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, in, in, right, br);
   bl[3] &= ~1u; br[3] &= ~1u;
   uint32_t vcw[4] = {cw[4], cw[5], cw[6], cw[7] & ~1u};
   vl = v; vl.add(g, bl); vl.add_if(g, tm, vcw);

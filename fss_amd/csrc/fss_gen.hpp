@@ -94,18 +94,14 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
       uint32_t v0l[4], v0r[4], v1l[4], v1r[4];
       if (SCHEME == S_DCF) {
         // two blocks at a time: eight interleaved AES states do not fit 128 VGPRs
-        aes_mmo<false>(L, c->rk[0], 0, s0, s0l); aes_mmo<false>(L, c->rk[1], 0, s0, v0l);
-        __builtin_amdgcn_sched_barrier(0);
-        aes_mmo<false>(L, c->rk[2], 0, s0, s0r); aes_mmo<false>(L, c->rk[3], 0, s0, v0r);
-        __builtin_amdgcn_sched_barrier(0);
-        aes_mmo<false>(L, c->rk[0], 0, s1, s1l); aes_mmo<false>(L, c->rk[1], 0, s1, v1l);
-        __builtin_amdgcn_sched_barrier(0);
-        aes_mmo<false>(L, c->rk[2], 0, s1, s1r); aes_mmo<false>(L, c->rk[3], 0, s1, v1r);
-        __builtin_amdgcn_sched_barrier(0);
+        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s0, s0, s0l, v0l);
+        aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, s0, s0, s0r, v0r);
+        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s1, s1, s1l, v1l);
+        aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, s1, s1, s1r, v1r);
         v0l[3] &= ~1u; v0r[3] &= ~1u; v1l[3] &= ~1u; v1r[3] &= ~1u;
       } else {
-        aes_mmo<false>(L, c->rk[0], 0, s0, s0l); aes_mmo<false>(L, c->rk[1], 0, s0, s0r);
-        aes_mmo<false>(L, c->rk[0], 0, s1, s1l); aes_mmo<false>(L, c->rk[1], 0, s1, s1r);
+        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s0, s0, s0l, s0r);
+        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s1, s1, s1l, s1r);
       }
       const uint32_t t0l = s0l[3] & 1u, t0r = s0r[3] & 1u, t1l = s1l[3] & 1u, t1r = s1r[3] & 1u;
       s0l[3] &= ~1u; s0r[3] &= ~1u; s1l[3] &= ~1u; s1r[3] &= ~1u;

@@ -24,6 +24,12 @@ struct EvalArgs {
   const uint64_t* tr_bits;  // DPF / Grotto
   const uint4* out_cw;      // DPF / DCF: cws[in_bits]; Half-Tree: ocw per key
   const uint32_t* extra;    // Half-Tree
+  // Shared-prefix start (one shared key only): the 2^start_level nodes of tree level
+  // start_level, expanded once per launch; evaluation i starts from node xs[i] >> (in_bits - start_level)
+  // instead of the root.  start_level = 0 / pre_nodes = nullptr: plain root-to-leaf walk.
+  int start_level;
+  const uint4* pre_nodes;
+  const uint4* pre_v;       // DCF: running group value of every node
 };
 
 __device__ __forceinline__ uint32_t bit_mask(uint64_t x, int pos) {  // 0 or ~0
@@ -53,11 +59,28 @@ struct DpfWalk {
     st[3] = (s0[3] & ~1u) | (uint32_t)party;  // dpf.cuh:171-173
     x = x_;
   }
+  __device__ __forceinline__ void resume(uint4 node, uint64_t x_) {
+    st[0] = node.x; st[1] = node.y; st[2] = node.z; st[3] = node.w;
+    x = x_;
+  }
   __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i, const CwDpf& cw) {
     uint32_t m = bit_mask(x, in_bits - 1 - i);  // dpf.cuh:196
     uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
     uint32_t o[4];
     aes_mmo<true>(L, &c->sel01[0][0], m, in, o);  // dpf.cuh:182, taken child only
+    apply(m, o, cw);
+  }
+  // Two walks, one level, the two AES blocks interleaved (aes_mmo2).
+  static __device__ __forceinline__ void level2(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i,
+                                                DpfWalk& a, const CwDpf& cwa, DpfWalk& b, const CwDpf& cwb) {
+    uint32_t ma = bit_mask(a.x, in_bits - 1 - i), mb = bit_mask(b.x, in_bits - 1 - i);
+    uint32_t ia[4] = {a.st[0], a.st[1], a.st[2], a.st[3] & ~1u}, ib[4] = {b.st[0], b.st[1], b.st[2], b.st[3] & ~1u};
+    uint32_t oa[4], ob[4];
+    aes_mmo2<true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob);
+    a.apply(ma, oa, cwa);
+    b.apply(mb, ob, cwb);
+  }
+  __device__ __forceinline__ void apply(uint32_t m, const uint32_t o[4], const CwDpf& cw) {
     uint32_t tm = lsb_mask(st[3]);
     // bit 0 of o[3] is tl/tr; bit 0 of the word below is tl_cw/tr_cw: one XOR does
     // both the seed and the control-bit correction (dpf.cuh:189-194).
@@ -92,13 +115,18 @@ struct DcfWalk {
     st[3] = (s0[3] & ~1u) | (uint32_t)party;
     x = x_;
   }
+  __device__ __forceinline__ void resume(uint4 node, uint4 val, uint64_t x_) {
+    st[0] = node.x; st[1] = node.y; st[2] = node.z; st[3] = node.w;
+    v.v[0] = val.x; v.v[1] = val.y; v.v[2] = val.z; v.v[3] = val.w;
+    x = x_;
+  }
   __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int g, int in_bits, int i,
                                         const CwDcf& cw) {
     uint32_t m = bit_mask(x, in_bits - 1 - i);
     uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
     uint32_t os[4], ov[4];
-    aes_mmo<true>(L, &c->sel02[0][0], m, in, os);  // sl (key 0) or sr (key 2), dcf.cuh:223
-    aes_mmo<true>(L, &c->sel13[0][0], m, in, ov);  // vl (key 1) or vr (key 3)
+    // sl (key 0) or sr (key 2), and vl (key 1) or vr (key 3): dcf.cuh:223, two interleaved blocks
+    aes_mmo2<true>(L, &c->sel02[0][0], &c->sel13[0][0], m, m, in, in, os, ov);
     uint32_t tm = lsb_mask(st[3]);
     ov[3] &= ~1u;  // dcf.cuh:227,232
     v.add(g, ov);  // dcf.cuh:244-252 (signs applied once in finish)
@@ -127,6 +155,24 @@ struct HtWalk {
     node[0] = s0[0]; node[1] = s0[1]; node[2] = s0[2];
     node[3] = (s0[3] & ~1u) | (uint32_t)party;
     x = x_;
+  }
+  __device__ __forceinline__ void resume(uint4 n, uint64_t x_) {
+    node[0] = n.x; node[1] = n.y; node[2] = n.z; node[3] = n.w;
+    x = x_;
+  }
+  static __device__ __forceinline__ void level2(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i,
+                                                HtWalk& a, const uint32_t cwa[4], HtWalk& b, const uint32_t cwb[4]) {
+    uint32_t ma = bit_mask(a.x, in_bits - 1 - i), mb = bit_mask(b.x, in_bits - 1 - i);
+    uint32_t ta = lsb_mask(a.node[3]), tb = lsb_mask(b.node[3]);
+    uint32_t ia[4], ib[4], ha[4], hb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ia[j] = a.node[j] ^ c->hash_key[j]; ib[j] = b.node[j] ^ c->hash_key[j]; }
+    aes_mmo2<false>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a.node[j] = and_xor(ma, a.node[j], and_xor(ta, cwa[j], ha[j]));
+      b.node[j] = and_xor(mb, b.node[j], and_xor(tb, cwb[j], hb[j]));
+    }
   }
   // levels 0 .. in_bits-2
   __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i, const uint32_t cw[4]) {
@@ -178,6 +224,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   FSS_LDS_PROLOGUE(te0);
 
   const int in_bits = a.in_bits, party = a.party, g = a.group;
+  const int lvl0 = SHARED ? a.start_level : 0;
   const int64_t T = (int64_t)gridDim.x * BS;
   const int64_t n = a.n;
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
@@ -198,6 +245,9 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+        if constexpr (SHARED) {
+          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
+        }
       }
       uint64_t trb[ILP];
       if constexpr (!SHARED) {
@@ -205,20 +255,21 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         for (int j = 0; j < ILP; ++j) trb[j] = a.tr_bits[idx[j]];
       }
 #pragma unroll 1
-      for (int i = 0; i < in_bits; ++i) {
+      for (int i = lvl0; i < in_bits; ++i) {
+        CwDpf cw[ILP];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
-          CwDpf cw;
           if constexpr (SHARED) {
             const uint32_t* p = k_cws + 8 * i;
-            cw.x = p[0]; cw.y = p[1]; cw.z = p[2]; cw.wl = p[3]; cw.tr = p[4];
+            cw[j].x = p[0]; cw[j].y = p[1]; cw[j].z = p[2]; cw[j].wl = p[3]; cw[j].tr = p[4];
           } else {
             uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
-            cw.x = t.x; cw.y = t.y; cw.z = t.z; cw.wl = t.w;
-            cw.tr = (uint32_t)(trb[j] >> i);
+            cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
+            cw[j].tr = (uint32_t)(trb[j] >> i);
           }
-          w[j].level(L, c, in_bits, i, cw);
         }
+        if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1]);
+        else w[0].level(L, c, in_bits, i, cw[0]);
       }
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {
@@ -236,9 +287,15 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+        if constexpr (SHARED) {
+          if (lvl0 > 0) {
+            const uint64_t q = (w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
+            w[j].resume(a.pre_nodes[q], a.pre_v[q], w[j].x);
+          }
+        }
       }
 #pragma unroll 1
-      for (int i = 0; i < in_bits; ++i) {
+      for (int i = lvl0; i < in_bits; ++i) {
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
           CwDcf cw;
@@ -271,16 +328,20 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+        if constexpr (SHARED) {
+          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
+        }
       }
 #pragma unroll 1
-      for (int i = 0; i < in_bits - 1; ++i) {
+      for (int i = lvl0; i < in_bits - 1; ++i) {
+        uint32_t cw[ILP][4];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
-          uint32_t cw[4];
-          if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * i; cw[0] = p[0]; cw[1] = p[1]; cw[2] = p[2]; cw[3] = p[3]; }
-          else { uint4 t = a.cw_s[(int64_t)i * n + idx[j]]; cw[0] = t.x; cw[1] = t.y; cw[2] = t.z; cw[3] = t.w; }
-          w[j].level(L, c, in_bits, i, cw);
+          if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * i; cw[j][0] = p[0]; cw[j][1] = p[1]; cw[j][2] = p[2]; cw[j][3] = p[3]; }
+          else { uint4 t = a.cw_s[(int64_t)i * n + idx[j]]; cw[j][0] = t.x; cw[j][1] = t.y; cw[j][2] = t.z; cw[j][3] = t.w; }
         }
+        if constexpr (ILP == 2) HtWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1]);
+        else w[0].level(L, c, in_bits, i, cw[0]);
       }
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {

@@ -121,6 +121,38 @@ class Engine:
         _lib.check(rc, "eval_points")
         return ys
 
+    def eval_points_shared(self, scheme, in_bits, group, party, seed, cws, xs, ocw=None, out=None, prefix_bits=None):
+        """eval_points with the shared top of the tree expanded once per launch (same outputs).
+        prefix_bits=None picks ~log2(len(xs)), capped by in_bits and 26."""
+        seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
+        n = xs.numel()
+        if prefix_bits is None:
+            prefix_bits = max(1, min(in_bits - (1 if scheme == HT else 0), 26, max(n, 2).bit_length() - 1))
+        if prefix_bits < 1:
+            return self.eval_points(scheme, in_bits, group, party, seed, cws, xs, ocw=ocw, out=out)
+        L, st = self._L, self._stream()
+        ws_bytes = L.fss_amd_eval_points_workspace(scheme, in_bits, prefix_bits)
+        if ws_bytes == 0:
+            raise ValueError(f"eval_points_shared: unsupported prefix_bits={prefix_bits} for in_bits={in_bits}")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
+        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        xb = self._xbytes(xs, in_bits)
+        if scheme == DPF:
+            rc = L.fss_amd_dpf_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
+                                                  _ptr(ys), prefix_bits, _ptr(ws), ws_bytes, st)
+        elif scheme == DCF:
+            rc = L.fss_amd_dcf_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
+                                                  _ptr(ys), prefix_bits, _ptr(ws), ws_bytes, st)
+        elif scheme == HT:
+            ocw = self._dev(ocw, torch.int32)
+            rc = L.fss_amd_ht_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(ocw),
+                                                 _ptr(xs), xb, n, _ptr(ys), prefix_bits, _ptr(ws), ws_bytes, st)
+        else:
+            raise ValueError("scheme")
+        _lib.check(rc, "eval_points_shared")
+        ws.record_stream(torch.cuda.current_stream(self.device))
+        return ys
+
     # ------------------------------------------------------------ relayout + independent keys
     def relayout(self, scheme, in_bits, cws):
         """cws: int32[nkeys, slots, 8] key-major raw Cw slots -> LevelMajorKeys."""

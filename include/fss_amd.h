@@ -87,6 +87,26 @@ int fss_amd_dcf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party,
 int fss_amd_ht_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
                            const void *ocw, const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
 
+/* ---- the same, with the shared top of the tree expanded once per launch ------------------
+ * All points of one key walk the same top levels.  These entry points first expand the top
+ * `prefix_bits` levels of the key's tree (2^prefix_bits nodes, 2 AES each for DPF -- the
+ * EvalAll expansion) into `workspace`, then every point starts from its depth-prefix_bits
+ * ancestor and walks only the remaining in_bits - prefix_bits levels.  Outputs are identical
+ * to fss_amd_*_eval_points; AES work drops from in_bits to about
+ * (in_bits - prefix_bits) + 2^(prefix_bits+1) / npoints per point (prefix_bits ~ log2(npoints)
+ * is the sweet spot).  1 <= prefix_bits <= min(in_bits, 26) (Half-Tree: <= in_bits - 1).
+ * workspace: device scratch of at least fss_amd_eval_points_workspace() bytes. */
+size_t fss_amd_eval_points_workspace(int scheme, int in_bits, int prefix_bits);
+int fss_amd_dpf_eval_points_shared(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed,
+                                   const void *cws, const void *xs, int x_bytes, int64_t npoints, void *ys,
+                                   int prefix_bits, void *workspace, size_t workspace_bytes, void *stream);
+int fss_amd_dcf_eval_points_shared(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed,
+                                   const void *cws, const void *xs, int x_bytes, int64_t npoints, void *ys,
+                                   int prefix_bits, void *workspace, size_t workspace_bytes, void *stream);
+int fss_amd_ht_eval_points_shared(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed,
+                                  const void *cws, const void *ocw, const void *xs, int x_bytes, int64_t npoints,
+                                  void *ys, int prefix_bits, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- key relayout: key-major Cw slots -> level-major arrays --------------------
  * Replaces fss::gpu::{Dpf,Dcf,HalfTreeDpf}RelayoutGpu
  * (include/fss/point_eval_gpu.cuh:324-375).  cws: device, key-major, stride

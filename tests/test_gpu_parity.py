@@ -126,6 +126,44 @@ def test_eval_points_vs_oracle(engine, O, scheme, n, g):
         assert (got == want).all(), (scheme, n, g, b, np.argwhere(got != want)[:4])
 
 
+@pytest.mark.parametrize("k", [1, 4, 11, 12, 13, 16])
+@pytest.mark.parametrize("scheme,n,g", [(DPF, 32, G.U64), (DPF, 17, G.BYTES), (DCF, 32, G.U64), (DCF, 20, G.U128),
+                                        (HT, 64, G.U64), (HT, 18, G.BYTES)])
+def test_eval_points_shared_prefix_vs_oracle(engine, O, scheme, n, g, k):
+    """Expanding the shared top k levels once must not change a single output bit."""
+    rng = SplitMix64(555 + 1000 * scheme + 10 * n + k)
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), beta_for(rng)
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 1, s, alpha, beta)
+    else:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    xs = edge_xs(rng, n, alpha, 500)
+    for b in (0, 1):
+        want = O.eval_points(p, scheme, n, g, b, s[b], cws, np.array(xs, dtype=np.uint64), ocw=ocw, nthreads=4)
+        got = engine.eval_points_shared(scheme, n, g, b, T(s[b]), T(cws), xs_tensor(xs, n),
+                                        ocw=None if ocw is None else T(ocw), prefix_bits=k).cpu().numpy()
+        assert (got == want).all(), (scheme, n, g, b, k)
+
+
+def test_eval_points_shared_prefix_full_size(engine):
+    """2^22 points, automatic prefix: identical to the plain walk."""
+    n, g = 32, G.U64
+    import fss_amd
+    d = fss_amd.Dpf(n, "u64", engine=engine)
+    gen = torch.Generator().manual_seed(5)
+    s0s = torch.randint(-2**31, 2**31, (2, 4), dtype=torch.int32, generator=gen)
+    cws = d.gen(s0s, 0x1234567, torch.tensor([9, 8, 7, 6], dtype=torch.int32))
+    xs = torch.randint(-2**31, 2**31, (1 << 22,), dtype=torch.int32, generator=gen).cuda()
+    a = engine.eval_points(DPF, n, g, 1, s0s[1], cws, xs)
+    b = engine.eval_points_shared(DPF, n, g, 1, s0s[1], cws, xs)
+    assert bool((a == b).all())
+
+
 def test_eval_points_empty(engine):
     out = engine.eval_points(DPF, 16, G.BYTES, 0, torch.zeros(4, dtype=torch.int32),
                              torch.zeros((17, 8), dtype=torch.int32), torch.zeros(0, dtype=torch.int32))
