@@ -126,17 +126,18 @@ struct SharedKey {
   const uint32_t *seed = nullptr, *cws = nullptr, *ocw = nullptr;
 };
 
-template <int SCHEME, bool SHARED>
+template <int SCHEME, bool SHARED, bool PREFIX = false>
 int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
   if (a.n == 0) return FSS_AMD_OK;
   const int ilp = tune().ilp, bs = tune().bs;
   int64_t thr = (a.n + ilp - 1) / ilp;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                    \
-  return launch_persistent(ctx, eval_points_kernel<SCHEME, SHARED, I, B>, name, B, thr, st, ctx->host, ctx->te0, \
+  return launch_persistent(ctx, eval_points_kernel<SCHEME, SHARED, I, B, PREFIX>, name, B, thr, st, ctx->host, ctx->te0, \
                            k.seed, k.cws, k.ocw, a)
   FSS_L(1, 1024);
   FSS_L(2, 1024);
+  if constexpr (PREFIX) return FSS_AMD_EINVAL;
   FSS_L(1, 512);
   FSS_L(2, 512);
   FSS_L(1, 256);

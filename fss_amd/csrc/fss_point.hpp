@@ -214,7 +214,9 @@ struct HtWalk {
 // K (by value), and the shared key's seed / cws / ocw as __restrict__ kernel
 // arguments, are wave-uniform and provably not clobbered by the ys stores, so they
 // are read with scalar loads.
-template <int SCHEME, bool SHARED, int ILP, int BS>
+// PREFIX: start every walk from the level-`start_level` node table (shared-prefix entry points);
+// a separate instantiation so profiles tell the two paths apart.
+template <int SCHEME, bool SHARED, int ILP, int BS, bool PREFIX = false>
 __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                          const uint32_t* __restrict__ k_seed,  // uint32[4]
                                                          const uint32_t* __restrict__ k_cws,   // raw Cw slots
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   FSS_LDS_PROLOGUE(te0);
 
   const int in_bits = a.in_bits, party = a.party, g = a.group;
-  const int lvl0 = SHARED ? a.start_level : 0;
+  const int lvl0 = PREFIX ? a.start_level : 0;
   const int64_t T = (int64_t)gridDim.x * BS;
   const int64_t n = a.n;
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
-        if constexpr (SHARED) {
+        if constexpr (PREFIX) {
           if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
         }
       }
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
-        if constexpr (SHARED) {
+        if constexpr (PREFIX) {
           if (lvl0 > 0) {
             const uint64_t q = (w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
             w[j].resume(a.pre_nodes[q], a.pre_v[q], w[j].x);
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
-        if constexpr (SHARED) {
+        if constexpr (PREFIX) {
           if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
         }
       }

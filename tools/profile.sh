@@ -4,6 +4,7 @@
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${1:-r1}"
 OUT="$R/gpurun_out/prof_$TAG"
+rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu --steps 5 --warmup 1"
@@ -22,7 +23,7 @@ res = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if "eval_points_kernel" in row["Kernel_Name"] or "expand_kernel" in row["Kernel_Name"]:
+        if any(t in row["Kernel_Name"] for t in ("eval_points_kernel", "expand_kernel", "frontier_kernel")):
             agg[(row["Kernel_Name"].split("(")[0], row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (k, c), v in agg.items():
         res.setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
