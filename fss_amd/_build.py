@@ -27,3 +27,20 @@ def build(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return SO
+
+
+SAMPLE_SRC = os.path.join(_HERE, "..", "samples", "dpf_dcf_gpu.cpp")
+SAMPLE_BIN = os.path.join(_HERE, "..", "samples", "dpf_dcf_gpu")
+
+
+def build_sample(force=False):
+    """Compile the C++ sample (include/fss_amd.hpp over the C ABI) against libfss_amd.so."""
+    build()
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("fss_amd.h", "fss_amd.hpp")]
+    if (not force and os.path.exists(SAMPLE_BIN)
+            and os.path.getmtime(SAMPLE_BIN) >= max(os.path.getmtime(f) for f in [SAMPLE_SRC, SO] + hdrs)):
+        return SAMPLE_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(_HERE, "..", "include"),
+                           SAMPLE_SRC, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../fss_amd", "-o", SAMPLE_BIN])
+    return SAMPLE_BIN

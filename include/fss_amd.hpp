@@ -1,0 +1,263 @@
+// fss_amd.hpp -- C++ host layer over the C ABI (fss_amd.h), spelled like the reference's
+// template surface so that code written against myl7/fss's batched GPU launchers ports by
+// changing includes.  Header-only; link with libfss_amd.so and the HIP runtime.
+//
+//   fss::prg::Aes128Mmo<mul>          <- include/fss/prg/aes128_mmo.cuh:27-95 (key material; here it
+//                                        owns the engine context instead of OpenSSL EVP contexts)
+//   fss::group::Bytes / Uint<T, mod>  <- include/fss/group/bytes.cuh, uint.cuh (type tags: the group
+//                                        arithmetic runs in the kernels)
+//   fss::Dpf / Dcf / HalfTreeDpf      <- include/fss/dpf.cuh:61-81, dcf.cuh:74-96,
+//                                        half_tree_dpf.cuh:39-57 (same template parameters, `prg`
+//                                        member, 32-byte `Cw`; methods are the batched device forms)
+//   fss::gpu::*RelayoutGpu, *EvalPointGpu, *EvalAllGpu
+//                                     <- include/fss/point_eval_gpu.cuh:324-491,
+//                                        include/fss/eval_all_gpu.cuh:451-535
+// Differences from the reference, all forced by the engine: every pointer is a device pointer;
+// the DPF tr bits are uint64_t per key (the reference packs 32 levels into uint32_t); EvalAll
+// takes a workspace; errors throw fss::Error instead of being ignored.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+
+#include "fss_amd.h"
+
+namespace fss {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(const char* what, int c) : std::runtime_error(std::string(what) + ": " + fss_amd_strerror(c)), code(c) {}
+};
+inline void Check(int rc, const char* what) {
+  if (rc != FSS_AMD_OK) throw Error(what, rc);
+}
+
+namespace group {
+struct Bytes {
+  static constexpr int kId = FSS_AMD_GROUP_BYTES;
+};
+template <typename T, unsigned __int128 mod = 0>
+struct Uint {
+  static_assert(std::is_unsigned_v<T> || std::is_same_v<T, unsigned __int128>);
+  static_assert(sizeof(T) < 16 || mod == (static_cast<unsigned __int128>(1) << 127),
+                "Uint<__uint128_t> is built for mod = 2^127 only");
+  static_assert(sizeof(T) == 16 || mod == 0, "modular Uint<T, mod> below 128 bits is not built");
+  static constexpr int kId = sizeof(T) == 1   ? FSS_AMD_GROUP_U8
+                             : sizeof(T) == 2 ? FSS_AMD_GROUP_U16
+                             : sizeof(T) == 4 ? FSS_AMD_GROUP_U32
+                             : sizeof(T) == 8 ? FSS_AMD_GROUP_U64
+                                              : FSS_AMD_GROUP_U128_M127;
+};
+}  // namespace group
+
+enum class DcfPred { kLt = FSS_AMD_PRED_LT, kGt = FSS_AMD_PRED_GT };  // include/fss/dcf.cuh:58-61
+
+namespace prg {
+// AES-128-MMO key material.  mul = number of PRG outputs a scheme uses (DPF/Grotto 2, DCF 4,
+// Half-Tree 1); key i produces output i.  Copyable handle (shared ownership of the context).
+template <int mul>
+class Aes128Mmo {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+
+ public:
+  // keys: mul pointers to 16-byte AES keys, as Aes128Mmo::CreateCtxs takes them (aes128_mmo.cuh:49).
+  explicit Aes128Mmo(const unsigned char* const keys[mul], int device = 0, const int32_t hash_key[4] = nullptr) {
+    uint8_t k[64] = {};
+    for (int i = 0; i < mul; ++i) std::memcpy(k + 16 * i, keys[i], 16);
+    fss_amd_ctx* c = nullptr;
+    Check(fss_amd_ctx_create(&c, device, k, hash_key), "fss_amd_ctx_create");
+    ctx_ = std::shared_ptr<fss_amd_ctx>(c, fss_amd_ctx_destroy);
+  }
+  fss_amd_ctx* handle() const { return ctx_.get(); }
+  // out[i * mul + j] = AES_{key j}(seeds[i]) ^ seeds[i]   (Aes128Mmo::Gen, aes128_mmo.cuh:72-93)
+  void Gen(const int4* d_seeds, int64_t n, int4* d_out, hipStream_t stream = 0) const {
+    Check(fss_amd_prg_gen(handle(), mul, d_seeds, n, d_out, stream), "fss_amd_prg_gen");
+  }
+
+ private:
+  std::shared_ptr<fss_amd_ctx> ctx_;
+};
+}  // namespace prg
+
+namespace detail {
+template <typename In>
+constexpr int XBytes() {
+  static_assert(sizeof(In) == 4 || sizeof(In) == 8, "In must be uint32_t or uint64_t");
+  return (int)sizeof(In);
+}
+}  // namespace detail
+
+// ---------------------------------------------------------------- DPF
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
+class Dpf {
+  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+
+ public:
+  Prg prg;
+  struct alignas(32) Cw {  // include/fss/dpf.cuh:76-81
+    int4 s;
+    bool tr;
+  };
+  static_assert(sizeof(Cw) == 32);
+  static constexpr int kSlots = in_bits + 1;
+
+  // nkeys keys at once: s0s[2k], s0s[2k+1] are the party seeds of key k; cws is key-major,
+  // kSlots slots per key (Dpf::Gen, dpf.cuh:93-159, one key per GPU lane).
+  void Gen(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+           hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
+                          d_cws, stream), "fss_amd_dpf_gen");
+  }
+  // ys[i] = Eval(b, *d_s0, d_cws, xs[i])   (Dpf::Eval, dpf.cuh:170-214, for a whole batch of x)
+  void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
+                  hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n,
+                                  d_ys, stream), "fss_amd_dpf_eval_points");
+  }
+  static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
+    return fss_amd_eval_all_workspace(FSS_AMD_DPF, in_bits, nleaves);
+  }
+  // ys[j] = Eval(b, *d_s0, d_cws, first_leaf + j)   (Dpf::EvalAll, dpf.cuh:232-303)
+  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, int4* d_ys, void* d_workspace, size_t ws_bytes,
+               int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, first_leaf, nleaves, d_ys,
+                               d_workspace, ws_bytes, stream), "fss_amd_dpf_eval_all");
+  }
+};
+
+// ---------------------------------------------------------------- DCF
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t, DcfPred pred = DcfPred::kLt>
+class Dcf {
+  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+
+ public:
+  Prg prg;
+  struct alignas(32) Cw {  // include/fss/dcf.cuh:91-96
+    int4 s;
+    int4 v;
+  };
+  static_assert(sizeof(Cw) == 32);
+  static constexpr int kSlots = in_bits + 1;
+
+  void Gen(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+           hipStream_t stream = 0) const {
+    Check(fss_amd_dcf_gen(prg.handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
+                          nkeys, d_cws, stream), "fss_amd_dcf_gen");
+  }
+  void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
+                  hipStream_t stream = 0) const {
+    Check(fss_amd_dcf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n,
+                                  d_ys, stream), "fss_amd_dcf_eval_points");
+  }
+  static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
+    return fss_amd_eval_all_workspace(FSS_AMD_DCF, in_bits, nleaves);
+  }
+  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, int4* d_ys, void* d_workspace, size_t ws_bytes,
+               int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
+    Check(fss_amd_dcf_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, first_leaf, nleaves, d_ys,
+                               d_workspace, ws_bytes, stream), "fss_amd_dcf_eval_all");
+  }
+};
+
+// ---------------------------------------------------------------- Half-Tree DPF
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
+class HalfTreeDpf {
+  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+
+ public:
+  Prg prg;  // its context carries hash_key (HalfTreeDpf::hash_key, half_tree_dpf.cuh:45)
+  struct alignas(32) Cw {  // include/fss/half_tree_dpf.cuh:53-57
+    int4 s;
+    bool extra;
+  };
+  static_assert(sizeof(Cw) == 32);
+  static constexpr int kSlots = in_bits;
+
+  void Gen(Cw* d_cws, int4* d_ocws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+           hipStream_t stream = 0) const {
+    Check(fss_amd_ht_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
+                         d_cws, d_ocws, stream), "fss_amd_ht_gen");
+  }
+  void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, const In* d_xs, int4* d_ys, int64_t n,
+                  hipStream_t stream = 0) const {
+    Check(fss_amd_ht_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, d_xs, detail::XBytes<In>(),
+                                 n, d_ys, stream), "fss_amd_ht_eval_points");
+  }
+  static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
+    return fss_amd_eval_all_workspace(FSS_AMD_HT, in_bits, nleaves);
+  }
+  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, int4* d_ys, void* d_workspace,
+               size_t ws_bytes, int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits,
+               hipStream_t stream = 0) const {
+    Check(fss_amd_ht_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, first_leaf, nleaves, d_ys,
+                              d_workspace, ws_bytes, stream), "fss_amd_ht_eval_all");
+  }
+};
+
+// ---------------------------------------------------------------- fss::gpu launchers
+namespace gpu {
+
+// include/fss/point_eval_gpu.cuh:346-353 (extra -> 64-bit tr_bits)
+template <int in_bits, typename Group, typename Prg, typename In>
+void DpfRelayoutGpu(const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s, uint64_t* tr_bits,
+                    int4* out_cw, const Dpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
+  Check(fss_amd_dpf_relayout(dpf.prg.handle(), in_bits, cws, nkeys, cw_s, tr_bits, out_cw, stream), "dpf_relayout");
+}
+// :368-375
+template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred>
+void DcfRelayoutGpu(const typename Dcf<in_bits, Group, Prg, In, pred>::Cw* cws, int64_t nkeys, int4* cw_s, int4* cw_v,
+                    int4* out_cw, const Dcf<in_bits, Group, Prg, In, pred>& dcf, hipStream_t stream = 0) {
+  Check(fss_amd_dcf_relayout(dcf.prg.handle(), in_bits, cws, nkeys, cw_s, cw_v, out_cw, stream), "dcf_relayout");
+}
+// :324-331
+template <int in_bits, typename Group, typename Prg, typename In>
+void HalfTreeDpfRelayoutGpu(const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s,
+                            uint32_t* extra, const HalfTreeDpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
+  Check(fss_amd_ht_relayout(dpf.prg.handle(), in_bits, cws, nkeys, cw_s, extra, stream), "ht_relayout");
+}
+
+// :448-460  ys[k] = Dpf::Eval(b, seeds[k], key k, xs[k])
+template <int in_bits, typename Group, typename Prg, typename In>
+void DpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* out_cw,
+                     const In* xs, int4* ys, int64_t nkeys, const Dpf<in_bits, Group, Prg, In>& dpf,
+                     hipStream_t stream = 0) {
+  Check(fss_amd_dpf_eval_keys(dpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, out_cw, xs,
+                              detail::XBytes<In>(), nkeys, ys, stream), "dpf_eval_keys");
+}
+// :479-491
+template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred>
+void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw_v, const int4* out_cw, const In* xs,
+                     int4* ys, int64_t nkeys, const Dcf<in_bits, Group, Prg, In, pred>& dcf, hipStream_t stream = 0) {
+  Check(fss_amd_dcf_eval_keys(dcf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs,
+                              detail::XBytes<In>(), nkeys, ys, stream), "dcf_eval_keys");
+}
+// :416-429
+template <int in_bits, typename Group, typename Prg, typename In>
+void HalfTreeDpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra, const int4* ocws,
+                             const In* xs, int4* ys, int64_t nkeys, const HalfTreeDpf<in_bits, Group, Prg, In>& dpf,
+                             hipStream_t stream = 0) {
+  Check(fss_amd_ht_eval_keys(dpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs,
+                             detail::XBytes<In>(), nkeys, ys, stream), "ht_eval_keys");
+}
+
+// include/fss/eval_all_gpu.cuh:478-488 (s0 and cws on the device; workspace from Dpf::EvalAllWorkspace)
+template <int in_bits, typename Group, typename Prg, typename In>
+void DpfEvalAllGpu(bool b, const int4* d_s0, const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int4* ys,
+                   void* workspace, size_t ws_bytes, const Dpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
+  dpf.EvalAll(b, d_s0, cws, ys, workspace, ws_bytes, 0, int64_t(1) << in_bits, stream);
+}
+// :451-461
+template <int in_bits, typename Group, typename Prg, typename In>
+void HalfTreeDpfEvalAllGpu(bool b, const int4* d_s0, const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws,
+                           const int4* d_ocw, int4* ys, void* workspace, size_t ws_bytes,
+                           const HalfTreeDpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
+  dpf.EvalAll(b, d_s0, cws, d_ocw, ys, workspace, ws_bytes, 0, int64_t(1) << in_bits, stream);
+}
+
+}  // namespace gpu
+}  // namespace fss

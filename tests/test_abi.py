@@ -66,3 +66,9 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".inc", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), (dirpath, f)
+
+
+def test_cxx_layer_compiles():
+    """include/fss_amd.hpp (the fss::Dpf / fss::gpu::* mirror) and the sample build with hipcc."""
+    from fss_amd import _build
+    assert os.path.exists(_build.build_sample())

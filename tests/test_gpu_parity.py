@@ -388,3 +388,14 @@ def test_full_size_half_tree_keys_reconstruct(engine, O):
     want0 = O.eval_keys(p, HT, n, g, 0, s0s[:, 0].numpy()[idx], cws.cpu().numpy()[idx],
                         xs.numpy().view(np.uint64)[idx], ocws=ocws.cpu().numpy()[idx], nthreads=4)
     assert (y[0].cpu().numpy()[idx] == want0).all()
+
+
+def test_cxx_sample_self_check():
+    """samples/dpf_dcf_gpu.cpp: device Gen -> relayout -> EvalPointGpu for both parties through
+    include/fss_amd.hpp, reconstructing beta (the reference's samples/dpf_dcf_gpu.cu:155-162,227-234)."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_sample()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 mismatches" in r.stdout and "OK" in r.stdout
