@@ -39,6 +39,8 @@ PROTOTYPES = {
     "fss_amd_dpf_eval_all": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "fss_amd_dcf_eval_all": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "fss_amd_ht_eval_all": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "fss_amd_grotto_preprocess": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fss_amd_grotto_eval_table": (_i, [_vp, _i, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_grotto_eval_all": (_i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "fss_amd_grotto_eval_keys": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_dpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),

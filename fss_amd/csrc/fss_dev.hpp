@@ -349,7 +349,8 @@ __device__ __forceinline__ void aes_load16(const Lds& L, const uint32_t ad[16], 
 }
 
 template <bool SEL>
-__device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k, uint32_t mask, uint32_t s[4]) {
+__device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k, const uint32_t* kd, uint32_t mask,
+                                        uint32_t s[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #if FSS_T4
@@ -357,13 +358,13 @@ __device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k,
 #else
     uint32_t x = xor3(v[j], rotl32(v[4 + j], 8), rotl32(v[8 + j], 16)), d = rotl32(v[12 + j], 24);
 #endif
-    s[j] = SEL ? xor3(x, and_xor(mask, k[4 + j], d), k[j]) : xor3(x, d, k[j]);
+    s[j] = SEL ? xor3(x, and_xor(mask, kd[j], d), k[j]) : xor3(x, d, k[j]);
   }
 }
 
 template <bool SEL>
-__device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], const uint32_t* k, uint32_t mask,
-                                        const uint32_t in[4], uint32_t out[4]) {
+__device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], const uint32_t* k, const uint32_t* kd,
+                                        uint32_t mask, const uint32_t in[4], uint32_t out[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #if FSS_T4
@@ -373,7 +374,7 @@ __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], cons
 #else
     uint32_t p = __builtin_amdgcn_perm(v[4 + j], v[j], 0x0c0c0501u) ^ __builtin_amdgcn_perm(v[12 + j], v[8 + j], 0x05010c0cu);
 #endif
-    out[j] = SEL ? xor3(and_xor(mask, k[4 + j], p), in[j], k[j]) : xor3(p, in[j], k[j]);
+    out[j] = SEL ? xor3(and_xor(mask, kd[j], p), in[j], k[j]) : xor3(p, in[j], k[j]);
   }
 }
 
@@ -387,13 +388,17 @@ __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], cons
 
 // outA = AES_{keyA}(inA) ^ inA and outB = AES_{keyB}(inB) ^ inB, interleaved.  keyA / keyB and
 // maskA / maskB as for aes_mmo<SEL>; they may be the same or different key schedules.
-template <bool SEL>
+// RESD (two-key schedules only, keyA == keyB): the 44 (rkA ^ rkB) words come from `kdv`, registers
+// loaded once per kernel, so half of the key operands are VGPRs (2-cycle issue instead of 4).
+template <bool SEL, bool RESD = false>
 __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restrict__ keyA,
                                          const uint32_t* __restrict__ keyB, uint32_t maskA, uint32_t maskB,
                                          const uint32_t inA[4], const uint32_t inB[4], uint32_t outA[4],
-                                         uint32_t outB[4]) {
+                                         uint32_t outB[4], const uint32_t* kdv = nullptr) {
   constexpr int RS = SEL ? 8 : 4;
-  uint32_t sA[4], sB[4], vA[16], vB[16], kA[RS], kB[RS];
+  constexpr int RL = (SEL && !RESD) ? 8 : 4;  // words fetched per main round by the scalar loads
+  // kdv covers rounds 1..9 (36 words); rounds 0 and 10 read the D words from the scalar copy.
+  uint32_t sA[4], sB[4], vA[16], vB[16], kA[RL], kB[RL];
   {
     const uint32_t* k0 = round_key(L, keyA, 0, inA[0]);
     const uint32_t* k1 = round_key(L, keyB, 0, inB[0]);
@@ -409,7 +414,7 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
     const uint32_t* kn = round_key(L, keyA, RS, sA[0]);
     aes_load16(L, vA, vA);
 #pragma unroll
-    for (int j = 0; j < RS; ++j) kA[j] = kn[j];
+    for (int j = 0; j < RL; ++j) kA[j] = kn[j];
   }
   FSS_FENCE();
   aes_addr16<false>(L, sB, vB);
@@ -420,10 +425,10 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
       const uint32_t* kn = round_key(L, keyB, RS * r, sB[0]);
       aes_load16(L, vB, vB);
 #pragma unroll
-      for (int j = 0; j < RS; ++j) kB[j] = kn[j];
+      for (int j = 0; j < RL; ++j) kB[j] = kn[j];
     }
     FSS_FENCE();
-    aes_mix<SEL>(vA, kA, maskA, sA);  // B's lookups fly during A's VALU
+    aes_mix<SEL>(vA, kA, RESD ? kdv + 4 * (r - 1) : kA + 4, maskA, sA);  // B's lookups fly during A's VALU
     if (r < 9) aes_addr16<false>(L, sA, vA);
     else aes_addr16<true>(L, sA, vA);
     FSS_DRAIN_LGKM();  // B's round-r lookups and keys
@@ -431,24 +436,25 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
       const uint32_t* kn = round_key(L, keyA, RS * (r + 1), sA[0]);
       aes_load16(L, vA, vA);
 #pragma unroll
-      for (int j = 0; j < RS; ++j) kA[j] = kn[j];
+      for (int j = 0; j < RL; ++j) kA[j] = kn[j];
     }
     FSS_FENCE();
-    aes_mix<SEL>(vB, kB, maskB, sB);
+    aes_mix<SEL>(vB, kB, RESD ? kdv + 4 * (r - 1) : kB + 4, maskB, sB);
     if (r < 9) aes_addr16<false>(L, sB, vB);
     else aes_addr16<true>(L, sB, vB);
   }
+  uint32_t kLA[RS], kLB[RS];  // last-round keys, all RS words from the scalar copy
   FSS_DRAIN_LGKM();  // A's last-round lookups
   {
     const uint32_t* kn = round_key(L, keyB, RS * 10, sB[0]);
+    const uint32_t* kna = round_key(L, keyA, RS * 10, sB[1]);
     aes_load16(L, vB, vB);
 #pragma unroll
-    for (int j = 0; j < RS; ++j) kB[j] = kn[j];
+    for (int j = 0; j < RS; ++j) { kLB[j] = kn[j]; kLA[j] = kna[j]; }
   }
-  FSS_FENCE();
-  aes_fin<SEL>(L, vA, kA, maskA, inA, outA);
   FSS_DRAIN_LGKM();
-  aes_fin<SEL>(L, vB, kB, maskB, inB, outB);
+  aes_fin<SEL>(L, vA, kLA, kLA + 4, maskA, inA, outA);
+  aes_fin<SEL>(L, vB, kLB, kLB + 4, maskB, inB, outB);
 }
 
 // ------------------------------------------------------------------ output groups

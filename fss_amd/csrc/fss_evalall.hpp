@@ -324,4 +324,34 @@ __global__ __launch_bounds__(256) void grotto_chunk_scan_kernel(uint8_t* __restr
   }
 }
 
+// GrottoDcf::Preprocess phase 2a (grotto_dcf.cuh:100-103): one tree level, p[j] = p[2j+1] ^ p[2j+2].
+__global__ __launch_bounds__(256) void grotto_tree_level_kernel(uint8_t* __restrict__ p, int64_t first, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    int64_t j = first + i;
+    p[j] = p[2 * j + 1] ^ p[2 * j + 2];
+  }
+}
+
+// GrottoDcf::Eval (grotto_dcf.cuh:116-135): prefix-parity walk over the table, one point per lane.
+__global__ __launch_bounds__(256) void grotto_table_eval_kernel(const uint8_t* __restrict__ p, int in_bits,
+                                                               const void* __restrict__ xs, int x_bytes, int64_t n,
+                                                               uint8_t* __restrict__ ys) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    uint64_t x = x_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t*>(xs)[i] : reinterpret_cast<const uint64_t*>(xs)[i];
+    uint64_t e = x + 1;
+    uint32_t pi;
+    if (e == (1ull << in_bits)) {
+      pi = p[0];
+    } else {
+      pi = 0;
+      uint64_t cur = 0;
+      for (int l = 0; l < in_bits; ++l) {
+        if ((e >> (in_bits - 1 - l)) & 1) { pi ^= p[2 * cur + 1]; cur = 2 * cur + 2; }
+        else cur = 2 * cur + 1;
+      }
+    }
+    ys[i] = (uint8_t)(pi & 1u);
+  }
+}
+
 }  // namespace fssamd

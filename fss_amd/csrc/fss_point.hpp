@@ -7,6 +7,12 @@
 #pragma once
 #include "fss_dev.hpp"
 
+// FSS_RESD = 1 (experiment, measured 1 % slower: the extra 36 registers spill at the 128-VGPR cap of
+// 16 waves/CU): the DPF two-stream walk keeps the (rk0 ^ rk1) words of rounds 1..9 in VGPRs.
+#ifndef FSS_RESD
+#define FSS_RESD 0
+#endif
+
 namespace fssamd {
 
 struct EvalArgs {
@@ -72,11 +78,16 @@ struct DpfWalk {
   }
   // Two walks, one level, the two AES blocks interleaved (aes_mmo2).
   static __device__ __forceinline__ void level2(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i,
-                                                DpfWalk& a, const CwDpf& cwa, DpfWalk& b, const CwDpf& cwb) {
+                                                DpfWalk& a, const CwDpf& cwa, DpfWalk& b, const CwDpf& cwb,
+                                                const uint32_t* kdv) {
     uint32_t ma = bit_mask(a.x, in_bits - 1 - i), mb = bit_mask(b.x, in_bits - 1 - i);
     uint32_t ia[4] = {a.st[0], a.st[1], a.st[2], a.st[3] & ~1u}, ib[4] = {b.st[0], b.st[1], b.st[2], b.st[3] & ~1u};
     uint32_t oa[4], ob[4];
+#if FSS_RESD
+    aes_mmo2<true, true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob, kdv);
+#else
     aes_mmo2<true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob);
+#endif
     a.apply(ma, oa, cwa);
     b.apply(mb, ob, cwb);
   }
@@ -240,6 +251,13 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
     }
 
     if constexpr (SCHEME == S_DPF) {
+      uint32_t kdv[36];  // (rk0 ^ rk1) of rounds 1..9, resident (FSS_RESD); dead otherwise
+#if FSS_RESD
+      if constexpr (ILP == 2) {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) kdv[q] = vconst(c->sel01[1 + (q >> 2)][4 + (q & 3)]);
+      }
+#endif
       DpfWalk w[ILP];
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {
@@ -270,7 +288,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
             cw[j].tr = (uint32_t)(trb[j] >> i);
           }
         }
-        if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1]);
+        if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1], kdv);
         else w[0].level(L, c, in_bits, i, cw[0]);
       }
 #pragma unroll

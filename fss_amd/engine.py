@@ -233,6 +233,29 @@ class Engine:
         ws.record_stream(torch.cuda.current_stream(self.device))
         return ys
 
+    # ------------------------------------------------------------ Grotto parity table
+    def grotto_preprocess(self, in_bits, party, seed, cws):
+        """GrottoDcf::Preprocess: uint8[2N-1] parity tree (device)."""
+        seed, cws = self._dev(seed, torch.int32), self._dev(cws, torch.int32)
+        N = 1 << in_bits
+        L, st = self._L, self._stream()
+        ws_bytes = L.fss_amd_eval_all_workspace(GROTTO, in_bits, N) + N
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
+        pt = torch.empty((2 * N - 1,), dtype=torch.uint8, device=self.device)
+        _lib.check(L.fss_amd_grotto_preprocess(self._h, in_bits, party, _ptr(seed), _ptr(cws), _ptr(pt), _ptr(ws),
+                                               ws_bytes, st), "grotto_preprocess")
+        ws.record_stream(torch.cuda.current_stream(self.device))
+        return pt
+
+    def grotto_eval_table(self, in_bits, pt, xs, out=None):
+        """GrottoDcf::Eval over a batch: uint8[n]."""
+        pt, xs = self._dev(pt, torch.uint8), self._dev(xs)
+        n = xs.numel()
+        ys = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.fss_amd_grotto_eval_table(self._h, in_bits, _ptr(pt), _ptr(xs), self._xbytes(xs, in_bits), n,
+                                                     _ptr(ys), self._stream()), "grotto_eval_table")
+        return ys
+
     # ------------------------------------------------------------ key generation
     def gen(self, scheme, in_bits, group, s0s, alphas, betas, pred=0):
         """s0s int32[n,2,4], alphas int32/int64[n], betas int32[n,4] -> (cws int32[n,slots,8], ocws|None)."""

@@ -233,6 +233,17 @@ class GrottoDcf(_Base):
                                   nleaves=nleaves)
         return self._back(ys, s0)
 
+    def preprocess(self, party, s0, cws):
+        """= GrottoDcf::Preprocess (grotto_dcf.cuh:94-104): the ParityTree table, uint8[2^(in_bits+1) - 1]."""
+        validate_party(party)
+        validate_s0(s0)
+        validate_cws(cws, self.in_bits)
+        return self.engine.grotto_preprocess(self.in_bits, party, s0, cws)
+
+    def eval(self, pt, xs):
+        """= GrottoDcf::Eval (grotto_dcf.cuh:116-135) for a batch of x: uint8[n] shares of 1[alpha <= x]."""
+        return self.engine.grotto_eval_table(self.in_bits, pt, xs)
+
     def eval_keys(self, party, seeds, keys, xs):
         """Path-walk shares for independent keys (any in_bits <= 64); see include/fss_amd.h."""
         validate_party(party)

@@ -168,6 +168,15 @@ int fss_amd_ht_eval_all(fss_amd_ctx *ctx, int in_bits, int group, int party, con
  * XOR of the control bits of the left siblings along the path of x+1.  It
  * reconstructs the same predicate; its per-party share is NOT the table-based
  * GrottoDcf::Eval share (grotto_dcf.cuh:116-135), see DESIGN.md. */
+/* GrottoDcf::Preprocess (grotto_dcf.cuh:94-104): pt = 2N-1 bytes (ParityTree::p, N = 2^in_bits): the leaf
+ * control bits in pt[N-1 .. 2N-2] and the parity segment tree above them.  workspace: at least
+ * fss_amd_eval_all_workspace(FSS_AMD_GROTTO, in_bits, N) + N bytes.
+ * GrottoDcf::Eval (grotto_dcf.cuh:116-135): ys[i] = prefix parity of pt over [0, xs[i]]; bit-exact with the
+ * reference's table walk per party. */
+int fss_amd_grotto_preprocess(fss_amd_ctx *ctx, int in_bits, int party, const void *seed, const void *cws, void *pt,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int fss_amd_grotto_eval_table(fss_amd_ctx *ctx, int in_bits, const void *pt, const void *xs, int x_bytes,
+                              int64_t npoints, void *ys_bytes, void *stream);
 int fss_amd_grotto_eval_all(fss_amd_ctx *ctx, int in_bits, int party, const void *seed, const void *cws,
                             int64_t first_leaf, int64_t nleaves, void *ys_bytes, void *workspace,
                             size_t workspace_bytes, void *stream);

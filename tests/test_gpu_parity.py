@@ -274,6 +274,66 @@ def test_eval_all_subblocks(engine, O, scheme):
         assert (got == whole[first:first + nl]).all(), (scheme, nl, first)
 
 
+def test_eval_all_deep_prefix_block(engine, O):
+    """A small block far into a 40-bit domain: 28 prefix levels walked, 64-bit leaf indices."""
+    n, g = 40, G.U64
+    rng = SplitMix64(77777)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    nl = 1 << 12
+    first = (0xABCDE12 << 12)
+    alpha = first + 1234  # inside the block
+    beta = beta_for(rng)
+    cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    xs = np.arange(first, first + nl, dtype=np.uint64)
+    for b in (0, 1):
+        want = O.eval_points(p, DPF, n, g, b, s[b], cws, xs, nthreads=4)
+        got = engine.eval_all(DPF, n, g, b, T(s[b]), T(cws), first_leaf=first, nleaves=nl).cpu().numpy()
+        assert (got == want).all()
+
+
+def test_eval_points_graph_capture(engine, O):
+    """The eval entry points only enqueue work: they can be captured in a HIP graph and replayed."""
+    n, g = 32, G.U64
+    rng = SplitMix64(31)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    cws = O.dpf_gen(p, n, g, s, 12345, beta_for(rng))
+    xs = xs_tensor([rng.below(n) for _ in range(5000)], n).cuda()
+    seed, cw = T(s[0]).cuda(), T(cws).cuda()
+    ys = torch.zeros((5000, 4), dtype=torch.int32, device="cuda")
+    eager = engine.eval_points(DPF, n, g, 0, seed, cw, xs).clone()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        engine.eval_points(DPF, n, g, 0, seed, cw, xs, out=ys)  # warm-up on the side stream
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            engine.eval_points(DPF, n, g, 0, seed, cw, xs, out=ys)
+    ys.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert bool((ys == eager).all())
+
+
+def test_grotto_eval_all_sharded_with_carry(engine, O):
+    """Domain-sharded Grotto EvalAll: per-block running XOR plus the parity carry of fss_amd.shard."""
+    from fss_amd import shard
+    n, world = 12, 4
+    rng = SplitMix64(4711)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    cws = O.grotto_gen(p, n, s, 1500)
+    whole = O.grotto_eval_all(p, n, 1, s[1], cws)
+    blocks = []
+    for r in range(world):
+        first, nl = shard.domain_block(n, r, world)
+        blocks.append(engine.eval_all(GROTTO, n, G.BYTES, 1, T(s[1]), T(cws), first_leaf=first, nleaves=nl).cpu().numpy())
+    carries = shard.grotto_carries([int(b[-1]) for b in blocks])
+    got = np.concatenate([b ^ c for b, c in zip(blocks, carries)])
+    assert (got == whole).all()
+
+
 # ---------------------------------------------------------------- Grotto
 @pytest.mark.parametrize("n", [1, 3, 10, 13, 16])
 def test_grotto_eval_all_vs_oracle(engine, O, n):
@@ -288,6 +348,28 @@ def test_grotto_eval_all_vs_oracle(engine, O, n):
             assert (y == O.grotto_eval_all(p, n, b, s[b], cws)).all(), (n, alpha, b)
             got.append(y)
         assert ((got[0] ^ got[1]) == (np.arange(1 << n) >= alpha)).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 14])
+def test_grotto_preprocess_and_table_eval_vs_oracle(engine, O, n):
+    """GrottoDcf::Preprocess + Eval (grotto_dcf.cuh:94-135): the table and every table lookup, per party."""
+    rng = SplitMix64(902 + n)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    for alpha in {0, (1 << n) - 1, rng.below(n)}:
+        cws = O.grotto_gen(p, n, s, alpha)
+        xs = np.arange(1 << n, dtype=np.uint64) if n <= 9 else np.array(
+            [0, (1 << n) - 1, alpha] + [rng.below(n) for _ in range(500)], dtype=np.uint64)
+        sh = []
+        for b in (0, 1):
+            want_pt = O.grotto_preprocess(p, n, b, s[b], cws)
+            pt = engine.grotto_preprocess(n, b, T(s[b]), T(cws))
+            assert (pt.cpu().numpy() == want_pt).all(), (n, alpha, b)
+            got = engine.grotto_eval_table(n, pt, xs_tensor(xs, n)).cpu().numpy()
+            want = np.array([O.grotto_eval(n, want_pt, int(x)) for x in xs], dtype=np.uint8)
+            assert (got == want).all()
+            sh.append(got)
+        assert ((sh[0] ^ sh[1]) == (xs >= alpha)).all()
 
 
 @pytest.mark.parametrize("n", [1, 16, 32, 64])
