@@ -312,6 +312,11 @@ template <int K, int T>
 __device__ __forceinline__ uint32_t lk_addr(const Lds& L, uint32_t w) {
 #if FSS_T4
   if (K == 1) return __builtin_amdgcn_bitop3_b32(w, L.m_ff00, L.lo[T], kAndOr);
+#if defined(FSS_ADDR_FAST)
+  // shift + (a & b) | c, both on the 2-cycle path, instead of one 4-cycle v_perm
+  const uint32_t sh = K == 0 ? (w << 8) : (K == 2 ? (w >> 8) : (w >> 16));
+  return __builtin_amdgcn_bitop3_b32(sh, L.m_ff00, L.lo[T], kAndOr);
+#endif
   constexpr uint32_t sel = 0x0c020000u | ((4u + K) << 8);
   return __builtin_amdgcn_perm(w, L.lo[T], sel);
 #else

@@ -242,7 +242,13 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
         if constexpr (SCHEME == S_DCF) y = vs[k];
         y.add(g, s);
         y.add_if(g, tm, oc);
+#if defined(FSS_EXP_ONE_STORE)
+        // timing experiment only: fold the leaves into one store per lane
+        uint4 yy = y.finish(g, party != 0);
+        if (k == 0) ys[ob] = yy; else if (yy.x == 0x12345u && yy.y == 7u) ys[ob + k] = yy;
+#else
         ys[ob + k] = y.finish(g, party != 0);
+#endif
       }
     }
   }

@@ -29,6 +29,9 @@ __global__ __launch_bounds__(BS) void k(const uint32_t* __restrict__ tab, uint32
 #pragma unroll
     for (int j = 0; j < NB; ++j) a[j] = a[j] ^ v[(j + 1) % NB];
   }
+  // time the WHOLE workgroup: the oldest wave of a SIMD wins issue arbitration and finishes far
+  // earlier than its younger neighbours, so one wave's own duration overstates the rate
+  __syncthreads();
   unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   uint32_t x = 0;
 #pragma unroll
