@@ -39,6 +39,23 @@ static thread_local int g_last_hip = 0;
 
 namespace {
 
+// The entry points run on the context's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    else if (err == hipSuccess) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define FSS_ON_DEVICE(ctx)             \
+  DeviceGuard guard_((ctx)->device);   \
+  HIP_TRY(guard_.err)
+
 // FIPS-197 S-box from the field inverse and the affine map.
 void make_sbox(uint8_t sbox[256]) {
   uint8_t p = 1, q = 1;
@@ -84,6 +101,7 @@ bool x_ok(int in_bits, int x_bytes) {
   if (in_bits < 1) return false;
   if (x_bytes == 4) return in_bits <= 32;
   if (x_bytes == 8) return in_bits <= 64;
+  if (x_bytes == 16) return in_bits <= 128;  // two little-endian uint64 per value (__uint128_t)
   return false;
 }
 
@@ -156,7 +174,8 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return FSS_AMD_EINVAL;
-  HIP_TRY(hipSetDevice(device));
+  DeviceGuard guard_(device);
+  HIP_TRY(guard_.err);
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
 
@@ -232,7 +251,7 @@ const char* fss_amd_last_kernel(const fss_amd_ctx* ctx, int* grid, int* block) {
 int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, void* out, void* stream) {
   if (!ctx || !seeds || !out || n < 0 || (mul != 1 && mul != 2 && mul != 4)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
+  FSS_ON_DEVICE(ctx);
   // one wave per workgroup for tiny batches (the LDS fill is per workgroup), 1024 lanes otherwise
   int bs = n <= 64 ? 64 : (n <= 256 ? 256 : 1024);
   int64_t want = (n + bs - 1) / bs;
@@ -251,7 +270,7 @@ static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, i
     return FSS_AMD_EINVAL;
   if (n > 0 && (!xs || !ys)) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !ocw) return FSS_AMD_EINVAL;
-  HIP_TRY(hipSetDevice(ctx->device));
+  FSS_ON_DEVICE(ctx);
   EvalArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;
   a.xs = xs; a.ys = ys;
@@ -282,10 +301,10 @@ int fss_amd_ht_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, 
 // ------------------------------------------------------------------ relayout
 int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
                          void* out_cw, void* stream) {
-  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 64) return FSS_AMD_EINVAL;
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !tr_bits || !out_cw) return FSS_AMD_EINVAL;
-  HIP_TRY(hipSetDevice(ctx->device));
+  FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_DPF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      (uint4*)nullptr, reinterpret_cast<uint64_t*>(tr_bits), reinterpret_cast<uint4*>(out_cw),
@@ -295,10 +314,10 @@ int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
 }
 int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* cw_v,
                          void* out_cw, void* stream) {
-  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 64) return FSS_AMD_EINVAL;
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !cw_v || !out_cw) return FSS_AMD_EINVAL;
-  HIP_TRY(hipSetDevice(ctx->device));
+  FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_DCF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      reinterpret_cast<uint4*>(cw_v), (uint64_t*)nullptr, reinterpret_cast<uint4*>(out_cw),
@@ -308,10 +327,10 @@ int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
 }
 int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* extra,
                         void* stream) {
-  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 64) return FSS_AMD_EINVAL;
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !extra) return FSS_AMD_EINVAL;
-  HIP_TRY(hipSetDevice(ctx->device));
+  FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_HT>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      (uint4*)nullptr, (uint64_t*)nullptr, (uint4*)nullptr, reinterpret_cast<uint32_t*>(extra));
@@ -329,7 +348,7 @@ static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int
   if (scheme == S_DPF && !tr_bits) return FSS_AMD_EINVAL;
   if (scheme == S_DCF && !cw_v) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !extra) return FSS_AMD_EINVAL;
-  HIP_TRY(hipSetDevice(ctx->device));
+  FSS_ON_DEVICE(ctx);
   EvalArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;
   a.xs = xs; a.ys = ys;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
     uint32_t s0[4] = {k_seed[0], k_seed[1], k_seed[2], k_seed[3]};
     if constexpr (SCHEME == S_DCF) {
       DcfWalk w;
-      w.init(s0, a.party, path);
+      w.init(s0, a.party, X128{path, 0});
       for (int i = 0; i < depth; ++i) {
         const uint32_t* p = k_cws + 8 * i;
         CwDcf cw;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
       a.out_v[j] = make_uint4(w.v.v[0], w.v.v[1], w.v.v[2], w.v.v[3]);
     } else if constexpr (SCHEME == S_HT) {
       HtWalk w;
-      w.init(s0, a.party, path);
+      w.init(s0, a.party, X128{path, 0});
       for (int i = 0; i < depth; ++i) {
         const uint32_t* p = k_cws + 8 * i;
         uint32_t cw[4] = {p[0], p[1], p[2], p[3]};
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
       a.out_nodes[j] = make_uint4(w.node[0], w.node[1], w.node[2], w.node[3]);
     } else {
       DpfWalk w;
-      w.init(s0, a.party, path);
+      w.init(s0, a.party, X128{path, 0});
       for (int i = 0; i < depth; ++i) {
         const uint32_t* p = k_cws + 8 * i;
         CwDpf cw{p[0], p[1], p[2], p[3], p[4]};

@@ -30,27 +30,32 @@ __global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, 
                                                        int64_t nkeys, uint4* __restrict__ cw_s,
                                                        uint4* __restrict__ cw_v, uint64_t* __restrict__ tr_bits,
                                                        uint4* __restrict__ out_cw, uint32_t* __restrict__ extra) {
-  __shared__ unsigned long long bits[64];
+  __shared__ unsigned long long bits[2][64];  // levels 0..63 / 64..127
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t k = (int64_t)blockIdx.x * 64 + lane;
-  if (wave == 0) bits[lane] = 0ull;
+  if (wave < 2) bits[wave][lane] = 0ull;
   __syncthreads();
   if (k < nkeys) {
     const uint4* slot = cws + k * (int64_t)stride * 2;
-    unsigned long long mine = 0ull;
+    unsigned long long mine = 0ull, mine_hi = 0ull;
     for (int i = wave; i < in_bits; i += 4) {
       uint4 s = slot[2 * i], v = slot[2 * i + 1];
       cw_s[(int64_t)i * nkeys + k] = s;
       if (SCHEME == S_DCF) cw_v[(int64_t)i * nkeys + k] = v;
-      if (SCHEME == S_DPF) mine |= (unsigned long long)(v.x & 1u) << i;
+      if (SCHEME == S_DPF) {
+        if (i < 64) mine |= (unsigned long long)(v.x & 1u) << i;
+        else mine_hi |= (unsigned long long)(v.x & 1u) << (i - 64);
+      }
     }
-    if (SCHEME == S_DPF && mine) atomicOr(&bits[lane], mine);
+    if (SCHEME == S_DPF && mine) atomicOr(&bits[0][lane], mine);
+    if (SCHEME == S_DPF && mine_hi) atomicOr(&bits[1][lane], mine_hi);
   }
   __syncthreads();
   if (wave == 0 && k < nkeys) {
     const uint4* slot = cws + k * (int64_t)stride * 2;
     if (SCHEME == S_DPF) {
-      tr_bits[k] = bits[lane];
+      tr_bits[k] = bits[0][lane];
+      if (in_bits > 64) tr_bits[nkeys + k] = bits[1][lane];
       out_cw[k] = slot[2 * in_bits];
     } else if (SCHEME == S_DCF) {
       out_cw[k] = slot[2 * in_bits + 1];
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
     ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
     s0[3] &= ~1u; s1[3] &= ~1u; beta[3] &= ~1u;
     uint32_t t0 = 0u, t1 = ~0u;  // masks
-    const uint64_t alpha = load_x(a.alphas, a.x_bytes, k);
+    const X128 alpha = load_x(a.alphas, a.x_bytes, k);
     uint4* slot = a.cws + k * (int64_t)(n + 1) * 2;
     Acc v;  // DCF running value (dcf.cuh:115)
 #pragma unroll 1
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
     uint32_t n0[4], n1[4], beta[4];
     ld4(n0, a.s0s[2 * k]); ld4(n1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
     n0[3] &= ~1u; n1[3] |= 1u; beta[3] &= ~1u;
-    const uint64_t alpha = load_x(a.alphas, a.x_bytes, k);
+    const X128 alpha = load_x(a.alphas, a.x_bytes, k);
     uint4* slot = a.cws + k * (int64_t)n * 2;
 #pragma unroll 1
     for (int i = 0; i < n - 1; ++i) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
       slot[2 * i + 1] = make_uint4(0, 0, 0, 0);
     }
     {
-      const uint32_t an = (uint32_t)alpha & 1u;
+      const uint32_t an = (uint32_t)alpha.lo & 1u;
       const uint32_t t0 = lsb_mask(n0[3]), t1 = lsb_mask(n1[3]);
       uint32_t p[4], h00[4], h01[4], h10[4], h11[4];
       p[0] = n0[0]; p[1] = n0[1]; p[2] = n0[2];

@@ -38,14 +38,26 @@ struct EvalArgs {
   const uint4* pre_v;       // DCF: running group value of every node
 };
 
-__device__ __forceinline__ uint32_t bit_mask(uint64_t x, int pos) {  // 0 or ~0
+// An evaluation point / alpha of up to 128 bits (In = uint32_t, uint64_t or __uint128_t in the reference).
+struct X128 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ uint32_t bit_mask(uint64_t x, int pos) {  // 0 or ~0, pos < 64
   uint32_t w = pos >= 32 ? (uint32_t)(x >> 32) : (uint32_t)x;
   return (uint32_t)__builtin_amdgcn_sbfe(w, pos & 31, 1);
 }
+__device__ __forceinline__ uint32_t bit_mask(const X128& x, int pos) {  // pos < 128 (wave-uniform)
+  return bit_mask(pos >= 64 ? x.hi : x.lo, pos & 63);
+}
 __device__ __forceinline__ uint32_t lsb_mask(uint32_t w) { return (uint32_t)__builtin_amdgcn_sbfe(w, 0, 1); }
 
-__device__ __forceinline__ uint64_t load_x(const void* xs, int x_bytes, int64_t i) {
-  return x_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t*>(xs)[i] : reinterpret_cast<const uint64_t*>(xs)[i];
+__device__ __forceinline__ X128 load_x(const void* xs, int x_bytes, int64_t i) {
+  X128 x;
+  x.hi = 0;
+  if (x_bytes == 4) x.lo = reinterpret_cast<const uint32_t*>(xs)[i];
+  else if (x_bytes == 8) x.lo = reinterpret_cast<const uint64_t*>(xs)[i];
+  else { x.lo = reinterpret_cast<const uint64_t*>(xs)[2 * i]; x.hi = reinterpret_cast<const uint64_t*>(xs)[2 * i + 1]; }
+  return x;
 }
 
 // Correction word of one level as the walk consumes it.
@@ -58,14 +70,14 @@ struct CwDpf {
 // ---------------------------------------------------------------- DPF (dpf.cuh:170-214)
 struct DpfWalk {
   uint32_t st[4];  // seed with the control bit t packed into bit 0 of w (dpf.cuh:233-235)
-  uint64_t x;
+  X128 x;
 
-  __device__ __forceinline__ void init(const uint32_t s0[4], int party, uint64_t x_) {
+  __device__ __forceinline__ void init(const uint32_t s0[4], int party, X128 x_) {
     st[0] = s0[0]; st[1] = s0[1]; st[2] = s0[2];
     st[3] = (s0[3] & ~1u) | (uint32_t)party;  // dpf.cuh:171-173
     x = x_;
   }
-  __device__ __forceinline__ void resume(uint4 node, uint64_t x_) {
+  __device__ __forceinline__ void resume(uint4 node, X128 x_) {
     st[0] = node.x; st[1] = node.y; st[2] = node.z; st[3] = node.w;
     x = x_;
   }
@@ -118,15 +130,15 @@ struct CwDcf {
 
 struct DcfWalk {
   uint32_t st[4];
-  uint64_t x;
+  X128 x;
   Acc v;  // dcf.cuh:208, zero
 
-  __device__ __forceinline__ void init(const uint32_t s0[4], int party, uint64_t x_) {
+  __device__ __forceinline__ void init(const uint32_t s0[4], int party, X128 x_) {
     st[0] = s0[0]; st[1] = s0[1]; st[2] = s0[2];
     st[3] = (s0[3] & ~1u) | (uint32_t)party;
     x = x_;
   }
-  __device__ __forceinline__ void resume(uint4 node, uint4 val, uint64_t x_) {
+  __device__ __forceinline__ void resume(uint4 node, uint4 val, X128 x_) {
     st[0] = node.x; st[1] = node.y; st[2] = node.z; st[3] = node.w;
     v.v[0] = val.x; v.v[1] = val.y; v.v[2] = val.z; v.v[3] = val.w;
     x = x_;
@@ -160,14 +172,14 @@ struct DcfWalk {
 // ---------------------------------------------------------------- Half-Tree DPF (half_tree_dpf.cuh:187-231)
 struct HtWalk {
   uint32_t node[4];  // control bit kept in bit 0 of w (half_tree_dpf.cuh:188)
-  uint64_t x;
+  X128 x;
 
-  __device__ __forceinline__ void init(const uint32_t s0[4], int party, uint64_t x_) {
+  __device__ __forceinline__ void init(const uint32_t s0[4], int party, X128 x_) {
     node[0] = s0[0]; node[1] = s0[1]; node[2] = s0[2];
     node[3] = (s0[3] & ~1u) | (uint32_t)party;
     x = x_;
   }
-  __device__ __forceinline__ void resume(uint4 n, uint64_t x_) {
+  __device__ __forceinline__ void resume(uint4 n, X128 x_) {
     node[0] = n.x; node[1] = n.y; node[2] = n.z; node[3] = n.w;
     x = x_;
   }
@@ -199,7 +211,7 @@ struct HtWalk {
   // last level + output conversion, :205-229
   __device__ __forceinline__ uint4 finish(const Lds& L, const DevCtx* __restrict__ c, int g, int party, const uint32_t cw[4],
                                           uint32_t extra, const uint32_t ocw[4]) const {
-    uint32_t xn = (uint32_t)x & 1u;
+    uint32_t xn = (uint32_t)x.lo & 1u;
     uint32_t tm = lsb_mask(node[3]);
     uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                       ((node[3] & ~1u) | xn) ^ c->hash_key[3]};
@@ -266,13 +278,16 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
         if constexpr (PREFIX) {
-          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
+          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
         }
       }
-      uint64_t trb[ILP];
+      uint64_t trb[ILP], trbh[ILP];  // tr bits of levels 0..63 and 64..127 (second plane at + n)
       if constexpr (!SHARED) {
 #pragma unroll
-        for (int j = 0; j < ILP; ++j) trb[j] = a.tr_bits[idx[j]];
+        for (int j = 0; j < ILP; ++j) {
+          trb[j] = a.tr_bits[idx[j]];
+          trbh[j] = in_bits > 64 ? a.tr_bits[n + idx[j]] : 0ull;
+        }
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           } else {
             uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
             cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
-            cw[j].tr = (uint32_t)(trb[j] >> i);
+            cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
           }
         }
         if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1], kdv);
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
         if constexpr (PREFIX) {
           if (lvl0 > 0) {
-            const uint64_t q = (w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
+            const uint64_t q = (w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
             w[j].resume(a.pre_nodes[q], a.pre_v[q], w[j].x);
           }
         }
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
         w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
         if constexpr (PREFIX) {
-          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
+          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
         }
       }
 #pragma unroll 1
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
   const int n = a.in_bits;
   uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
   for (int64_t k = (int64_t)blockIdx.x * BS + threadIdx.x; k < a.n; k += (int64_t)gridDim.x * BS) {
-    const uint64_t x = load_x(a.xs, a.x_bytes, k);
+    const uint64_t x = load_x(a.xs, a.x_bytes, k).lo;
     const uint64_t e = x + 1;
     const bool whole = n == 64 ? (e == 0) : (e == (1ull << n));
     uint4 s4 = a.seeds[k];

@@ -82,7 +82,11 @@ class Engine:
             if in_bits > 32:
                 raise ValueError("int32 xs only cover in_bits <= 32; pass int64")
             return 4
+        if xs.dtype == torch.int64 and xs.dim() == 2 and xs.shape[-1] == 2:
+            return 16  # (lo, hi) pairs = __uint128_t
         if xs.dtype == torch.int64:
+            if in_bits > 64:
+                raise ValueError("in_bits > 64 needs xs of shape (n, 2): (lo, hi) int64 bit patterns")
             return 8
         raise TypeError(f"xs must be int32 (uint32 bit pattern) or int64 (uint64 bit pattern), got {xs.dtype}")
 
@@ -102,9 +106,9 @@ class Engine:
     # ------------------------------------------------------------ one key, many points
     def eval_points(self, scheme, in_bits, group, party, seed, cws, xs, ocw=None, out=None):
         seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
-        n = xs.numel()
-        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
         xb = self._xbytes(xs, in_bits)
+        n = xs.shape[0] if xb == 16 else xs.numel()
+        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
         L, st = self._L, self._stream()
         if scheme == DPF:
             rc = L.fss_amd_dpf_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
@@ -161,7 +165,7 @@ class Engine:
         dev, L, st = self.device, self._L, self._stream()
         cw_s = torch.empty((in_bits, nkeys, 4), dtype=torch.int32, device=dev)
         if scheme in (DPF, GROTTO):
-            tr = torch.empty((nkeys,), dtype=torch.int64, device=dev)
+            tr = torch.empty(((in_bits + 63) // 64 * nkeys,), dtype=torch.int64, device=dev)
             oc = torch.empty((nkeys, 4), dtype=torch.int32, device=dev)
             _lib.check(L.fss_amd_dpf_relayout(self._h, in_bits, _ptr(cws), nkeys, _ptr(cw_s), _ptr(tr), _ptr(oc), st),
                        "dpf_relayout")
@@ -260,8 +264,8 @@ class Engine:
     def gen(self, scheme, in_bits, group, s0s, alphas, betas, pred=0):
         """s0s int32[n,2,4], alphas int32/int64[n], betas int32[n,4] -> (cws int32[n,slots,8], ocws|None)."""
         s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)
-        n = alphas.numel()
         xb = self._xbytes(alphas, in_bits)
+        n = alphas.shape[0] if xb == 16 else alphas.numel()
         slots = in_bits if scheme == HT else in_bits + 1
         cws = torch.empty((n, slots, 8), dtype=torch.int32, device=self.device)
         L, st = self._L, self._stream()

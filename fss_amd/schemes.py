@@ -21,16 +21,20 @@ from ._validate import (validate_alpha, validate_beta, validate_cpu_only, valida
                         validate_domain_value, validate_group, validate_in_bits, validate_party, validate_pred,
                         validate_prg, validate_s0, validate_s0s)
 
-_MAX_IN_BITS = 64  # kernels take x as uint32 / uint64
+_MAX_IN_BITS = 128  # kernels take x as uint32 / uint64 / two uint64 (__uint128_t)
 
 
 def _xs_tensor(values, in_bits, device):
     """Python ints / tensor -> int32 (in_bits <= 32) or int64 bit patterns."""
     if isinstance(values, torch.Tensor):
         return values
+    def s64(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
     if in_bits <= 32:
         return torch.tensor([v - (1 << 32) if v >= (1 << 31) else v for v in values], dtype=torch.int32, device=device)
-    return torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in values], dtype=torch.int64, device=device)
+    if in_bits <= 64:
+        return torch.tensor([s64(v) for v in values], dtype=torch.int64, device=device)
+    return torch.tensor([[s64(v & ((1 << 64) - 1)), s64(v >> 64)] for v in values], dtype=torch.int64, device=device)
 
 
 def _check_group(group):

@@ -20,8 +20,11 @@
  *  - Return value: 0 on success, a negative FSS_AMD_E* code otherwise.  No
  *    exceptions cross the ABI.  There is no CPU fallback: without a usable HIP
  *    device fss_amd_ctx_create fails with FSS_AMD_EHIP.
- *  - x values: `x_bytes` = 4 (uint32_t, in_bits <= 32) or 8 (uint64_t,
- *    in_bits <= 64).  Bits are consumed MSB-first (dpf.cuh:196).
+ *  - x values: `x_bytes` = 4 (uint32_t, in_bits <= 32), 8 (uint64_t, in_bits <= 64)
+ *    or 16 (__uint128_t as two little-endian uint64_t, in_bits <= 128) -- the
+ *    reference's `In` types (fss_crypto/_jit.py:57-62).  Bits are consumed
+ *    MSB-first (dpf.cuh:196).  EvalAll, the shared-prefix entry points and the
+ *    Grotto calls need in_bits <= 62 / 64 / 64.
  */
 #ifndef FSS_AMD_H_
 #define FSS_AMD_H_
@@ -114,7 +117,8 @@ int fss_amd_ht_eval_points_shared(fss_amd_ctx *ctx, int in_bits, int group, int 
  *   cw_s  int4[in_bits][nkeys]          cw_s[i*nkeys + k] = cws[k][i].s
  *   cw_v  int4[in_bits][nkeys]          (DCF)
  *   tr_bits uint64[nkeys]               (DPF) bit i = cws[k][i].tr  -- 64 bits, the
- *                                        reference packs 32 (point_eval_gpu.cuh:57-62)
+ *                                        reference packs 32 (point_eval_gpu.cuh:57-62);
+ *                                        in_bits > 64: uint64[2][nkeys], plane 1 = levels 64..127
  *   out_cw int4[nkeys]                  cws[k][in_bits].s (DPF) / .v (DCF)
  *   extra uint32[nkeys]                 (Half-Tree) bit 0 = cws[k][in_bits-1].extra */
 int fss_amd_dpf_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *tr_bits,

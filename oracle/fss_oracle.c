@@ -679,11 +679,11 @@ static void prg_thread_copy(const fo_prg *src, fo_prg *dst) {
 }
 
 static fo_i4 eval_one(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, fo_i4 s0,
-                      const fo_cw *cws, fo_i4 ocw, uint64_t x) {
+                      const fo_cw *cws, fo_i4 ocw, uint64_t x, uint64_t xh) {
   switch (scheme) {
-    case FO_DPF: return fo_dpf_eval(p, in_bits, group, b, s0, cws, x, 0);
-    case FO_DCF: return fo_dcf_eval(p, in_bits, group, b, s0, cws, x, 0);
-    case FO_HT: return fo_ht_eval(p, hk, in_bits, group, b, s0, cws, ocw, x, 0);
+    case FO_DPF: return fo_dpf_eval(p, in_bits, group, b, s0, cws, x, xh);
+    case FO_DCF: return fo_dcf_eval(p, in_bits, group, b, s0, cws, x, xh);
+    case FO_HT: return fo_ht_eval(p, hk, in_bits, group, b, s0, cws, ocw, x, xh);
     default: {
       fo_i4 r = {fo_grotto_eval_walk(p, in_bits, b, s0, cws, x), 0, 0, 0};
       return r;
@@ -692,21 +692,22 @@ static fo_i4 eval_one(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int gr
 }
 
 void fo_eval_points(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws,
-                    fo_i4 ocw, const uint64_t *xs, size_t n, fo_i4 *ys, int nthreads) {
+                    fo_i4 ocw, const uint64_t *xs, const uint64_t *xs_hi, size_t n, fo_i4 *ys, int nthreads) {
   if (nthreads < 1) nthreads = 1;
 #pragma omp parallel num_threads(nthreads)
   {
     fo_prg tp;
     prg_thread_copy(p, &tp);
 #pragma omp for schedule(static)
-    for (long long i = 0; i < (long long)n; ++i) ys[i] = eval_one(&tp, hk, scheme, in_bits, group, b, s0, cws, ocw, xs[i]);
+    for (long long i = 0; i < (long long)n; ++i)
+      ys[i] = eval_one(&tp, hk, scheme, in_bits, group, b, s0, cws, ocw, xs[i], xs_hi ? xs_hi[i] : 0);
     fo_prg_free(&tp);
   }
 }
 
 void fo_eval_keys(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, const fo_i4 *s0s,
-                  const fo_cw *cws, size_t stride, const fo_i4 *ocws, const uint64_t *xs, size_t n, fo_i4 *ys,
-                  int nthreads) {
+                  const fo_cw *cws, size_t stride, const fo_i4 *ocws, const uint64_t *xs, const uint64_t *xs_hi,
+                  size_t n, fo_i4 *ys, int nthreads) {
   if (nthreads < 1) nthreads = 1;
 #pragma omp parallel num_threads(nthreads)
   {
@@ -715,14 +716,14 @@ void fo_eval_keys(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group,
 #pragma omp for schedule(static)
     for (long long i = 0; i < (long long)n; ++i)
       ys[i] = eval_one(&tp, hk, scheme, in_bits, group, b, s0s[i], cws + (size_t)i * stride, ocws ? ocws[i] : kZero4,
-                       xs[i]);
+                       xs[i], xs_hi ? xs_hi[i] : 0);
     fo_prg_free(&tp);
   }
 }
 
 void fo_gen_keys(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int pred, const fo_i4 *s0s,
-                 const uint64_t *alphas, const fo_i4 *betas, size_t n, fo_cw *cws, size_t stride, fo_i4 *ocws,
-                 int nthreads) {
+                 const uint64_t *alphas, const uint64_t *alphas_hi, const fo_i4 *betas, size_t n, fo_cw *cws,
+                 size_t stride, fo_i4 *ocws, int nthreads) {
   if (nthreads < 1) nthreads = 1;
 #pragma omp parallel num_threads(nthreads)
   {
@@ -732,11 +733,12 @@ void fo_gen_keys(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, 
     for (long long i = 0; i < (long long)n; ++i) {
       fo_cw *c = cws + (size_t)i * stride;
       const fo_i4 *ss = s0s + 2 * (size_t)i;
+      const uint64_t ah = alphas_hi ? alphas_hi[i] : 0;
       switch (scheme) {
-        case FO_DPF: fo_dpf_gen(&tp, in_bits, group, c, ss, alphas[i], 0, betas[i]); break;
-        case FO_DCF: fo_dcf_gen(&tp, in_bits, group, pred, c, ss, alphas[i], 0, betas[i]); break;
-        case FO_HT: fo_ht_gen(&tp, hk, in_bits, group, c, &ocws[i], ss, alphas[i], 0, betas[i]); break;
-        default: fo_grotto_gen(&tp, in_bits, c, ss, alphas[i], 0); break;
+        case FO_DPF: fo_dpf_gen(&tp, in_bits, group, c, ss, alphas[i], ah, betas[i]); break;
+        case FO_DCF: fo_dcf_gen(&tp, in_bits, group, pred, c, ss, alphas[i], ah, betas[i]); break;
+        case FO_HT: fo_ht_gen(&tp, hk, in_bits, group, c, &ocws[i], ss, alphas[i], ah, betas[i]); break;
+        default: fo_grotto_gen(&tp, in_bits, c, ss, alphas[i], ah); break;
       }
     }
     fo_prg_free(&tp);

@@ -113,16 +113,18 @@ int fo_grotto_eval_walk(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_
 /* scheme: 0 DPF, 1 DCF, 2 Half-Tree, 3 Grotto walk (ys then holds 0/1 in .x). */
 enum { FO_DPF = 0, FO_DCF = 1, FO_HT = 2, FO_GROTTO = 3 };
 /* one key, many points */
+/* xs_hi / alphas_hi: high 64 bits of every input (NULL = 0), for in_bits > 64. */
 void fo_eval_points(const fo_prg *p, fo_i4 hash_key, int scheme, int in_bits, int group, int b, fo_i4 s0,
-                    const fo_cw *cws, fo_i4 ocw, const uint64_t *xs, size_t n, fo_i4 *ys, int nthreads);
+                    const fo_cw *cws, fo_i4 ocw, const uint64_t *xs, const uint64_t *xs_hi, size_t n, fo_i4 *ys,
+                    int nthreads);
 /* many keys (key-major cws with `stride` slots per key), one point each */
 void fo_eval_keys(const fo_prg *p, fo_i4 hash_key, int scheme, int in_bits, int group, int b, const fo_i4 *s0s,
-                  const fo_cw *cws, size_t stride, const fo_i4 *ocws, const uint64_t *xs, size_t n, fo_i4 *ys,
-                  int nthreads);
+                  const fo_cw *cws, size_t stride, const fo_i4 *ocws, const uint64_t *xs, const uint64_t *xs_hi,
+                  size_t n, fo_i4 *ys, int nthreads);
 /* many keys generated at once; s0s has 2 seeds per key; cws key-major with `stride`. */
 void fo_gen_keys(const fo_prg *p, fo_i4 hash_key, int scheme, int in_bits, int group, int pred, const fo_i4 *s0s,
-                 const uint64_t *alphas, const fo_i4 *betas, size_t n, fo_cw *cws, size_t stride, fo_i4 *ocws,
-                 int nthreads);
+                 const uint64_t *alphas, const uint64_t *alphas_hi, const fo_i4 *betas, size_t n, fo_cw *cws,
+                 size_t stride, fo_i4 *ocws, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -85,9 +85,9 @@ def lib():
         L.fo_grotto_eval_all.argtypes = [P, i, i, _I4, vp, vp]
         L.fo_grotto_eval_walk.argtypes = [P, i, i, _I4, vp, u64]
         L.fo_grotto_eval_walk.restype = i
-        L.fo_eval_points.argtypes = [P, _I4, i, i, i, i, _I4, vp, _I4, vp, sz, vp, i]
-        L.fo_eval_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, sz, vp, vp, sz, vp, i]
-        L.fo_gen_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, vp, sz, vp, sz, vp, i]
+        L.fo_eval_points.argtypes = [P, _I4, i, i, i, i, _I4, vp, _I4, vp, vp, sz, vp, i]
+        L.fo_eval_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, sz, vp, vp, vp, sz, vp, i]
+        L.fo_gen_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, vp, vp, sz, vp, sz, vp, i]
         _lib = L
     return _lib
 
@@ -254,20 +254,31 @@ def grotto_eval_walk(prg, in_bits, b, s0, cws, x):
 
 
 # ---------------------------------------------------------------- batched
+def _lohi(vals):
+    """uint64 array, or a list of Python ints (any width <= 128) -> (lo uint64[n], hi uint64[n] or None)."""
+    if isinstance(vals, np.ndarray) and vals.dtype != object:
+        return np.ascontiguousarray(vals, dtype=np.uint64), None
+    vals = [int(v) for v in vals]
+    lo = np.array([v & 0xFFFFFFFFFFFFFFFF for v in vals], dtype=np.uint64)
+    if all(v < (1 << 64) for v in vals):
+        return lo, None
+    return lo, np.array([v >> 64 for v in vals], dtype=np.uint64)
+
+
 def eval_points(prg, scheme, in_bits, group, b, s0, cws, xs, ocw=None, hash_key=HASH_KEY, nthreads=1):
-    """One key, many points.  xs: uint64[n].  Returns int32[n,4]."""
-    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    """One key, many points.  xs: uint64[n] or a list of ints (<= 128 bits).  Returns int32[n,4]."""
+    xs, xh = _lohi(xs)
     cws = np.ascontiguousarray(cws, dtype=np.int32)
     ys = np.zeros((xs.size, 4), dtype=np.int32)
     oc = _i4(ocw if ocw is not None else [0, 0, 0, 0])
     lib().fo_eval_points(prg.ref, _i4(hash_key), scheme, in_bits, group, int(b), _i4(s0), _ptr(cws), oc, _ptr(xs),
-                         xs.size, _ptr(ys), nthreads)
+                         None if xh is None else _ptr(xh), xs.size, _ptr(ys), nthreads)
     return ys
 
 
 def eval_keys(prg, scheme, in_bits, group, b, s0s, cws, xs, ocws=None, hash_key=HASH_KEY, nthreads=1):
-    """Many keys x one point each.  s0s int32[n,4]; cws int32[n,stride,8]; xs uint64[n]."""
-    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    """Many keys x one point each.  s0s int32[n,4]; cws int32[n,stride,8]; xs uint64[n] or list of ints."""
+    xs, xh = _lohi(xs)
     cws = np.ascontiguousarray(cws, dtype=np.int32)
     s0s = np.ascontiguousarray(s0s, dtype=np.int32)
     n, stride = cws.shape[0], cws.shape[1]
@@ -277,7 +288,7 @@ def eval_keys(prg, scheme, in_bits, group, b, s0s, cws, xs, ocws=None, hash_key=
         ocws = np.ascontiguousarray(ocws, dtype=np.int32)
         op = _ptr(ocws)
     lib().fo_eval_keys(prg.ref, _i4(hash_key), scheme, in_bits, group, int(b), _ptr(s0s), _ptr(cws), stride, op,
-                       _ptr(xs), n, _ptr(ys), nthreads)
+                       _ptr(xs), None if xh is None else _ptr(xh), n, _ptr(ys), nthreads)
     return ys
 
 
@@ -285,12 +296,12 @@ def gen_keys(prg, scheme, in_bits, group, s0s, alphas, betas, pred=LT, hash_key=
     """Many keys.  s0s int32[n,2,4]; alphas uint64[n]; betas int32[n,4].
     Returns (cws int32[n,stride,8], ocws int32[n,4] or None)."""
     s0s = np.ascontiguousarray(s0s, dtype=np.int32)
-    alphas = np.ascontiguousarray(alphas, dtype=np.uint64)
+    alphas, ah = _lohi(alphas)
     betas = np.ascontiguousarray(betas, dtype=np.int32)
     n = alphas.size
     stride = in_bits if scheme == HT else in_bits + 1
     cws = np.zeros((n, stride, 8), dtype=np.int32)
     ocws = np.zeros((n, 4), dtype=np.int32)
-    lib().fo_gen_keys(prg.ref, _i4(hash_key), scheme, in_bits, group, pred, _ptr(s0s), _ptr(alphas), _ptr(betas), n,
-                      _ptr(cws), stride, _ptr(ocws), nthreads)
+    lib().fo_gen_keys(prg.ref, _i4(hash_key), scheme, in_bits, group, pred, _ptr(s0s), _ptr(alphas),
+                      None if ah is None else _ptr(ah), _ptr(betas), n, _ptr(cws), stride, _ptr(ocws), nthreads)
     return cws, (ocws if scheme == HT else None)

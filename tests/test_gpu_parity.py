@@ -23,13 +23,21 @@ def T(a):
 
 
 def xs_tensor(xs, n):
+    if n > 64:  # __uint128_t as (lo, hi) pairs
+        m = (1 << 64) - 1
+        a = np.array([[int(v) & m, int(v) >> 64] for v in xs], dtype=np.uint64)
+        return T(a.view(np.int64))
     a = np.array(xs, dtype=np.uint64)
     return T(a.astype(np.uint32).view(np.int32)) if n <= 32 else T(a.view(np.int64))
 
 
+def rand_below(rng, n):
+    return rng.below(n) if n <= 64 else ((rng.next() << 64) | rng.next()) & ((1 << n) - 1)
+
+
 def edge_xs(rng, n, alpha, extra):
     top = (1 << n) - 1
-    xs = [0, top, alpha, max(alpha - 1, 0), min(alpha + 1, top)] + [rng.below(n) for _ in range(extra)]
+    xs = [0, top, alpha, max(alpha - 1, 0), min(alpha + 1, top)] + [rand_below(rng, n) for _ in range(extra)]
     return xs
 
 
@@ -103,14 +111,14 @@ def test_reference_kats_on_gpu(engine):
 
 # ---------------------------------------------------------------- one key, many points
 @pytest.mark.parametrize("g", GROUPS)
-@pytest.mark.parametrize("n", [1, 7, 16, 32, 33, 64])
+@pytest.mark.parametrize("n", [1, 7, 16, 32, 33, 64, 65, 100, 128])
 @pytest.mark.parametrize("scheme", [DPF, DCF, HT])
 def test_eval_points_vs_oracle(engine, O, scheme, n, g):
     rng = SplitMix64(1000 * scheme + 10 * n + g)
     mul = {DPF: 2, DCF: 4, HT: 1}[scheme]
     p = O.Prg(mul)
     s = [rng.i4(), rng.i4()]
-    alpha, beta = rng.below(n), beta_for(rng)
+    alpha, beta = rand_below(rng, n), beta_for(rng)
     ocw = None
     if scheme == DPF:
         cws = O.dpf_gen(p, n, g, s, alpha, beta)
@@ -120,7 +128,7 @@ def test_eval_points_vs_oracle(engine, O, scheme, n, g):
         cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
     xs = edge_xs(rng, n, alpha, 300)  # ragged: not a multiple of the wave or block size
     for b in (0, 1):
-        want = O.eval_points(p, scheme, n, g, b, s[b], cws, np.array(xs, dtype=np.uint64), ocw=ocw)
+        want = O.eval_points(p, scheme, n, g, b, s[b], cws, xs if n > 64 else np.array(xs, dtype=np.uint64), ocw=ocw)
         got = engine.eval_points(scheme, n, g, b, T(s[b]), T(cws), xs_tensor(xs, n),
                                  ocw=None if ocw is None else T(ocw)).cpu().numpy()
         assert (got == want).all(), (scheme, n, g, b, np.argwhere(got != want)[:4])
@@ -173,25 +181,31 @@ def test_eval_points_empty(engine):
 # ---------------------------------------------------------------- independent keys (relayout + eval_keys)
 @pytest.mark.parametrize("scheme,n,g", [(DPF, 32, G.U64), (DPF, 64, G.BYTES), (DPF, 5, G.U8), (DCF, 32, G.U64),
                                         (DCF, 64, G.U128), (DCF, 9, G.BYTES), (HT, 64, G.U64), (HT, 32, G.BYTES),
-                                        (HT, 1, G.U16), (HT, 2, G.U64)])
+                                        (HT, 1, G.U16), (HT, 2, G.U64), (DPF, 128, G.U128), (DPF, 77, G.BYTES),
+                                        (DCF, 128, G.U128), (HT, 100, G.U64)])
 def test_eval_keys_vs_oracle(engine, O, scheme, n, g):
     rng = SplitMix64(77 + 1000 * scheme + n)
     nkeys = 333
     mul = {DPF: 2, DCF: 4, HT: 1}[scheme]
     p = O.Prg(mul)
     s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
-    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    if n > 64:
+        alphas = [rand_below(rng, n) for _ in range(nkeys)]
+        xs = [alphas[i] if i % 3 == 0 else rand_below(rng, n) for i in range(nkeys)]
+    else:
+        alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
     betas = np.stack([rng.i4() for _ in range(nkeys)])
     cws, ocws = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=O.GT if n == 9 else O.LT, nthreads=4)
-    xs = np.array([alphas[i] if i % 3 == 0 else rng.below(n) for i in range(nkeys)], dtype=np.uint64)
+    if n <= 64:
+        xs = np.array([alphas[i] if i % 3 == 0 else rng.below(n) for i in range(nkeys)], dtype=np.uint64)
     keys = engine.relayout(scheme, n, T(cws))
     # the relayout itself, against a numpy transposition (point_eval_gpu.cuh:53-91)
     assert (keys.cw_s.cpu().numpy() == np.transpose(cws[:, :n, :4], (1, 0, 2))).all()
     if scheme == DPF:
-        tr = np.zeros(nkeys, dtype=np.uint64)
+        tr = np.zeros(((n + 63) // 64, nkeys), dtype=np.uint64)
         for i in range(n):
-            tr |= (cws[:, i, 4].astype(np.uint64) & np.uint64(1)) << np.uint64(i)
-        assert (keys.tr_bits.cpu().numpy().view(np.uint64) == tr).all()
+            tr[i // 64] |= (cws[:, i, 4].astype(np.uint64) & np.uint64(1)) << np.uint64(i % 64)
+        assert (keys.tr_bits.cpu().numpy().view(np.uint64) == tr.reshape(-1)).all()
         assert (keys.out_cw.cpu().numpy() == cws[:, n, :4]).all()
     elif scheme == DCF:
         assert (keys.cw_v.cpu().numpy() == np.transpose(cws[:, :n, 4:], (1, 0, 2))).all()
@@ -209,13 +223,15 @@ def test_eval_keys_vs_oracle(engine, O, scheme, n, g):
 @pytest.mark.parametrize("scheme,n,g,pred", [(DPF, 32, G.U64, 0), (DPF, 64, G.U128, 0), (DPF, 1, G.BYTES, 0),
                                              (DCF, 32, G.U64, 0), (DCF, 16, G.BYTES, 1), (DCF, 64, G.U128, 1),
                                              (DCF, 8, G.U8, 0), (HT, 64, G.U64, 0), (HT, 1, G.BYTES, 0),
-                                             (HT, 17, G.U128, 0), (HT, 8, G.U16, 0)])
+                                             (HT, 17, G.U128, 0), (HT, 8, G.U16, 0), (DPF, 128, G.U128, 0),
+                                             (DCF, 100, G.BYTES, 1), (HT, 128, G.U128, 0)])
 def test_gen_vs_oracle(engine, O, scheme, n, g, pred):
     rng = SplitMix64(5 + 100 * scheme + n)
     nkeys = 130
     p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
     s0s = np.stack([np.stack([rng.i4(clear_lsb=False), rng.i4(clear_lsb=False)]) for _ in range(nkeys)])
-    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    alphas = ([rand_below(rng, n) for _ in range(nkeys)] if n > 64
+              else np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64))
     betas = np.stack([rng.i4(clear_lsb=False) for _ in range(nkeys)])
     want, want_ocw = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=pred, nthreads=4)
     got, got_ocw = engine.gen(scheme, n, g, T(s0s), xs_tensor(alphas, n), T(betas), pred=pred)

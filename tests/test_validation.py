@@ -11,8 +11,7 @@ def test_in_bits_range():
     for bad in (0, 129, -1):
         with pytest.raises(ValueError, match="in_bits must be between 1 and 128"):
             fss_amd.Dpf(bad)
-    with pytest.raises(NotImplementedError, match="in_bits <= 64"):
-        fss_amd.Dpf(100)
+    assert fss_amd.Dpf(100, "uint")._g == fss_amd.U128 and fss_amd.Dpf(128).in_bits == 128
 
 
 def test_group_prg_pred():
