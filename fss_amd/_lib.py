@@ -19,6 +19,7 @@ PROTOTYPES = {
     "fss_amd_ctx_create": (_i, [C.POINTER(_vp), _i, _vp, _vp]),
     "fss_amd_ctx_destroy": (None, [_vp]),
     "fss_amd_ctx_device": (_i, [_vp]),
+    "fss_amd_ctx_set_prg": (_i, [_vp, _i, _vp, _i]),
     "fss_amd_strerror": (C.c_char_p, [_i]),
     "fss_amd_last_hip_error": (_i, []),
     "fss_amd_prg_gen": (_i, [_vp, _i, _vp, _i64, _vp, _vp]),

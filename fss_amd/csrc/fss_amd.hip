@@ -22,6 +22,7 @@ struct fss_amd_ctx {
   int num_cu;
   uint32_t* te0;  // device: Te0 table, 1 KiB, followed by the device copy of `host`
   DevCtx host;    // round keys etc., passed to kernels by value
+  int prg;        // FSS_AMD_PRG_AES128_MMO or FSS_AMD_PRG_CHACHA
   const char* last_kernel;
   int last_grid, last_block;
 };
@@ -140,6 +141,23 @@ int launch_persistent(fss_amd_ctx* ctx, K kernel, const char* name, int bs, int6
   return FSS_AMD_OK;
 }
 
+// Instantiate CALL once per PRG (LT = Lds: AES-128-MMO with LDS tables; LT = ChaChaL) and run the one
+// the context is set to.
+#define FSS_BY_PRG(ctx, CALL)                                  \
+  ((ctx)->prg == FSS_AMD_PRG_CHACHA ? [&] { using LT = ChaChaL; return CALL; }() \
+                                    : [&] { using LT = Lds; return CALL; }())
+
+#define FSS_BY_PRG_DO(ctx, ...)                      \
+  do {                                               \
+    if ((ctx)->prg == FSS_AMD_PRG_CHACHA) {          \
+      using LT = ChaChaL;                            \
+      __VA_ARGS__;                                   \
+    } else {                                         \
+      using LT = Lds;                                \
+      __VA_ARGS__;                                   \
+    }                                                \
+  } while (0)
+
 struct SharedKey {
   const uint32_t *seed = nullptr, *cws = nullptr, *ocw = nullptr;
 };
@@ -150,9 +168,9 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   const int ilp = tune().ilp, bs = tune().bs;
   int64_t thr = (a.n + ilp - 1) / ilp;
 #define FSS_L(I, B) \
-  if (ilp == I && bs == B)                                                                                    \
-  return launch_persistent(ctx, eval_points_kernel<SCHEME, SHARED, I, B, PREFIX>, name, B, thr, st, ctx->host, ctx->te0, \
-                           k.seed, k.cws, k.ocw, a)
+  if (ilp == I && bs == B)                                                                                      \
+  return FSS_BY_PRG(ctx, (launch_persistent(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, B, thr, st, \
+                                            ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;
@@ -185,6 +203,9 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   c->num_cu = prop.multiProcessorCount;
   c->last_kernel = "";
   c->last_grid = c->last_block = 0;
+  c->prg = FSS_AMD_PRG_AES128_MMO;
+  c->host.chacha_nonce[0] = c->host.chacha_nonce[1] = 0;
+  c->host.chacha_rounds = 20;
 
   uint8_t sbox[256];
   uint32_t te0[256];
@@ -228,6 +249,20 @@ void fss_amd_ctx_destroy(fss_amd_ctx* ctx) {
 
 int fss_amd_ctx_device(const fss_amd_ctx* ctx) { return ctx ? ctx->device : -1; }
 
+int fss_amd_ctx_set_prg(fss_amd_ctx* ctx, int prg, const int32_t nonce[2], int rounds) {
+  if (!ctx) return FSS_AMD_EINVAL;
+  if (prg == FSS_AMD_PRG_AES128_MMO) {
+    ctx->prg = prg;
+    return FSS_AMD_OK;
+  }
+  if (prg != FSS_AMD_PRG_CHACHA || rounds < 2 || rounds > 64 || (rounds & 1)) return FSS_AMD_EINVAL;
+  ctx->prg = prg;
+  ctx->host.chacha_nonce[0] = nonce ? (uint32_t)nonce[0] : 0u;
+  ctx->host.chacha_nonce[1] = nonce ? (uint32_t)nonce[1] : 0u;
+  ctx->host.chacha_rounds = rounds;
+  return FSS_AMD_OK;
+}
+
 const char* fss_amd_strerror(int code) {
   switch (code) {
     case FSS_AMD_OK: return "ok";
@@ -256,8 +291,8 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
   int bs = n <= 64 ? 64 : (n <= 256 ? 256 : 1024);
   int64_t want = (n + bs - 1) / bs;
   int grid = (int)(want < (int64_t)ctx->num_cu ? want : (int64_t)ctx->num_cu);
-  hipLaunchKernelGGL(prg_gen_kernel, dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, mul,
-                     reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out));
+  FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL(prg_gen_kernel<LT>, dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, mul,
+                                      reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out)));
   HIP_TRY(hipGetLastError());
   return FSS_AMD_OK;
 }

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace fssamd {
 
 // Group ids (shared with include/fss_amd.h).
@@ -43,6 +45,8 @@ struct DevCtx {
   uint32_t sel13[11][8];  // A = key 1, B = key 3   DCF value: left / right
   uint32_t hash_key[4];
   const uint32_t* self_dev;  // device-memory copy of this struct (for per-lane vector loads of round keys)
+  uint32_t chacha_nonce[2];  // ChaCha PRG (contexts created with fss_amd_ctx_set_chacha)
+  int chacha_rounds;
 };
 
 constexpr int kLdsTableBytes = 256 * 256;  // 64 KiB: 256 indices x 64 lane copies x 4 B
@@ -144,6 +148,19 @@ __device__ __forceinline__ void lds_table_fill(uint32_t* lds, const uint32_t* __
   lds_table_fill(lds_te, te0);                                            \
   __syncthreads();                                                        \
   const Lds L = make_lds(lds_te, K)
+
+// Stands in for `Lds` in kernels instantiated for the ChaCha PRG: no tables, no LDS.
+struct ChaChaL {};
+
+// Kernel prologue for either PRG: LT = Lds fills the AES tables, LT = ChaChaL does nothing.
+#define FSS_PRG_PROLOGUE(LT, te0)                                            \
+  LT L{};                                                                    \
+  if constexpr (std::is_same_v<LT, Lds>) {                                   \
+    __shared__ __attribute__((aligned(16))) uint32_t lds_te[kLdsWords];     \
+    lds_table_fill(lds_te, te0);                                            \
+    __syncthreads();                                                        \
+    L = make_lds(lds_te, K);                                                \
+  }
 
 // One table lookup: T_T[byte K of w]  (T_T = Te0 rotated left by 8T bits).
 template <int K, int T>
@@ -460,6 +477,140 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
   FSS_DRAIN_LGKM();
   aes_fin<SEL>(L, vA, kLA, kLA + 4, maskA, inA, outA);
   aes_fin<SEL>(L, vB, kLB, kLB + 4, maskB, inB, outB);
+}
+
+// ------------------------------------------------------------------ ChaCha PRG
+// fss::prg::ChaCha<mul, rounds> (include/fss/prg/chacha.cuh:24-128): one ChaCha permutation of
+// [constant | seed | seed | 0, 0, nonce] per Gen, XOR feed-forward, rows 0..3 are the outputs
+// (mul = 1: row 1; mul = 2: rows 0, 1; mul = 4: rows 0..3).  Pure VALU, no tables.
+__device__ __forceinline__ void chacha_qr(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d) {
+  a += b; d ^= a; d = rotl32(d, 16);
+  c += d; b ^= c; b = rotl32(b, 12);
+  a += b; d ^= a; d = rotl32(d, 8);
+  c += d; b ^= c; b = rotl32(b, 7);
+}
+
+// rows[r][j] after the feed-forward XORs of Gen (chacha.cuh:115-126).  WIDE: the 32-byte-key
+// constant of mul = 4, otherwise the 16-byte-key constant of mul = 1, 2.
+template <bool WIDE>
+__device__ __forceinline__ void chacha_rows(const DevCtx* __restrict__ c, const uint32_t seed[4], uint32_t x[16]) {
+  constexpr uint32_t k0 = 0x61707865u, k1 = WIDE ? 0x3320646eu : 0x3120646eu, k2 = WIDE ? 0x79622d32u : 0x79622d36u,
+                     k3 = 0x6b206574u;
+  const uint32_t n0 = c->chacha_nonce[0], n1 = c->chacha_nonce[1];
+  x[0] = k0; x[1] = k1; x[2] = k2; x[3] = k3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { x[4 + j] = seed[j]; x[8 + j] = seed[j]; }
+  x[12] = 0; x[13] = 0; x[14] = n0; x[15] = n1;
+  const int rounds = c->chacha_rounds;
+#pragma unroll 1
+  for (int i = 0; i < rounds; i += 2) {
+    chacha_qr(x[0], x[4], x[8], x[12]);
+    chacha_qr(x[1], x[5], x[9], x[13]);
+    chacha_qr(x[2], x[6], x[10], x[14]);
+    chacha_qr(x[3], x[7], x[11], x[15]);
+    chacha_qr(x[0], x[5], x[10], x[15]);
+    chacha_qr(x[1], x[6], x[11], x[12]);
+    chacha_qr(x[2], x[7], x[8], x[13]);
+    chacha_qr(x[3], x[4], x[9], x[14]);
+  }
+  x[0] ^= k0; x[1] ^= k1; x[2] ^= k2; x[3] ^= k3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { x[4 + j] ^= seed[j]; x[8 + j] ^= seed[j]; }
+  x[14] ^= n0; x[15] ^= n1;
+}
+
+// ------------------------------------------------------------------ PRG interface
+// What the walks need from a PRG, overloaded on the kernel's table type (Lds = AES-128-MMO in LDS,
+// ChaChaL = ChaCha).  "take" = only the output(s) of the child selected per lane by mask
+// (0 = left, ~0 = right); "gen" = all outputs.
+//   mul 2 (DPF, Grotto): [left, right]              mul 4 (DCF): [sl, vl, sr, vr]   (dcf.cuh:223)
+//   mul 1 (Half-Tree):   h = Gen(hash_key ^ node)[0]
+__device__ __forceinline__ void prg_gen2(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t l[4],
+                                         uint32_t r[4]) {
+  aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
+}
+__device__ __forceinline__ void prg_take2(const Lds& L, const DevCtx* __restrict__ c, uint32_t m, const uint32_t s[4],
+                                          uint32_t o[4]) {
+  aes_mmo<true>(L, &c->sel01[0][0], m, s, o);
+}
+__device__ __forceinline__ void prg_take2x2(const Lds& L, const DevCtx* __restrict__ c, uint32_t ma, uint32_t mb,
+                                            const uint32_t sa[4], const uint32_t sb[4], uint32_t oa[4], uint32_t ob[4]) {
+  aes_mmo2<true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, sa, sb, oa, ob);
+}
+__device__ __forceinline__ void prg_gen4(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t sl[4],
+                                         uint32_t vl[4], uint32_t sr[4], uint32_t vr[4]) {
+  aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s, s, sl, vl);
+  aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, s, s, sr, vr);
+}
+__device__ __forceinline__ void prg_take4(const Lds& L, const DevCtx* __restrict__ c, uint32_t m, const uint32_t s[4],
+                                          uint32_t os[4], uint32_t ov[4]) {
+  aes_mmo2<true>(L, &c->sel02[0][0], &c->sel13[0][0], m, m, s, s, os, ov);
+}
+__device__ __forceinline__ void prg_hash(const Lds& L, const DevCtx* __restrict__ c, const uint32_t in[4], uint32_t h[4]) {
+  aes_mmo<false>(L, c->rk[0], 0, in, h);
+}
+__device__ __forceinline__ void prg_hash2(const Lds& L, const DevCtx* __restrict__ c, const uint32_t ia[4],
+                                          const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
+  aes_mmo2<false>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
+}
+
+__device__ __forceinline__ void prg_gen2(const ChaChaL&, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t l[4],
+                                         uint32_t r[4]) {
+  uint32_t x[16];
+  chacha_rows<false>(c, s, x);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { l[j] = x[j]; r[j] = x[4 + j]; }
+}
+__device__ __forceinline__ void prg_take2(const ChaChaL& L, const DevCtx* __restrict__ c, uint32_t m, const uint32_t s[4],
+                                          uint32_t o[4]) {
+  uint32_t l[4], r[4];
+  prg_gen2(L, c, s, l, r);  // one permutation yields both children
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_bitop3_b32(m, r[j], l[j], kSelect);
+}
+__device__ __forceinline__ void prg_take2x2(const ChaChaL& L, const DevCtx* __restrict__ c, uint32_t ma, uint32_t mb,
+                                            const uint32_t sa[4], const uint32_t sb[4], uint32_t oa[4], uint32_t ob[4]) {
+  prg_take2(L, c, ma, sa, oa);
+  prg_take2(L, c, mb, sb, ob);
+}
+__device__ __forceinline__ void prg_gen4(const ChaChaL&, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t sl[4],
+                                         uint32_t vl[4], uint32_t sr[4], uint32_t vr[4]) {
+  uint32_t x[16];
+  chacha_rows<true>(c, s, x);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sl[j] = x[j]; vl[j] = x[4 + j]; sr[j] = x[8 + j]; vr[j] = x[12 + j]; }
+}
+__device__ __forceinline__ void prg_take4(const ChaChaL& L, const DevCtx* __restrict__ c, uint32_t m, const uint32_t s[4],
+                                          uint32_t os[4], uint32_t ov[4]) {
+  uint32_t sl[4], vl[4], sr[4], vr[4];
+  prg_gen4(L, c, s, sl, vl, sr, vr);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    os[j] = __builtin_amdgcn_bitop3_b32(m, sr[j], sl[j], kSelect);
+    ov[j] = __builtin_amdgcn_bitop3_b32(m, vr[j], vl[j], kSelect);
+  }
+}
+__device__ __forceinline__ void prg_hash(const ChaChaL&, const DevCtx* __restrict__ c, const uint32_t in[4], uint32_t h[4]) {
+  uint32_t x[16];
+  chacha_rows<false>(c, in, x);  // mul = 1: row 1 (chacha.cuh:116-118)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[j] = x[4 + j];
+}
+__device__ __forceinline__ void prg_hash2(const ChaChaL& L, const DevCtx* __restrict__ c, const uint32_t ia[4],
+                                          const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
+  prg_hash(L, c, ia, ha);
+  prg_hash(L, c, ib, hb);
+}
+// Raw PRG outputs for fss_amd_prg_gen: out[j] for j < mul.
+__device__ __forceinline__ void prg_raw(const Lds& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],
+                                        uint32_t out[4][4]) {
+  for (int j = 0; j < mul; ++j) aes_mmo<false>(L, c->rk[j], 0, s, out[j]);
+}
+__device__ __forceinline__ void prg_raw(const ChaChaL& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],
+                                        uint32_t out[4][4]) {
+  if (mul == 1) prg_hash(L, c, s, out[0]);
+  else if (mul == 2) prg_gen2(L, c, s, out[0], out[1]);
+  else prg_gen4(L, c, s, out[0], out[1], out[2], out[3]);
 }
 
 // ------------------------------------------------------------------ output groups

@@ -38,11 +38,12 @@ struct ExpandArgs {
 
 // -- one-node expansions ------------------------------------------------------
 // DPF / Grotto node -> both children, control bits packed (dpf.cuh:266-289).
-__device__ __forceinline__ void dpf_expand(const Lds& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
+template <class LT>
+__device__ __forceinline__ void dpf_expand(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
                                            const uint32_t st[4], uint32_t left[4], uint32_t right[4]) {
   uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
-  aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, in, in, left, right);  // both children, interleaved
+  prg_gen2(L, c, in, left, right);  // both children (AES: two interleaved blocks)
   uint32_t wl = cw[3], wr = (cw[3] & ~1u) | (cw[4] & 1u);
   left[0] = and_xor(tm, cw[0], left[0]);   right[0] = and_xor(tm, cw[0], right[0]);
   left[1] = and_xor(tm, cw[1], left[1]);   right[1] = and_xor(tm, cw[1], right[1]);
@@ -52,14 +53,14 @@ __device__ __forceinline__ void dpf_expand(const Lds& L, const DevCtx* __restric
 
 // DCF node (dcf.cuh:331-366): children plus their running values (positive terms;
 // the party sign is applied at the leaf).
-__device__ __forceinline__ void dcf_expand(const Lds& L, const DevCtx* __restrict__ c, int g,
+template <class LT>
+__device__ __forceinline__ void dcf_expand(const LT& L, const DevCtx* __restrict__ c, int g,
                                            const uint32_t* __restrict__ cw, const uint32_t st[4], const Acc& v,
                                            uint32_t left[4], Acc& vl, uint32_t right[4], Acc& vr) {
   uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
   uint32_t bl[4], br[4];
-  aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, in, in, left, bl);
-  aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, in, in, right, br);
+  prg_gen4(L, c, in, left, bl, right, br);
   bl[3] &= ~1u; br[3] &= ~1u;
   uint32_t vcw[4] = {cw[4], cw[5], cw[6], cw[7] & ~1u};
   vl = v; vl.add(g, bl); vl.add_if(g, tm, vcw);
@@ -72,13 +73,14 @@ __device__ __forceinline__ void dcf_expand(const Lds& L, const DevCtx* __restric
 }
 
 // Half-Tree inner node (half_tree_dpf.cuh:293-302): one hash, right = left ^ parent.
-__device__ __forceinline__ void ht_expand(const Lds& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
+template <class LT>
+__device__ __forceinline__ void ht_expand(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
                                           const uint32_t node[4], uint32_t left[4], uint32_t right[4]) {
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(node[3], 0, 1);
   uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                     node[3] ^ c->hash_key[3]};
   uint32_t h[4];
-  aes_mmo<false>(L, c->rk[0], 0, in, h);
+  prg_hash(L, c, in, h);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     left[j] = and_xor(tm, cw[j], h[j]);
@@ -87,14 +89,15 @@ __device__ __forceinline__ void ht_expand(const Lds& L, const DevCtx* __restrict
 }
 
 // Half-Tree last level for one sigma (half_tree_dpf.cuh:325-354).
-__device__ __forceinline__ uint4 ht_convert(const Lds& L, const DevCtx* __restrict__ c, int g, int party,
+template <class LT>
+__device__ __forceinline__ uint4 ht_convert(const LT& L, const DevCtx* __restrict__ c, int g, int party,
                                             const uint32_t* __restrict__ cw, const uint32_t* __restrict__ ocw,
                                             const uint32_t parent[4], uint32_t sigma) {
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(parent[3], 0, 1);
   uint32_t in[4] = {parent[0] ^ c->hash_key[0], parent[1] ^ c->hash_key[1], parent[2] ^ c->hash_key[2],
                     ((parent[3] & ~1u) | sigma) ^ c->hash_key[3]};
   uint32_t h[4];
-  aes_mmo<false>(L, c->rk[0], 0, in, h);
+  prg_hash(L, c, in, h);
   uint32_t lcw = sigma ? (cw[4] & 1u) : (cw[3] & 1u);
   uint32_t low = (h[3] ^ (tm & lcw)) & 1u;
   uint32_t high[4] = {and_xor(tm, cw[0], h[0]), and_xor(tm, cw[1], h[1]), and_xor(tm, cw[2], h[2]),
@@ -110,12 +113,12 @@ __device__ __forceinline__ uint4 ht_convert(const Lds& L, const DevCtx* __restri
 // Produces the 2^top nodes at depth level0 = p + top under the subtree root whose
 // path is `prefix` (p bits).  Same walk as point evaluation, but the node (and the
 // DCF running value) is stored instead of converted.
-template <int SCHEME>
+template <class LT, int SCHEME>
 __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                        const uint32_t* __restrict__ k_seed,
                                                        const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   const int depth = a.level0;  // p + top
   const int64_t nout = (int64_t)1 << top;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += (int64_t)gridDim.x * blockDim.x) {
@@ -160,13 +163,13 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
 // writes children (j << D) + k.  LEAF: the outputs are the tree's leaves and are
 // converted (dpf.cuh:255-263, dcf.cuh:318-329, half_tree_dpf.cuh ConvertLastLevel,
 // grotto_dcf.cuh:194-198) instead of stored as nodes.
-template <int SCHEME, int D, bool LEAF, int BS>
+template <class LT, int SCHEME, int D, bool LEAF, int BS>
 __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                     const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
                                                     const uint32_t* __restrict__ k_ocw,  // Half-Tree
                                                     ExpandArgs a) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   const int g = a.group, party = a.party;
 
   constexpr int NN = 1 << D;

@@ -6,19 +6,20 @@
 namespace fssamd {
 
 // out[i*mul + j] = AES_{key j}(seeds[i]) ^ seeds[i]   (include/fss/prg/aes128_mmo.cuh:79-89)
+template <class LT>
 __global__ __launch_bounds__(1024) void prg_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, int mul,
                                                       const uint4* __restrict__ seeds, int64_t n,
                                                       uint4* __restrict__ out) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint4 s = seeds[i];
     uint32_t in[4] = {s.x, s.y, s.z, s.w};
-    for (int j = 0; j < mul; ++j) {
-      uint32_t o[4];
-      aes_mmo<false>(L, c->rk[j], 0, in, o);
-      out[i * mul + j] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
+    uint32_t o[4][4];
+    prg_raw(L, c, mul, in, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < mul) out[i * mul + j] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
   }
 }
 
@@ -79,10 +80,10 @@ __device__ __forceinline__ void ld4(uint32_t d[4], uint4 v) { d[0] = v.x; d[1] =
 __device__ __forceinline__ uint4 mk4(const uint32_t d[4]) { return make_uint4(d[0], d[1], d[2], d[3]); }
 
 // fss::Dpf::Gen (include/fss/dpf.cuh:93-159) and fss::Dcf::Gen (include/fss/dcf.cuh:108-194).
-template <int SCHEME>
+template <class LT, int SCHEME>
 __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t s0[4], s1[4], beta[4];
@@ -99,14 +100,12 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
       uint32_t v0l[4], v0r[4], v1l[4], v1r[4];
       if (SCHEME == S_DCF) {
         // two blocks at a time: eight interleaved AES states do not fit 128 VGPRs
-        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s0, s0, s0l, v0l);
-        aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, s0, s0, s0r, v0r);
-        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s1, s1, s1l, v1l);
-        aes_mmo2<false>(L, c->rk[2], c->rk[3], 0, 0, s1, s1, s1r, v1r);
+        prg_gen4(L, c, s0, s0l, v0l, s0r, v0r);
+        prg_gen4(L, c, s1, s1l, v1l, s1r, v1r);
         v0l[3] &= ~1u; v0r[3] &= ~1u; v1l[3] &= ~1u; v1r[3] &= ~1u;
       } else {
-        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s0, s0, s0l, s0r);
-        aes_mmo2<false>(L, c->rk[0], c->rk[1], 0, 0, s1, s1, s1l, s1r);
+        prg_gen2(L, c, s0, s0l, s0r);
+        prg_gen2(L, c, s1, s1l, s1r);
       }
       const uint32_t t0l = s0l[3] & 1u, t0r = s0r[3] & 1u, t1l = s1l[3] & 1u, t1r = s1r[3] & 1u;
       s0l[3] &= ~1u; s0r[3] &= ~1u; s1l[3] &= ~1u; s1r[3] &= ~1u;
@@ -176,14 +175,15 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
 }
 
 // fss::HalfTreeDpf::Gen (include/fss/half_tree_dpf.cuh:68-175).
+template <class LT>
 __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
   auto hash = [&](const uint32_t node[4], uint32_t h[4]) {
     uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                       node[3] ^ c->hash_key[3]};
-    aes_mmo<false>(L, c->rk[0], 0, in, h);
+    prg_hash(L, c, in, h);
   };
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t n0[4], n1[4], beta[4];

@@ -81,24 +81,28 @@ struct DpfWalk {
     st[0] = node.x; st[1] = node.y; st[2] = node.z; st[3] = node.w;
     x = x_;
   }
-  __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i, const CwDpf& cw) {
+  template <class LT>
+  __device__ __forceinline__ void level(const LT& L, const DevCtx* __restrict__ c, int in_bits, int i, const CwDpf& cw) {
     uint32_t m = bit_mask(x, in_bits - 1 - i);  // dpf.cuh:196
     uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
     uint32_t o[4];
-    aes_mmo<true>(L, &c->sel01[0][0], m, in, o);  // dpf.cuh:182, taken child only
+    prg_take2(L, c, m, in, o);  // dpf.cuh:182, taken child only
     apply(m, o, cw);
   }
   // Two walks, one level, the two AES blocks interleaved (aes_mmo2).
-  static __device__ __forceinline__ void level2(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i,
+  template <class LT>
+  static __device__ __forceinline__ void level2(const LT& L, const DevCtx* __restrict__ c, int in_bits, int i,
                                                 DpfWalk& a, const CwDpf& cwa, DpfWalk& b, const CwDpf& cwb,
                                                 const uint32_t* kdv) {
     uint32_t ma = bit_mask(a.x, in_bits - 1 - i), mb = bit_mask(b.x, in_bits - 1 - i);
     uint32_t ia[4] = {a.st[0], a.st[1], a.st[2], a.st[3] & ~1u}, ib[4] = {b.st[0], b.st[1], b.st[2], b.st[3] & ~1u};
     uint32_t oa[4], ob[4];
 #if FSS_RESD
-    aes_mmo2<true, true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob, kdv);
+    if constexpr (std::is_same_v<LT, Lds>) aes_mmo2<true, true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob, kdv);
+    else prg_take2x2(L, c, ma, mb, ia, ib, oa, ob);
 #else
-    aes_mmo2<true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob);
+    (void)kdv;
+    prg_take2x2(L, c, ma, mb, ia, ib, oa, ob);
 #endif
     a.apply(ma, oa, cwa);
     b.apply(mb, ob, cwb);
@@ -143,13 +147,14 @@ struct DcfWalk {
     v.v[0] = val.x; v.v[1] = val.y; v.v[2] = val.z; v.v[3] = val.w;
     x = x_;
   }
-  __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int g, int in_bits, int i,
+  template <class LT>
+  __device__ __forceinline__ void level(const LT& L, const DevCtx* __restrict__ c, int g, int in_bits, int i,
                                         const CwDcf& cw) {
     uint32_t m = bit_mask(x, in_bits - 1 - i);
     uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
     uint32_t os[4], ov[4];
-    // sl (key 0) or sr (key 2), and vl (key 1) or vr (key 3): dcf.cuh:223, two interleaved blocks
-    aes_mmo2<true>(L, &c->sel02[0][0], &c->sel13[0][0], m, m, in, in, os, ov);
+    // sl or sr, and vl or vr (dcf.cuh:223); AES: keys 0/2 and 1/3, two interleaved blocks
+    prg_take4(L, c, m, in, os, ov);
     uint32_t tm = lsb_mask(st[3]);
     ov[3] &= ~1u;  // dcf.cuh:227,232
     v.add(g, ov);  // dcf.cuh:244-252 (signs applied once in finish)
@@ -183,14 +188,15 @@ struct HtWalk {
     node[0] = n.x; node[1] = n.y; node[2] = n.z; node[3] = n.w;
     x = x_;
   }
-  static __device__ __forceinline__ void level2(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i,
+  template <class LT>
+  static __device__ __forceinline__ void level2(const LT& L, const DevCtx* __restrict__ c, int in_bits, int i,
                                                 HtWalk& a, const uint32_t cwa[4], HtWalk& b, const uint32_t cwb[4]) {
     uint32_t ma = bit_mask(a.x, in_bits - 1 - i), mb = bit_mask(b.x, in_bits - 1 - i);
     uint32_t ta = lsb_mask(a.node[3]), tb = lsb_mask(b.node[3]);
     uint32_t ia[4], ib[4], ha[4], hb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { ia[j] = a.node[j] ^ c->hash_key[j]; ib[j] = b.node[j] ^ c->hash_key[j]; }
-    aes_mmo2<false>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
+    prg_hash2(L, c, ia, ib, ha, hb);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       a.node[j] = and_xor(ma, a.node[j], and_xor(ta, cwa[j], ha[j]));
@@ -198,25 +204,27 @@ struct HtWalk {
     }
   }
   // levels 0 .. in_bits-2
-  __device__ __forceinline__ void level(const Lds& L, const DevCtx* __restrict__ c, int in_bits, int i, const uint32_t cw[4]) {
+  template <class LT>
+  __device__ __forceinline__ void level(const LT& L, const DevCtx* __restrict__ c, int in_bits, int i, const uint32_t cw[4]) {
     uint32_t m = bit_mask(x, in_bits - 1 - i);
     uint32_t tm = lsb_mask(node[3]);
     uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                       node[3] ^ c->hash_key[3]};
     uint32_t h[4];
-    aes_mmo<false>(L, c->rk[0], 0, in, h);  // prg.Gen(hash_key ^ node)[0], :195
+    prg_hash(L, c, in, h);  // prg.Gen(hash_key ^ node)[0], :195
 #pragma unroll
     for (int j = 0; j < 4; ++j) node[j] = and_xor(m, node[j], and_xor(tm, cw[j], h[j]));  // :197-201
   }
   // last level + output conversion, :205-229
-  __device__ __forceinline__ uint4 finish(const Lds& L, const DevCtx* __restrict__ c, int g, int party, const uint32_t cw[4],
+  template <class LT>
+  __device__ __forceinline__ uint4 finish(const LT& L, const DevCtx* __restrict__ c, int g, int party, const uint32_t cw[4],
                                           uint32_t extra, const uint32_t ocw[4]) const {
     uint32_t xn = (uint32_t)x.lo & 1u;
     uint32_t tm = lsb_mask(node[3]);
     uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                       ((node[3] & ~1u) | xn) ^ c->hash_key[3]};
     uint32_t h[4];
-    aes_mmo<false>(L, c->rk[0], 0, in, h);
+    prg_hash(L, c, in, h);
     uint32_t lcw = xn ? (extra & 1u) : (cw[3] & 1u);
     uint32_t low = (h[3] ^ (tm & lcw)) & 1u;
     uint32_t high[4] = {and_xor(tm, cw[0], h[0]), and_xor(tm, cw[1], h[1]), and_xor(tm, cw[2], h[2]),
@@ -239,14 +247,14 @@ struct HtWalk {
 // are read with scalar loads.
 // PREFIX: start every walk from the level-`start_level` node table (shared-prefix entry points);
 // a separate instantiation so profiles tell the two paths apart.
-template <int SCHEME, bool SHARED, int ILP, int BS, bool PREFIX = false>
+template <class LT, int SCHEME, bool SHARED, int ILP, int BS, bool PREFIX = false>
 __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                          const uint32_t* __restrict__ k_seed,  // uint32[4]
                                                          const uint32_t* __restrict__ k_cws,   // raw Cw slots
                                                          const uint32_t* __restrict__ k_ocw,   // Half-Tree
                                                          EvalArgs a) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
 
   const int in_bits = a.in_bits, party = a.party, g = a.group;
   const int lvl0 = PREFIX ? a.start_level : 0;
@@ -405,10 +413,10 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 // (the whole-domain case e = 2^n is the root's control bit).  Keys are DPF keys
 // over Bytes (include/fss/grotto_dcf.cuh:63-67); the per-level expansion is
 // ExpandTreeRec's (grotto_dcf.cuh:201-222).  Independent keys, level-major.
-template <int BS>
+template <class LT, int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
   const DevCtx* c = &K;
-  FSS_LDS_PROLOGUE(te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits;
   uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
   for (int64_t k = (int64_t)blockIdx.x * BS + threadIdx.x; k < a.n; k += (int64_t)gridDim.x * BS) {
@@ -426,8 +434,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
       uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
       const uint32_t tm = lsb_mask(st[3]);
       uint32_t l[4], r[4];
-      aes_mmo<false>(L, c->rk[0], 0, in, l);
-      aes_mmo<false>(L, c->rk[1], 0, in, r);
+      prg_gen2(L, c, in, l, r);
       const uint32_t wl = t.w, wr = (t.w & ~1u) | ((uint32_t)(trb >> i) & 1u);
       l[0] = and_xor(tm, t.x, l[0]); l[1] = and_xor(tm, t.y, l[1]); l[2] = and_xor(tm, t.z, l[2]); l[3] = and_xor(tm, wl, l[3]);
       r[0] = and_xor(tm, t.x, r[0]); r[1] = and_xor(tm, t.y, r[1]); r[2] = and_xor(tm, t.z, r[2]); r[3] = and_xor(tm, wr, r[3]);

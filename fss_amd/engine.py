@@ -21,6 +21,12 @@ DEFAULT_AES_KEYS = (
     bytes([8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1]),
 )
 DEFAULT_HASH_KEY = (0x12345678, 0x9ABCDEF0, 0x13572468, 0x2468ACE0)
+# Nonce of the reference's C++ tests (src/dcf_test.cu:35).  The reference's Python binding draws a random
+# process-global nonce instead (fss_crypto/_csrc/binding_common.cuh:13-37), so its ChaCha outputs are not
+# reproducible across processes; here the nonce is an explicit, fixed engine parameter.
+DEFAULT_CHACHA_NONCE = (0x12345678, 0x9ABCDEF0)
+PRG_AES128_MMO, PRG_CHACHA = 0, 1
+PRG_IDS = {"aes128_mmo": PRG_AES128_MMO, "chacha": PRG_CHACHA}
 
 
 def resolve_group(group, in_bits):
@@ -45,7 +51,8 @@ class LevelMajorKeys:
 
 
 class Engine:
-    def __init__(self, device=None, aes_keys=DEFAULT_AES_KEYS, hash_key=DEFAULT_HASH_KEY):
+    def __init__(self, device=None, aes_keys=DEFAULT_AES_KEYS, hash_key=DEFAULT_HASH_KEY, prg="aes128_mmo",
+                 chacha_nonce=DEFAULT_CHACHA_NONCE, chacha_rounds=20):
         L = _lib.lib()
         if not torch.cuda.is_available():
             raise RuntimeError("fss_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
@@ -59,6 +66,12 @@ class Engine:
         h = C.c_void_p()
         _lib.check(L.fss_amd_ctx_create(C.byref(h), self.device.index, C.c_char_p(keys), hk), "fss_amd_ctx_create")
         self._h, self._L = h, L
+        self.prg = prg
+        if prg not in PRG_IDS:
+            raise ValueError(f"prg must be one of {tuple(PRG_IDS)}, got {prg!r}")
+        if prg == "chacha":
+            nn = (C.c_int32 * 2)(*[int(np.uint32(v).astype(np.int32)) for v in chacha_nonce])
+            _lib.check(L.fss_amd_ctx_set_prg(h, PRG_CHACHA, nn, chacha_rounds), "fss_amd_ctx_set_prg")
 
     def __del__(self):
         try:
@@ -130,9 +143,10 @@ class Engine:
         prefix_bits=None picks ~log2(len(xs)), capped by in_bits and 26."""
         seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
         n = xs.numel()
+        cap = min(in_bits - (1 if scheme == HT else 0), 26)
         if prefix_bits is None:
-            prefix_bits = max(1, min(in_bits - (1 if scheme == HT else 0), 26, max(n, 2).bit_length() - 1))
-        if prefix_bits < 1:
+            prefix_bits = min(cap, max(n, 2).bit_length() - 1)
+        if prefix_bits < 1 or cap < 1:  # nothing to share (e.g. a 1-level Half-Tree key): plain walk
             return self.eval_points(scheme, in_bits, group, party, seed, cws, xs, ocw=ocw, out=out)
         L, st = self._L, self._stream()
         ws_bytes = L.fss_amd_eval_points_workspace(scheme, in_bits, prefix_bits)
@@ -286,11 +300,11 @@ class Engine:
 _default = {}
 
 
-def default_engine(device=None):
-    """Process-wide engine per device with the reference's bench AES keys."""
+def default_engine(device=None, prg="aes128_mmo"):
+    """Process-wide engine per (device, prg): the reference's bench AES keys / test ChaCha nonce."""
     if not torch.cuda.is_available():
         raise RuntimeError("fss_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
     idx = torch.cuda.current_device() if device is None else (device if isinstance(device, int) else torch.device(device).index or 0)
-    if idx not in _default:
-        _default[idx] = Engine(idx)
-    return _default[idx]
+    if (idx, prg) not in _default:
+        _default[(idx, prg)] = Engine(idx, prg=prg)
+    return _default[(idx, prg)]

@@ -3,8 +3,9 @@
 `Dpf` and `Dcf` keep the constructor / method surface and the error behaviour of
 the reference's Python binding (fss_crypto/dpf.py:23-109, fss_crypto/dcf.py:24-113):
 gen / eval / eval_all with the same tensor shapes.  Differences, all deliberate:
-  * only prg="aes128_mmo" is built (ChaCha is a "next" row); it runs on the GPU,
-    where the reference rejects it (fss_crypto/dpf.py:82-87);
+  * prg="aes128_mmo" (default here; the headline path) runs on the GPU, where the reference rejects it
+    (fss_crypto/dpf.py:82-87); prg="chacha" uses a fixed engine nonce instead of the reference
+    binding's per-process random one;
   * CPU tensors are accepted everywhere and results come back on the input's
     device, but the arithmetic always runs in the HIP kernels -- no CPU path;
   * batched methods are added: eval_points (one key, many x), relayout +
@@ -52,8 +53,6 @@ class _Base:
         _check_group(group)
         if prg not in ("chacha", "aes128_mmo"):
             raise ValueError(f"prg must be one of ('chacha', 'aes128_mmo'), got {prg!r}")
-        if prg != "aes128_mmo":
-            raise NotImplementedError("fss_amd builds the AES-128-MMO PRG only; pass prg='aes128_mmo'")
         if in_bits > _MAX_IN_BITS:
             raise NotImplementedError(f"fss_amd kernels cover in_bits <= {_MAX_IN_BITS}, got {in_bits}")
         self.in_bits, self.group, self.prg = in_bits, group, prg
@@ -63,7 +62,7 @@ class _Base:
     @property
     def engine(self):
         if self._engine is None:
-            self._engine = E.default_engine()
+            self._engine = E.default_engine(prg=self.prg)
         return self._engine
 
     @property

@@ -66,6 +66,13 @@ typedef struct fss_amd_ctx fss_amd_ctx;
 int fss_amd_ctx_create(fss_amd_ctx **out, int device, const uint8_t aes_keys[64], const int32_t hash_key[4]);
 void fss_amd_ctx_destroy(fss_amd_ctx *ctx);
 int fss_amd_ctx_device(const fss_amd_ctx *ctx);
+/* Select the context's PRG.  FSS_AMD_PRG_AES128_MMO (default): fss::prg::Aes128Mmo<mul> with the keys given
+ * at creation.  FSS_AMD_PRG_CHACHA: fss::prg::ChaCha<mul, rounds>(nonce) (include/fss/prg/chacha.cuh:24-128;
+ * nonce = 2 ints as the reference's constructor takes them, rounds even, 20 in the reference's default);
+ * mul follows the scheme (Half-Tree 1, DPF/Grotto 2, DCF 4).  Every entry point below then uses it. */
+#define FSS_AMD_PRG_AES128_MMO 0
+#define FSS_AMD_PRG_CHACHA 1
+int fss_amd_ctx_set_prg(fss_amd_ctx *ctx, int prg, const int32_t nonce[2], int rounds);
 const char *fss_amd_strerror(int code);
 /* Last hipError_t seen by this library on the calling thread (0 = hipSuccess). */
 int fss_amd_last_hip_error(void);

@@ -160,8 +160,68 @@ void fo_prg_free(fo_prg *p) {
   memset(p->evp, 0, sizeof(p->evp));
 }
 
+/* ---- ChaCha PRG, include/fss/prg/chacha.cuh ---- */
+static inline uint32_t rotl_u32(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+#define FO_QR(a, b, c, d)                                   \
+  do {                                                      \
+    a += b; d ^= a; d = rotl_u32(d, 16);                    \
+    c += d; b ^= c; b = rotl_u32(b, 12);                    \
+    a += b; d ^= a; d = rotl_u32(d, 8);                     \
+    c += d; b ^= c; b = rotl_u32(b, 7);                     \
+  } while (0)
+
+/* chacha.cuh:46-60 (Rounds): x[row] is an int4, so word (row, col) = state[4*row + col]. */
+void fo_chacha_permute(uint32_t x[16], int rounds) {
+  for (int i = 0; i < rounds; i += 2) {
+    FO_QR(x[0], x[4], x[8], x[12]);
+    FO_QR(x[1], x[5], x[9], x[13]);
+    FO_QR(x[2], x[6], x[10], x[14]);
+    FO_QR(x[3], x[7], x[11], x[15]);
+    FO_QR(x[0], x[5], x[10], x[15]);
+    FO_QR(x[1], x[6], x[11], x[12]);
+    FO_QR(x[2], x[7], x[8], x[13]);
+    FO_QR(x[3], x[4], x[9], x[14]);
+  }
+}
+
+int fo_prg_init_chacha(fo_prg *p, int mul, int rounds, const int32_t nonce[2]) {
+  memset(p, 0, sizeof(*p));
+  if ((mul != 1 && mul != 2 && mul != 4) || rounds < 2 || (rounds & 1)) return -1;
+  p->mul = mul;
+  p->kind = 1;
+  p->rounds = rounds;
+  p->nonce[0] = nonce[0];
+  p->nonce[1] = nonce[1];
+  return 0;
+}
+
+/* chacha.cuh:95-127 (Gen) */
+static void chacha_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) {
+  static const uint32_t k16[4] = {0x61707865, 0x3120646e, 0x79622d36, 0x6b206574}; /* "expand 16-byte k" */
+  static const uint32_t k32[4] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574}; /* "expand 32-byte k" */
+  const uint32_t *kc = p->mul <= 2 ? k16 : k32;
+  uint32_t sd[4], x[16];
+  memcpy(sd, &seed, 16);
+  for (int j = 0; j < 4; ++j) { x[j] = kc[j]; x[4 + j] = sd[j]; x[8 + j] = sd[j]; } /* ExpandKey: x[2] = x[1] */
+  x[12] = 0; x[13] = 0; x[14] = (uint32_t)p->nonce[0]; x[15] = (uint32_t)p->nonce[1];
+  fo_chacha_permute(x, p->rounds);
+  uint32_t r[4][4];
+  for (int j = 0; j < 4; ++j) {
+    r[0][j] = x[j] ^ kc[j];
+    r[1][j] = x[4 + j] ^ sd[j];
+    r[2][j] = x[8 + j] ^ sd[j];
+    r[3][j] = x[12 + j];
+  }
+  r[3][2] ^= (uint32_t)p->nonce[0];
+  r[3][3] ^= (uint32_t)p->nonce[1];
+  if (p->mul == 1) memcpy(&out[0], r[1], 16);
+  else if (p->mul == 2) { memcpy(&out[0], r[0], 16); memcpy(&out[1], r[1], 16); }
+  else for (int i = 0; i < 4; ++i) memcpy(&out[i], r[i], 16);
+}
+
 /* out[i] = AES128-ECB_{key_i}(seed) ^ seed -- aes128_mmo.cuh:79-89 */
 void fo_prg_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) {
+  if (p->kind == 1) { chacha_gen(p, seed, out); return; }
   for (int i = 0; i < p->mul; ++i) {
 #ifdef FO_HAVE_OPENSSL
     if (p->use_evp) {

@@ -65,9 +65,16 @@ typedef struct {
   uint8_t key[4][16];
   uint32_t rk[4][44];   /* own AES: little-endian round-key words */
   void *evp[4];         /* EVP_CIPHER_CTX* when use_evp */
+  int kind;             /* 0: AES-128-MMO (above); 1: ChaCha (include/fss/prg/chacha.cuh:24-128) */
+  int rounds;           /* ChaCha rounds (20) */
+  int32_t nonce[2];     /* ChaCha nonce */
 } fo_prg;
 
 int fo_prg_init(fo_prg *p, const uint8_t *keys /* mul*16 bytes */, int mul, int use_evp);
+/* fss::prg::ChaCha<mul, rounds>(nonce), include/fss/prg/chacha.cuh:93. */
+int fo_prg_init_chacha(fo_prg *p, int mul, int rounds, const int32_t nonce[2]);
+/* The bare ChaCha permutation (`rounds` rounds, no feed-forward) on 16 words, for the RFC 7539 KAT. */
+void fo_chacha_permute(uint32_t state[16], int rounds);
 void fo_prg_free(fo_prg *p);
 void fo_prg_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out /* mul */);
 /* Raw AES-128 single block (FIPS-197), for KATs. */

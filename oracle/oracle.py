@@ -48,7 +48,8 @@ class _I4(C.Structure):
 
 class _Prg(C.Structure):
     _fields_ = [("mul", C.c_int), ("use_evp", C.c_int), ("key", (C.c_uint8 * 16) * 4),
-                ("rk", (C.c_uint32 * 44) * 4), ("evp", C.c_void_p * 4)]
+                ("rk", (C.c_uint32 * 44) * 4), ("evp", C.c_void_p * 4), ("kind", C.c_int), ("rounds", C.c_int),
+                ("nonce", C.c_int32 * 2)]
 
 
 _lib = None
@@ -66,6 +67,9 @@ def lib():
         L.fo_prg_free.argtypes = [P]
         L.fo_prg_gen.argtypes = [P, _I4, vp]
         L.fo_aes128_encrypt.argtypes = [vp, vp, vp]
+        L.fo_prg_init_chacha.argtypes = [P, i, i, vp]
+        L.fo_prg_init_chacha.restype = i
+        L.fo_chacha_permute.argtypes = [vp, i]
         L.fo_dpf_gen.argtypes = [P, i, i, vp, vp, u64, u64, _I4]
         L.fo_dpf_eval.argtypes = [P, i, i, i, _I4, vp, u64, u64]
         L.fo_dpf_eval.restype = _I4
@@ -117,14 +121,29 @@ def aes128_encrypt(key: bytes, block: bytes) -> bytes:
     return bytes(out)
 
 
-class Prg:
-    """fss::prg::Aes128Mmo<mul> (include/fss/prg/aes128_mmo.cuh:27-95)."""
+CHACHA_NONCE = (0x12345678, 0x9ABCDEF0)  # the nonce of the reference's C++ tests (src/dcf_test.cu:35)
 
-    def __init__(self, mul, keys=None, use_evp=False):
-        keys = KEYS[:mul] if keys is None else keys
-        assert len(keys) == mul
+
+def chacha_permute(words, rounds=20):
+    a = np.array(words, dtype=np.uint32)
+    lib().fo_chacha_permute(_ptr(a), rounds)
+    return a
+
+
+class Prg:
+    """fss::prg::Aes128Mmo<mul> (include/fss/prg/aes128_mmo.cuh:27-95), or with chacha=True
+    fss::prg::ChaCha<mul, rounds> (include/fss/prg/chacha.cuh:24-128)."""
+
+    def __init__(self, mul, keys=None, use_evp=False, chacha=False, nonce=CHACHA_NONCE, rounds=20):
         self.mul = mul
         self._p = _Prg()
+        if chacha:
+            nn = (C.c_int32 * 2)(*[int(np.uint32(v).astype(np.int32)) for v in nonce])
+            if lib().fo_prg_init_chacha(C.byref(self._p), mul, rounds, nn) != 0:
+                raise RuntimeError("fo_prg_init_chacha failed")
+            return
+        keys = KEYS[:mul] if keys is None else keys
+        assert len(keys) == mul
         buf = b"".join(keys)
         rc = lib().fo_prg_init(C.byref(self._p), C.c_char_p(buf), mul, 1 if use_evp else 0)
         if rc != 0:

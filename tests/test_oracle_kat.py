@@ -76,3 +76,35 @@ def test_ht64_u64(O):
     assert (O.ht_eval(p, 64, O.U64, 0, S0, cws, ocw, k["alpha"]) == words(k["y0_alpha"])).all()
     assert (O.ht_eval(p, 64, O.U64, 1, S1, cws, ocw, k["alpha"]) == words(k["y1_alpha"])).all()
     assert (O.ht_eval(p, 64, O.U64, 0, S0, cws, ocw, k["x_other"]) == words(k["y0_other"])).all()
+
+
+# ---------------------------------------------------------------- ChaCha PRG (include/fss/prg/chacha.cuh)
+def test_chacha_permutation_rfc7539(O):
+    """The permutation core against RFC 7539 section 2.3.2 (block = permute(state) + state)."""
+    key = bytes(range(32))
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(np.frombuffer(key, dtype="<u4")) + \
+         [1, 0x09000000, 0x4A000000, 0]
+    out = O.chacha_permute(st)
+    block = (out.astype(np.uint64) + np.array(st, dtype=np.uint64)) & 0xFFFFFFFF
+    want = [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+            0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    assert [int(v) for v in block] == want
+
+
+def test_chacha_gen_structure(O, rng):
+    """Gen as chacha.cuh:95-127 builds it: rows of one permutation of [const | seed | seed | 0,0,nonce]
+    with the XOR feed-forward; mul = 1 is row 1 of the 16-byte-constant state, mul = 2 rows 0-1."""
+    nonce = (0x12345678, 0x9ABCDEF0)
+    for _ in range(20):
+        seed = rng.i4(clear_lsb=False)
+        sd = [int(v) & 0xFFFFFFFF for v in seed]
+        for mul, const in ((1, [0x61707865, 0x3120646E, 0x79622D36, 0x6B206574]),
+                           (2, [0x61707865, 0x3120646E, 0x79622D36, 0x6B206574]),
+                           (4, [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574])):
+            st = const + sd + sd + [0, 0, nonce[0], nonce[1]]
+            x = [int(v) for v in O.chacha_permute(st)]
+            rows = [[x[j] ^ const[j] for j in range(4)], [x[4 + j] ^ sd[j] for j in range(4)],
+                    [x[8 + j] ^ sd[j] for j in range(4)], [x[12], x[13], x[14] ^ nonce[0], x[15] ^ nonce[1]]]
+            want = {1: [rows[1]], 2: rows[:2], 4: rows}[mul]
+            got = O.Prg(mul, chacha=True, nonce=nonce).gen(seed).view(np.uint32)
+            assert [[int(v) for v in r] for r in got] == want

@@ -127,3 +127,26 @@ def test_grotto_walk_64(O, rng):
     for x in [0, alpha - 1, alpha, alpha + 1, (1 << 64) - 1, rng.below(64), rng.below(64)]:
         r = O.grotto_eval_walk(p, n, 0, s[0], cws, x) ^ O.grotto_eval_walk(p, n, 1, s[1], cws, x)
         assert r == int(alpha <= x)
+
+
+# ---------------------------------------------------------------- the same properties with the ChaCha PRG
+# (the reference's own test PRG: src/dpf_test.cu, src/dcf_test.cu, src/half_tree_dpf_test.cu use ChaCha too)
+@pytest.mark.parametrize("g", [G.BYTES, G.U64, G.U128])
+@pytest.mark.parametrize("n", [1, 16, 64, 128])
+def test_chacha_schemes_reconstruct(O, rng, g, n):
+    alpha = ((rng.next() << 64) | rng.next()) & ((1 << n) - 1)
+    s = [rng.i4(), rng.i4()]
+    beta = beta_for(g)
+    top = (1 << n) - 1
+    xs = {0, top, alpha, max(alpha - 1, 0), min(alpha + 1, top)}
+    p2, p4, p1 = O.Prg(2, chacha=True), O.Prg(4, chacha=True), O.Prg(1, chacha=True)
+    cws = O.dpf_gen(p2, n, g, s, alpha, beta)
+    dc = O.dcf_gen(p4, n, g, O.LT, s, alpha, beta)
+    hc, ocw = O.ht_gen(p1, n, g, s, alpha, beta)
+    for x in xs:
+        y = G.add(g, O.dpf_eval(p2, n, g, 0, s[0], cws, x), O.dpf_eval(p2, n, g, 1, s[1], cws, x))
+        assert (y == (G.canon(g, beta) if x == alpha else np.zeros(4, np.int32))).all()
+        y = G.add(g, O.dcf_eval(p4, n, g, 0, s[0], dc, x), O.dcf_eval(p4, n, g, 1, s[1], dc, x))
+        assert (y == (G.canon(g, beta) if x < alpha else np.zeros(4, np.int32))).all()
+        y = G.add(g, O.ht_eval(p1, n, g, 0, s[0], hc, ocw, x), O.ht_eval(p1, n, g, 1, s[1], hc, ocw, x))
+        assert (y == (G.canon(g, beta) if x == alpha else np.zeros(4, np.int32))).all()

@@ -19,8 +19,7 @@ def test_group_prg_pred():
         fss_amd.Dpf(16, group="floats")
     with pytest.raises(ValueError, match="prg must be one of"):
         fss_amd.Dpf(16, prg="sha")
-    with pytest.raises(NotImplementedError, match="AES-128-MMO"):
-        fss_amd.Dcf(16, prg="chacha")
+    assert fss_amd.Dcf(16, prg="chacha").prg == "chacha"
     with pytest.raises(ValueError, match="pred must be one of"):
         fss_amd.Dcf(16, pred="le")
     assert fss_amd.Dcf(16, pred="gt").pred == "gt"
