@@ -47,6 +47,9 @@ PROTOTYPES = {
     "fss_amd_dpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_dcf_gen": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_ht_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_dpf_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fss_amd_dcf_gen_level_major": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fss_amd_ht_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_last_kernel": (C.c_char_p, [_vp, C.POINTER(_i), C.POINTER(_i)]),
 }
 

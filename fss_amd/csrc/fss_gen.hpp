@@ -74,24 +74,34 @@ struct GenArgs {
   const uint4* betas;
   uint4* cws;           // key-major raw slots
   uint4* ocws;          // Half-Tree
+  // level-major outputs (LM kernels): the arrays relayout_kernel would produce
+  uint4* cw_s;
+  uint4* cw_v;
+  uint64_t* tr_bits;
+  uint4* out_cw;
+  uint32_t* extra;
 };
 
 __device__ __forceinline__ void ld4(uint32_t d[4], uint4 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
 __device__ __forceinline__ uint4 mk4(const uint32_t d[4]) { return make_uint4(d[0], d[1], d[2], d[3]); }
 
 // fss::Dpf::Gen (include/fss/dpf.cuh:93-159) and fss::Dcf::Gen (include/fss/dcf.cuh:108-194).
-template <class LT, int SCHEME>
+// LM: write the level-major arrays of point_eval_gpu.cuh:39-91 directly (lane k's 16-byte store
+// at level i lands next to lane k+1's: whole 1 KiB lines per wave) instead of key-major slots.
+template <class LT, int SCHEME, bool LM>
 __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t s0[4], s1[4], beta[4];
-    ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
+    ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]);
+    ld4(beta, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));  // betas == nullptr: beta = 0 (Grotto keys)
     s0[3] &= ~1u; s1[3] &= ~1u; beta[3] &= ~1u;
     uint32_t t0 = 0u, t1 = ~0u;  // masks
     const X128 alpha = load_x(a.alphas, a.x_bytes, k);
-    uint4* slot = a.cws + k * (int64_t)(n + 1) * 2;
+    uint4* slot = LM ? nullptr : a.cws + k * (int64_t)(n + 1) * 2;
+    unsigned long long tr_lo = 0ull, tr_hi = 0ull;
     Acc v;  // DCF running value (dcf.cuh:115)
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
@@ -154,8 +164,15 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
         t0 = 0u - ((k0 ^ ((t0 & 1u) & keep_cw)) & 1u);
         t1 = 0u - ((k1 ^ ((t1 & 1u) & keep_cw)) & 1u);
       }
-      slot[2 * i] = make_uint4(scw[0], scw[1], scw[2], (scw[3] & ~1u) | tl_cw);
-      slot[2 * i + 1] = mk4(vcw_buf);
+      if (LM) {
+        a.cw_s[(int64_t)i * a.nkeys + k] = make_uint4(scw[0], scw[1], scw[2], (scw[3] & ~1u) | tl_cw);
+        if (SCHEME == S_DCF) a.cw_v[(int64_t)i * a.nkeys + k] = mk4(vcw_buf);
+        else if (i < 64) tr_lo |= (unsigned long long)tr_cw << i;
+        else tr_hi |= (unsigned long long)tr_cw << (i - 64);
+      } else {
+        slot[2 * i] = make_uint4(scw[0], scw[1], scw[2], (scw[3] & ~1u) | tl_cw);
+        slot[2 * i + 1] = mk4(vcw_buf);
+      }
     }
     Acc y;
     if (SCHEME == S_DCF) {
@@ -163,19 +180,29 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
       uint4 vb = v.finish(g, false);
       uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
       y.add(g, s1); y.sub(g, s0); y.sub(g, vbuf);
-      slot[2 * n] = make_uint4(0, 0, 0, 0);
-      slot[2 * n + 1] = y.finish(g, t1 != 0u);
+      if (LM) {
+        a.out_cw[k] = y.finish(g, t1 != 0u);
+      } else {
+        slot[2 * n] = make_uint4(0, 0, 0, 0);
+        slot[2 * n + 1] = y.finish(g, t1 != 0u);
+      }
     } else {
       // beta - s0 + s1, negated when t1 (dpf.cuh:156-158)
       y.add(g, beta); y.sub(g, s0); y.add(g, s1);
-      slot[2 * n] = y.finish(g, t1 != 0u);
-      slot[2 * n + 1] = make_uint4(0, 0, 0, 0);
+      if (LM) {
+        a.out_cw[k] = y.finish(g, t1 != 0u);
+        a.tr_bits[k] = tr_lo;
+        if (n > 64) a.tr_bits[a.nkeys + k] = tr_hi;
+      } else {
+        slot[2 * n] = y.finish(g, t1 != 0u);
+        slot[2 * n + 1] = make_uint4(0, 0, 0, 0);
+      }
     }
   }
 }
 
 // fss::HalfTreeDpf::Gen (include/fss/half_tree_dpf.cuh:68-175).
-template <class LT>
+template <class LT, bool LM>
 __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
   FSS_PRG_PROLOGUE(LT, te0);
@@ -187,10 +214,11 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
   };
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
     uint32_t n0[4], n1[4], beta[4];
-    ld4(n0, a.s0s[2 * k]); ld4(n1, a.s0s[2 * k + 1]); ld4(beta, a.betas[k]);
+    ld4(n0, a.s0s[2 * k]); ld4(n1, a.s0s[2 * k + 1]);
+    ld4(beta, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));
     n0[3] &= ~1u; n1[3] |= 1u; beta[3] &= ~1u;
     const X128 alpha = load_x(a.alphas, a.x_bytes, k);
-    uint4* slot = a.cws + k * (int64_t)n * 2;
+    uint4* slot = LM ? nullptr : a.cws + k * (int64_t)n * 2;
 #pragma unroll 1
     for (int i = 0; i < n - 1; ++i) {
       const uint32_t am = bit_mask(alpha, n - 1 - i);
@@ -204,8 +232,12 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
         uint32_t a1 = h1[q] ^ (am & n1[q]) ^ (t1 & cw[q]);
         n0[q] = a0; n1[q] = a1;
       }
-      slot[2 * i] = mk4(cw);
-      slot[2 * i + 1] = make_uint4(0, 0, 0, 0);
+      if (LM) {
+        a.cw_s[(int64_t)i * a.nkeys + k] = mk4(cw);
+      } else {
+        slot[2 * i] = mk4(cw);
+        slot[2 * i + 1] = make_uint4(0, 0, 0, 0);
+      }
     }
     {
       const uint32_t an = (uint32_t)alpha.lo & 1u;
@@ -223,8 +255,13 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
 #pragma unroll
       for (int q = 0; q < 4; ++q) hcw[q] = an ? (h00[q] ^ h10[q]) : (h01[q] ^ h11[q]);  // :123-125
       const uint32_t lcw0 = l00 ^ l10 ^ (an ^ 1u), lcw1 = l01 ^ l11 ^ an;                // :132-133
-      slot[2 * (n - 1)] = make_uint4(hcw[0], hcw[1], hcw[2], (hcw[3] & ~1u) | lcw0);
-      slot[2 * (n - 1) + 1] = make_uint4(lcw1, 0, 0, 0);
+      if (LM) {
+        a.cw_s[(int64_t)(n - 1) * a.nkeys + k] = make_uint4(hcw[0], hcw[1], hcw[2], (hcw[3] & ~1u) | lcw0);
+        a.extra[k] = lcw1;
+      } else {
+        slot[2 * (n - 1)] = make_uint4(hcw[0], hcw[1], hcw[2], (hcw[3] & ~1u) | lcw0);
+        slot[2 * (n - 1) + 1] = make_uint4(lcw1, 0, 0, 0);
+      }
       uint32_t leaf0[4], leaf1[4];
       const uint32_t lcw_an = an ? lcw1 : lcw0;
 #pragma unroll

@@ -296,6 +296,35 @@ class Engine:
         _lib.check(rc, "gen")
         return cws, ocws
 
+    def gen_level_major(self, scheme, in_bits, group, s0s, alphas, betas, pred=0):
+        """Same keys as gen() written level-major directly -> (LevelMajorKeys, ocws|None); equals
+        relayout(gen(...)) without the key-major intermediate."""
+        s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)
+        xb = self._xbytes(alphas, in_bits)
+        n = alphas.shape[0] if xb == 16 else alphas.numel()
+        dev, L, st = self.device, self._L, self._stream()
+        cw_s = torch.empty((in_bits, n, 4), dtype=torch.int32, device=dev)
+        if scheme in (DPF, GROTTO):
+            tr = torch.empty(((in_bits + 63) // 64 * n,), dtype=torch.int64, device=dev)
+            oc = torch.empty((n, 4), dtype=torch.int32, device=dev)
+            rc = L.fss_amd_dpf_gen_level_major(self._h, in_bits, group, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n,
+                                               _ptr(cw_s), _ptr(tr), _ptr(oc), st)
+            _lib.check(rc, "dpf_gen_level_major")
+            return LevelMajorKeys(scheme, in_bits, n, cw_s, tr_bits=tr, out_cw=oc), None
+        if scheme == DCF:
+            cw_v = torch.empty((in_bits, n, 4), dtype=torch.int32, device=dev)
+            oc = torch.empty((n, 4), dtype=torch.int32, device=dev)
+            rc = L.fss_amd_dcf_gen_level_major(self._h, in_bits, group, pred, _ptr(s0s), _ptr(alphas), xb, _ptr(betas),
+                                               n, _ptr(cw_s), _ptr(cw_v), _ptr(oc), st)
+            _lib.check(rc, "dcf_gen_level_major")
+            return LevelMajorKeys(scheme, in_bits, n, cw_s, cw_v=cw_v, out_cw=oc), None
+        ex = torch.empty((n,), dtype=torch.int32, device=dev)
+        ocws = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        rc = L.fss_amd_ht_gen_level_major(self._h, in_bits, group, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n,
+                                          _ptr(cw_s), _ptr(ex), _ptr(ocws), st)
+        _lib.check(rc, "ht_gen_level_major")
+        return LevelMajorKeys(scheme, in_bits, n, cw_s, extra=ex), ocws
+
 
 _default = {}
 

@@ -199,7 +199,8 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx *ctx, int in_bits, int party, const voi
  * One key per lane; writes key-major raw Cw slots, identical to the reference's Gen
  * for the same seeds / alpha / beta: fss::Dpf::Gen (dpf.cuh:93-159), fss::Dcf::Gen
  * (dcf.cuh:108-194), fss::HalfTreeDpf::Gen (half_tree_dpf.cuh:68-175).
- * s0s: int4[nkeys][2]; alphas: x_bytes-wide; betas: int4[nkeys];
+ * s0s: int4[nkeys][2]; alphas: x_bytes-wide; betas: int4[nkeys], or NULL for beta = 0
+ * (GrottoDcf::Gen, grotto_dcf.cuh:63-67, is fss_amd_dpf_gen over Bytes with NULL betas);
  * cws: (in_bits+1)*nkeys slots (in_bits for Half-Tree), padding bytes zero;
  * ocws (Half-Tree): int4[nkeys]. */
 int fss_amd_dpf_gen(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas, int x_bytes,
@@ -208,6 +209,20 @@ int fss_amd_dcf_gen(fss_amd_ctx *ctx, int in_bits, int group, int pred, const vo
                     int x_bytes, const void *betas, int64_t nkeys, void *cws, void *stream);
 int fss_amd_ht_gen(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas, int x_bytes,
                    const void *betas, int64_t nkeys, void *cws, void *ocws, void *stream);
+
+/* The same Gen writing the level-major arrays of fss_amd_*_relayout directly (what
+ * fss::gpu::*RelayoutGpu, point_eval_gpu.cuh:324-375, would make of the key-major slots):
+ * the dealer-to-evaluator hand-off with no key-major intermediate and no relayout pass
+ * (src/bench_gpu.cu:72-83 + :616-619 fused).  Array shapes as in fss_amd_*_relayout. */
+int fss_amd_dpf_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas,
+                                int x_bytes, const void *betas, int64_t nkeys, void *cw_s, void *tr_bits,
+                                void *out_cw, void *stream);
+int fss_amd_dcf_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, int pred, const void *s0s,
+                                const void *alphas, int x_bytes, const void *betas, int64_t nkeys, void *cw_s,
+                                void *cw_v, void *out_cw, void *stream);
+int fss_amd_ht_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas,
+                               int x_bytes, const void *betas, int64_t nkeys, void *cw_s, void *extra, void *ocws,
+                               void *stream);
 
 /* ---- tuning / introspection -------------------------------------------------------- */
 /* Name and launch geometry of the kernel the last eval call on this ctx launched

@@ -4,11 +4,13 @@
 //
 //   fss::prg::Aes128Mmo<mul>          <- include/fss/prg/aes128_mmo.cuh:27-95 (key material; here it
 //                                        owns the engine context instead of OpenSSL EVP contexts)
+//   fss::prg::ChaCha<mul, rounds>     <- include/fss/prg/chacha.cuh:24-128 (nonce in the context)
 //   fss::group::Bytes / Uint<T, mod>  <- include/fss/group/bytes.cuh, uint.cuh (type tags: the group
 //                                        arithmetic runs in the kernels)
 //   fss::Dpf / Dcf / HalfTreeDpf      <- include/fss/dpf.cuh:61-81, dcf.cuh:74-96,
 //                                        half_tree_dpf.cuh:39-57 (same template parameters, `prg`
 //                                        member, 32-byte `Cw`; methods are the batched device forms)
+//   fss::GrottoDcf                    <- include/fss/grotto_dcf.cuh:46-238
 //   fss::gpu::*RelayoutGpu, *EvalPointGpu, *EvalAllGpu
 //                                     <- include/fss/point_eval_gpu.cuh:324-491,
 //                                        include/fss/eval_all_gpu.cuh:451-535
@@ -82,12 +84,37 @@ class Aes128Mmo {
  private:
   std::shared_ptr<fss_amd_ctx> ctx_;
 };
+
+// ChaCha PRG (include/fss/prg/chacha.cuh:24-128): one permutation of [constant | seed | seed | 0,0,nonce]
+// per Gen.  The nonce the reference keeps in __constant__ memory (chacha.cuh:93) lives in the context.
+template <int mul, int rounds = 20>
+class ChaCha {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+  static_assert(rounds > 0 && rounds % 2 == 0);
+
+ public:
+  explicit ChaCha(const int32_t nonce[2], int device = 0, const int32_t hash_key[4] = nullptr) {
+    const uint8_t unused_aes_keys[64] = {};
+    fss_amd_ctx* c = nullptr;
+    Check(fss_amd_ctx_create(&c, device, unused_aes_keys, hash_key), "fss_amd_ctx_create");
+    ctx_ = std::shared_ptr<fss_amd_ctx>(c, fss_amd_ctx_destroy);
+    Check(fss_amd_ctx_set_prg(c, FSS_AMD_PRG_CHACHA, nonce, rounds), "fss_amd_ctx_set_prg");
+  }
+  fss_amd_ctx* handle() const { return ctx_.get(); }
+  // out[i * mul + j] = output j of ChaCha::Gen(seeds[i])   (chacha.cuh:95-127)
+  void Gen(const int4* d_seeds, int64_t n, int4* d_out, hipStream_t stream = 0) const {
+    Check(fss_amd_prg_gen(handle(), mul, d_seeds, n, d_out, stream), "fss_amd_prg_gen");
+  }
+
+ private:
+  std::shared_ptr<fss_amd_ctx> ctx_;
+};
 }  // namespace prg
 
 namespace detail {
 template <typename In>
 constexpr int XBytes() {
-  static_assert(sizeof(In) == 4 || sizeof(In) == 8, "In must be uint32_t or uint64_t");
+  static_assert(sizeof(In) == 4 || sizeof(In) == 8 || sizeof(In) == 16, "In must be uint32_t, uint64_t or __uint128_t");
   return (int)sizeof(In);
 }
 }  // namespace detail
@@ -112,6 +139,12 @@ class Dpf {
            hipStream_t stream = 0) const {
     Check(fss_amd_dpf_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
                           d_cws, stream), "fss_amd_dpf_gen");
+  }
+  // The same keys written level-major (what gpu::DpfRelayoutGpu would make of d_cws), no intermediate.
+  void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* out_cw, const int4* d_s0s, const In* d_alphas,
+                     const int4* d_betas, int64_t nkeys, hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_gen_level_major(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(),
+                                      d_betas, nkeys, cw_s, tr_bits, out_cw, stream), "fss_amd_dpf_gen_level_major");
   }
   // ys[i] = Eval(b, *d_s0, d_cws, xs[i])   (Dpf::Eval, dpf.cuh:170-214, for a whole batch of x)
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
@@ -149,6 +182,12 @@ class Dcf {
     Check(fss_amd_dcf_gen(prg.handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
                           nkeys, d_cws, stream), "fss_amd_dcf_gen");
   }
+  void GenLevelMajor(int4* cw_s, int4* cw_v, int4* out_cw, const int4* d_s0s, const In* d_alphas, const int4* d_betas,
+                     int64_t nkeys, hipStream_t stream = 0) const {
+    Check(fss_amd_dcf_gen_level_major(prg.handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas,
+                                      detail::XBytes<In>(), d_betas, nkeys, cw_s, cw_v, out_cw, stream),
+          "fss_amd_dcf_gen_level_major");
+  }
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
     Check(fss_amd_dcf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n,
@@ -183,6 +222,11 @@ class HalfTreeDpf {
     Check(fss_amd_ht_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
                          d_cws, d_ocws, stream), "fss_amd_ht_gen");
   }
+  void GenLevelMajor(int4* cw_s, uint32_t* extra, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
+                     const int4* d_betas, int64_t nkeys, hipStream_t stream = 0) const {
+    Check(fss_amd_ht_gen_level_major(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
+                                     nkeys, cw_s, extra, d_ocws, stream), "fss_amd_ht_gen_level_major");
+  }
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
     Check(fss_amd_ht_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, d_xs, detail::XBytes<In>(),
@@ -196,6 +240,62 @@ class HalfTreeDpf {
                hipStream_t stream = 0) const {
     Check(fss_amd_ht_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, first_leaf, nleaves, d_ys,
                               d_workspace, ws_bytes, stream), "fss_amd_ht_eval_all");
+  }
+};
+
+// ---------------------------------------------------------------- Grotto DCF
+// include/fss/grotto_dcf.cuh:46-238: keys are DPF keys over Bytes with beta = 0; shares are bools (1 byte).
+template <int in_bits, typename Prg, typename In = uint32_t>
+class GrottoDcf {
+  static_assert(in_bits >= 1 && in_bits <= 64 && in_bits <= (int)sizeof(In) * 8);
+
+ public:
+  Prg prg;
+  using Cw = typename Dpf<in_bits, group::Bytes, Prg, In>::Cw;
+  static constexpr int kSlots = in_bits + 1;
+
+  // GrottoDcf::Gen (grotto_dcf.cuh:63-67), nkeys keys at once.
+  void Gen(Cw* d_cws, const int4* d_s0s, const In* d_alphas, int64_t nkeys, hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_gen(prg.handle(), in_bits, group::Bytes::kId, d_s0s, d_alphas, detail::XBytes<In>(), nullptr,
+                          nkeys, d_cws, stream), "fss_amd_dpf_gen");
+  }
+  void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* out_cw, const int4* d_s0s, const In* d_alphas, int64_t nkeys,
+                     hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_gen_level_major(prg.handle(), in_bits, group::Bytes::kId, d_s0s, d_alphas, detail::XBytes<In>(),
+                                      nullptr, nkeys, cw_s, tr_bits, out_cw, stream), "fss_amd_dpf_gen_level_major");
+  }
+  // ParityTree::p = 2N-1 bytes (grotto_dcf.cuh:76-84); workspace >= PreprocessWorkspace() bytes.
+  static size_t ParityTreeBytes() { return (size_t(2) << in_bits) - 1; }
+  static size_t PreprocessWorkspace() {
+    return fss_amd_eval_all_workspace(FSS_AMD_GROTTO, in_bits, int64_t(1) << in_bits) + (size_t(1) << in_bits);
+  }
+  // GrottoDcf::Preprocess (grotto_dcf.cuh:94-104)
+  void Preprocess(bool b, uint8_t* d_pt, const int4* d_s0, const Cw* d_cws, void* d_workspace, size_t ws_bytes,
+                  hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_preprocess(prg.handle(), in_bits, b, d_s0, d_cws, d_pt, d_workspace, ws_bytes, stream),
+          "fss_amd_grotto_preprocess");
+  }
+  // GrottoDcf::Eval (grotto_dcf.cuh:116-135) for a batch of x against one parity tree
+  void Eval(const uint8_t* d_pt, const In* d_xs, uint8_t* d_ys, int64_t n, hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_eval_table(prg.handle(), in_bits, d_pt, d_xs, detail::XBytes<In>(), n, d_ys, stream),
+          "fss_amd_grotto_eval_table");
+  }
+  static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
+    return fss_amd_eval_all_workspace(FSS_AMD_GROTTO, in_bits, nleaves);
+  }
+  // GrottoDcf::EvalAll (grotto_dcf.cuh:151-163); a sub-block needs the carry of the blocks before it
+  // (fss_amd/shard.py: grotto_fix_shard).
+  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, uint8_t* d_ys, void* d_workspace, size_t ws_bytes,
+               int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_eval_all(prg.handle(), in_bits, b, d_s0, d_cws, first_leaf, nleaves, d_ys, d_workspace,
+                                  ws_bytes, stream), "fss_amd_grotto_eval_all");
+  }
+  // Path-walk evaluator on level-major keys, one point per key (domains with no table, in_bits up to 64):
+  // reconstructs the predicate; the per-party share is not the table share (see fss_amd.h).
+  void EvalKeysWalk(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const In* xs, uint8_t* ys,
+                    int64_t nkeys, hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_eval_keys(prg.handle(), in_bits, b, seeds, cw_s, tr_bits, xs, detail::XBytes<In>(), nkeys, ys,
+                                   stream), "fss_amd_grotto_eval_keys");
   }
 };
 

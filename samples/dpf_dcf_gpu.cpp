@@ -1,7 +1,9 @@
 // Batched DPF and DCF on the GPU through the C++ layer (include/fss_amd.hpp).
 // Same flow as the reference's samples/dpf_dcf_gpu.cu:84-236 -- one key per lane: Gen on the
 // device, evaluate both parties, reconstruct on the host and self-check -- with the AES-128-MMO
-// PRG instead of ChaCha, plus the level-major relayout + EvalPointGpu launchers.
+// PRG instead of ChaCha, plus the level-major relayout + EvalPointGpu launchers.  Then the flows of
+// samples/half_tree_dpf_cpu.cu (Half-Tree, here n = 64 with the ChaCha PRG and Gen straight into the
+// level-major layout) and samples/grotto_dcf_cpu.cu (Gen, Preprocess + Eval, EvalAll, reconstruct).
 //
 // build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude samples/dpf_dcf_gpu.cpp \
 //              -Lfss_amd -lfss_amd -Wl,-rpath,$PWD/fss_amd -o samples/dpf_dcf_gpu
@@ -108,6 +110,75 @@ int main() {
       }
       std::printf("DCF  n=%d: %d keys, %d mismatches\n", kInBits, kN, errors - before);
       HIP_OK(hipFree(d_cws));
+    }
+    {  // ---- Half-Tree DPF, n = 64, ChaCha PRG, keys generated level-major (no relayout)
+      int before = errors;
+      using HtPrg = fss::prg::ChaCha<1>;
+      using HtT = fss::HalfTreeDpf<64, Group, HtPrg, uint64_t>;
+      const int32_t nonce[2] = {0x12345678, (int32_t)0x9abcdef0};
+      const int32_t hash_key[4] = {0x12345678, (int32_t)0x9abcdef0, 0x13572468, 0x2468ace0};
+      HtT ht{HtPrg(nonce, 0, hash_key)};
+      std::vector<uint64_t> a64(kN), x64(kN);
+      for (int i = 0; i < kN; ++i) {
+        a64[i] = ((uint64_t)std::rand() << 40) ^ ((uint64_t)std::rand() << 20) ^ (uint64_t)std::rand();
+        x64[i] = (i % 2) ? a64[i] : a64[i] ^ (1ull << (i % 64));
+      }
+      uint64_t *d_a64 = ToDevice(a64), *d_x64 = ToDevice(x64);
+      int4 *d_ht_s, *d_ocws;
+      uint32_t* d_extra;
+      HIP_OK(hipMalloc(&d_ht_s, (size_t)64 * kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_ocws, kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_extra, kN * sizeof(uint32_t)));
+      ht.GenLevelMajor(d_ht_s, d_extra, d_ocws, d_s0s, d_a64, d_betas, kN);
+      fss::gpu::HalfTreeDpfEvalPointGpu(false, d_seeds0, d_ht_s, d_extra, d_ocws, d_x64, d_y0, kN, ht);
+      fss::gpu::HalfTreeDpfEvalPointGpu(true, d_seeds1, d_ht_s, d_extra, d_ocws, d_x64, d_y1, kN, ht);
+      HIP_OK(hipMemcpy(y0.data(), d_y0, kN * sizeof(int4), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(y1.data(), d_y1, kN * sizeof(int4), hipMemcpyDeviceToHost));
+      for (int i = 0; i < kN; ++i) {
+        uint64_t want = x64[i] == a64[i] ? Val(betas[i]) : 0;
+        if (Val(y0[i]) + Val(y1[i]) != want) ++errors;
+      }
+      std::printf("HalfTree n=64 (ChaCha): %d keys, %d mismatches\n", kN, errors - before);
+      HIP_OK(hipFree(d_ht_s)); HIP_OK(hipFree(d_ocws)); HIP_OK(hipFree(d_extra)); HIP_OK(hipFree(d_a64)); HIP_OK(hipFree(d_x64));
+    }
+    {  // ---- Grotto DCF, n = 16: share0 ^ share1 == (alpha <= x), by table and by EvalAll
+      int before = errors;
+      constexpr int kG = 16;
+      using GrT = fss::GrottoDcf<kG, DpfPrg, In>;
+      GrT gr{DpfPrg(keys2)};
+      const In alpha = 12345;
+      std::vector<In> ga(1, alpha), gx(kN);
+      for (int i = 0; i < kN; ++i) gx[i] = (In)(std::rand() & ((1 << kG) - 1));
+      gx[0] = alpha; gx[1] = alpha - 1; gx[2] = 0; gx[3] = (1 << kG) - 1;
+      In *d_ga = ToDevice(ga), *d_gx = ToDevice(gx);
+      GrT::Cw* d_cws;
+      uint8_t *d_pt[2], *d_b[2], *d_all[2];
+      void* d_ws;
+      const size_t ws_bytes = GrT::PreprocessWorkspace();
+      HIP_OK(hipMalloc(&d_cws, GrT::kSlots * sizeof(GrT::Cw)));
+      HIP_OK(hipMalloc(&d_ws, ws_bytes));
+      gr.Gen(d_cws, d_s0s, d_ga, 1);
+      std::vector<uint8_t> b[2], all[2];
+      for (int p = 0; p < 2; ++p) {
+        HIP_OK(hipMalloc(&d_pt[p], GrT::ParityTreeBytes()));
+        HIP_OK(hipMalloc(&d_b[p], kN));
+        HIP_OK(hipMalloc(&d_all[p], size_t(1) << kG));
+        gr.Preprocess(p, d_pt[p], d_s0s + p, d_cws, d_ws, ws_bytes);
+        gr.Eval(d_pt[p], d_gx, d_b[p], kN);
+        gr.EvalAll(p, d_s0s + p, d_cws, d_all[p], d_ws, ws_bytes);
+        b[p].resize(kN); all[p].resize(size_t(1) << kG);
+        HIP_OK(hipMemcpy(b[p].data(), d_b[p], kN, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(all[p].data(), d_all[p], size_t(1) << kG, hipMemcpyDeviceToHost));
+      }
+      for (int i = 0; i < kN; ++i) {
+        if ((b[0][i] ^ b[1][i]) != (alpha <= gx[i])) ++errors;
+        if (b[0][i] != all[0][gx[i]] || b[1][i] != all[1][gx[i]]) ++errors;  // Preprocess + Eval == EvalAll per party
+      }
+      for (In x = 0; x < (1u << kG); ++x)
+        if ((all[0][x] ^ all[1][x]) != (alpha <= x)) ++errors;
+      std::printf("Grotto n=%d: %d points + full domain, %d mismatches\n", kG, kN, errors - before);
+      for (int p = 0; p < 2; ++p) { HIP_OK(hipFree(d_pt[p])); HIP_OK(hipFree(d_b[p])); HIP_OK(hipFree(d_all[p])); }
+      HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_ws)); HIP_OK(hipFree(d_ga)); HIP_OK(hipFree(d_gx));
     }
   } catch (const fss::Error& e) {
     std::fprintf(stderr, "fss error: %s\n", e.what());

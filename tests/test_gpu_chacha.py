@@ -3,6 +3,7 @@ instantiated without tables, bit-compared with the oracle's restatement (itself 
 the permutation; the reference holds no ChaCha vectors, and its Python binding draws a random nonce per
 process, so there are no reference outputs to pin the construction to beyond the source)."""
 import numpy as np
+import torch
 import pytest
 
 import groups as G
@@ -81,6 +82,12 @@ def test_chacha_gen_relayout_eval_keys_vs_oracle(ceng, O, scheme, n, g, pred):
     if scheme == HT:
         assert (ocws.cpu().numpy() == want_ocw).all()
     keys = ceng.relayout(scheme, n, cws)
+    lm, lm_ocws = ceng.gen_level_major(scheme, n, g, T(s0s), xs_tensor(alphas, n), T(betas), pred=pred)
+    for name in ("cw_s", "cw_v", "tr_bits", "out_cw", "extra"):  # Gen straight into the level-major layout
+        a, b = getattr(lm, name), getattr(keys, name)
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), name
+    if scheme == HT:
+        assert torch.equal(lm_ocws, ocws)
     for b in (0, 1):
         want = O.eval_keys(p, scheme, n, g, b, s0s[:, b], want_cws, xs if n > 64 else np.array(xs, dtype=np.uint64),
                            ocws=want_ocw, nthreads=4)

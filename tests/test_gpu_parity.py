@@ -240,6 +240,48 @@ def test_gen_vs_oracle(engine, O, scheme, n, g, pred):
         assert (got_ocw.cpu().numpy() == want_ocw).all()
 
 
+@pytest.mark.parametrize("scheme,n,g,pred", [(DPF, 32, G.U64, 0), (DPF, 1, G.BYTES, 0), (DPF, 64, G.U128, 0),
+                                             (DPF, 100, G.BYTES, 0), (DCF, 32, G.U64, 1), (DCF, 7, G.U8, 0),
+                                             (DCF, 128, G.U128, 0), (HT, 64, G.U64, 0), (HT, 1, G.BYTES, 0),
+                                             (HT, 33, G.U32, 0)])
+def test_gen_level_major_vs_oracle(engine, O, scheme, n, g, pred):
+    """Gen writing level-major directly = the oracle's key-major Gen transposed (numpy, not the
+    relayout kernel) = relayout(gen()); and the keys evaluate to the oracle's shares."""
+    rng = SplitMix64(77 + 100 * scheme + n)
+    nkeys = 193
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s0s = np.stack([np.stack([rng.i4(clear_lsb=False), rng.i4(clear_lsb=False)]) for _ in range(nkeys)])
+    alphas = ([rand_below(rng, n) for _ in range(nkeys)] if n > 64
+              else np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64))
+    betas = np.stack([rng.i4(clear_lsb=False) for _ in range(nkeys)])
+    want, want_ocw = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=pred, nthreads=4)
+    keys, ocws = engine.gen_level_major(scheme, n, g, T(s0s), xs_tensor(alphas, n), T(betas), pred=pred)
+    assert (keys.cw_s.cpu().numpy() == want[:, :n, 0:4].transpose(1, 0, 2)).all()
+    if scheme == DPF:
+        tr = keys.tr_bits.cpu().numpy().view(np.uint64).reshape(-1, nkeys)
+        for i in range(n):
+            assert (((tr[i // 64] >> np.uint64(i % 64)) & np.uint64(1)) == (want[:, i, 4] & 1)).all(), i
+        assert (keys.out_cw.cpu().numpy() == want[:, n, 0:4]).all()
+    elif scheme == DCF:
+        assert (keys.cw_v.cpu().numpy() == want[:, :n, 4:8].transpose(1, 0, 2)).all()
+        assert (keys.out_cw.cpu().numpy() == want[:, n, 4:8]).all()
+    else:
+        assert (keys.extra.cpu().numpy() == (want[:, n - 1, 4] & 1)).all()
+        assert (ocws.cpu().numpy() == want_ocw).all()
+    ref = engine.relayout(scheme, n, T(want))
+    for name in ("cw_s", "cw_v", "tr_bits", "out_cw", "extra"):
+        a, b = getattr(keys, name), getattr(ref, name)
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b), name
+    xs = ([rand_below(rng, n) for _ in range(nkeys)] if n > 64
+          else np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64))
+    for b in (0, 1):
+        exp = O.eval_keys(p, scheme, n, g, b, s0s[:, b], want, xs, ocws=want_ocw, nthreads=4)
+        got = engine.eval_keys(keys, g, b, T(np.ascontiguousarray(s0s[:, b])), xs_tensor(xs, n), ocws=ocws).cpu().numpy()
+        assert (got == exp).all(), (scheme, n, g, b)
+
+
 # ---------------------------------------------------------------- full domain
 @pytest.mark.parametrize("g", [G.BYTES, G.U32, G.U64, G.U128])
 @pytest.mark.parametrize("n", [1, 2, 5, 11, 12, 13, 14, 16])
