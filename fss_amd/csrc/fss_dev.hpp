@@ -479,6 +479,17 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
   aes_fin<SEL>(L, vB, kLB, kLB + 4, maskB, inB, outB);
 }
 
+// The DevCtx a kernel received by value as its FIRST argument, addressed in the kernarg segment
+// (offset 0) so that its fields stay scalar loads whatever the optimizer makes of &K.
+__device__ __forceinline__ const DevCtx* first_kernarg(const DevCtx& K) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)K;
+  return (const DevCtx*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  return &K;  // host pass of the single-source compile; never executed
+#endif
+}
+
 // ------------------------------------------------------------------ ChaCha PRG
 // fss::prg::ChaCha<mul, rounds> (include/fss/prg/chacha.cuh:24-128): one ChaCha permutation of
 // [constant | seed | seed | 0, 0, nonce] per Gen, XOR feed-forward, rows 0..3 are the outputs

@@ -1,5 +1,6 @@
 // Dealer-side kernels: raw PRG, key relayout, key generation (one key per lane).
 #pragma once
+#include <type_traits>
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
 
@@ -90,7 +91,9 @@ __device__ __forceinline__ uint4 mk4(const uint32_t d[4]) { return make_uint4(d[
 // at level i lands next to lane k+1's: whole 1 KiB lines per wave) instead of key-major slots.
 template <class LT, int SCHEME, bool LM>
 __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
-  const DevCtx* c = &K;
+  // K is the first kernel argument = offset 0 of the kernarg segment.  Taking &K instead makes the
+  // DCF/AES instantiation copy all 1.8 KiB of it to scratch and fetch round keys from there.
+  const DevCtx* c = first_kernarg(K);
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
@@ -106,39 +109,28 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
       const uint32_t am = bit_mask(alpha, n - 1 - i);  // ~0 when a_bit
-      uint32_t s0l[4], s0r[4], s1l[4], s1r[4];
-      uint32_t v0l[4], v0r[4], v1l[4], v1r[4];
-      if (SCHEME == S_DCF) {
-        // two blocks at a time: eight interleaved AES states do not fit 128 VGPRs
-        prg_gen4(L, c, s0, s0l, v0l, s0r, v0r);
-        prg_gen4(L, c, s1, s1l, v1l, s1r, v1r);
-        v0l[3] &= ~1u; v0r[3] &= ~1u; v1l[3] &= ~1u; v1r[3] &= ~1u;
-      } else {
-        prg_gen2(L, c, s0, s0l, s0r);
-        prg_gen2(L, c, s1, s1l, s1r);
-      }
-      const uint32_t t0l = s0l[3] & 1u, t0r = s0r[3] & 1u, t1l = s1l[3] & 1u, t1r = s1r[3] & 1u;
-      s0l[3] &= ~1u; s0r[3] &= ~1u; s1l[3] &= ~1u; s1r[3] &= ~1u;
-      const uint32_t ab = am & 1u;
-      uint32_t scw[4];
+      uint32_t scw[4], vcw_buf[4], tl_cw, tr_cw;
+      if constexpr (SCHEME == S_DCF && std::is_same<LT, Lds>::value) {
+        // AES: evaluate by side (lose pair, fold, keep pair) with the per-lane key choice, so at most 16
+        // PRG output words are live across an AES call instead of 32 (the all-children order spilled 2 KiB).
+        uint32_t ls0[4], lv0[4], ls1[4], lv1[4];
+        prg_take4(L, c, ~am, s0, ls0, lv0);
+        prg_take4(L, c, ~am, s1, ls1, lv1);
+        const uint32_t lose_cw = (ls0[3] ^ ls1[3]) & 1u;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) scw[q] = am ? (s0l[q] ^ s1l[q]) : (s0r[q] ^ s1r[q]);  // lose side
-      const uint32_t tl_cw = t0l ^ t1l ^ ab ^ 1u, tr_cw = t0r ^ t1r ^ ab;
-
-      uint32_t vcw_buf[4] = {tr_cw, 0, 0, 0};
-      if (SCHEME == S_DCF) {
+        for (int q = 0; q < 4; ++q) scw[q] = ls0[q] ^ ls1[q];
+        scw[3] &= ~1u;
+        lv0[3] &= ~1u; lv1[3] &= ~1u;
         // v_cw = -v + (v1_lose - v0_lose) [+ beta]   (dcf.cuh:146-154); negated when t1
         Acc vc;
-        uint32_t lose1[4], lose0[4], keep1[4], keep0[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          lose1[q] = am ? v1l[q] : v1r[q]; lose0[q] = am ? v0l[q] : v0r[q];
-          keep1[q] = am ? v1r[q] : v1l[q]; keep0[q] = am ? v0r[q] : v0l[q];
-        }
-        vc.add(g, lose1); vc.sub(g, lose0);
+        vc.add(g, lv1); vc.sub(g, lv0);
         const bool add_beta = am ? (a.pred == 0) : (a.pred == 1);
-        if (add_beta) vc.add(g, beta);
-        // vc -= v
+        if (add_beta) {  // reloaded per level (an L2 hit) rather than held across the AES calls
+          uint32_t bb[4];
+          ld4(bb, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));
+          bb[3] &= ~1u;
+          vc.add(g, bb);
+        }
         {
           uint4 vb = v.finish(g, false);
           uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
@@ -146,23 +138,83 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
         }
         uint4 vcw4 = vc.finish(g, t1 != 0u);
         uint32_t vcw[4] = {vcw4.x, vcw4.y, vcw4.z, vcw4.w};
+        uint32_t ks0[4], kv0[4], ks1[4], kv1[4];
+        prg_take4(L, c, am, s0, ks0, kv0);
+        prg_take4(L, c, am, s1, ks1, kv1);
+        const uint32_t kt0 = ks0[3] & 1u, kt1 = ks1[3] & 1u;
+        const uint32_t keep_cw = (kt0 ^ kt1 ^ 1u) & 1u;
+        ks0[3] &= ~1u; ks1[3] &= ~1u; kv0[3] &= ~1u; kv1[3] &= ~1u;
         // v = v - v1_keep + v0_keep + (t1 ? -v_cw : v_cw)   (dcf.cuh:156-159)
-        v.sub(g, keep1); v.add(g, keep0);
+        v.sub(g, kv1); v.add(g, kv0);
         if (t1) v.sub(g, vcw); else v.add(g, vcw);
-        vcw_buf[0] = vcw[0]; vcw_buf[1] = vcw[1]; vcw_buf[2] = vcw[2]; vcw_buf[3] = (vcw[3] & ~1u) | tr_cw;
-      }
-      // keep side, corrected (dpf.cuh:124-144)
-      const uint32_t keep_cw = am ? tr_cw : tl_cw;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        uint32_t k0 = am ? s0r[q] : s0l[q], k1 = am ? s1r[q] : s1l[q];
-        s0[q] = k0 ^ (t0 & scw[q]);
-        s1[q] = k1 ^ (t1 & scw[q]);
-      }
-      {
-        uint32_t k0 = am ? t0r : t0l, k1 = am ? t1r : t1l;
-        t0 = 0u - ((k0 ^ ((t0 & 1u) & keep_cw)) & 1u);
-        t1 = 0u - ((k1 ^ ((t1 & 1u) & keep_cw)) & 1u);
+        for (int q = 0; q < 4; ++q) {
+          s0[q] = ks0[q] ^ (t0 & scw[q]);
+          s1[q] = ks1[q] ^ (t1 & scw[q]);
+        }
+        t0 = 0u - ((kt0 ^ ((t0 & 1u) & keep_cw)) & 1u);
+        t1 = 0u - ((kt1 ^ ((t1 & 1u) & keep_cw)) & 1u);
+        tl_cw = am ? lose_cw : keep_cw;
+        tr_cw = am ? keep_cw : lose_cw;
+        vcw_buf[0] = vcw[0]; vcw_buf[1] = vcw[1]; vcw_buf[2] = vcw[2]; vcw_buf[3] = (vcw[3] & ~1u) | tr_cw;
+      } else {
+        uint32_t s0l[4], s0r[4], s1l[4], s1r[4];
+        uint32_t v0l[4], v0r[4], v1l[4], v1r[4];
+        if (SCHEME == S_DCF) {
+          // two blocks at a time: eight interleaved AES states do not fit 128 VGPRs
+          prg_gen4(L, c, s0, s0l, v0l, s0r, v0r);
+          prg_gen4(L, c, s1, s1l, v1l, s1r, v1r);
+          v0l[3] &= ~1u; v0r[3] &= ~1u; v1l[3] &= ~1u; v1r[3] &= ~1u;
+        } else {
+          prg_gen2(L, c, s0, s0l, s0r);
+          prg_gen2(L, c, s1, s1l, s1r);
+        }
+        const uint32_t t0l = s0l[3] & 1u, t0r = s0r[3] & 1u, t1l = s1l[3] & 1u, t1r = s1r[3] & 1u;
+        s0l[3] &= ~1u; s0r[3] &= ~1u; s1l[3] &= ~1u; s1r[3] &= ~1u;
+        const uint32_t ab = am & 1u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scw[q] = am ? (s0l[q] ^ s1l[q]) : (s0r[q] ^ s1r[q]);  // lose side
+        tl_cw = t0l ^ t1l ^ ab ^ 1u; tr_cw = t0r ^ t1r ^ ab;
+
+        vcw_buf[0] = tr_cw; vcw_buf[1] = 0; vcw_buf[2] = 0; vcw_buf[3] = 0;
+        if (SCHEME == S_DCF) {
+          // v_cw = -v + (v1_lose - v0_lose) [+ beta]   (dcf.cuh:146-154); negated when t1
+          Acc vc;
+          uint32_t lose1[4], lose0[4], keep1[4], keep0[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            lose1[q] = am ? v1l[q] : v1r[q]; lose0[q] = am ? v0l[q] : v0r[q];
+            keep1[q] = am ? v1r[q] : v1l[q]; keep0[q] = am ? v0r[q] : v0l[q];
+          }
+          vc.add(g, lose1); vc.sub(g, lose0);
+          const bool add_beta = am ? (a.pred == 0) : (a.pred == 1);
+          if (add_beta) vc.add(g, beta);
+          // vc -= v
+          {
+            uint4 vb = v.finish(g, false);
+            uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
+            vc.sub(g, vbuf);
+          }
+          uint4 vcw4 = vc.finish(g, t1 != 0u);
+          uint32_t vcw[4] = {vcw4.x, vcw4.y, vcw4.z, vcw4.w};
+          // v = v - v1_keep + v0_keep + (t1 ? -v_cw : v_cw)   (dcf.cuh:156-159)
+          v.sub(g, keep1); v.add(g, keep0);
+          if (t1) v.sub(g, vcw); else v.add(g, vcw);
+          vcw_buf[0] = vcw[0]; vcw_buf[1] = vcw[1]; vcw_buf[2] = vcw[2]; vcw_buf[3] = (vcw[3] & ~1u) | tr_cw;
+        }
+        // keep side, corrected (dpf.cuh:124-144)
+        const uint32_t keep_cw = am ? tr_cw : tl_cw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t k0 = am ? s0r[q] : s0l[q], k1 = am ? s1r[q] : s1l[q];
+          s0[q] = k0 ^ (t0 & scw[q]);
+          s1[q] = k1 ^ (t1 & scw[q]);
+        }
+        {
+          uint32_t k0 = am ? t0r : t0l, k1 = am ? t1r : t1l;
+          t0 = 0u - ((k0 ^ ((t0 & 1u) & keep_cw)) & 1u);
+          t1 = 0u - ((k1 ^ ((t1 & 1u) & keep_cw)) & 1u);
+        }
       }
       if (LM) {
         a.cw_s[(int64_t)i * a.nkeys + k] = make_uint4(scw[0], scw[1], scw[2], (scw[3] & ~1u) | tl_cw);
