@@ -5,7 +5,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.path.join(_HERE, "libfss_amd.so")
-SOURCES = ["fss_amd.hip", "fss_dev.hpp", "fss_point.hpp", "fss_evalall.hpp", "fss_gen.hpp", "fss_abi_rest.inc"]
+SOURCES = ["fss_amd.hip", "fss_dev.hpp", "fss_point.hpp", "fss_evalall.hpp", "fss_gen.hpp", "fss_vdpf.hpp", "fss_abi_rest.inc",
+           "fss_abi_vdpf.inc"]
 
 
 def _stale():

@@ -47,6 +47,14 @@ PROTOTYPES = {
     "fss_amd_dpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_dcf_gen": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_ht_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_ctx_set_hash_iv": (_i, [_vp, _vp]),
+    "fss_amd_vdpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "fss_amd_vdpf_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fss_amd_vdpf_relayout": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_vdpf_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "fss_amd_vdpf_eval_keys": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "fss_amd_vdpf_prove": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_vdpf_prove_keys": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fss_amd_dpf_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_dcf_gen_level_major": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_ht_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),

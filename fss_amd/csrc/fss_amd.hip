@@ -13,6 +13,7 @@
 #include "fss_evalall.hpp"
 #include "fss_gen.hpp"
 #include "fss_point.hpp"
+#include "fss_vdpf.hpp"
 
 using namespace fssamd;
 
@@ -206,6 +207,10 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   c->prg = FSS_AMD_PRG_AES128_MMO;
   c->host.chacha_nonce[0] = c->host.chacha_nonce[1] = 0;
   c->host.chacha_rounds = 20;
+  {  // default VDPF hash key: the reference bench's kBlake3Iv (src/bench_gpu.cu:27-30)
+    const uint32_t iv[8] = {0x11223344u, 0x55667788u, 0x99aabbccu, 0xddeeff00u, 0x00112233u, 0x44556677u, 0x8899aabbu, 0xccddeeffu};
+    for (int i = 0; i < 8; ++i) c->host.blake3_iv[i] = iv[i];
+  }
 
   uint8_t sbox[256];
   uint32_t te0[256];
@@ -422,3 +427,4 @@ int fss_amd_ht_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, co
 }  // extern "C"
 
 #include "fss_abi_rest.inc"
+#include "fss_abi_vdpf.inc"

@@ -47,6 +47,7 @@ struct DevCtx {
   const uint32_t* self_dev;  // device-memory copy of this struct (for per-lane vector loads of round keys)
   uint32_t chacha_nonce[2];  // ChaCha PRG (contexts created with fss_amd_ctx_set_chacha)
   int chacha_rounds;
+  uint32_t blake3_iv[8];     // VDPF: key of the keyed BLAKE3 hashes H and H' (fss::hash::Blake3::iv_)
 };
 
 constexpr int kLdsTableBytes = 256 * 256;  // 64 KiB: 256 indices x 64 lane copies x 4 B
@@ -528,6 +529,55 @@ __device__ __forceinline__ void chacha_rows(const DevCtx* __restrict__ c, const 
 #pragma unroll
   for (int j = 0; j < 4; ++j) { x[4 + j] ^= seed[j]; x[8 + j] ^= seed[j]; }
   x[14] ^= n0; x[15] ^= n1;
+}
+
+// ------------------------------------------------------------------ BLAKE3 (VDPF hashes)
+// fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): one keyed-hash compression (7 rounds) of a
+// single block, flags CHUNK_START | CHUNK_END | ROOT | KEYED_HASH, counter 0; out = first 8 words of the
+// output (v[0..7] ^ v[8..15]).  Fully unrolled so the message schedule is register renaming and the
+// zero message words of the 32-byte inputs fold away.  Pure VALU like ChaCha.
+__device__ __forceinline__ void blake3_g(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t x, uint32_t y) {
+  a += b + x; d = rotl32(d ^ a, 16);
+  c += d; b = rotl32(b ^ c, 20);
+  a += b + y; d = rotl32(d ^ a, 24);
+  c += d; b = rotl32(b ^ c, 25);
+}
+__device__ __forceinline__ void blake3_compress8(const DevCtx* __restrict__ c, const uint32_t msg[16], uint32_t block_len,
+                                                 uint32_t out[8]) {
+  constexpr uint32_t kFlags = 1u | 2u | 8u | 16u;
+  uint32_t v[16], m[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = c->blake3_iv[i];
+  v[8] = 0x6A09E667u; v[9] = 0xBB67AE85u; v[10] = 0x3C6EF372u; v[11] = 0xA54FF53Au;
+  v[12] = 0; v[13] = 0; v[14] = block_len; v[15] = kFlags;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m[i] = msg[i];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    blake3_g(v[0], v[4], v[8], v[12], m[0], m[1]);
+    blake3_g(v[1], v[5], v[9], v[13], m[2], m[3]);
+    blake3_g(v[2], v[6], v[10], v[14], m[4], m[5]);
+    blake3_g(v[3], v[7], v[11], v[15], m[6], m[7]);
+    blake3_g(v[0], v[5], v[10], v[15], m[8], m[9]);
+    blake3_g(v[1], v[6], v[11], v[12], m[10], m[11]);
+    blake3_g(v[2], v[7], v[8], v[13], m[12], m[13]);
+    blake3_g(v[3], v[4], v[9], v[14], m[14], m[15]);
+    if (r < 6) {  // blake3.cuh:43-52
+      uint32_t t[16] = {m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8]};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m[i] = t[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = v[i] ^ v[8 + i];
+}
+// XorHashable: H(a, b) = compress(a with lsb 0 | b) | compress(a with lsb 1 | b), block_len 32 (blake3.cuh:157-169)
+__device__ __forceinline__ void blake3_xorhash(const DevCtx* __restrict__ c, const uint32_t a[4], const uint32_t b[4],
+                                               uint32_t out[16]) {
+  uint32_t m[16] = {a[0], a[1], a[2], a[3] & ~1u, b[0], b[1], b[2], b[3], 0, 0, 0, 0, 0, 0, 0, 0};
+  blake3_compress8(c, m, 32, out);
+  m[3] |= 1u;
+  blake3_compress8(c, m, 32, out + 8);
 }
 
 // ------------------------------------------------------------------ PRG interface

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, 
     if (SCHEME == S_DPF) {
       tr_bits[k] = bits[0][lane];
       if (in_bits > 64) tr_bits[nkeys + k] = bits[1][lane];
-      out_cw[k] = slot[2 * in_bits];
+      if (out_cw) out_cw[k] = slot[2 * in_bits];  // VDPF keys (stride in_bits) have no such slot
     } else if (SCHEME == S_DCF) {
       out_cw[k] = slot[2 * in_bits + 1];
     } else {

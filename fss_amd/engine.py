@@ -12,6 +12,7 @@ from . import _lib
 BYTES, U8, U16, U32, U64, U128 = 0, 1, 2, 3, 4, 5
 GROUP_IDS = {"bytes": BYTES, "u8": U8, "u16": U16, "u32": U32, "u64": U64, "u128": U128}
 DPF, DCF, HT, GROTTO = 0, 1, 2, 3
+VDPF = 4  # host-side tag only (LevelMajorKeys of a verifiable DPF); the C ABI has its own fss_amd_vdpf_* calls
 
 # AES keys / hash key of the reference's benches and samples (src/bench_cpu.cu:37-40, :509).
 DEFAULT_AES_KEYS = (
@@ -324,6 +325,87 @@ class Engine:
                                           _ptr(cw_s), _ptr(ex), _ptr(ocws), st)
         _lib.check(rc, "ht_gen_level_major")
         return LevelMajorKeys(scheme, in_bits, n, cw_s, extra=ex), ocws
+
+
+    # ---------------------------------------------------------------- verifiable DPF
+    def set_hash_iv(self, iv):
+        """Key of the keyed-BLAKE3 hashes H and H' of the VDPF (fss::hash::Blake3's iv, 8 words)."""
+        v = (C.c_int32 * 8)(*[int(np.uint32(int(x) & 0xFFFFFFFF).astype(np.int32)) for x in iv])
+        _lib.check(self._L.fss_amd_ctx_set_hash_iv(self._h, v), "fss_amd_ctx_set_hash_iv")
+
+    def vdpf_gen(self, in_bits, group, s0s, alphas, betas, level_major=False):
+        """-> (cws int32[n, in_bits, 8] | LevelMajorKeys, cs int32[n,4,4], ocws int32[n,4], retry int32[n])."""
+        s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)
+        xb = self._xbytes(alphas, in_bits)
+        n = alphas.shape[0] if xb == 16 else alphas.numel()
+        dev, L, st = self.device, self._L, self._stream()
+        cs = torch.empty((n, 4, 4), dtype=torch.int32, device=dev)
+        ocws = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        retry = torch.empty((n,), dtype=torch.int32, device=dev)
+        if level_major:
+            cw_s = torch.empty((in_bits, n, 4), dtype=torch.int32, device=dev)
+            tr = torch.empty(((in_bits + 63) // 64 * n,), dtype=torch.int64, device=dev)
+            rc = L.fss_amd_vdpf_gen_level_major(self._h, in_bits, group, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n,
+                                                _ptr(cw_s), _ptr(tr), _ptr(cs), _ptr(ocws), _ptr(retry), st)
+            _lib.check(rc, "vdpf_gen_level_major")
+            return LevelMajorKeys(VDPF, in_bits, n, cw_s, tr_bits=tr), cs, ocws, retry
+        cws = torch.empty((n, in_bits, 8), dtype=torch.int32, device=dev)
+        rc = L.fss_amd_vdpf_gen(self._h, in_bits, group, _ptr(s0s), _ptr(alphas), xb, _ptr(betas), n, _ptr(cws), _ptr(cs),
+                                _ptr(ocws), _ptr(retry), st)
+        _lib.check(rc, "vdpf_gen")
+        return cws, cs, ocws, retry
+
+    def vdpf_relayout(self, in_bits, cws):
+        cws = self._dev(cws, torch.int32)
+        n = cws.shape[0]
+        cw_s = torch.empty((in_bits, n, 4), dtype=torch.int32, device=self.device)
+        tr = torch.empty(((in_bits + 63) // 64 * n,), dtype=torch.int64, device=self.device)
+        _lib.check(self._L.fss_amd_vdpf_relayout(self._h, in_bits, _ptr(cws), n, _ptr(cw_s), _ptr(tr), self._stream()),
+                   "vdpf_relayout")
+        return LevelMajorKeys(VDPF, in_bits, n, cw_s, tr_bits=tr)
+
+    def vdpf_eval_points(self, in_bits, group, party, s0, cws, cs, ocw, xs):
+        """One key at many points -> (ys int32[n,4], pi_tildes int32[n,4,4])."""
+        s0, cws, cs, ocw, xs = (self._dev(s0, torch.int32), self._dev(cws, torch.int32), self._dev(cs, torch.int32),
+                                self._dev(ocw, torch.int32), self._dev(xs))
+        xb = self._xbytes(xs, in_bits)
+        n = xs.shape[0] if xb == 16 else xs.numel()
+        ys = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        pis = torch.empty((n, 4, 4), dtype=torch.int32, device=self.device)
+        rc = self._L.fss_amd_vdpf_eval_points(self._h, in_bits, group, party, _ptr(s0), _ptr(cws), _ptr(cs), _ptr(ocw),
+                                              _ptr(xs), xb, n, _ptr(ys), _ptr(pis), self._stream())
+        _lib.check(rc, "vdpf_eval_points")
+        return ys, pis
+
+    def vdpf_eval_keys(self, keys, group, party, seeds, cs, ocws, xs, out=None):
+        """ys[k], pi_tildes[k] = Vdpf::Eval(party, seeds[k], key k, xs[k]) on a LevelMajorKeys batch."""
+        seeds, cs, ocws, xs = (self._dev(seeds, torch.int32), self._dev(cs, torch.int32), self._dev(ocws, torch.int32),
+                               self._dev(xs))
+        n, nb = keys.nkeys, keys.in_bits
+        xb = self._xbytes(xs, nb)
+        ys, pis = out if out is not None else (torch.empty((n, 4), dtype=torch.int32, device=self.device),
+                                                torch.empty((n, 4, 4), dtype=torch.int32, device=self.device))
+        rc = self._L.fss_amd_vdpf_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.tr_bits),
+                                            _ptr(cs), _ptr(ocws), _ptr(xs), xb, n, _ptr(ys), _ptr(pis), self._stream())
+        _lib.check(rc, "vdpf_eval_keys")
+        return ys, pis
+
+    def vdpf_prove(self, pi_tildes, cs):
+        """Vdpf::Prove over the hashes of ONE key (sequential chain) -> int32[4,4]."""
+        pis, cs = self._dev(pi_tildes, torch.int32), self._dev(cs, torch.int32)
+        out = torch.empty((4, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.fss_amd_vdpf_prove(self._h, _ptr(pis), pis.numel() // 16, _ptr(cs), _ptr(out), self._stream()),
+                   "vdpf_prove")
+        return out
+
+    def vdpf_prove_keys(self, pi_tildes, cs):
+        """Per key, one evaluation each -> int32[n,4,4]."""
+        pis, cs = self._dev(pi_tildes, torch.int32), self._dev(cs, torch.int32)
+        n = pis.numel() // 16
+        out = torch.empty((n, 4, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self._L.fss_amd_vdpf_prove_keys(self._h, _ptr(pis), _ptr(cs), n, _ptr(out), self._stream()),
+                   "vdpf_prove_keys")
+        return out
 
 
 _default = {}

@@ -251,3 +251,63 @@ class GrottoDcf(_Base):
         """Path-walk shares for independent keys (any in_bits <= 64); see include/fss_amd.h."""
         validate_party(party)
         return self.engine.eval_keys(keys, E.BYTES, party, seeds, xs)
+
+
+class Vdpf(_Base):
+    """2-party verifiable DPF (fss::Vdpf, include/fss/vdpf.cuh:57-404) with the BLAKE3 hashes
+    (fss::hash::Blake3 as both XorHash and Hash; key = the engine's hash IV, Engine.set_hash_iv).
+    A key is (cws int32[in_bits, 8], cs int32[4, 4], ocw int32[4]) plus the party's seed."""
+    scheme = E.VDPF
+    _slots_extra = 0
+
+    def __init__(self, in_bits, group="bytes", prg="aes128_mmo", engine=None):
+        super().__init__(in_bits, group, prg, engine)
+
+    def gen(self, s0s, alpha, beta):
+        """-> (cws, cs, ocw) on the CPU; raises if the reference's Gen would ask for fresh seeds (vdpf.cuh:177)."""
+        validate_s0s(s0s)
+        validate_alpha(alpha, self.in_bits)
+        validate_beta(beta)
+        cws, cs, ocws, retry = self.engine.vdpf_gen(self.in_bits, self._g, s0s.view(1, 2, 4),
+                                                    _xs_tensor([alpha], self.in_bits, "cpu"), beta.view(1, 4))
+        if int(retry[0]) != 0:
+            raise RuntimeError("Vdpf.gen: t0 == t1 at the last level, resample s0s and retry")
+        return cws[0].cpu(), cs[0].cpu(), ocws[0].cpu()
+
+    def gen_batch(self, s0s, alphas, betas, level_major=False):
+        """-> (cws | LevelMajorKeys, cs int32[n,4,4], ocws int32[n,4], retry int32[n]) on the device."""
+        return self.engine.vdpf_gen(self.in_bits, self._g, s0s, alphas, betas, level_major=level_major)
+
+    def relayout(self, cws):
+        return self.engine.vdpf_relayout(self.in_bits, cws)
+
+    def eval(self, party, s0, cws, cs, ocw, x):
+        """-> (y int32[4], pi_tilde int32[4,4])   (Vdpf::Eval, vdpf.cuh:204-257)."""
+        validate_party(party)
+        validate_s0(s0)
+        validate_domain_value("x", x, self.in_bits)
+        ys, pis = self.engine.vdpf_eval_points(self.in_bits, self._g, party, s0, cws, cs, ocw,
+                                               _xs_tensor([x], self.in_bits, "cpu"))
+        return self._back(ys[0], s0), self._back(pis[0], s0)
+
+    def eval_points(self, party, s0, cws, cs, ocw, xs):
+        validate_party(party)
+        validate_s0(s0)
+        ys, pis = self.engine.vdpf_eval_points(self.in_bits, self._g, party, s0, cws, cs, ocw, xs)
+        return self._back(ys, xs), self._back(pis, xs)
+
+    def eval_keys(self, party, seeds, keys, cs, ocws, xs):
+        validate_party(party)
+        return self.engine.vdpf_eval_keys(keys, self._g, party, seeds, cs, ocws, xs)
+
+    def prove(self, pi_tildes, cs):
+        """Vdpf::Prove (vdpf.cuh:268-278) over all hashes of one key."""
+        return self._back(self.engine.vdpf_prove(pi_tildes, cs), pi_tildes)
+
+    def prove_keys(self, pi_tildes, cs):
+        return self.engine.vdpf_prove_keys(pi_tildes, cs)
+
+    @staticmethod
+    def verify(pi0, pi1):
+        """Vdpf::Verify (vdpf.cuh:287-292)."""
+        return bool(torch.equal(pi0.cpu(), pi1.cpu()))

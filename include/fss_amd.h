@@ -224,6 +224,38 @@ int fss_amd_ht_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const v
                                int x_bytes, const void *betas, int64_t nkeys, void *cw_s, void *extra, void *ocws,
                                void *stream);
 
+/* ---- verifiable DPF (include/fss/vdpf.cuh; de Castro-Polychroniadou, EUROCRYPT'22) -------------
+ * The DPF walk plus, per evaluation, the verification hash pi~ = H(Pack(x), s) [^ cs when t], with
+ * H = H' = fss::hash::Blake3 keyed with the context's 8-word IV (blake3.cuh:13-172; the SHA-256 pair of
+ * hash/sha256.cuh is not built).  A key is in_bits raw Cw slots (vdpf.cuh:77-82, same 32-byte {s, tr}
+ * slot as the DPF, no output slot), cs = int4[4] and ocw = int4.
+ *   gen            Vdpf::Gen (vdpf.cuh:103-189), one key per lane; retry[k] = 1 where the reference
+ *                  returns 1 (t0 == t1; resample the seeds), may be NULL.
+ *   relayout       fss::gpu::VdpfRelayoutGpu (point_eval_gpu.cuh:389-396); tr_bits as for the DPF.
+ *   eval_points    Vdpf::Eval (vdpf.cuh:204-257) of ONE key at npoints points: ys int4[n], pi_tildes int4[n][4].
+ *   eval_keys      fss::gpu::VdpfEvalPointGpu (point_eval_gpu.cuh:514-526): nkeys keys, one point each.
+ *   prove          Vdpf::Prove (vdpf.cuh:268-278) over the npoints hashes of one key: a sequential
+ *                  hash chain by definition, run by a single lane.
+ *   prove_keys     the same fold for nkeys keys with one evaluation each, one key per lane.
+ * Vdpf::Verify (vdpf.cuh:287-292) is a 64-byte comparison of the two parties' pi and is left to the caller. */
+int fss_amd_ctx_set_hash_iv(fss_amd_ctx *ctx, const int32_t iv[8]);
+int fss_amd_vdpf_gen(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas, int x_bytes,
+                     const void *betas, int64_t nkeys, void *cws, void *cs, void *ocws, int32_t *retry, void *stream);
+int fss_amd_vdpf_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas,
+                                 int x_bytes, const void *betas, int64_t nkeys, void *cw_s, void *tr_bits, void *cs,
+                                 void *ocws, int32_t *retry, void *stream);
+int fss_amd_vdpf_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *tr_bits,
+                          void *stream);
+int fss_amd_vdpf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
+                             const void *cs, const void *ocw, const void *xs, int x_bytes, int64_t npoints, void *ys,
+                             void *pi_tildes, void *stream);
+int fss_amd_vdpf_eval_keys(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
+                           const void *tr_bits, const void *cs, const void *ocws, const void *xs, int x_bytes,
+                           int64_t nkeys, void *ys, void *pi_tildes, void *stream);
+int fss_amd_vdpf_prove(fss_amd_ctx *ctx, const void *pi_tildes, int64_t npoints, const void *cs, void *pi, void *stream);
+int fss_amd_vdpf_prove_keys(fss_amd_ctx *ctx, const void *pi_tildes, const void *cs, int64_t nkeys, void *pis,
+                            void *stream);
+
 /* ---- tuning / introspection -------------------------------------------------------- */
 /* Name and launch geometry of the kernel the last eval call on this ctx launched
  * (for bench.py / profiles). */

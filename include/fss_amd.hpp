@@ -11,6 +11,7 @@
 //                                        half_tree_dpf.cuh:39-57 (same template parameters, `prg`
 //                                        member, 32-byte `Cw`; methods are the batched device forms)
 //   fss::GrottoDcf                    <- include/fss/grotto_dcf.cuh:46-238
+//   fss::Vdpf + fss::hash::Blake3     <- include/fss/vdpf.cuh:57-404, include/fss/hash/blake3.cuh
 //   fss::gpu::*RelayoutGpu, *EvalPointGpu, *EvalAllGpu
 //                                     <- include/fss/point_eval_gpu.cuh:324-491,
 //                                        include/fss/eval_all_gpu.cuh:451-535
@@ -26,6 +27,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 
 #include "fss_amd.h"
 
@@ -299,6 +301,60 @@ class GrottoDcf {
   }
 };
 
+// ---------------------------------------------------------------- verifiable DPF
+namespace hash {
+// fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): the 8-word key of the keyed BLAKE3 hashes.
+// A tag carrying the IV; the hashing runs in the kernels (Vdpf installs the IV in its PRG's context).
+struct Blake3 {
+  int32_t iv[8];
+  explicit Blake3(const int4 iv2[2]) { std::memcpy(iv, iv2, sizeof(iv)); }
+};
+}  // namespace hash
+
+// include/fss/vdpf.cuh:57-404 with XorHash = Hash = hash::Blake3 (one IV for both, as the reference's
+// tests and benches use them).  A key = kSlots Cw slots + cs (4 int4) + ocw.
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
+class Vdpf {
+  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+
+ public:
+  Prg prg;
+  Vdpf(Prg p, const hash::Blake3& h) : prg(std::move(p)) {
+    Check(fss_amd_ctx_set_hash_iv(prg.handle(), h.iv), "fss_amd_ctx_set_hash_iv");
+  }
+  using Cw = typename Dpf<in_bits, Group, Prg, In>::Cw;  // vdpf.cuh:77-82
+  static constexpr int kSlots = in_bits;
+
+  // Vdpf::Gen (vdpf.cuh:103-189) for nkeys keys; d_retry[k] = its return value (may be null).
+  void Gen(Cw* d_cws, int4* d_cs /* 4 per key */, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
+           const int4* d_betas, int64_t nkeys, int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
+    Check(fss_amd_vdpf_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
+                           d_cws, d_cs, d_ocws, d_retry, stream), "fss_amd_vdpf_gen");
+  }
+  void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* d_cs, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
+                     const int4* d_betas, int64_t nkeys, int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
+    Check(fss_amd_vdpf_gen_level_major(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(),
+                                       d_betas, nkeys, cw_s, tr_bits, d_cs, d_ocws, d_retry, stream),
+          "fss_amd_vdpf_gen_level_major");
+  }
+  // Vdpf::Eval (vdpf.cuh:204-257) of one key at n points: ys[i], pi_tildes[4i..4i+3]
+  void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_cs, const int4* d_ocw, const In* d_xs,
+                  int4* d_ys, int4* d_pi_tildes, int64_t n, hipStream_t stream = 0) const {
+    Check(fss_amd_vdpf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_cs, d_ocw, d_xs,
+                                   detail::XBytes<In>(), n, d_ys, d_pi_tildes, stream), "fss_amd_vdpf_eval_points");
+  }
+  // Vdpf::Prove (vdpf.cuh:268-278) over the n hashes of one key (a sequential chain)
+  void Prove(const int4* d_pi_tildes, int64_t n, const int4* d_cs, int4* d_pi, hipStream_t stream = 0) const {
+    Check(fss_amd_vdpf_prove(prg.handle(), d_pi_tildes, n, d_cs, d_pi, stream), "fss_amd_vdpf_prove");
+  }
+  // ... and for nkeys keys with one evaluation each
+  void ProveKeys(const int4* d_pi_tildes, const int4* d_cs, int64_t nkeys, int4* d_pis, hipStream_t stream = 0) const {
+    Check(fss_amd_vdpf_prove_keys(prg.handle(), d_pi_tildes, d_cs, nkeys, d_pis, stream), "fss_amd_vdpf_prove_keys");
+  }
+  // Vdpf::Verify (vdpf.cuh:287-292), host copies of the two proofs
+  static bool Verify(const int4 pi0[4], const int4 pi1[4]) { return std::memcmp(pi0, pi1, 4 * sizeof(int4)) == 0; }
+};
+
 // ---------------------------------------------------------------- fss::gpu launchers
 namespace gpu {
 
@@ -343,6 +399,21 @@ void HalfTreeDpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const 
                              hipStream_t stream = 0) {
   Check(fss_amd_ht_eval_keys(dpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs,
                              detail::XBytes<In>(), nkeys, ys, stream), "ht_eval_keys");
+}
+
+// :389-396 (extra -> 64-bit tr_bits)
+template <int in_bits, typename Group, typename Prg, typename In>
+void VdpfRelayoutGpu(const typename Vdpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s, uint64_t* tr_bits,
+                     const Vdpf<in_bits, Group, Prg, In>& vdpf, hipStream_t stream = 0) {
+  Check(fss_amd_vdpf_relayout(vdpf.prg.handle(), in_bits, cws, nkeys, cw_s, tr_bits, stream), "vdpf_relayout");
+}
+// :514-526  ys[k], pi[4k..4k+3] = Vdpf::Eval(b, seeds[k], key k, cs[k], ocws[k], xs[k])
+template <int in_bits, typename Group, typename Prg, typename In>
+void VdpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* cs,
+                      const int4* ocws, const In* xs, int4* ys, int4* pi, int64_t nkeys,
+                      const Vdpf<in_bits, Group, Prg, In>& vdpf, hipStream_t stream = 0) {
+  Check(fss_amd_vdpf_eval_keys(vdpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, cs, ocws, xs,
+                               detail::XBytes<In>(), nkeys, ys, pi, stream), "vdpf_eval_keys");
 }
 
 // include/fss/eval_all_gpu.cuh:478-488 (s0 and cws on the device; workspace from Dpf::EvalAllWorkspace)

@@ -731,6 +731,152 @@ int fo_grotto_eval_walk(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_
   return pi;
 }
 
+/* ------------------------------------------------------------------ BLAKE3 + VDPF
+ * fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): the BLAKE3 compression function (7 rounds)
+ * in keyed-hash mode with the 8-word key `iv`, one block, flags CHUNK_START|CHUNK_END|ROOT|KEYED_HASH. */
+static const uint32_t kBlake3Iv[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                      0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+static inline uint32_t rotr_u32(uint32_t v, int n) { return (v >> n) | (v << (32 - n)); }
+#define B3_G(a, b, c, d, x, y)                                           \
+  do {                                                                   \
+    a += b + (x); d = rotr_u32(d ^ a, 16); c += d; b = rotr_u32(b ^ c, 12); \
+    a += b + (y); d = rotr_u32(d ^ a, 8);  c += d; b = rotr_u32(b ^ c, 7);  \
+  } while (0)
+
+/* blake3.cuh:82-110 (Compress); out = the 16-word extended output. */
+void fo_blake3_compress(const uint32_t h[8], const uint32_t msg[16], uint64_t counter, uint32_t block_len,
+                        uint32_t flags, uint32_t out[16]) {
+  static const int perm[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8}; /* blake3.cuh:44 */
+  uint32_t v[16], m[16], t[16];
+  for (int i = 0; i < 8; ++i) v[i] = h[i];
+  for (int i = 0; i < 4; ++i) v[8 + i] = kBlake3Iv[i];
+  v[12] = (uint32_t)counter; v[13] = (uint32_t)(counter >> 32); v[14] = block_len; v[15] = flags;
+  for (int i = 0; i < 16; ++i) m[i] = msg[i];
+  for (int r = 0; r < 7; ++r) {
+    B3_G(v[0], v[4], v[8], v[12], m[0], m[1]);
+    B3_G(v[1], v[5], v[9], v[13], m[2], m[3]);
+    B3_G(v[2], v[6], v[10], v[14], m[4], m[5]);
+    B3_G(v[3], v[7], v[11], v[15], m[6], m[7]);
+    B3_G(v[0], v[5], v[10], v[15], m[8], m[9]);
+    B3_G(v[1], v[6], v[11], v[12], m[10], m[11]);
+    B3_G(v[2], v[7], v[8], v[13], m[12], m[13]);
+    B3_G(v[3], v[4], v[9], v[14], m[14], m[15]);
+    if (r < 6) {
+      for (int i = 0; i < 16; ++i) t[i] = m[perm[i]];
+      for (int i = 0; i < 16; ++i) m[i] = t[i];
+    }
+  }
+  for (int i = 0; i < 8; ++i) { out[i] = v[i] ^ v[8 + i]; out[8 + i] = v[8 + i] ^ h[i]; }
+}
+
+enum { B3_CHUNK_START = 1, B3_CHUNK_END = 2, B3_ROOT = 8, B3_KEYED = 16 };
+
+static inline void i4_words(fo_i4 v, uint32_t *w) {
+  w[0] = (uint32_t)v.x; w[1] = (uint32_t)v.y; w[2] = (uint32_t)v.z; w[3] = (uint32_t)v.w;
+}
+static inline fo_i4 words_i4(const uint32_t *w) {
+  fo_i4 v = {(int32_t)w[0], (int32_t)w[1], (int32_t)w[2], (int32_t)w[3]};
+  return v;
+}
+
+/* Hashable: 64-byte message -> 2 int4 (blake3.cuh:151-155). */
+void fo_blake3_hash(const int32_t iv[8], const fo_i4 msg[4], fo_i4 out[2]) {
+  uint32_t m[16], o[16];
+  for (int i = 0; i < 4; ++i) i4_words(msg[i], m + 4 * i);
+  fo_blake3_compress((const uint32_t *)iv, m, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT | B3_KEYED, o);
+  out[0] = words_i4(o); out[1] = words_i4(o + 4);
+}
+
+/* XorHashable: (a, b) -> 4 int4 = H(a with lsb 0 | b) | H(a with lsb 1 | b), block_len 32 (blake3.cuh:157-169). */
+void fo_blake3_xorhash(const int32_t iv[8], fo_i4 a, fo_i4 b, fo_i4 out[4]) {
+  uint32_t m[16] = {0}, o[16];
+  const uint32_t fl = B3_CHUNK_START | B3_CHUNK_END | B3_ROOT | B3_KEYED;
+  i4_words(set_lsb(a, 0), m); i4_words(b, m + 4);
+  fo_blake3_compress((const uint32_t *)iv, m, 0, 32, fl, o);
+  out[0] = words_i4(o); out[1] = words_i4(o + 4);
+  i4_words(set_lsb(a, 1), m);
+  fo_blake3_compress((const uint32_t *)iv, m, 0, 32, fl, o);
+  out[2] = words_i4(o); out[3] = words_i4(o + 4);
+}
+
+static inline fo_i4 pack_in(u128 x) { /* util.cuh:47-64 (Pack), as the 128-bit In */
+  fo_i4 v = {(int32_t)(uint32_t)x, (int32_t)(uint32_t)(x >> 32), (int32_t)(uint32_t)(x >> 64), (int32_t)(uint32_t)(x >> 96)};
+  return v;
+}
+
+/* fss::Vdpf::Gen (include/fss/vdpf.cuh:103-189): DPF levels, then cs = H(a, s0) ^ H(a, s1) and the output
+ * correction word.  cws: in_bits slots.  Returns 1 when t0 == t1 at the end (vdpf.cuh:177). */
+int fo_vdpf_gen(const fo_prg *p, const int32_t iv[8], int in_bits, int group, fo_cw *cws, fo_i4 cs[4], fo_i4 *ocw,
+                const fo_i4 s0s[2], uint64_t a_lo, uint64_t a_hi, fo_i4 beta) {
+  u128 a = mk128(a_lo, a_hi);
+  fo_i4 s0 = set_lsb(s0s[0], 0), s1 = set_lsb(s0s[1], 0);
+  int t0 = 0, t1 = 1;
+  beta = set_lsb(beta, 0);
+  for (int i = 0; i < in_bits; ++i) {
+    fo_i4 g0[2], g1[2];
+    fo_prg_gen(p, s0, g0);
+    fo_prg_gen(p, s1, g1);
+    int t0l = get_lsb(g0[0]), t0r = get_lsb(g0[1]), t1l = get_lsb(g1[0]), t1r = get_lsb(g1[1]);
+    fo_i4 s0l = set_lsb(g0[0], 0), s0r = set_lsb(g0[1], 0), s1l = set_lsb(g1[0], 0), s1r = set_lsb(g1[1], 0);
+    int a_bit = bit_of(a, in_bits - 1 - i);
+    fo_i4 s_cw = !a_bit ? xor4(s0r, s1r) : xor4(s0l, s1l);
+    int tl_cw = t0l ^ t1l ^ a_bit ^ 1;
+    int tr_cw = t0r ^ t1r ^ a_bit;
+    if (!a_bit) {
+      s0 = s0l; if (t0) s0 = xor4(s0, s_cw);
+      s1 = s1l; if (t1) s1 = xor4(s1, s_cw);
+      t0 = t0 ? (t0l ^ tl_cw) : t0l;
+      t1 = t1 ? (t1l ^ tl_cw) : t1l;
+    } else {
+      s0 = s0r; if (t0) s0 = xor4(s0, s_cw);
+      s1 = s1r; if (t1) s1 = xor4(s1, s_cw);
+      t0 = t0 ? (t0r ^ tr_cw) : t0r;
+      t1 = t1 ? (t1r ^ tr_cw) : t1r;
+    }
+    cws[i] = mk_cw(set_lsb(s_cw, tl_cw), tr_cw);
+  }
+  fo_i4 a_buf = pack_in(a), p0[4], p1[4];
+  fo_blake3_xorhash(iv, a_buf, s0, p0);
+  fo_blake3_xorhash(iv, a_buf, s1, p1);
+  for (int j = 0; j < 4; ++j) cs[j] = xor4(p0[j], p1[j]);
+  if (t0 == t1) return 1;
+  gel v = g_add(group, g_add(group, g_from(group, beta), g_neg(group, g_from(group, s0))), g_from(group, s1));
+  if (t1) v = g_neg(group, v);
+  *ocw = g_into(group, v);
+  return 0;
+}
+
+/* fss::Vdpf::Eval (vdpf.cuh:204-257): y and the corrected verification hash pi_tilde (4 int4). */
+fo_i4 fo_vdpf_eval(const fo_prg *p, const int32_t iv[8], int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws,
+                   const fo_i4 cs[4], fo_i4 ocw, uint64_t x_lo, uint64_t x_hi, fo_i4 pi_tilde[4]) {
+  u128 x = mk128(x_lo, x_hi);
+  fo_i4 s = set_lsb(s0, 0);
+  int t = b;
+  for (int i = 0; i < in_bits; ++i) {
+    fo_i4 sl, sr; int tl, tr;
+    dpf_expand(p, s, t, &cws[i], &sl, &tl, &sr, &tr);
+    if (!bit_of(x, in_bits - 1 - i)) { s = sl; t = tl; } else { s = sr; t = tr; }
+  }
+  gel y = g_from(group, s);
+  if (t) y = g_add(group, y, g_from(group, ocw));
+  if (b) y = g_neg(group, y);
+  fo_blake3_xorhash(iv, pack_in(x), s, pi_tilde);
+  if (t) for (int j = 0; j < 4; ++j) pi_tilde[j] = xor4(pi_tilde[j], cs[j]);
+  return g_into(group, y);
+}
+
+/* fss::Vdpf::Prove (vdpf.cuh:268-278): pi = cs; for every pi_tilde: pi[0..1] ^= H'(pi ^ pi_tilde). */
+void fo_vdpf_prove(const int32_t iv[8], const fo_i4 *pi_tildes, size_t n, const fo_i4 cs[4], fo_i4 pi[4]) {
+  for (int j = 0; j < 4; ++j) pi[j] = cs[j];
+  for (size_t i = 0; i < n; ++i) {
+    fo_i4 in[4], h[2];
+    for (int j = 0; j < 4; ++j) in[j] = xor4(pi[j], pi_tildes[4 * i + j]);
+    fo_blake3_hash(iv, in, h);
+    pi[0] = xor4(pi[0], h[0]);
+    pi[1] = xor4(pi[1], h[1]);
+  }
+}
+
 /* ------------------------------------------------------------------ batched drivers */
 static void prg_thread_copy(const fo_prg *src, fo_prg *dst) {
   *dst = *src;

@@ -115,6 +115,20 @@ void fo_grotto_eval_all(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_
  * share differs from fo_grotto_eval's by a party-independent mask. */
 int fo_grotto_eval_walk(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_cw *cws, uint64_t x);
 
+/* ---- BLAKE3 compression and VDPF (include/fss/hash/blake3.cuh, include/fss/vdpf.cuh) ----
+ * Parity pinning: the compression function against the official BLAKE3 test vectors (empty input, one
+ * zero byte, keyed empty input; tests/test_oracle_kat.py), the construction around it against the source. */
+void fo_blake3_compress(const uint32_t h[8], const uint32_t msg[16], uint64_t counter, uint32_t block_len,
+                        uint32_t flags, uint32_t out[16]);
+void fo_blake3_hash(const int32_t iv[8], const fo_i4 msg[4], fo_i4 out[2]);
+void fo_blake3_xorhash(const int32_t iv[8], fo_i4 a, fo_i4 b, fo_i4 out[4]);
+int fo_vdpf_gen(const fo_prg *p, const int32_t iv[8], int in_bits, int group, fo_cw *cws /* in_bits */, fo_i4 cs[4],
+                fo_i4 *ocw, const fo_i4 s0s[2], uint64_t a_lo, uint64_t a_hi, fo_i4 beta);
+fo_i4 fo_vdpf_eval(const fo_prg *p, const int32_t iv[8], int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws,
+                   const fo_i4 cs[4], fo_i4 ocw, uint64_t x_lo, uint64_t x_hi, fo_i4 pi_tilde[4]);
+void fo_vdpf_prove(const int32_t iv[8], const fo_i4 *pi_tildes /* 4 per point */, size_t n, const fo_i4 cs[4],
+                   fo_i4 pi[4]);
+
 /* ---- batched drivers (loops over the functions above; nthreads>1 uses OpenMP,
  * each thread with its own EVP contexts when use_evp) ---- */
 /* scheme: 0 DPF, 1 DCF, 2 Half-Tree, 3 Grotto walk (ys then holds 0/1 in .x). */

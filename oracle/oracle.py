@@ -89,6 +89,15 @@ def lib():
         L.fo_grotto_eval_all.argtypes = [P, i, i, _I4, vp, vp]
         L.fo_grotto_eval_walk.argtypes = [P, i, i, _I4, vp, u64]
         L.fo_grotto_eval_walk.restype = i
+        u32 = C.c_uint32
+        L.fo_blake3_compress.argtypes = [vp, vp, u64, u32, u32, vp]
+        L.fo_blake3_hash.argtypes = [vp, vp, vp]
+        L.fo_blake3_xorhash.argtypes = [vp, _I4, _I4, vp]
+        L.fo_vdpf_gen.argtypes = [P, vp, i, i, vp, vp, vp, vp, u64, u64, _I4]
+        L.fo_vdpf_gen.restype = i
+        L.fo_vdpf_eval.argtypes = [P, vp, i, i, i, _I4, vp, vp, _I4, u64, u64, vp]
+        L.fo_vdpf_eval.restype = _I4
+        L.fo_vdpf_prove.argtypes = [vp, vp, sz, vp, vp]
         L.fo_eval_points.argtypes = [P, _I4, i, i, i, i, _I4, vp, _I4, vp, vp, sz, vp, i]
         L.fo_eval_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, sz, vp, vp, vp, sz, vp, i]
         L.fo_gen_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, vp, vp, sz, vp, sz, vp, i]
@@ -273,6 +282,72 @@ def grotto_eval_walk(prg, in_bits, b, s0, cws, x):
 
 
 # ---------------------------------------------------------------- batched
+# ---------------------------------------------------------------- BLAKE3 + VDPF
+BLAKE3_IV = np.array([0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19],
+                     dtype=np.uint32)
+# hash IV of the reference's VDPF tests (src/vdpf_test.cu:35-36)
+HASH_IV = np.array([0x11111111, 0x22222222, 0x33333333, 0x44444444, 0x55555555, 0x66666666, 0x77777777, 0x88888888],
+                   dtype=np.uint32).view(np.int32)
+
+
+def blake3_compress(h, msg, counter=0, block_len=64, flags=0):
+    h = np.ascontiguousarray(h, dtype=np.uint32)
+    msg = np.ascontiguousarray(msg, dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    lib().fo_blake3_compress(_ptr(h), _ptr(msg), counter, block_len, flags, _ptr(out))
+    return out
+
+
+def _iv(iv):
+    return np.ascontiguousarray(np.asarray(iv, dtype=np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+
+
+def blake3_hash(iv, msg4):
+    """fss::hash::Blake3::Hash(span<int4,4>) -> int32[2,4]."""
+    m = np.ascontiguousarray(msg4, dtype=np.int32).reshape(4, 4)
+    out = np.zeros((2, 4), dtype=np.int32)
+    lib().fo_blake3_hash(_ptr(_iv(iv)), _ptr(m), _ptr(out))
+    return out
+
+
+def blake3_xorhash(iv, a, b):
+    """fss::hash::Blake3::Hash(tuple<int4, int4>) -> int32[4,4]."""
+    out = np.zeros((4, 4), dtype=np.int32)
+    lib().fo_blake3_xorhash(_ptr(_iv(iv)), _i4(a), _i4(b), _ptr(out))
+    return out
+
+
+def vdpf_gen(prg, in_bits, group, s0s, alpha, beta, iv=HASH_IV):
+    """-> (cws int32[in_bits, 8], cs int32[4, 4], ocw int32[4], retry flag)."""
+    cws = _cws_buf(in_bits)
+    cs = np.zeros((4, 4), dtype=np.int32)
+    ocw = np.zeros(4, dtype=np.int32)
+    s = _seeds2(s0s)
+    lo, hi = _split(alpha)
+    rc = lib().fo_vdpf_gen(prg.ref, _ptr(_iv(iv)), in_bits, group, _ptr(cws), _ptr(cs), _ptr(ocw), _ptr(s), lo, hi,
+                           _i4(beta))
+    return cws, cs, ocw, rc
+
+
+def vdpf_eval(prg, in_bits, group, b, s0, cws, cs, ocw, x, iv=HASH_IV):
+    """-> (y int32[4], pi_tilde int32[4, 4])."""
+    lo, hi = _split(x)
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    cs = np.ascontiguousarray(cs, dtype=np.int32)
+    pt = np.zeros((4, 4), dtype=np.int32)
+    y = _arr(lib().fo_vdpf_eval(prg.ref, _ptr(_iv(iv)), in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(cs), _i4(ocw),
+                                lo, hi, _ptr(pt)))
+    return y, pt
+
+
+def vdpf_prove(pi_tildes, cs, iv=HASH_IV):
+    pts = np.ascontiguousarray(pi_tildes, dtype=np.int32).reshape(-1, 4, 4)
+    cs = np.ascontiguousarray(cs, dtype=np.int32)
+    pi = np.zeros((4, 4), dtype=np.int32)
+    lib().fo_vdpf_prove(_ptr(_iv(iv)), _ptr(pts), pts.shape[0], _ptr(cs), _ptr(pi))
+    return pi
+
+
 def _lohi(vals):
     """uint64 array, or a list of Python ints (any width <= 128) -> (lo uint64[n], hi uint64[n] or None)."""
     if isinstance(vals, np.ndarray) and vals.dtype != object:

@@ -180,6 +180,49 @@ int main() {
       for (int p = 0; p < 2; ++p) { HIP_OK(hipFree(d_pt[p])); HIP_OK(hipFree(d_b[p])); HIP_OK(hipFree(d_all[p])); }
       HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_ws)); HIP_OK(hipFree(d_ga)); HIP_OK(hipFree(d_gx));
     }
+    {  // ---- VDPF (ChaCha + BLAKE3): shares reconstruct, the two parties' proofs agree, a forged key is caught
+      int before = errors;
+      using VPrg = fss::prg::ChaCha<2>;
+      using VT = fss::Vdpf<kInBits, Group, VPrg, In>;
+      const int32_t nonce[2] = {0x12345678, (int32_t)0x9abcdef0};
+      const int4 iv[2] = {{0x11223344, 0x55667788, (int)0x99aabbccu, (int)0xddeeff00u},
+                          {0x00112233, 0x44556677, (int)0x8899aabbu, (int)0xccddeeffu}};
+      VT vdpf{VPrg(nonce), fss::hash::Blake3(iv)};
+      int4 *d_cs, *d_ocws, *d_pi0, *d_pi1, *d_pr0, *d_pr1;
+      HIP_OK(hipMalloc(&d_cs, 4 * kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_ocws, kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_pi0, 4 * kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_pi1, 4 * kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_pr0, 4 * kN * sizeof(int4)));
+      HIP_OK(hipMalloc(&d_pr1, 4 * kN * sizeof(int4)));
+      vdpf.GenLevelMajor(d_cw_s, d_tr, d_cs, d_ocws, d_s0s, d_alphas, d_betas, kN);
+      fss::gpu::VdpfEvalPointGpu(false, d_seeds0, d_cw_s, d_tr, d_cs, d_ocws, d_xs, d_y0, d_pi0, kN, vdpf);
+      fss::gpu::VdpfEvalPointGpu(true, d_seeds1, d_cw_s, d_tr, d_cs, d_ocws, d_xs, d_y1, d_pi1, kN, vdpf);
+      vdpf.ProveKeys(d_pi0, d_cs, kN, d_pr0);
+      vdpf.ProveKeys(d_pi1, d_cs, kN, d_pr1);
+      std::vector<int4> pr0(4 * kN), pr1(4 * kN);
+      HIP_OK(hipMemcpy(y0.data(), d_y0, kN * sizeof(int4), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(y1.data(), d_y1, kN * sizeof(int4), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(pr0.data(), d_pr0, 4 * kN * sizeof(int4), hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(pr1.data(), d_pr1, 4 * kN * sizeof(int4), hipMemcpyDeviceToHost));
+      for (int i = 0; i < kN; ++i) {
+        uint64_t want = xs[i] == alphas[i] ? Val(betas[i]) : 0;
+        if (Val(y0[i]) + Val(y1[i]) != want) ++errors;
+        if (!VT::Verify(&pr0[4 * i], &pr1[4 * i])) ++errors;
+      }
+      // party 1 is handed a key with one flipped seed-correction bit at level 3: every proof must differ
+      int4 forged;
+      HIP_OK(hipMemcpy(&forged, d_cw_s + (size_t)3 * kN, sizeof(int4), hipMemcpyDeviceToHost));
+      forged.y ^= 0x100;
+      HIP_OK(hipMemcpy(d_cw_s + (size_t)3 * kN, &forged, sizeof(int4), hipMemcpyHostToDevice));
+      fss::gpu::VdpfEvalPointGpu(true, d_seeds1, d_cw_s, d_tr, d_cs, d_ocws, d_xs, d_y1, d_pi1, 1, vdpf);
+      vdpf.ProveKeys(d_pi1, d_cs, 1, d_pr1);
+      HIP_OK(hipMemcpy(pr1.data(), d_pr1, 4 * sizeof(int4), hipMemcpyDeviceToHost));
+      if (VT::Verify(&pr0[0], &pr1[0])) ++errors;
+      std::printf("VDPF n=%d (ChaCha+BLAKE3): %d keys, %d mismatches\n", kInBits, kN, errors - before);
+      HIP_OK(hipFree(d_cs)); HIP_OK(hipFree(d_ocws)); HIP_OK(hipFree(d_pi0)); HIP_OK(hipFree(d_pi1));
+      HIP_OK(hipFree(d_pr0)); HIP_OK(hipFree(d_pr1));
+    }
   } catch (const fss::Error& e) {
     std::fprintf(stderr, "fss error: %s\n", e.what());
     return 3;

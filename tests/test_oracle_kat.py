@@ -108,3 +108,39 @@ def test_chacha_gen_structure(O, rng):
             want = {1: [rows[1]], 2: rows[:2], 4: rows}[mul]
             got = O.Prg(mul, chacha=True, nonce=nonce).gen(seed).view(np.uint32)
             assert [[int(v) for v in r] for r in got] == want
+
+
+# ---------------------------------------------------------------- BLAKE3 (VDPF hashes)
+def test_blake3_compress_official_vectors(O):
+    """The compression function against the official BLAKE3 test vectors (BLAKE3 test_vectors.json: `hash`
+    of the empty input and of one zero byte; `keyed_hash` of the empty input with the key
+    "whats the Elvish word for friend") -- single-block inputs are one compression with
+    CHUNK_START | CHUNK_END | ROOT (| KEYED_HASH)."""
+    iv = O.BLAKE3_IV
+    z = np.zeros(16, dtype=np.uint32)
+    assert O.blake3_compress(iv, z, 0, 0, 1 | 2 | 8)[:8].tobytes().hex() == \
+        "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    assert O.blake3_compress(iv, z, 0, 1, 1 | 2 | 8)[:8].tobytes().hex() == \
+        "2d3adedff11b61f14c886e35afa036736dcd87a74d27b5c1510225d0f592e213"
+    key = np.frombuffer(b"whats the Elvish word for friend", dtype=np.uint32)
+    assert O.blake3_compress(key, z, 0, 0, 1 | 2 | 8 | 16)[:8].tobytes().hex() == \
+        "92b2b75604ed3c761f9d6f62392c8a9227ad0ea3f09573e783f1498a4ed60d26"
+
+
+def test_blake3_hash_forms(O):
+    """fss::hash::Blake3's two Hash overloads are keyed single-block compressions (blake3.cuh:151-169)."""
+    iv = O.HASH_IV
+    a = np.array([0x01020305, 7, 8, 9], dtype=np.int32)
+    b = np.array([11, 12, 13, 14], dtype=np.int32)
+    h4 = O.blake3_xorhash(iv, a, b)
+    for half, lsb in ((0, 0), (1, 1)):
+        m = np.zeros(16, dtype=np.uint32)
+        m[:4] = a.view(np.uint32)
+        m[3] = (m[3] & ~np.uint32(1)) | np.uint32(lsb)
+        m[4:8] = b.view(np.uint32)
+        want = O.blake3_compress(iv.view(np.uint32), m, 0, 32, 1 | 2 | 8 | 16)[:8]
+        assert (h4[2 * half:2 * half + 2].reshape(-1).view(np.uint32) == want).all()
+    msg = np.arange(16, dtype=np.int32).reshape(4, 4)
+    h2 = O.blake3_hash(iv, msg)
+    want = O.blake3_compress(iv.view(np.uint32), msg.reshape(-1).view(np.uint32), 0, 64, 1 | 2 | 8 | 16)[:8]
+    assert (h2.reshape(-1).view(np.uint32) == want).all()

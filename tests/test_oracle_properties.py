@@ -150,3 +150,34 @@ def test_chacha_schemes_reconstruct(O, rng, g, n):
         assert (y == (G.canon(g, beta) if x < alpha else np.zeros(4, np.int32))).all()
         y = G.add(g, O.ht_eval(p1, n, g, 0, s[0], hc, ocw, x), O.ht_eval(p1, n, g, 1, s[1], hc, ocw, x))
         assert (y == (G.canon(g, beta) if x == alpha else np.zeros(4, np.int32))).all()
+
+
+# ---------------------------------------------------------------- VDPF (src/vdpf_test.cu)
+@pytest.mark.parametrize("chacha", [True, False])
+@pytest.mark.parametrize("g", [G.BYTES, G.U64, G.U128])
+def test_vdpf_reconstructs_and_verifies(O, rng, g, chacha):
+    """src/vdpf_test.cu: shares reconstruct the point function, both parties compute the same pi~ at every
+    point, Prove gives equal proofs, and a tampered key is caught by Verify."""
+    n = 16
+    p = O.Prg(2, chacha=chacha)
+    s = [rng.i4(), rng.i4()]
+    beta = beta_for(g)
+    cws, cs, ocw, rc = O.vdpf_gen(p, n, g, s, ALPHA, beta)
+    assert rc == 0
+    xs = [0, ALPHA, ALPHA - 1, ALPHA + 1, (1 << n) - 1] + [rng.below(n) for _ in range(20)]
+    pts = [[], []]
+    for x in xs:
+        ys = []
+        for b in (0, 1):
+            y, pt = O.vdpf_eval(p, n, g, b, s[b], cws, cs, ocw, x)
+            ys.append(y)
+            pts[b].append(pt)
+        want = G.canon(g, beta) if x == ALPHA else np.zeros(4, np.int32)
+        assert (G.add(g, ys[0], ys[1]) == want).all(), x
+        assert (pts[0][-1] == pts[1][-1]).all()
+    pi0, pi1 = O.vdpf_prove(np.array(pts[0]), cs), O.vdpf_prove(np.array(pts[1]), cs)
+    assert (pi0 == pi1).all()
+    bad = cws.copy()
+    bad[3, 0] ^= 0x10  # a malicious dealer hands party 1 a different correction word
+    pts1 = [O.vdpf_eval(p, n, g, 1, s[1], bad, cs, ocw, x)[1] for x in xs]
+    assert not (O.vdpf_prove(np.array(pts1), cs) == pi0).all()
