@@ -139,6 +139,7 @@ static int evp_make(fo_prg *p) {
 #endif
 }
 
+int fo_have_aesni(void);
 int fo_prg_init(fo_prg *p, const uint8_t *keys, int mul, int use_evp) {
   memset(p, 0, sizeof(*p));
   if (mul < 1 || mul > 4) return -1;
@@ -148,6 +149,7 @@ int fo_prg_init(fo_prg *p, const uint8_t *keys, int mul, int use_evp) {
     memcpy(p->key[i], keys + 16 * i, 16);
     aes_expand(p->key[i], p->rk[i]);
   }
+  if (use_evp == 2) return fo_have_aesni() ? 0 : -1;
   if (use_evp) return evp_make(p);
   return 0;
 }
@@ -220,11 +222,33 @@ static void chacha_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) {
 }
 
 /* out[i] = AES128-ECB_{key_i}(seed) ^ seed -- aes128_mmo.cuh:79-89 */
+/* AES-NI variant, the reference's fss::prg::Aes128MmoRaw<mul> (include/fss/prg/aes128_mmo_raw.cuh:62-87):
+ * same function as the OpenSSL path, the "best CPU" line of the baseline (README.md:341).  Uses the round
+ * keys of aes_expand (little-endian words = the key bytes in memory order). */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("aes,sse2"))) static void aesni_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) {
+  __m128i s = _mm_loadu_si128((const __m128i *)&seed);
+  for (int i = 0; i < p->mul; ++i) {
+    const __m128i *rk = (const __m128i *)p->rk[i];
+    __m128i b = _mm_xor_si128(s, _mm_loadu_si128(rk));
+    for (int r = 1; r < 10; ++r) b = _mm_aesenc_si128(b, _mm_loadu_si128(rk + r));
+    b = _mm_aesenclast_si128(b, _mm_loadu_si128(rk + 10));
+    _mm_storeu_si128((__m128i *)&out[i], _mm_xor_si128(b, s));
+  }
+}
+int fo_have_aesni(void) { return __builtin_cpu_supports("aes") ? 1 : 0; }
+#else
+static void aesni_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) { (void)p; (void)seed; (void)out; }
+int fo_have_aesni(void) { return 0; }
+#endif
+
 void fo_prg_gen(const fo_prg *p, fo_i4 seed, fo_i4 *out) {
   if (p->kind == 1) { chacha_gen(p, seed, out); return; }
+  if (p->use_evp == 2) { aesni_gen(p, seed, out); return; }
   for (int i = 0; i < p->mul; ++i) {
 #ifdef FO_HAVE_OPENSSL
-    if (p->use_evp) {
+    if (p->use_evp == 1) {
       int len = 0;
       EVP_EncryptUpdate((EVP_CIPHER_CTX *)p->evp[i], (unsigned char *)&out[i], &len, (const unsigned char *)&seed, 16);
       out[i] = xor4(out[i], seed);
@@ -881,7 +905,7 @@ void fo_vdpf_prove(const int32_t iv[8], const fo_i4 *pi_tildes, size_t n, const 
 static void prg_thread_copy(const fo_prg *src, fo_prg *dst) {
   *dst = *src;
   memset(dst->evp, 0, sizeof(dst->evp));
-  if (src->use_evp) evp_make(dst); /* one EVP ctx set per thread */
+  if (src->use_evp == 1) evp_make(dst); /* one EVP ctx set per thread */
 }
 
 static fo_i4 eval_one(const fo_prg *p, fo_i4 hk, int scheme, int in_bits, int group, int b, fo_i4 s0,

@@ -61,7 +61,7 @@ enum { FO_PRED_LT = 0, FO_PRED_GT = 1 }; /* include/fss/dcf.cuh:58-61 */
 /* AES-128-MMO PRG, include/fss/prg/aes128_mmo.cuh:27-95. */
 typedef struct {
   int mul;
-  int use_evp;          /* 1: OpenSSL EVP exactly as the reference calls it */
+  int use_evp;          /* 1: OpenSSL EVP exactly as the reference calls it; 2: AES-NI (Aes128MmoRaw) */
   uint8_t key[4][16];
   uint32_t rk[4][44];   /* own AES: little-endian round-key words */
   void *evp[4];         /* EVP_CIPHER_CTX* when use_evp */
@@ -71,6 +71,7 @@ typedef struct {
 } fo_prg;
 
 int fo_prg_init(fo_prg *p, const uint8_t *keys /* mul*16 bytes */, int mul, int use_evp);
+int fo_have_aesni(void);
 /* fss::prg::ChaCha<mul, rounds>(nonce), include/fss/prg/chacha.cuh:93. */
 int fo_prg_init_chacha(fo_prg *p, int mul, int rounds, const int32_t nonce[2]);
 /* The bare ChaCha permutation (`rounds` rounds, no feed-forward) on 16 words, for the RFC 7539 KAT. */

@@ -124,6 +124,10 @@ def _split(v):
     return v & ((1 << 64) - 1), (v >> 64) & ((1 << 64) - 1)
 
 
+def have_aesni() -> bool:
+    return bool(lib().fo_have_aesni())
+
+
 def aes128_encrypt(key: bytes, block: bytes) -> bytes:
     out = (C.c_uint8 * 16)()
     lib().fo_aes128_encrypt(C.c_char_p(key), C.c_char_p(block), out)
@@ -143,7 +147,7 @@ class Prg:
     """fss::prg::Aes128Mmo<mul> (include/fss/prg/aes128_mmo.cuh:27-95), or with chacha=True
     fss::prg::ChaCha<mul, rounds> (include/fss/prg/chacha.cuh:24-128)."""
 
-    def __init__(self, mul, keys=None, use_evp=False, chacha=False, nonce=CHACHA_NONCE, rounds=20):
+    def __init__(self, mul, keys=None, use_evp=False, chacha=False, nonce=CHACHA_NONCE, rounds=20, aesni=False):
         self.mul = mul
         self._p = _Prg()
         if chacha:
@@ -154,9 +158,9 @@ class Prg:
         keys = KEYS[:mul] if keys is None else keys
         assert len(keys) == mul
         buf = b"".join(keys)
-        rc = lib().fo_prg_init(C.byref(self._p), C.c_char_p(buf), mul, 1 if use_evp else 0)
+        rc = lib().fo_prg_init(C.byref(self._p), C.c_char_p(buf), mul, 2 if aesni else (1 if use_evp else 0))
         if rc != 0:
-            raise RuntimeError("fo_prg_init failed (OpenSSL missing?)")
+            raise RuntimeError("fo_prg_init failed (OpenSSL missing, or no AES-NI on this CPU?)")
 
     def __del__(self):
         try:

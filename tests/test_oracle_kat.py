@@ -144,3 +144,15 @@ def test_blake3_hash_forms(O):
     h2 = O.blake3_hash(iv, msg)
     want = O.blake3_compress(iv.view(np.uint32), msg.reshape(-1).view(np.uint32), 0, 64, 1 | 2 | 8 | 16)[:8]
     assert (h2.reshape(-1).view(np.uint32) == want).all()
+
+
+def test_aesni_prg_equals_evp_and_table_aes(O, rng):
+    """The AES-NI PRG (the reference's Aes128MmoRaw, prg/aes128_mmo_raw.cuh:62-87; the baseline's "best CPU"
+    line) is the same function as the OpenSSL and table paths."""
+    if not O.have_aesni():
+        pytest.skip("no AES-NI on this CPU")
+    for mul in (1, 2, 4):
+        a, b, c = O.Prg(mul), O.Prg(mul, use_evp=True), O.Prg(mul, aesni=True)
+        for _ in range(50):
+            s = rng.i4(clear_lsb=False)
+            assert (a.gen(s) == c.gen(s)).all() and (b.gen(s) == c.gen(s)).all()
