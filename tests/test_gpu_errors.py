@@ -1,0 +1,82 @@
+"""Error behaviour of the C ABI on a GPU box: bad arguments come back as FSS_AMD_EINVAL (-1) before any
+kernel is launched; the reference has asserts only (dpf.cuh:209,237), so these are the library's own contract
+(include/fss_amd.h)."""
+import ctypes as C
+
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+EINVAL = -1
+
+
+@pytest.fixture(scope="module")
+def raw():
+    import fss_amd
+    from fss_amd import _lib
+    eng = fss_amd.default_engine(0)
+    bufs = {k: torch.zeros(4096, dtype=torch.int32, device="cuda") for k in ("seed", "cws", "xs", "ys", "ws", "ocw")}
+    return _lib.lib(), eng._h, {k: C.c_void_p(v.data_ptr()) for k, v in bufs.items()}, bufs
+
+
+def test_point_eval_argument_errors(raw):
+    L, h, p, _ = raw
+    ok = lambda **kw: L.fss_amd_dpf_eval_points(kw.get("ctx", h), kw.get("n", 32), kw.get("g", 4), kw.get("party", 0),
+                                                kw.get("seed", p["seed"]), kw.get("cws", p["cws"]), kw.get("xs", p["xs"]),
+                                                kw.get("xb", 4), kw.get("cnt", 8), kw.get("ys", p["ys"]), None)
+    assert ok() == 0
+    assert ok(cnt=0) == 0  # empty batch is fine
+    for bad in (dict(ctx=None), dict(n=0), dict(n=33), dict(n=129, xb=16), dict(g=6), dict(g=-1), dict(party=2),
+                dict(xb=3), dict(xb=2), dict(cnt=-1), dict(seed=None), dict(cws=None), dict(xs=None), dict(ys=None)):
+        assert ok(**bad) == EINVAL, bad
+    assert ok(n=64, xb=8) == 0 and ok(n=65, xb=8) == EINVAL and ok(n=128, xb=16) == 0
+    # Half-Tree needs its output correction word
+    assert L.fss_amd_ht_eval_points(h, 32, 4, 0, p["seed"], p["cws"], None, p["xs"], 4, 8, p["ys"], None) == EINVAL
+
+
+def test_eval_all_argument_errors(raw):
+    L, h, p, bufs = raw
+    L.fss_amd_eval_all_workspace.restype = C.c_size_t
+    need = L.fss_amd_eval_all_workspace(0, 12, 256)
+    assert 0 < need <= bufs["ws"].numel() * 4
+    call = lambda first, n, ws=need, in_bits=12, ys=p["ys"]: L.fss_amd_dpf_eval_all(
+        h, in_bits, 4, 0, p["seed"], p["cws"], first, n, ys, p["ws"], ws, None)
+    assert call(0, 256) == 0 and call(256, 256) == 0 and call(4096 - 256, 256) == 0
+    assert call(128, 256) == EINVAL       # block not aligned to its size
+    assert call(0, 255) == EINVAL         # not a power of two
+    assert call(4096, 256) == EINVAL      # outside the domain
+    assert call(0, 256, ws=need - 16) == EINVAL
+    assert call(0, 256, in_bits=63) == EINVAL
+    assert call(0, 256, ys=C.c_void_p(bufs["ys"].data_ptr() + 4)) == EINVAL  # misaligned output
+
+
+def test_keys_gen_and_misc_argument_errors(raw):
+    L, h, p, _ = raw
+    assert L.fss_amd_dpf_eval_keys(h, 32, 4, 0, p["seed"], p["cws"], p["xs"], p["ocw"], p["xs"], 4, 8, p["ys"], None) == 0
+    assert L.fss_amd_dpf_eval_keys(h, 32, 4, 0, p["seed"], p["cws"], None, p["ocw"], p["xs"], 4, 8, p["ys"], None) == EINVAL
+    assert L.fss_amd_dcf_gen(h, 32, 4, 2, p["seed"], p["xs"], 4, p["ocw"], 4, p["cws"], None) == EINVAL  # pred
+    assert L.fss_amd_dcf_gen(h, 32, 4, 1, p["seed"], p["xs"], 4, None, 4, p["cws"], None) == 0           # beta = 0
+    assert L.fss_amd_grotto_eval_keys(h, 65, 0, p["seed"], p["cws"], p["xs"], p["xs"], 16, 4, p["ys"], None) == EINVAL
+    assert L.fss_amd_prg_gen(h, 3, p["seed"], 4, p["ys"], None) == EINVAL
+    assert L.fss_amd_ctx_set_prg(h, 7, None, 20) == EINVAL
+    assert L.fss_amd_ctx_set_prg(h, 1, None, 21) == EINVAL  # odd round count
+    assert L.fss_amd_ctx_set_prg(h, 0, None, 0) == 0
+    assert L.fss_amd_ctx_set_hash_iv(h, None) == EINVAL
+    L.fss_amd_strerror.restype = C.c_char_p
+    assert L.fss_amd_strerror(EINVAL) == b"invalid argument"
+    bad = C.c_void_p()
+    assert L.fss_amd_ctx_create(C.byref(bad), 99, C.c_char_p(b"\0" * 64), None) == EINVAL and not bad.value
+
+
+def test_python_layer_raises(raw):
+    import fss_amd
+    d = fss_amd.Dpf(in_bits=16)
+    s0 = torch.zeros(4, dtype=torch.int32)
+    cws = torch.zeros((17, 8), dtype=torch.int32)
+    with pytest.raises(fss_amd._lib.FssAmdError, match="invalid argument"):
+        d.engine.eval_all(fss_amd.DPF, 16, fss_amd.U64, 0, s0, cws, first_leaf=3, nleaves=8)
+    with pytest.raises(ValueError):
+        d.eval(0, s0, cws, 1 << 16)
+    with pytest.raises(ValueError):
+        d.eval(2, s0, cws, 1)
