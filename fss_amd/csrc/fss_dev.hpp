@@ -134,6 +134,21 @@ __device__ __forceinline__ Lds make_lds(const uint32_t* lds, const DevCtx& K) {
 // Fill the workgroup's LDS tables.  Call from every thread, then __syncthreads().
 __device__ __forceinline__ void lds_table_fill(uint32_t* lds, const uint32_t* __restrict__ te0) {
 #if FSS_T4
+  if (blockDim.x == 1024) {
+    // word i = tid + 1024 k holds entry ((tid >> 6) + 16 k) & 255 of table ((k >> 4) << 1) | ((tid >> 5) & 1):
+    // 16 distinct entries per lane, requested together (one memory latency instead of 32 in turn;
+    // 0.8 us per workgroup instead of 3.0, tools/ubench/fill_rate.hip).
+    const int tid = threadIdx.x, odd = (tid >> 5) & 1;
+    uint32_t t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = te0[((tid >> 6) + 16 * k) & 255];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const int tbl = ((k >> 4) << 1) | odd;
+      lds[tid + 1024 * k] = __builtin_amdgcn_alignbit(t[k & 15], t[k & 15], (32 - 8 * tbl) & 31);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 32768; i += blockDim.x) {
     uint32_t t = te0[(i >> 6) & 255];
     int tbl = ((i >> 14) << 1) | ((i >> 5) & 1);
