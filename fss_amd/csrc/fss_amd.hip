@@ -166,7 +166,7 @@ struct SharedKey {
 template <int SCHEME, bool SHARED, bool PREFIX = false>
 int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
   if (a.n == 0) return FSS_AMD_OK;
-  const int ilp = tune().ilp, bs = tune().bs;
+  const int ilp = tune().ilp, bs = PREFIX ? 1024 : tune().bs;  // the shared-prefix walk is built for 1024 only
   int64_t thr = (a.n + ilp - 1) / ilp;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
