@@ -8,8 +8,8 @@
  *
  * Parity pinning: the reference's own tests hold no golden vectors (every seed is
  * random per run), and the reference cannot be compiled in this
- * image without writing stand-ins for <cuda_runtime.h> and libcu++ <cuda/std/...>,
- * so no oracle/_ref build exists.  The oracle is pinned against
+ * image without writing stand-ins for libcu++ <cuda/std/array|span|tuple> (prg.cuh:10,
+ * util.cuh:10-11; no package here provides them), so no oracle/_ref build exists.  The oracle is pinned against
  *   (1) the known-answer values recorded from the reference's CPU OpenSSL path in
  *       SURVEY.md section 8(c) (PRG outputs, DPF/DCF n=8 CWs, Eval outputs and
  *       EvalAll SHA-256, DPF n=32 Uint<u64>, Half-Tree n=64) -- tests/test_oracle_kat.py,
