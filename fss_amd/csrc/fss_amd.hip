@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 
 #include "fss_dev.hpp"
@@ -26,7 +27,10 @@ struct fss_amd_ctx {
   int prg;        // FSS_AMD_PRG_AES128_MMO or FSS_AMD_PRG_CHACHA
   const char* last_kernel;
   int last_grid, last_block;
+  unsigned long long* work_ctr;  // device: kWqSlots chunk counters (WorkQueue), zero between launches
+  std::atomic<unsigned> wq_next;  // next counter slot (launches that may overlap on different streams get different slots)
 };
+constexpr int kWqSlots = 64;
 
 static thread_local int g_last_hip = 0;
 
@@ -110,7 +114,9 @@ bool x_ok(int in_bits, int x_bytes) {
 // Tunables (env, read once): FSS_AMD_ILP in {1,2}, FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU.
 struct Tune {
   int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
+  int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
   Tune() {
+    if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_ILP")) ilp = atoi(e);
     if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
     if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
@@ -123,23 +129,50 @@ const Tune& tune() {
   return t;
 }
 
-template <typename K, typename... Args>
-int launch_persistent(fss_amd_ctx* ctx, K kernel, const char* name, int bs, int64_t threads_needed, hipStream_t st,
-                      Args... args) {
+// Grid of a persistent launch: one workgroup per resident slot, fewer when the batch is smaller.
+template <typename K>
+int persistent_grid(fss_amd_ctx* ctx, K kernel, int bs, int64_t threads_needed, int* grid) {
   int occ = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, bs, 0));
   if (occ < 1) occ = 1;
   if (tune().wgs_per_cu > 0 && tune().wgs_per_cu < occ) occ = tune().wgs_per_cu;
   int64_t want = (threads_needed + bs - 1) / bs;
   int64_t cap = (int64_t)ctx->num_cu * occ;
-  int grid = (int)(want < cap ? want : cap);
-  if (grid < 1) grid = 1;
+  *grid = (int)(want < cap ? want : cap);
+  if (*grid < 1) *grid = 1;
+  return FSS_AMD_OK;
+}
+
+// Work queue for a launch of `grid` workgroups of `bs` lanes over `units` units taken `per_chunk` at a time
+// (fss_dev.hpp).  Static distribution (ctr = nullptr) when a wave would get fewer than 8 chunks.
+WorkQueue make_wq(fss_amd_ctx* ctx, int64_t units, int per_chunk, int grid, int bs) {
+  WorkQueue q{};
+  const int64_t nchunks = (units + per_chunk - 1) / per_chunk, waves = (int64_t)grid * (bs / 64);
+  const bool dyn = tune().dyn < 0 ? nchunks >= 8 * waves : tune().dyn != 0;
+  if (!dyn || bs % 64 != 0) return q;
+  q.ctr = ctx->work_ctr + (ctx->wq_next.fetch_add(1) % kWqSlots);
+  q.nchunks = nchunks;
+  q.last = (unsigned long long)(nchunks + waves - 1);
+  return q;
+}
+
+template <typename K, typename... Args>
+int launch_grid(fss_amd_ctx* ctx, K kernel, const char* name, int grid, int bs, hipStream_t st, Args... args) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bs), 0, st, args...);
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = name;
   ctx->last_grid = grid;
   ctx->last_block = bs;
   return FSS_AMD_OK;
+}
+
+template <typename K, typename... Args>
+int launch_persistent(fss_amd_ctx* ctx, K kernel, const char* name, int bs, int64_t threads_needed, hipStream_t st,
+                      Args... args) {
+  int grid = 0;
+  int rc = persistent_grid(ctx, kernel, bs, threads_needed, &grid);
+  if (rc != FSS_AMD_OK) return rc;
+  return launch_grid(ctx, kernel, name, grid, bs, st, args...);
 }
 
 // Instantiate CALL once per PRG (LT = Lds: AES-128-MMO with LDS tables; LT = ChaChaL) and run the one
@@ -163,15 +196,23 @@ struct SharedKey {
   const uint32_t *seed = nullptr, *cws = nullptr, *ocw = nullptr;
 };
 
+template <typename K>
+int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int bs, const SharedKey& k, EvalArgs a,
+                    hipStream_t st) {
+  int grid = 0;
+  int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
+  if (rc != FSS_AMD_OK) return rc;
+  a.wq = make_wq(ctx, a.n, 64 * ilp, grid, bs);
+  return launch_grid(ctx, kernel, name, grid, bs, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a);
+}
+
 template <int SCHEME, bool SHARED, bool PREFIX = false>
 int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
   if (a.n == 0) return FSS_AMD_OK;
   const int ilp = tune().ilp, bs = PREFIX ? 1024 : tune().bs;  // the shared-prefix walk is built for 1024 only
-  int64_t thr = (a.n + ilp - 1) / ilp;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
-  return FSS_BY_PRG(ctx, (launch_persistent(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, B, thr, st, \
-                                            ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)))
+  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;
@@ -230,7 +271,11 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   for (int i = 0; i < 4; ++i) c->host.hash_key[i] = hash_key ? (uint32_t)hash_key[i] : 0u;
 
   c->te0 = nullptr;
-  hipError_t e = hipMalloc(&c->te0, sizeof(te0) + sizeof(DevCtx));
+  constexpr size_t kCtrOff = (sizeof(te0) + sizeof(DevCtx) + 63) & ~size_t(63);
+  hipError_t e = hipMalloc(&c->te0, kCtrOff + kWqSlots * sizeof(unsigned long long));
+  c->work_ctr = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->te0) + kCtrOff);
+  c->wq_next = 0;
+  if (e == hipSuccess) e = hipMemset(c->work_ctr, 0, kWqSlots * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemcpy(c->te0, te0, sizeof(te0), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     c->host.self_dev = c->te0 + 256;

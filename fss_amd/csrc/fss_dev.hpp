@@ -546,6 +546,29 @@ __device__ __forceinline__ void chacha_rows(const DevCtx* __restrict__ c, const 
   x[14] ^= n0; x[15] ^= n1;
 }
 
+// ------------------------------------------------------------------ dynamic work distribution
+// A persistent grid whose waves each own a fixed 1/Nth of the batch finishes ragged: the SIMD issues its
+// oldest wave first, so that wave retires at about half of the kernel time and the younger ones finish
+// on a half-empty SIMD (measured: mean wave lifetime 71 % of the kernel, SQ_WAVE_CYCLES).  Instead every
+// wave takes chunks of 64 units from a counter until the batch is used up: all 16 waves of a CU stay
+// resident to the end (+15 % on the headline walk).  ctr == nullptr: static grid-stride (small batches,
+// where a wave would get fewer than ~8 chunks and the imbalance of whole chunks costs more).
+struct WorkQueue {
+  unsigned long long* ctr;   // zero before the launch; reset to zero by the last fetch of the launch
+  long long nchunks;
+  unsigned long long last;   // nchunks + (number of waves) - 1: every wave ends on one out-of-range fetch
+};
+// Next chunk index for this wave (wave-uniform); >= nchunks when the batch is used up.
+__device__ __forceinline__ long long wq_fetch(const WorkQueue& q) {
+  unsigned long long v = 0;
+  if ((threadIdx.x & 63) == 0) {
+    v = atomicAdd(q.ctr, 1ull);
+    if (v == q.last) *q.ctr = 0ull;  // nobody fetches after the last fetch: leave the counter ready for the next launch
+  }
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------ BLAKE3 (VDPF hashes)
 // fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): one keyed-hash compression (7 rounds) of a
 // single block, flags CHUNK_START | CHUNK_END | ROOT | KEYED_HASH, counter 0; out = first 8 words of the

@@ -36,6 +36,7 @@ struct EvalArgs {
   int start_level;
   const uint4* pre_nodes;
   const uint4* pre_v;       // DCF: running group value of every node
+  WorkQueue wq;             // wq.ctr != nullptr: chunks of 64 * ILP evaluations per wave (fss_dev.hpp)
 };
 
 // An evaluation point / alpha of up to 128 bits (In = uint32_t, uint64_t or __uint128_t in the reference).
@@ -262,11 +263,21 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   const int64_t n = a.n;
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
 
-  for (int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x; base < n; base += T * ILP) {
+  const bool dyn = a.wq.ctr != nullptr;
+  const int64_t SJ = dyn ? 64 : T;  // distance between the ILP evaluations of a lane
+  long long next = dyn ? wq_fetch(a.wq) : 0;
+  for (int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;; base += T * ILP) {
+    if (dyn) {
+      if (next >= a.wq.nchunks) break;
+      base = (int64_t)next * (64 * ILP) + (threadIdx.x & 63);
+      next = wq_fetch(a.wq);  // requested one chunk ahead
+    } else if (base >= n) {
+      break;
+    }
     int64_t idx[ILP];
 #pragma unroll
     for (int j = 0; j < ILP; ++j) {
-      int64_t e = base + (int64_t)j * T;
+      int64_t e = base + (int64_t)j * SJ;
       idx[j] = e < n ? e : n - 1;  // clamp: keeps the tail lanes converged, the store is masked
     }
 
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * in_bits; oc[0] = p[0]; oc[1] = p[1]; oc[2] = p[2]; oc[3] = p[3]; }
         else { uint4 t = a.out_cw[idx[j]]; oc[0] = t.x; oc[1] = t.y; oc[2] = t.z; oc[3] = t.w; }
         uint4 y = w[j].finish(g, party, oc);
-        if (base + (int64_t)j * T < n) ys[idx[j]] = y;
+        if (base + (int64_t)j * SJ < n) ys[idx[j]] = y;
       }
     } else if constexpr (SCHEME == S_DCF) {
       DcfWalk w[ILP];
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * in_bits + 4; oc[0] = p[0]; oc[1] = p[1]; oc[2] = p[2]; oc[3] = p[3]; }
         else { uint4 t = a.out_cw[idx[j]]; oc[0] = t.x; oc[1] = t.y; oc[2] = t.z; oc[3] = t.w; }
         uint4 y = w[j].finish(g, party, oc);
-        if (base + (int64_t)j * T < n) ys[idx[j]] = y;
+        if (base + (int64_t)j * SJ < n) ys[idx[j]] = y;
       }
     } else if constexpr (SCHEME == S_HT) {
       HtWalk w[ILP];
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           oc[0] = u.x; oc[1] = u.y; oc[2] = u.z; oc[3] = u.w;
         }
         uint4 y = w[j].finish(L, c, g, party, cw, extra, oc);
-        if (base + (int64_t)j * T < n) ys[idx[j]] = y;
+        if (base + (int64_t)j * SJ < n) ys[idx[j]] = y;
       }
     }
   }
