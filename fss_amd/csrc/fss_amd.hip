@@ -7,7 +7,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <atomic>
 #include <new>
 
 #include "fss_dev.hpp"
@@ -27,10 +26,7 @@ struct fss_amd_ctx {
   int prg;        // FSS_AMD_PRG_AES128_MMO or FSS_AMD_PRG_CHACHA
   const char* last_kernel;
   int last_grid, last_block;
-  unsigned long long* work_ctr;  // device: kWqSlots chunk counters (WorkQueue), zero between launches
-  std::atomic<unsigned> wq_next;  // next counter slot (launches that may overlap on different streams get different slots)
 };
-constexpr int kWqSlots = 64;
 
 static thread_local int g_last_hip = 0;
 
@@ -143,17 +139,12 @@ int persistent_grid(fss_amd_ctx* ctx, K kernel, int bs, int64_t threads_needed, 
   return FSS_AMD_OK;
 }
 
-// Work queue for a launch of `grid` workgroups of `bs` lanes over `units` units taken `per_chunk` at a time
-// (fss_dev.hpp).  Static distribution (ctr = nullptr) when a wave would get fewer than 8 chunks.
-WorkQueue make_wq(fss_amd_ctx* ctx, int64_t units, int per_chunk, int grid, int bs) {
-  WorkQueue q{};
+// Dynamic (per-workgroup LDS counter, WaveQ in fss_dev.hpp) or static distribution of `units` units taken
+// `per_chunk` at a time over `grid` workgroups of `bs` lanes: dynamic when a wave gets at least 8 chunks.
+int use_dyn(int64_t units, int per_chunk, int grid, int bs) {
+  if (tune().dyn >= 0) return tune().dyn;
   const int64_t nchunks = (units + per_chunk - 1) / per_chunk, waves = (int64_t)grid * (bs / 64);
-  const bool dyn = tune().dyn < 0 ? nchunks >= 8 * waves : tune().dyn != 0;
-  if (!dyn || bs % 64 != 0) return q;
-  q.ctr = ctx->work_ctr + (ctx->wq_next.fetch_add(1) % kWqSlots);
-  q.nchunks = nchunks;
-  q.last = (unsigned long long)(nchunks + waves - 1);
-  return q;
+  return nchunks >= 8 * waves ? 1 : 0;
 }
 
 template <typename K, typename... Args>
@@ -202,7 +193,7 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   int grid = 0;
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
-  a.wq = make_wq(ctx, a.n, 64 * ilp, grid, bs);
+  a.dyn = use_dyn(a.n, 64 * ilp, grid, bs);
   return launch_grid(ctx, kernel, name, grid, bs, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a);
 }
 
@@ -271,11 +262,7 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   for (int i = 0; i < 4; ++i) c->host.hash_key[i] = hash_key ? (uint32_t)hash_key[i] : 0u;
 
   c->te0 = nullptr;
-  constexpr size_t kCtrOff = (sizeof(te0) + sizeof(DevCtx) + 63) & ~size_t(63);
-  hipError_t e = hipMalloc(&c->te0, kCtrOff + kWqSlots * sizeof(unsigned long long));
-  c->work_ctr = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->te0) + kCtrOff);
-  c->wq_next = 0;
-  if (e == hipSuccess) e = hipMemset(c->work_ctr, 0, kWqSlots * sizeof(unsigned long long));
+  hipError_t e = hipMalloc(&c->te0, sizeof(te0) + sizeof(DevCtx));
   if (e == hipSuccess) e = hipMemcpy(c->te0, te0, sizeof(te0), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     c->host.self_dev = c->te0 + 256;

@@ -547,27 +547,47 @@ __device__ __forceinline__ void chacha_rows(const DevCtx* __restrict__ c, const 
 }
 
 // ------------------------------------------------------------------ dynamic work distribution
-// A persistent grid whose waves each own a fixed 1/Nth of the batch finishes ragged: the SIMD issues its
+// A persistent grid whose waves each own a fixed 1/Nth of the batch finishes ragged: a SIMD issues its
 // oldest wave first, so that wave retires at about half of the kernel time and the younger ones finish
-// on a half-empty SIMD (measured: mean wave lifetime 71 % of the kernel, SQ_WAVE_CYCLES).  Instead every
-// wave takes chunks of 64 units from a counter until the batch is used up: all 16 waves of a CU stay
-// resident to the end (+15 % on the headline walk).  ctr == nullptr: static grid-stride (small batches,
-// where a wave would get fewer than ~8 chunks and the imbalance of whole chunks costs more).
-struct WorkQueue {
-  unsigned long long* ctr;   // zero before the launch; reset to zero by the last fetch of the launch
-  long long nchunks;
-  unsigned long long last;   // nchunks + (number of waves) - 1: every wave ends on one out-of-range fetch
-};
-// Next chunk index for this wave (wave-uniform); >= nchunks when the batch is used up.
-__device__ __forceinline__ long long wq_fetch(const WorkQueue& q) {
-  unsigned long long v = 0;
-  if ((threadIdx.x & 63) == 0) {
-    v = atomicAdd(q.ctr, 1ull);
-    if (v == q.last) *q.ctr = 0ull;  // nobody fetches after the last fetch: leave the counter ready for the next launch
-  }
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return (long long)(((unsigned long long)hi << 32) | lo);
+// on a half-empty SIMD (measured: mean wave lifetime 71 % of the kernel, SQ_WAVE_CYCLES).  So the batch is
+// cut into chunks of 64 units (one per lane), workgroup b owns chunks b, b + G, b + 2G, ... (G = grid size:
+// every CU gets the same share), and the waves of a workgroup take their workgroup's chunks one at a time
+// from a counter in LDS: all 16 waves of a CU stay resident until the CU's share is used up (+15 % on the
+// headline walk).  dyn = 0: every wave walks its own fixed chunks (small batches, where a wave would get
+// fewer than ~8 chunks and the imbalance of whole chunks costs more than the ragged finish).
+#define FSS_WAVEQ_PROLOGUE()            \
+  __shared__ uint32_t waveq_ctr_;       \
+  if (threadIdx.x == 0) waveq_ctr_ = 0; \
+  __syncthreads()
+// Next chunk index (global numbering) for this wave; wave-uniform.
+__device__ __forceinline__ int64_t waveq_fetch(uint32_t* lds_ctr) {
+  uint32_t v = 0;
+  if ((threadIdx.x & 63) == 0) v = atomicAdd(lds_ctr, 1u);
+  v = __builtin_amdgcn_readfirstlane(v);
+  return (int64_t)blockIdx.x + (int64_t)gridDim.x * v;
 }
+// Loop control shared by the persistent kernels: UNITS_PER_LANE units per lane and chunk, `unit0` = first
+// unit of this lane in the current chunk.  Usage:
+//   FSS_WAVEQ_PROLOGUE();  WaveQ q(dyn, &waveq_ctr_, total_units, units_per_lane);
+//   for (int64_t u; q.next(u);) { ... lane handles units u + j * q.stride(), j < units_per_lane ... }
+struct WaveQ {
+  uint32_t* ctr;
+  int64_t nchunks, cur, per_chunk;
+  bool dyn;
+  __device__ __forceinline__ WaveQ(int dyn_, uint32_t* lds_ctr, int64_t total_units, int units_per_lane)
+      : ctr(lds_ctr), per_chunk(64 * (int64_t)units_per_lane), dyn(dyn_ != 0) {
+    nchunks = (total_units + per_chunk - 1) / per_chunk;
+    // static: the wave's own chunks, spaced by the number of waves in the grid
+    cur = dyn ? waveq_fetch(ctr) : ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+  }
+  // first unit of this lane in the next chunk of this wave; false when the wave is done
+  __device__ __forceinline__ bool next(int64_t& unit0) {
+    if (cur >= nchunks) return false;
+    unit0 = cur * per_chunk + (threadIdx.x & 63);
+    cur = dyn ? waveq_fetch(ctr) : cur + (int64_t)gridDim.x * (blockDim.x >> 6);
+    return true;
+  }
+};
 
 // ------------------------------------------------------------------ BLAKE3 (VDPF hashes)
 // fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): one keyed-hash compression (7 rounds) of a

@@ -34,6 +34,7 @@ struct ExpandArgs {
   uint4* out_nodes;
   uint4* out_v;
   void* ys;             // leaf stage: uint4 per leaf (Grotto: uint8 control bit per leaf)
+  int dyn;              // expand_kernel: waves take 64-node chunks from the workgroup's LDS counter (WaveQ)
 };
 
 // -- one-node expansions ------------------------------------------------------
@@ -169,11 +170,14 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
                                                     const uint32_t* __restrict__ k_ocw,  // Half-Tree
                                                     ExpandArgs a) {
   const DevCtx* c = &K;
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int g = a.group, party = a.party;
 
   constexpr int NN = 1 << D;
-  for (int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x; j < a.n_in; j += (int64_t)gridDim.x * BS) {
+  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1);
+  for (int64_t j; q.next(j);) {
+    if (j >= a.n_in) continue;  // ragged last chunk
     uint32_t nodes[NN][4];
     Acc vs[SCHEME == S_DCF ? NN : 1];
     {

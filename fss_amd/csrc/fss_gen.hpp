@@ -81,6 +81,7 @@ struct GenArgs {
   uint64_t* tr_bits;
   uint4* out_cw;
   uint32_t* extra;
+  int dyn;              // waves take 64-key chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
 };
 
 __device__ __forceinline__ void ld4(uint32_t d[4], uint4 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
@@ -94,9 +95,12 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
   // K is the first kernel argument = offset 0 of the kernarg segment.  Taking &K instead makes the
   // DCF/AES instantiation copy all 1.8 KiB of it to scratch and fetch round keys from there.
   const DevCtx* c = first_kernarg(K);
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
+  WaveQ q(a.dyn, &waveq_ctr_, a.nkeys, 1);
+  for (int64_t k; q.next(k);) {
+    if (k >= a.nkeys) continue;
     uint32_t s0[4], s1[4], beta[4];
     ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]);
     ld4(beta, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));  // betas == nullptr: beta = 0 (Grotto keys)
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
 template <class LT, bool LM>
 __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
   const DevCtx* c = &K;
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
   auto hash = [&](const uint32_t node[4], uint32_t h[4]) {
@@ -264,7 +269,9 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
                       node[3] ^ c->hash_key[3]};
     prg_hash(L, c, in, h);
   };
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
+  WaveQ q(a.dyn, &waveq_ctr_, a.nkeys, 1);
+  for (int64_t k; q.next(k);) {
+    if (k >= a.nkeys) continue;
     uint32_t n0[4], n1[4], beta[4];
     ld4(n0, a.s0s[2 * k]); ld4(n1, a.s0s[2 * k + 1]);
     ld4(beta, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));

@@ -36,7 +36,7 @@ struct EvalArgs {
   int start_level;
   const uint4* pre_nodes;
   const uint4* pre_v;       // DCF: running group value of every node
-  WorkQueue wq;             // wq.ctr != nullptr: chunks of 64 * ILP evaluations per wave (fss_dev.hpp)
+  int dyn;                  // waves take chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
 };
 
 // An evaluation point / alpha of up to 128 bits (In = uint32_t, uint64_t or __uint128_t in the reference).
@@ -255,25 +255,17 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_ocw,   // Half-Tree
                                                          EvalArgs a) {
   const DevCtx* c = &K;
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
 
   const int in_bits = a.in_bits, party = a.party, g = a.group;
   const int lvl0 = PREFIX ? a.start_level : 0;
-  const int64_t T = (int64_t)gridDim.x * BS;
   const int64_t n = a.n;
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
 
-  const bool dyn = a.wq.ctr != nullptr;
-  const int64_t SJ = dyn ? 64 : T;  // distance between the ILP evaluations of a lane
-  long long next = dyn ? wq_fetch(a.wq) : 0;
-  for (int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x;; base += T * ILP) {
-    if (dyn) {
-      if (next >= a.wq.nchunks) break;
-      base = (int64_t)next * (64 * ILP) + (threadIdx.x & 63);
-      next = wq_fetch(a.wq);  // requested one chunk ahead
-    } else if (base >= n) {
-      break;
-    }
+  constexpr int64_t SJ = 64;  // a lane's ILP evaluations are 64 apart: a chunk is 64 * ILP consecutive evaluations
+  WaveQ q(a.dyn, &waveq_ctr_, n, ILP);
+  for (int64_t base; q.next(base);) {
     int64_t idx[ILP];
 #pragma unroll
     for (int j = 0; j < ILP; ++j) {
@@ -427,10 +419,13 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 template <class LT, int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
   const DevCtx* c = &K;
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits;
   uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
-  for (int64_t k = (int64_t)blockIdx.x * BS + threadIdx.x; k < a.n; k += (int64_t)gridDim.x * BS) {
+  WaveQ q(a.dyn, &waveq_ctr_, a.n, 1);
+  for (int64_t k; q.next(k);) {
+    if (k >= a.n) continue;
     const uint64_t x = load_x(a.xs, a.x_bytes, k).lo;
     const uint64_t e = x + 1;
     const bool whole = n == 64 ? (e == 0) : (e == (1ull << n));

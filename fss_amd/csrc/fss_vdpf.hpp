@@ -18,6 +18,7 @@ struct VdpfArgs {
   const uint64_t* tr_bits;
   const uint4* cs;          // 4 per key
   const uint4* ocws;
+  int dyn;                  // WaveQ: chunks of 64 * ILP evaluations from the workgroup's LDS counter
 };
 
 // fss::Vdpf::Eval (vdpf.cuh:204-257) for a batch; fss::gpu::VdpfEvalPointKernel (point_eval_gpu.cuh:254-308).
@@ -29,17 +30,19 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_cs,
                                                          const uint32_t* __restrict__ k_ocw, VdpfArgs a) {
   const DevCtx* c = &K;
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int in_bits = a.in_bits, party = a.party, g = a.group;
-  const int64_t T = (int64_t)gridDim.x * BS;
   const int64_t n = a.n;
-  for (int64_t base = (int64_t)blockIdx.x * BS + threadIdx.x; base < n; base += T * ILP) {
+  constexpr int64_t SJ = 64;
+  WaveQ q(a.dyn, &waveq_ctr_, n, ILP);
+  for (int64_t base; q.next(base);) {
     int64_t idx[ILP];
     DpfWalk w[ILP];
     uint64_t trb[ILP], trbh[ILP];
 #pragma unroll
     for (int j = 0; j < ILP; ++j) {
-      int64_t e = base + (int64_t)j * T;
+      int64_t e = base + (int64_t)j * SJ;
       idx[j] = e < n ? e : n - 1;
       uint32_t s0[4];
       if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[4 * q + r] ^= tm & cq[r];
       }
-      if (base + (int64_t)j * T < n) {
+      if (base + (int64_t)j * SJ < n) {
         a.ys[idx[j]] = y;
 #pragma unroll
         for (int q = 0; q < 4; ++q) a.pis[4 * idx[j] + q] = make_uint4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
@@ -108,15 +111,19 @@ struct VdpfGenArgs {
   uint4* cs;         // 4 per key
   uint4* ocws;
   int32_t* retry;    // optional: 1 where t0 == t1 at the end (vdpf.cuh:177)
+  int dyn;           // WaveQ: 64-key chunks from the workgroup's LDS counter
 };
 
 // fss::Vdpf::Gen (vdpf.cuh:103-189): the DPF levels of gen_kernel, then cs and the output correction word.
 template <class LT, bool LM>
 __global__ __launch_bounds__(1024) void vdpf_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, VdpfGenArgs a) {
   const DevCtx* c = first_kernarg(K);
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;
-  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.nkeys; k += (int64_t)gridDim.x * blockDim.x) {
+  WaveQ q(a.dyn, &waveq_ctr_, a.nkeys, 1);
+  for (int64_t k; q.next(k);) {
+    if (k >= a.nkeys) continue;
     uint32_t s0[4], s1[4];
     ld4(s0, a.s0s[2 * k]); ld4(s1, a.s0s[2 * k + 1]);
     s0[3] &= ~1u; s1[3] &= ~1u;
