@@ -111,7 +111,9 @@ bool x_ok(int in_bits, int x_bytes) {
 struct Tune {
   int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
   int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
+  int rot_prio = -1;  // FSS_AMD_ROTPRIO: 1 / 0 force; default: on for static launches
   Tune() {
+    if (const char* e = getenv("FSS_AMD_ROTPRIO")) rot_prio = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_ILP")) ilp = atoi(e);
     if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
@@ -194,6 +196,7 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
   a.dyn = use_dyn(a.n, 64 * ilp, grid, bs);
+  a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : !a.dyn;
   return launch_grid(ctx, kernel, name, grid, bs, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a);
 }
 

@@ -37,6 +37,7 @@ struct EvalArgs {
   const uint4* pre_nodes;
   const uint4* pre_v;       // DCF: running group value of every node
   int dyn;                  // waves take chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
+  int rot_prio;             // statically distributed launches: rotate the wave priority every level (rotate_prio)
 };
 
 // An evaluation point / alpha of up to 128 bits (In = uint32_t, uint64_t or __uint128_t in the reference).
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
+        if (a.rot_prio) rotate_prio(i);
         CwDpf cw[ILP];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
+        if (a.rot_prio) rotate_prio(i);
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
           CwDcf cw;
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits - 1; ++i) {
+        if (a.rot_prio) rotate_prio(i);
         uint32_t cw[ILP][4];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
