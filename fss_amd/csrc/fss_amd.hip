@@ -110,12 +110,13 @@ bool x_ok(int in_bits, int x_bytes) {
 // Tunables (env, read once): FSS_AMD_ILP in {1,2}, FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU.
 struct Tune {
   int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
+  bool ilp_set = false;  // FSS_AMD_ILP given: do not second-guess it for small batches
   int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
   int rot_prio = -1;  // FSS_AMD_ROTPRIO: 1 / 0 force; default: on for static launches
   Tune() {
     if (const char* e = getenv("FSS_AMD_ROTPRIO")) rot_prio = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
-    if (const char* e = getenv("FSS_AMD_ILP")) ilp = atoi(e);
+    if (const char* e = getenv("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
     if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
     if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
     if (ilp != 1 && ilp != 2) ilp = 2;
@@ -142,11 +143,11 @@ int persistent_grid(fss_amd_ctx* ctx, K kernel, int bs, int64_t threads_needed, 
 }
 
 // Dynamic (per-workgroup LDS counter, WaveQ in fss_dev.hpp) or static distribution of `units` units taken
-// `per_chunk` at a time over `grid` workgroups of `bs` lanes: dynamic when a wave gets at least 8 chunks.
+// `per_chunk` at a time over `grid` workgroups of `bs` lanes: dynamic when a wave gets at least 4 chunks.
 int use_dyn(int64_t units, int per_chunk, int grid, int bs) {
   if (tune().dyn >= 0) return tune().dyn;
   const int64_t nchunks = (units + per_chunk - 1) / per_chunk, waves = (int64_t)grid * (bs / 64);
-  return nchunks >= 8 * waves ? 1 : 0;
+  return nchunks >= 4 * waves ? 1 : 0;
 }
 
 template <typename K, typename... Args>
@@ -203,7 +204,12 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
 template <int SCHEME, bool SHARED, bool PREFIX = false>
 int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
   if (a.n == 0) return FSS_AMD_OK;
-  const int ilp = tune().ilp, bs = PREFIX ? 1024 : tune().bs;  // the shared-prefix walk is built for 1024 only
+  const int bs = PREFIX ? 1024 : tune().bs;  // the shared-prefix walk is built for 1024 only
+  int ilp = tune().ilp;
+  // two evaluations per lane only pay when there are enough to give every resident wave a chunk of 128
+  // (2^18 points: 0.10 ms with one per lane, 0.17 ms with two and half of the waves idle)
+  const int64_t resident_waves = (int64_t)ctx->num_cu * (ctx->prg == FSS_AMD_PRG_CHACHA ? 2 : 1) * (bs / 64);
+  if (!tune().ilp_set && a.n < 128 * resident_waves) ilp = 1;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
   return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st)))

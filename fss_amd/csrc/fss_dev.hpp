@@ -554,7 +554,7 @@ __device__ __forceinline__ void chacha_rows(const DevCtx* __restrict__ c, const 
 // every CU gets the same share), and the waves of a workgroup take their workgroup's chunks one at a time
 // from a counter in LDS: all 16 waves of a CU stay resident until the CU's share is used up (+15 % on the
 // headline walk).  dyn = 0: every wave walks its own fixed chunks (small batches, where a wave would get
-// fewer than ~8 chunks and the imbalance of whole chunks costs more than the ragged finish).
+// fewer than ~4 chunks and the imbalance of whole chunks costs more than the ragged finish).
 #define FSS_WAVEQ_PROLOGUE()            \
   __shared__ uint32_t waveq_ctr_;       \
   if (threadIdx.x == 0) waveq_ctr_ = 0; \
