@@ -118,7 +118,7 @@ template <class LT, int SCHEME>
 __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                        const uint32_t* __restrict__ k_seed,
                                                        const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_PRG_PROLOGUE(LT, te0);
   const int depth = a.level0;  // p + top
   const int64_t nout = (int64_t)1 << top;
@@ -160,39 +160,65 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
 }
 
 // -- expansion stage ------------------------------------------------------------
-// Lane j takes input node j at level `level0`, expands D levels in registers and
-// writes children (j << D) + k.  LEAF: the outputs are the tree's leaves and are
-// converted (dpf.cuh:255-263, dcf.cuh:318-329, half_tree_dpf.cuh ConvertLastLevel,
-// grotto_dcf.cuh:194-198) instead of stored as nodes.
-template <class LT, int SCHEME, int D, bool LEAF, int BS>
+// Lane j takes input node j at level `level0` and writes its descendants E + D levels down at
+// (j << (E + D)) + k.  The last D levels are expanded in registers (all 2^D nodes live); the E levels
+// above them are walked depth-first by rolled loops (one pair of children live per level), which keeps the
+// code and the register count of a deep stage close to those of a D-level one.  LEAF: the outputs are
+// the tree's leaves and are converted (dpf.cuh:255-263, dcf.cuh:318-329, half_tree_dpf.cuh
+// ConvertLastLevel, grotto_dcf.cuh:194-198) instead of stored as nodes.
+template <class LT, int SCHEME, int E>
+struct OuterLevels {
+  template <class Body>
+  static __device__ __forceinline__ void run(const LT& L, const DevCtx* __restrict__ c, int g,
+                                             const uint32_t* __restrict__ k_cws, int lvl, const uint32_t node[4],
+                                             const Acc& v, int64_t ob, int sub_log2, Body& body) {
+    if constexpr (E == 0) {
+      body(node, v, lvl, ob);
+    } else {
+      uint32_t l[4], r[4];
+      Acc vl, vr;
+      const uint32_t* cw = k_cws + 8 * lvl;
+      if constexpr (SCHEME == S_DCF) dcf_expand(L, c, g, cw, node, v, l, vl, r, vr);
+      else if constexpr (SCHEME == S_HT) ht_expand(L, c, cw, node, l, r);
+      else dpf_expand(L, c, cw, node, l, r);
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        uint32_t ch[4];
+        Acc cv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ch[q] = h ? r[q] : l[q];
+          if constexpr (SCHEME == S_DCF) cv.v[q] = h ? vr.v[q] : vl.v[q];
+        }
+        OuterLevels<LT, SCHEME, E - 1>::run(L, c, g, k_cws, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
+                                            sub_log2 - 1, body);
+      }
+    }
+  }
+};
+
+template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0>
 __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                     const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
                                                     const uint32_t* __restrict__ k_ocw,  // Half-Tree
                                                     ExpandArgs a) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int g = a.group, party = a.party;
 
   constexpr int NN = 1 << D;
-  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1);
-  for (int64_t j; q.next(j);) {
-    if (j >= a.n_in) continue;  // ragged last chunk
+  // the D levels expanded in registers, from one node at level `lvl` to outputs ob .. ob + 2^D - 1
+  auto body = [&](const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob) {
     uint32_t nodes[NN][4];
     Acc vs[SCHEME == S_DCF ? NN : 1];
-    {
-      uint4 t = a.in_nodes[j];
-      nodes[0][0] = t.x; nodes[0][1] = t.y; nodes[0][2] = t.z; nodes[0][3] = t.w;
-      if constexpr (SCHEME == S_DCF) {
-        uint4 u = a.in_v[j];
-        vs[0].v[0] = u.x; vs[0].v[1] = u.y; vs[0].v[2] = u.z; vs[0].v[3] = u.w;
-      }
-    }
+    nodes[0][0] = nin[0]; nodes[0][1] = nin[1]; nodes[0][2] = nin[2]; nodes[0][3] = nin[3];
+    if constexpr (SCHEME == S_DCF) vs[0] = vin;
     // Half-Tree: the tree's last level is the conversion, not an expansion.
     constexpr int DE = (SCHEME == S_HT && LEAF) ? D - 1 : D;
 #pragma unroll
     for (int lev = 0; lev < DE; ++lev) {
-      const uint32_t* cw = k_cws + 8 * (a.level0 + lev);
+      const uint32_t* cw = k_cws + 8 * (lvl + lev);
 #pragma unroll
       for (int k = (1 << lev) - 1; k >= 0; --k) {
         uint32_t l[4], r[4];
@@ -209,7 +235,6 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
         for (int q = 0; q < 4; ++q) { nodes[2 * k][q] = l[q]; nodes[2 * k + 1][q] = r[q]; }
       }
     }
-    const int64_t ob = j << D;
     if constexpr (!LEAF) {
 #pragma unroll
       for (int k = 0; k < NN; ++k) {
@@ -258,6 +283,22 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
 #endif
       }
     }
+  };
+
+  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1);
+  for (int64_t j; q.next(j);) {
+    if (j >= a.n_in) continue;  // ragged last chunk
+    uint32_t n0[4];
+    Acc v0;
+    {
+      uint4 t = a.in_nodes[j];
+      n0[0] = t.x; n0[1] = t.y; n0[2] = t.z; n0[3] = t.w;
+      if constexpr (SCHEME == S_DCF) {
+        uint4 u = a.in_v[j];
+        v0.v[0] = u.x; v0.v[1] = u.y; v0.v[2] = u.z; v0.v[3] = u.w;
+      }
+    }
+    OuterLevels<LT, SCHEME, E>::run(L, c, g, k_cws, a.level0, n0, v0, j << (E + D), E + D, body);
   }
 }
 

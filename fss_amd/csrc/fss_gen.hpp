@@ -11,7 +11,7 @@ template <class LT>
 __global__ __launch_bounds__(1024) void prg_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, int mul,
                                                       const uint4* __restrict__ seeds, int64_t n,
                                                       uint4* __restrict__ out) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_PRG_PROLOGUE(LT, te0);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     uint4 s = seeds[i];
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
 // fss::HalfTreeDpf::Gen (include/fss/half_tree_dpf.cuh:68-175).
 template <class LT, bool LM>
 __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, GenArgs a) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits, g = a.group;

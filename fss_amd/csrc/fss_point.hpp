@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_cws,   // raw Cw slots
                                                          const uint32_t* __restrict__ k_ocw,   // Half-Tree
                                                          EvalArgs a) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
 
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 // ExpandTreeRec's (grotto_dcf.cuh:201-222).  Independent keys, level-major.
 template <class LT, int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_cws,
                                                          const uint32_t* __restrict__ k_cs,
                                                          const uint32_t* __restrict__ k_ocw, VdpfArgs a) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const int in_bits = a.in_bits, party = a.party, g = a.group;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void vdpf_gen_kernel(const DevCtx K, const ui
 template <bool CHAIN>
 __global__ __launch_bounds__(256) void vdpf_prove_kernel(const DevCtx K, const uint4* __restrict__ pis,
                                                          const uint4* __restrict__ cs, int64_t n, uint4* __restrict__ out) {
-  const DevCtx* c = &K;
+  const DevCtx* c = first_kernarg(K);
   auto ld = [](uint32_t* d, uint4 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
   if constexpr (CHAIN) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
