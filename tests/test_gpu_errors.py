@@ -80,3 +80,20 @@ def test_python_layer_raises(raw):
         d.eval(0, s0, cws, 1 << 16)
     with pytest.raises(ValueError):
         d.eval(2, s0, cws, 1)
+
+
+@pytest.mark.parametrize("env", [{"FSS_AMD_DYN": "1"}, {"FSS_AMD_DYN": "0", "FSS_AMD_ROTPRIO": "0"},
+                                 {"FSS_AMD_ILP": "1", "FSS_AMD_BS": "256"}, {"FSS_AMD_LEAF_E": "1", "FSS_AMD_TOPMAX": "3"}])
+def test_parity_under_forced_tunables(env):
+    """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
+    depths) pick by batch size, so the small oracle-checked cases would only ever see one of each; run the
+    oracle comparisons again with the other choices forced (the tunables are read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_vdpf.py"),
+                        "-k", "vs_oracle or kats or subblocks or deep_prefix"],
+                       env={**os.environ, **env}, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
