@@ -1,11 +1,12 @@
 // Device-side building blocks for the MI355X (gfx950) DPF/DCF evaluation engine.
 //
-//  * AES-128 with the round function as T-table lookups in LDS.  The 256-entry
-//    Te0 table is replicated once per lane of a wavefront ("row" = 64 x 4 B =
-//    256 B per table index), so lane l always hits bank l % 32 and a wave64
-//    ds_read_b32 is conflict-free whatever the 64 indices are (ds_read_b32 is
-//    serviced as two 32-lane groups; bank = (addr / 4) % 32).  The 256-byte row
-//    also makes the LDS byte address  idx << 8 | lane * 4  a single v_perm_b32.
+//  * AES-128 with the round function as T-table lookups in LDS: four tables T0..T3 (Te0 rotated by
+//    0/8/16/24 bits), each entry replicated once per bank (32 copies), so lane l always reads bank
+//    l % 32 and a wave64 ds_read_b32 is conflict-free whatever the 64 indices are (it is serviced as two
+//    32-lane groups; bank = (addr / 4) % 32).  Layout and addressing: "LDS table layouts" below.
+//  * ChaCha20 and the keyed BLAKE3 compression (the reference's other PRG and the VDPF hashes) as
+//    straight VALU code, behind the same PRG interface (`Lds` / `ChaChaL` overloads).
+//  * WaveQ: work distribution for the persistent kernels (per-workgroup LDS counter).
 //  * State columns are kept as little-endian words, i.e. exactly the int4's
 //    x, y, z, w -- no byte swaps around the cipher (the reference's software AES
 //    loads big-endian words, include/fss/prg/aes128_mmo_soft.cuh:113-129; the
@@ -50,7 +51,6 @@ struct DevCtx {
   uint32_t blake3_iv[8];     // VDPF: key of the keyed BLAKE3 hashes H and H' (fss::hash::Blake3::iv_)
 };
 
-constexpr int kLdsTableBytes = 256 * 256;  // 64 KiB: 256 indices x 64 lane copies x 4 B
 
 // v_bitop3_b32 truth tables (a = 0xF0, b = 0xCC, c = 0xAA).
 constexpr uint32_t kXor3 = 0xF0 ^ 0xCC ^ 0xAA;        // a ^ b ^ c
