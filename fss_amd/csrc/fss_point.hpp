@@ -13,6 +13,22 @@
 #define FSS_RESD 0
 #endif
 
+// Correction words of independent keys are read exactly once: FSS_NT_CW = 1 (default) marks those loads
+// non-temporal (+1 % on the 2^24-key walks, which stream 1.7 TB/s and run power-limited).
+#ifndef FSS_NT_CW
+#define FSS_NT_CW 1
+#endif
+#if FSS_NT_CW
+typedef uint32_t fss_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 fss_ld_stream(const uint4* p) {
+  fss_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const fss_u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+#define FSS_LD_STREAM(p) fss_ld_stream(p)
+#else
+#define FSS_LD_STREAM(p) (*(p))
+#endif
+
 namespace fssamd {
 
 struct EvalArgs {
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
             const uint32_t* p = k_cws + 8 * i;
             cw[j].x = p[0]; cw[j].y = p[1]; cw[j].z = p[2]; cw[j].wl = p[3]; cw[j].tr = p[4];
           } else {
-            uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
+            uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * n + idx[j]);
             cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
             cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
           }
@@ -353,8 +369,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #pragma unroll
             for (int q = 0; q < 4; ++q) { cw.s[q] = p[q]; cw.v[q] = p[4 + q]; }
           } else {
-            uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
-            uint4 u = a.cw_v[(int64_t)i * n + idx[j]];
+            uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * n + idx[j]);
+            uint4 u = FSS_LD_STREAM(a.cw_v + (int64_t)i * n + idx[j]);
             cw.s[0] = t.x; cw.s[1] = t.y; cw.s[2] = t.z; cw.s[3] = t.w;
             cw.v[0] = u.x; cw.v[1] = u.y; cw.v[2] = u.z; cw.v[3] = u.w;
           }
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
           if constexpr (SHARED) { const uint32_t* p = k_cws + 8 * i; cw[j][0] = p[0]; cw[j][1] = p[1]; cw[j][2] = p[2]; cw[j][3] = p[3]; }
-          else { uint4 t = a.cw_s[(int64_t)i * n + idx[j]]; cw[j][0] = t.x; cw[j][1] = t.y; cw[j][2] = t.z; cw[j][3] = t.w; }
+          else { uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * n + idx[j]); cw[j][0] = t.x; cw[j][1] = t.y; cw[j][2] = t.z; cw[j][3] = t.w; }
         }
         if constexpr (ILP == 2) HtWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1]);
         else w[0].level(L, c, in_bits, i, cw[0]);
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
     uint32_t pi = 0;
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
-      uint4 t = a.cw_s[(int64_t)i * a.n + k];
+      uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * a.n + k);
       const uint32_t m = bit_mask(e, n - 1 - i);
       uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
       const uint32_t tm = lsb_mask(st[3]);

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
           const uint32_t* p = k_cws + 8 * i;
           cw[j].x = p[0]; cw[j].y = p[1]; cw[j].z = p[2]; cw[j].wl = p[3]; cw[j].tr = p[4];
         } else {
-          uint4 t = a.cw_s[(int64_t)i * n + idx[j]];
+          uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * n + idx[j]);
           cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
           cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
         }
