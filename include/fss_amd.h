@@ -62,7 +62,12 @@ typedef struct fss_amd_ctx fss_amd_ctx;
  * (include/fss/prg/aes128_mmo.cuh:49-70) and the HalfTreeDpf::hash_key member
  * (include/fss/half_tree_dpf.cuh:45): four AES-128 keys (key i produces PRG
  * output i; DPF/Grotto use 0-1, DCF 0-3, Half-Tree 0) and the Half-Tree hash
- * key, expanded once and kept resident on `device`. */
+ * key, expanded once and kept resident on `device`.
+ * Threading: a context is not synchronised.  Calls that only launch work (every eval / gen / relayout call)
+ * may be issued from several host threads at once (they record nothing but the name of the last kernel, which
+ * is then unspecified); fss_amd_ctx_set_prg / set_hash_iv / destroy must not run concurrently with anything else
+ * on the same context.  All work is asynchronous on the given stream; nothing is allocated, freed or
+ * synchronised inside a call after creation. */
 int fss_amd_ctx_create(fss_amd_ctx **out, int device, const uint8_t aes_keys[64], const int32_t hash_key[4]);
 void fss_amd_ctx_destroy(fss_amd_ctx *ctx);
 int fss_amd_ctx_device(const fss_amd_ctx *ctx);
