@@ -101,6 +101,8 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 bool group_ok(int g) { return g >= 0 && g <= 5; }
 bool x_ok(int in_bits, int x_bytes) {
   if (in_bits < 1) return false;
+  if (x_bytes == 1) return in_bits <= 8;
+  if (x_bytes == 2) return in_bits <= 16;
   if (x_bytes == 4) return in_bits <= 32;
   if (x_bytes == 8) return in_bits <= 64;
   if (x_bytes == 16) return in_bits <= 128;  // two little-endian uint64 per value (__uint128_t)

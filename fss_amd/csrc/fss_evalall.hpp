@@ -391,7 +391,10 @@ __global__ __launch_bounds__(256) void grotto_table_eval_kernel(const uint8_t* _
                                                                const void* __restrict__ xs, int x_bytes, int64_t n,
                                                                uint8_t* __restrict__ ys) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    uint64_t x = x_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t*>(xs)[i] : reinterpret_cast<const uint64_t*>(xs)[i];
+    uint64_t x = x_bytes == 1   ? (uint64_t) reinterpret_cast<const uint8_t*>(xs)[i]
+                 : x_bytes == 2 ? (uint64_t) reinterpret_cast<const uint16_t*>(xs)[i]
+                 : x_bytes == 4 ? (uint64_t) reinterpret_cast<const uint32_t*>(xs)[i]
+                                : reinterpret_cast<const uint64_t*>(xs)[i];
     uint64_t e = x + 1;
     uint32_t pi;
     if (e == (1ull << in_bits)) {

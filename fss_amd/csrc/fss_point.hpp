@@ -72,7 +72,9 @@ __device__ __forceinline__ uint32_t lsb_mask(uint32_t w) { return (uint32_t)__bu
 __device__ __forceinline__ X128 load_x(const void* xs, int x_bytes, int64_t i) {
   X128 x;
   x.hi = 0;
-  if (x_bytes == 4) x.lo = reinterpret_cast<const uint32_t*>(xs)[i];
+  if (x_bytes == 1) x.lo = reinterpret_cast<const uint8_t*>(xs)[i];
+  else if (x_bytes == 2) x.lo = reinterpret_cast<const uint16_t*>(xs)[i];
+  else if (x_bytes == 4) x.lo = reinterpret_cast<const uint32_t*>(xs)[i];
   else if (x_bytes == 8) x.lo = reinterpret_cast<const uint64_t*>(xs)[i];
   else { x.lo = reinterpret_cast<const uint64_t*>(xs)[2 * i]; x.hi = reinterpret_cast<const uint64_t*>(xs)[2 * i + 1]; }
   return x;

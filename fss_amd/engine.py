@@ -92,6 +92,11 @@ class Engine:
 
     @staticmethod
     def _xbytes(xs, in_bits):
+        if xs.dtype in (torch.uint8, torch.int16):  # In = uint8_t / uint16_t (bit patterns)
+            w = 1 if xs.dtype == torch.uint8 else 2
+            if in_bits > 8 * w:
+                raise ValueError(f"{xs.dtype} xs only cover in_bits <= {8 * w}")
+            return w
         if xs.dtype == torch.int32:
             if in_bits > 32:
                 raise ValueError("int32 xs only cover in_bits <= 32; pass int64")
@@ -102,7 +107,7 @@ class Engine:
             if in_bits > 64:
                 raise ValueError("in_bits > 64 needs xs of shape (n, 2): (lo, hi) int64 bit patterns")
             return 8
-        raise TypeError(f"xs must be int32 (uint32 bit pattern) or int64 (uint64 bit pattern), got {xs.dtype}")
+        raise TypeError(f"xs must be uint8, int16, int32 or int64 bit patterns (or (n, 2) int64 pairs), got {xs.dtype}")
 
     def last_kernel(self):
         g, b = C.c_int(0), C.c_int(0)

@@ -20,9 +20,9 @@
  *  - Return value: 0 on success, a negative FSS_AMD_E* code otherwise.  No
  *    exceptions cross the ABI.  There is no CPU fallback: without a usable HIP
  *    device fss_amd_ctx_create fails with FSS_AMD_EHIP.
- *  - x values: `x_bytes` = 4 (uint32_t, in_bits <= 32), 8 (uint64_t, in_bits <= 64)
+ *  - x values: `x_bytes` = sizeof(In): 1, 2, 4 or 8 (uint8_t .. uint64_t, in_bits <= 8 * x_bytes)
  *    or 16 (__uint128_t as two little-endian uint64_t, in_bits <= 128) -- the
- *    reference's `In` types (fss_crypto/_jit.py:57-62).  Bits are consumed
+ *    reference's `In` types (dpf.cuh:61-63, fss_crypto/_jit.py:57-62).  Bits are consumed
  *    MSB-first (dpf.cuh:196).  EvalAll, the shared-prefix entry points and the
  *    Grotto calls need in_bits <= 62 / 64 / 64.
  */

@@ -116,7 +116,8 @@ class ChaCha {
 namespace detail {
 template <typename In>
 constexpr int XBytes() {
-  static_assert(sizeof(In) == 4 || sizeof(In) == 8 || sizeof(In) == 16, "In must be uint32_t, uint64_t or __uint128_t");
+  static_assert(sizeof(In) == 1 || sizeof(In) == 2 || sizeof(In) == 4 || sizeof(In) == 8 || sizeof(In) == 16,
+                "In must be an unsigned integer of 1, 2, 4 or 8 bytes or __uint128_t");
   return (int)sizeof(In);
 }
 }  // namespace detail

@@ -539,3 +539,42 @@ def test_cxx_sample_self_check():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 mismatches" in r.stdout and "OK" in r.stdout
+
+
+@pytest.mark.parametrize("scheme,n,dtype", [(DPF, 8, "uint8"), (DCF, 5, "uint8"), (HT, 8, "uint8"), (DPF, 16, "int16"),
+                                            (DCF, 16, "int16"), (HT, 11, "int16")])
+def test_narrow_input_types_vs_oracle(engine, O, scheme, n, dtype):
+    """In = uint8_t / uint16_t (the reference's C1 sample is Dpf<8, Bytes, Aes128Mmo<2>, uint8_t>): x arrays of
+    1- and 2-byte elements through the shared-key, shared-prefix, independent-keys and Gen entry points."""
+    rng = SplitMix64(555 + 10 * scheme + n)
+    g = G.U64
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), beta_for(rng)
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 0, s, alpha, beta)
+    else:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    xs = np.array([alpha] + [rng.below(n) for _ in range(300)], dtype=np.uint64)
+    tdt = torch.uint8 if dtype == "uint8" else torch.int16
+    xt = torch.from_numpy(xs.astype(np.uint8) if dtype == "uint8" else xs.astype(np.uint16).view(np.int16)).cuda()
+    assert xt.dtype == tdt
+    m = len(xs)
+    s0s = np.broadcast_to(np.stack(s), (m, 2, 4)).copy()
+    at = torch.full((m,), int(alpha), dtype=torch.int64).to(tdt).cuda() if dtype == "uint8" else \
+        torch.from_numpy(np.full(m, alpha, dtype=np.uint16).view(np.int16)).cuda()
+    keys, ocws = engine.gen_level_major(scheme, n, g, T(s0s), at, T(np.broadcast_to(beta, (m, 4)).copy()))
+    for b in (0, 1):
+        want = O.eval_points(p, scheme, n, g, b, s[b], cws, xs, ocw=ocw)
+        got = engine.eval_points(scheme, n, g, b, T(s[b]), T(cws), xt, ocw=None if ocw is None else T(ocw)).cpu().numpy()
+        assert (got == want).all()
+        k = min(4, n - (scheme == HT))
+        if k >= 1:
+            got = engine.eval_points_shared(scheme, n, g, b, T(s[b]), T(cws), xt, ocw=None if ocw is None else T(ocw),
+                                            prefix_bits=k).cpu().numpy()
+            assert (got == want).all()
+        got = engine.eval_keys(keys, g, b, T(np.ascontiguousarray(s0s[:, b])), xt, ocws=ocws).cpu().numpy()
+        assert (got == want).all()
