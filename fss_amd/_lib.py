@@ -48,6 +48,7 @@ PROTOTYPES = {
     "fss_amd_dcf_gen": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_ht_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
     "fss_amd_ctx_set_hash_iv": (_i, [_vp, _vp]),
+    "fss_amd_ctx_set_uint_modulus": (_i, [_vp, C.c_uint64]),
     "fss_amd_vdpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fss_amd_vdpf_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fss_amd_vdpf_relayout": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp]),

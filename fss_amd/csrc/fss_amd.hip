@@ -98,7 +98,13 @@ void expand_key(const uint8_t sbox[256], const uint8_t key[16], uint32_t rk[44])
 
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-bool group_ok(int g) { return g >= 0 && g <= 5; }
+// group id in range and, for Uint<T, mod> with a context modulus, the modulus representable in T
+bool group_ok(const fss_amd_ctx* ctx, int g) {
+  if (g < 0 || g > 5) return false;
+  const uint64_t m = ctx->host.uint_mod;
+  if (m == 0 || g < G_U8 || g > G_U32) return true;
+  return m <= (1ull << (g == G_U8 ? 8 : (g == G_U16 ? 16 : 32)));
+}
 bool x_ok(int in_bits, int x_bytes) {
   if (in_bits < 1) return false;
   if (x_bytes == 1) return in_bits <= 8;
@@ -250,6 +256,7 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   c->prg = FSS_AMD_PRG_AES128_MMO;
   c->host.chacha_nonce[0] = c->host.chacha_nonce[1] = 0;
   c->host.chacha_rounds = 20;
+  c->host.uint_mod = 0;
   {  // default VDPF hash key: the reference bench's kBlake3Iv (src/bench_gpu.cu:27-30)
     const uint32_t iv[8] = {0x11223344u, 0x55667788u, 0x99aabbccu, 0xddeeff00u, 0x00112233u, 0x44556677u, 0x8899aabbu, 0xccddeeffu};
     for (int i = 0; i < 8; ++i) c->host.blake3_iv[i] = iv[i];
@@ -311,6 +318,12 @@ int fss_amd_ctx_set_prg(fss_amd_ctx* ctx, int prg, const int32_t nonce[2], int r
   return FSS_AMD_OK;
 }
 
+int fss_amd_ctx_set_uint_modulus(fss_amd_ctx* ctx, uint64_t mod) {
+  if (!ctx) return FSS_AMD_EINVAL;
+  ctx->host.uint_mod = mod;
+  return FSS_AMD_OK;
+}
+
 const char* fss_amd_strerror(int code) {
   switch (code) {
     case FSS_AMD_OK: return "ok";
@@ -349,7 +362,7 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
 static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seed,
                          const void* cws, const void* ocw, const void* xs, int x_bytes, int64_t n, void* ys,
                          void* stream) {
-  if (!ctx || !seed || !cws || n < 0 || !group_ok(group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes))
+  if (!ctx || !seed || !cws || n < 0 || !group_ok(ctx, group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes))
     return FSS_AMD_EINVAL;
   if (n > 0 && (!xs || !ys)) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !ocw) return FSS_AMD_EINVAL;
@@ -425,7 +438,7 @@ int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t 
 static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seeds,
                        const void* cw_s, const void* cw_v, const void* tr_bits, const void* out_cw, const void* extra,
                        const void* xs, int x_bytes, int64_t n, void* ys, void* stream) {
-  if (!ctx || n < 0 || !group_ok(group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
+  if (!ctx || n < 0 || !group_ok(ctx, group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
   if (!seeds || !cw_s || !xs || !ys || !out_cw) return FSS_AMD_EINVAL;
   if (scheme == S_DPF && !tr_bits) return FSS_AMD_EINVAL;

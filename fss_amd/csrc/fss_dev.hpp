@@ -49,6 +49,7 @@ struct DevCtx {
   uint32_t chacha_nonce[2];  // ChaCha PRG (contexts created with fss_amd_ctx_set_chacha)
   int chacha_rounds;
   uint32_t blake3_iv[8];     // VDPF: key of the keyed BLAKE3 hashes H and H' (fss::hash::Blake3::iv_)
+  uint64_t uint_mod;         // modulus of Uint<T, mod> for T up to 64 bits; 0 = 2^(8 sizeof T)
 };
 
 
@@ -753,6 +754,16 @@ __device__ __forceinline__ void prg_raw(const ChaChaL& L, const DevCtx* __restri
 // arithmetic is exact, so this equals the reference's term-by-term signs bit for
 // bit.  Uint<uint8/16/32/64> all accumulate mod 2^64 and are reduced in finish();
 // Uint<__uint128_t, 1 << 127> is arithmetic mod 2^127 on x | y<<32 | z<<64 | (w>>1)<<96.
+// A group as the kernels see it: the id and, for Uint<T, mod> with a modulus other than 2^(8 sizeof T)
+// (uint.cuh:17-30, T up to 64 bits), that modulus; mod == 0 is the wrapping group.  Wave-uniform.
+struct Grp {
+  int id;
+  uint64_t mod;
+};
+__device__ __forceinline__ Grp make_grp(int id, const DevCtx* __restrict__ c) {
+  return Grp{id, (id >= G_U8 && id <= G_U64) ? c->uint_mod : 0ull};
+}
+
 struct Acc {
   uint32_t v[4] = {0, 0, 0, 0};
 
@@ -763,46 +774,68 @@ struct Acc {
   __device__ __forceinline__ void set128(unsigned __int128 r) {
     v[0] = (uint32_t)r; v[1] = (uint32_t)(r >> 32); v[2] = (uint32_t)(r >> 64); v[3] = (uint32_t)(r >> 96);
   }
+  // Uint<T, mod>::From for mod != 0 (uint.cuh:36-53): the low sizeof(T) bytes, reduced.
+  static __device__ __forceinline__ uint64_t from_mod(const Grp& g, const uint32_t b[4]) {
+    uint64_t x = (uint64_t)b[0] | ((uint64_t)b[1] << 32);
+    if (g.id == G_U8) x &= 0xffull;
+    else if (g.id == G_U16) x &= 0xffffull;
+    else if (g.id == G_U32) x &= 0xffffffffull;
+    return x % g.mod;
+  }
+  __device__ __forceinline__ void add_mod(const Grp& g, uint64_t x) {  // uint.cuh:20-24, both operands < mod
+    uint64_t a = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    a = a >= g.mod - x ? a + x - g.mod : a + x;
+    v[0] = (uint32_t)a; v[1] = (uint32_t)(a >> 32);
+  }
   // b: 16-byte buffer whose control bit the caller has cleared where the reference does.
-  __device__ __forceinline__ void add(int g, const uint32_t b[4]) {
-    if (g == G_BYTES) {
+  __device__ __forceinline__ void add(const Grp& g, const uint32_t b[4]) {
+    if (g.id == G_BYTES) {
       v[0] ^= b[0]; v[1] ^= b[1]; v[2] ^= b[2]; v[3] ^= b[3];
-    } else if (g == G_U128M127) {
+    } else if (g.id == G_U128M127) {
       uint32_t t[4] = {b[0], b[1], b[2], b[3] >> 1};  // uint.cuh:58-62
       set128(to128(v) + to128(t));
+    } else if (g.mod) {
+      add_mod(g, from_mod(g, b));
     } else {
       uint64_t r = ((uint64_t)v[0] | ((uint64_t)v[1] << 32)) + ((uint64_t)b[0] | ((uint64_t)b[1] << 32));
       v[0] = (uint32_t)r; v[1] = (uint32_t)(r >> 32);
     }
   }
-  __device__ __forceinline__ void sub(int g, const uint32_t b[4]) {
-    if (g == G_BYTES) {
+  __device__ __forceinline__ void sub(const Grp& g, const uint32_t b[4]) {
+    if (g.id == G_BYTES) {
       v[0] ^= b[0]; v[1] ^= b[1]; v[2] ^= b[2]; v[3] ^= b[3];
-    } else if (g == G_U128M127) {
+    } else if (g.id == G_U128M127) {
       uint32_t t[4] = {b[0], b[1], b[2], b[3] >> 1};
       set128(to128(v) - to128(t));
+    } else if (g.mod) {
+      const uint64_t x = from_mod(g, b);
+      add_mod(g, x ? g.mod - x : 0ull);  // uint.cuh:26-31
     } else {
       uint64_t r = ((uint64_t)v[0] | ((uint64_t)v[1] << 32)) - ((uint64_t)b[0] | ((uint64_t)b[1] << 32));
       v[0] = (uint32_t)r; v[1] = (uint32_t)(r >> 32);
     }
   }
-  __device__ __forceinline__ void add_if(int g, uint32_t m, const uint32_t b[4]) {
+  __device__ __forceinline__ void add_if(const Grp& g, uint32_t m, const uint32_t b[4]) {
     uint32_t t[4] = {m & b[0], m & b[1], m & b[2], m & b[3]};
     add(g, t);
   }
-  __device__ __forceinline__ uint4 finish(int g, bool neg) const {
-    if (g == G_BYTES) return make_uint4(v[0], v[1], v[2], v[3]);  // bytes.cuh:26-28: -x == x
-    if (g == G_U128M127) {
+  __device__ __forceinline__ uint4 finish(const Grp& g, bool neg) const {
+    if (g.id == G_BYTES) return make_uint4(v[0], v[1], v[2], v[3]);  // bytes.cuh:26-28: -x == x
+    if (g.id == G_U128M127) {
       unsigned __int128 r = to128(v);
       if (neg) r = (unsigned __int128)0 - r;
       r &= (((unsigned __int128)1) << 127) - 1;
       return make_uint4((uint32_t)r, (uint32_t)(r >> 32), (uint32_t)(r >> 64), ((uint32_t)(r >> 96)) << 1);  // uint.cuh:76-82
     }
     uint64_t r = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+    if (g.mod) {
+      if (neg && r) r = g.mod - r;
+      return make_uint4((uint32_t)r, (uint32_t)(r >> 32), 0, 0);
+    }
     if (neg) r = 0ull - r;
-    if (g == G_U8) r &= 0xffull;
-    else if (g == G_U16) r &= 0xffffull;
-    else if (g == G_U32) r &= 0xffffffffull;
+    if (g.id == G_U8) r &= 0xffull;
+    else if (g.id == G_U16) r &= 0xffffull;
+    else if (g.id == G_U32) r &= 0xffffffffull;
     return make_uint4((uint32_t)r, (uint32_t)(r >> 32), 0, 0);
   }
 };

@@ -55,7 +55,7 @@ __device__ __forceinline__ void dpf_expand(const LT& L, const DevCtx* __restrict
 // DCF node (dcf.cuh:331-366): children plus their running values (positive terms;
 // the party sign is applied at the leaf).
 template <class LT>
-__device__ __forceinline__ void dcf_expand(const LT& L, const DevCtx* __restrict__ c, int g,
+__device__ __forceinline__ void dcf_expand(const LT& L, const DevCtx* __restrict__ c, const Grp& g,
                                            const uint32_t* __restrict__ cw, const uint32_t st[4], const Acc& v,
                                            uint32_t left[4], Acc& vl, uint32_t right[4], Acc& vr) {
   uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
@@ -91,7 +91,7 @@ __device__ __forceinline__ void ht_expand(const LT& L, const DevCtx* __restrict_
 
 // Half-Tree last level for one sigma (half_tree_dpf.cuh:325-354).
 template <class LT>
-__device__ __forceinline__ uint4 ht_convert(const LT& L, const DevCtx* __restrict__ c, int g, int party,
+__device__ __forceinline__ uint4 ht_convert(const LT& L, const DevCtx* __restrict__ c, const Grp& g, int party,
                                             const uint32_t* __restrict__ cw, const uint32_t* __restrict__ ocw,
                                             const uint32_t parent[4], uint32_t sigma) {
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(parent[3], 0, 1);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
         CwDcf cw;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { cw.s[q] = p[q]; cw.v[q] = p[4 + q]; }
-        w.level(L, c, a.group, depth, i, cw);
+        w.level(L, c, make_grp(a.group, c), depth, i, cw);
       }
       a.out_nodes[j] = make_uint4(w.st[0], w.st[1], w.st[2], w.st[3]);
       a.out_v[j] = make_uint4(w.v.v[0], w.v.v[1], w.v.v[2], w.v.v[3]);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
 template <class LT, int SCHEME, int E>
 struct OuterLevels {
   template <class Body>
-  static __device__ __forceinline__ void run(const LT& L, const DevCtx* __restrict__ c, int g,
+  static __device__ __forceinline__ void run(const LT& L, const DevCtx* __restrict__ c, const Grp& g,
                                              const uint32_t* __restrict__ k_cws, int lvl, const uint32_t node[4],
                                              const Acc& v, int64_t ob, int sub_log2, Body& body) {
     if constexpr (E == 0) {
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
   const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
-  const int g = a.group, party = a.party;
+  const Grp g = make_grp(a.group, c);
+  const int party = a.party;
 
   constexpr int NN = 1 << D;
   // the D levels expanded in registers, from one node at level `lvl` to outputs ob .. ob + 2^D - 1

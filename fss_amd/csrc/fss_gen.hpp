@@ -97,7 +97,8 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
   const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
-  const int n = a.in_bits, g = a.group;
+  const int n = a.in_bits;
+  const Grp g = make_grp(a.group, c);
   WaveQ q(a.dyn, &waveq_ctr_, a.nkeys, 1);
   for (int64_t k; q.next(k);) {
     if (k >= a.nkeys) continue;
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
   const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
-  const int n = a.in_bits, g = a.group;
+  const int n = a.in_bits;
+  const Grp g = make_grp(a.group, c);
   auto hash = [&](const uint32_t node[4], uint32_t h[4]) {
     uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
                       node[3] ^ c->hash_key[3]};

@@ -137,7 +137,7 @@ struct DpfWalk {
     st[2] = and_xor(tm, cw.z, o[2]);
     st[3] = and_xor(tm, cww, o[3]);
   }
-  __device__ __forceinline__ uint4 finish(int g, int party, const uint32_t out_cw[4]) const {
+  __device__ __forceinline__ uint4 finish(const Grp& g, int party, const uint32_t out_cw[4]) const {
     Acc y;  // dpf.cuh:207-213
     uint32_t s[4] = {st[0], st[1], st[2], st[3] & ~1u};
     y.add(g, s);
@@ -168,7 +168,7 @@ struct DcfWalk {
     x = x_;
   }
   template <class LT>
-  __device__ __forceinline__ void level(const LT& L, const DevCtx* __restrict__ c, int g, int in_bits, int i,
+  __device__ __forceinline__ void level(const LT& L, const DevCtx* __restrict__ c, const Grp& g, int in_bits, int i,
                                         const CwDcf& cw) {
     uint32_t m = bit_mask(x, in_bits - 1 - i);
     uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
@@ -186,7 +186,7 @@ struct DcfWalk {
     st[2] = and_xor(tm, cw.s[2], os[2]);
     st[3] = and_xor(tm, cww, os[3]);
   }
-  __device__ __forceinline__ uint4 finish(int g, int party, const uint32_t out_cw[4]) {
+  __device__ __forceinline__ uint4 finish(const Grp& g, int party, const uint32_t out_cw[4]) {
     uint32_t s[4] = {st[0], st[1], st[2], st[3] & ~1u};  // dcf.cuh:263-273
     v.add(g, s);
     v.add_if(g, lsb_mask(st[3]), out_cw);
@@ -237,7 +237,7 @@ struct HtWalk {
   }
   // last level + output conversion, :205-229
   template <class LT>
-  __device__ __forceinline__ uint4 finish(const LT& L, const DevCtx* __restrict__ c, int g, int party, const uint32_t cw[4],
+  __device__ __forceinline__ uint4 finish(const LT& L, const DevCtx* __restrict__ c, const Grp& g, int party, const uint32_t cw[4],
                                           uint32_t extra, const uint32_t ocw[4]) const {
     uint32_t xn = (uint32_t)x.lo & 1u;
     uint32_t tm = lsb_mask(node[3]);
@@ -277,7 +277,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
 
-  const int in_bits = a.in_bits, party = a.party, g = a.group;
+  const int in_bits = a.in_bits, party = a.party;
+  const Grp g = make_grp(a.group, c);
   const int lvl0 = PREFIX ? a.start_level : 0;
   const int64_t n = a.n;
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
   const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
-  const int in_bits = a.in_bits, party = a.party, g = a.group;
+  const int in_bits = a.in_bits, party = a.party;
+  const Grp g = make_grp(a.group, c);
   const int64_t n = a.n;
   constexpr int64_t SJ = 64;
   WaveQ q(a.dyn, &waveq_ctr_, n, ILP);
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(1024) void vdpf_gen_kernel(const DevCtx K, const ui
   const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
-  const int n = a.in_bits, g = a.group;
+  const int n = a.in_bits;
+  const Grp g = make_grp(a.group, c);
   WaveQ q(a.dyn, &waveq_ctr_, a.nkeys, 1);
   for (int64_t k; q.next(k);) {
     if (k >= a.nkeys) continue;

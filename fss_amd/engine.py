@@ -332,6 +332,10 @@ class Engine:
         return LevelMajorKeys(scheme, in_bits, n, cw_s, extra=ex), ocws
 
 
+    def set_uint_modulus(self, mod):
+        """fss::group::Uint<T, mod> for the u8..u64 groups (0 = the wrapping group, the default)."""
+        _lib.check(self._L.fss_amd_ctx_set_uint_modulus(self._h, int(mod)), "fss_amd_ctx_set_uint_modulus")
+
     # ---------------------------------------------------------------- verifiable DPF
     def set_hash_iv(self, iv):
         """Key of the keyed-BLAKE3 hashes H and H' of the VDPF (fss::hash::Blake3's iv, 8 words)."""

@@ -78,6 +78,10 @@ int fss_amd_ctx_device(const fss_amd_ctx *ctx);
 #define FSS_AMD_PRG_AES128_MMO 0
 #define FSS_AMD_PRG_CHACHA 1
 int fss_amd_ctx_set_prg(fss_amd_ctx *ctx, int prg, const int32_t nonce[2], int rounds);
+/* Modulus of the FSS_AMD_GROUP_U8 .. U64 groups: fss::group::Uint<T, mod> with mod != 0 (uint.cuh:11-31:
+ * values reduced by From, modular add and negate).  0 (default) = the wrapping group Uint<T>.  Must fit T
+ * (checked by the calls that take a group); Bytes and Uint<__uint128_t, 2^127> ignore it. */
+int fss_amd_ctx_set_uint_modulus(fss_amd_ctx *ctx, uint64_t mod);
 const char *fss_amd_strerror(int code);
 /* Last hipError_t seen by this library on the calling thread (0 = hipSuccess). */
 int fss_amd_last_hip_error(void);

@@ -50,7 +50,8 @@ struct Uint {
   static_assert(std::is_unsigned_v<T> || std::is_same_v<T, unsigned __int128>);
   static_assert(sizeof(T) < 16 || mod == (static_cast<unsigned __int128>(1) << 127),
                 "Uint<__uint128_t> is built for mod = 2^127 only");
-  static_assert(sizeof(T) == 16 || mod == 0, "modular Uint<T, mod> below 128 bits is not built");
+  // mod != 0 below 128 bits: fss_amd_ctx_set_uint_modulus(prg.handle(), kMod) before using the scheme object
+  static constexpr uint64_t kMod = sizeof(T) == 16 ? 0 : (uint64_t)mod;
   static constexpr int kId = sizeof(T) == 1   ? FSS_AMD_GROUP_U8
                              : sizeof(T) == 2 ? FSS_AMD_GROUP_U16
                              : sizeof(T) == 4 ? FSS_AMD_GROUP_U32

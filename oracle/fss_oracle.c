@@ -270,6 +270,12 @@ typedef struct {
 } gel;
 #define M127 (((u128)1) << 127)
 
+/* Uint<T, mod> with mod != 0 for T up to 64 bits (uint.cuh:11-31, :64): one process-wide modulus for the
+ * U8..U64 groups, 0 = the wrapping group.  Test infrastructure: set before a run, read-only during it. */
+static uint64_t g_uint_mod = 0;
+void fo_set_uint_modulus(uint64_t mod) { g_uint_mod = mod; }
+static inline int g_is_mod(int g) { return g_uint_mod != 0 && g >= FO_GROUP_U8 && g <= FO_GROUP_U64; }
+
 static inline u128 gmask(int g) {
   switch (g) {
     case FO_GROUP_U8: return 0xff;
@@ -293,6 +299,7 @@ static gel g_from(int g, fo_i4 b) {
       r.v = (x | (y << 32) | (z << 64) | ((w >> 1) << 96)) % M127;
       break;
   }
+  if (g_is_mod(g)) r.v %= g_uint_mod; /* uint.cuh:64 */
   return r;
 }
 
@@ -302,6 +309,9 @@ static gel g_add(int g, gel a, gel b) {
   else if (g == FO_GROUP_U128_M127) { /* uint.cuh:33-35 */
     if (a.v >= M127 - b.v) r.v = a.v + b.v - M127;
     else r.v = a.v + b.v;
+  } else if (g_is_mod(g)) { /* uint.cuh:20-24 */
+    if (a.v >= (u128)g_uint_mod - b.v) r.v = a.v + b.v - g_uint_mod;
+    else r.v = a.v + b.v;
   } else r.v = (a.v + b.v) & gmask(g);
   return r;
 }
@@ -310,6 +320,7 @@ static gel g_neg(int g, gel a) {
   gel r;
   if (g == FO_GROUP_BYTES) r.v = a.v;
   else if (g == FO_GROUP_U128_M127) r.v = a.v == 0 ? 0 : M127 - a.v; /* uint.cuh:41-42 */
+  else if (g_is_mod(g)) r.v = a.v == 0 ? 0 : (u128)g_uint_mod - a.v; /* uint.cuh:26-31 */
   else r.v = (0 - a.v) & gmask(g);
   return r;
 }

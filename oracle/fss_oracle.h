@@ -56,6 +56,9 @@ enum {
   FO_GROUP_U128_M127 = 5 /* Uint<__uint128_t, 1<<127> */
 };
 
+/* Modulus of Uint<T, mod> for the U8..U64 groups (uint.cuh:11-31); 0 = wrapping.  Process-wide. */
+void fo_set_uint_modulus(uint64_t mod);
+
 enum { FO_PRED_LT = 0, FO_PRED_GT = 1 }; /* include/fss/dcf.cuh:58-61 */
 
 /* AES-128-MMO PRG, include/fss/prg/aes128_mmo.cuh:27-95. */

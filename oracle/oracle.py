@@ -98,6 +98,7 @@ def lib():
         L.fo_vdpf_eval.argtypes = [P, vp, i, i, i, _I4, vp, vp, _I4, u64, u64, vp]
         L.fo_vdpf_eval.restype = _I4
         L.fo_vdpf_prove.argtypes = [vp, vp, sz, vp, vp]
+        L.fo_set_uint_modulus.argtypes = [u64]
         L.fo_eval_points.argtypes = [P, _I4, i, i, i, i, _I4, vp, _I4, vp, vp, sz, vp, i]
         L.fo_eval_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, sz, vp, vp, vp, sz, vp, i]
         L.fo_gen_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, vp, vp, sz, vp, sz, vp, i]
@@ -122,6 +123,11 @@ def _ptr(a):
 def _split(v):
     v = int(v)
     return v & ((1 << 64) - 1), (v >> 64) & ((1 << 64) - 1)
+
+
+def set_uint_modulus(mod: int):
+    """Uint<T, mod> for the U8..U64 groups (0 = wrapping); process-wide."""
+    lib().fo_set_uint_modulus(int(mod))
 
 
 def have_aesni() -> bool:

@@ -578,3 +578,62 @@ def test_narrow_input_types_vs_oracle(engine, O, scheme, n, dtype):
             assert (got == want).all()
         got = engine.eval_keys(keys, g, b, T(np.ascontiguousarray(s0s[:, b])), xt, ocws=ocws).cpu().numpy()
         assert (got == want).all()
+
+
+@pytest.mark.parametrize("scheme,n,g,mod", [(DPF, 16, G.U32, 1000003), (DCF, 16, G.U32, 1000003), (HT, 16, G.U32, 97),
+                                            (DPF, 33, G.U64, (1 << 61) - 1), (DCF, 20, G.U64, (1 << 63) + 29),
+                                            (HT, 9, G.U8, 251), (DCF, 12, G.U16, 65521), (DPF, 8, G.U16, 1 << 16)])
+def test_modular_uint_groups_vs_oracle(O, scheme, n, g, mod):
+    """fss::group::Uint<T, mod> with mod != 0 (uint.cuh:11-31): shared key, independent keys through device Gen,
+    EvalAll; and the shares reconstruct beta mod `mod`."""
+    import fss_amd
+    eng = fss_amd.Engine(0)
+    eng.set_uint_modulus(mod)
+    O.set_uint_modulus(mod)
+    try:
+        rng = SplitMix64(9000 + 7 * n + scheme)
+        p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+        s = [rng.i4(), rng.i4()]
+        alpha, beta = rng.below(n), rng.i4()
+        ocw = None
+        if scheme == DPF:
+            cws = O.dpf_gen(p, n, g, s, alpha, beta)
+        elif scheme == DCF:
+            cws = O.dcf_gen(p, n, g, 0, s, alpha, beta)
+        else:
+            cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+        xs = np.array([alpha, max(alpha - 1, 0)] + [rng.below(n) for _ in range(200)], dtype=np.uint64)
+        m = len(xs)
+        s0s = np.broadcast_to(np.stack(s), (m, 2, 4)).copy()
+        got_cws, got_ocws = eng.gen(scheme, n, g, T(s0s[:3]), xs_tensor([alpha] * 3, n), T(np.broadcast_to(beta, (3, 4)).copy()))
+        assert (got_cws.cpu().numpy()[1] == cws).all()
+        if scheme == HT:
+            assert (got_ocws.cpu().numpy()[2] == ocw).all()
+        keys, ocws = eng.gen_level_major(scheme, n, g, T(s0s), xs_tensor([alpha] * m, n), T(np.broadcast_to(beta, (m, 4)).copy()))
+        ys = []
+        for b in (0, 1):
+            want = O.eval_points(p, scheme, n, g, b, s[b], cws, xs, ocw=ocw)
+            got = eng.eval_points(scheme, n, g, b, T(s[b]), T(cws), xs_tensor(xs, n), ocw=None if ocw is None else T(ocw)).cpu().numpy()
+            assert (got == want).all()
+            got = eng.eval_keys(keys, g, b, T(np.ascontiguousarray(s0s[:, b])), xs_tensor(xs, n), ocws=ocws).cpu().numpy()
+            assert (got == want).all()
+            if n <= 16:
+                ref = {DPF: O.dpf_eval_all, DCF: O.dcf_eval_all}.get(scheme)
+                full = ref(p, n, g, b, s[b], cws) if ref else O.ht_eval_all(p, n, g, b, s[b], cws, ocw)
+                got_all = eng.eval_all(scheme, n, g, b, T(s[b]), T(cws), ocw=None if ocw is None else T(ocw)).cpu().numpy()
+                assert (got_all == full).all()
+            ys.append(want)
+        val = lambda y: (int(np.uint32(y[0])) | (int(np.uint32(y[1])) << 32))
+        bits = {G.U8: 8, G.U16: 16, G.U32: 32, G.U64: 64}[g]
+        bval = (val(beta) & ((1 << bits) - 1)) % mod
+        for i, x in enumerate(xs):
+            tot = (val(ys[0][i]) + val(ys[1][i])) % mod
+            hit = (int(x) == alpha) if scheme != DCF else (int(x) < alpha)
+            assert tot == (bval if hit else 0), (i, int(x), alpha)
+        # a modulus that does not fit the group's T is refused
+        if g == G.U8:
+            eng.set_uint_modulus(300)
+            with pytest.raises(fss_amd._lib.FssAmdError):
+                eng.eval_points(scheme, n, g, 0, T(s[0]), T(cws), xs_tensor(xs, n), ocw=None if ocw is None else T(ocw))
+    finally:
+        O.set_uint_modulus(0)

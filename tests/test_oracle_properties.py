@@ -181,3 +181,26 @@ def test_vdpf_reconstructs_and_verifies(O, rng, g, chacha):
     bad[3, 0] ^= 0x10  # a malicious dealer hands party 1 a different correction word
     pts1 = [O.vdpf_eval(p, n, g, 1, s[1], bad, cs, ocw, x)[1] for x in xs]
     assert not (O.vdpf_prove(np.array(pts1), cs) == pi0).all()
+
+
+@pytest.mark.parametrize("g,mod", [(G.U32, 1000003), (G.U64, (1 << 61) - 1), (G.U8, 251)])
+def test_modular_uint_group_reconstructs(O, rng, g, mod):
+    """fss::group::Uint<T, mod>, mod != 0 (uint.cuh:11-31; src/group_test.cu): DPF and DCF shares add up to
+    beta mod `mod` at / below alpha and to zero elsewhere."""
+    O.set_uint_modulus(mod)
+    try:
+        n = 12
+        s = [rng.i4(), rng.i4()]
+        beta = rng.i4()
+        bits = {G.U8: 8, G.U32: 32, G.U64: 64}[g]
+        val = lambda y: int(np.uint32(y[0])) | (int(np.uint32(y[1])) << 32)
+        bval = (val(beta) & ((1 << bits) - 1)) % mod
+        p2, p4 = O.Prg(2), O.Prg(4)
+        cws, dcw = O.dpf_gen(p2, n, g, s, ALPHA, beta), O.dcf_gen(p4, n, g, O.LT, s, ALPHA, beta)
+        for x in [0, ALPHA - 1, ALPHA, ALPHA + 1, (1 << n) - 1] + [rng.below(n) for _ in range(20)]:
+            y = [val(O.dpf_eval(p2, n, g, b, s[b], cws, x)) for b in (0, 1)]
+            assert all(v < mod for v in y) and (y[0] + y[1]) % mod == (bval if x == ALPHA else 0)
+            y = [val(O.dcf_eval(p4, n, g, b, s[b], dcw, x)) for b in (0, 1)]
+            assert (y[0] + y[1]) % mod == (bval if x < ALPHA else 0)
+    finally:
+        O.set_uint_modulus(0)
