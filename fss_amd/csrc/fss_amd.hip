@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "fss_dev.hpp"
 #include "fss_evalall.hpp"
@@ -139,9 +141,22 @@ const Tune& tune() {
 // Grid of a persistent launch: one workgroup per resident slot, fewer when the batch is smaller.
 template <typename K>
 int persistent_grid(fss_amd_ctx* ctx, K kernel, int bs, int64_t threads_needed, int* grid) {
+  // resident workgroups per CU of this kernel at this block size: asked once per (kernel, block size)
+  static std::mutex mu;
+  static std::unordered_map<uint64_t, int> cache;
+  const uint64_t key = (uint64_t)reinterpret_cast<uintptr_t>(reinterpret_cast<const void*>(kernel)) * 4099u + (uint64_t)bs;
   int occ = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, bs, 0));
-  if (occ < 1) occ = 1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) occ = it->second;
+  }
+  if (occ == 0) {
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, bs, 0));
+    if (occ < 1) occ = 1;
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = occ;
+  }
   if (tune().wgs_per_cu > 0 && tune().wgs_per_cu < occ) occ = tune().wgs_per_cu;
   int64_t want = (threads_needed + bs - 1) / bs;
   int64_t cap = (int64_t)ctx->num_cu * occ;
