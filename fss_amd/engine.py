@@ -91,6 +91,18 @@ class Engine:
         return t.to(self.device).contiguous()
 
     @staticmethod
+    def _need(t, numel, what):
+        """The C ABI takes raw pointers: refuse tensors that are too small before a kernel reads past them."""
+        if t is None or t.numel() < numel:
+            have = "None" if t is None else f"{tuple(t.shape)}"
+            raise ValueError(f"{what}: expected at least {numel} elements, got {have}")
+        return t
+
+    @staticmethod
+    def _slots(scheme, in_bits):
+        return in_bits if scheme in (HT, VDPF) else in_bits + 1
+
+    @staticmethod
     def _xbytes(xs, in_bits):
         if xs.dtype in (torch.uint8, torch.int16):  # In = uint8_t / uint16_t (bit patterns)
             w = 1 if xs.dtype == torch.uint8 else 2
@@ -127,7 +139,8 @@ class Engine:
         seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
         xb = self._xbytes(xs, in_bits)
         n = xs.shape[0] if xb == 16 else xs.numel()
-        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(scheme, in_bits), "cws")
+        ys = self._need(out, 4 * n, "out") if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
         L, st = self._L, self._stream()
         if scheme == DPF:
             rc = L.fss_amd_dpf_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
@@ -136,7 +149,7 @@ class Engine:
             rc = L.fss_amd_dcf_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
                                            _ptr(ys), st)
         elif scheme == HT:
-            ocw = self._dev(ocw, torch.int32)
+            ocw = self._need(self._dev(self._need(ocw, 4, "ocw"), torch.int32), 4, "ocw")
             rc = L.fss_amd_ht_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(ocw), _ptr(xs),
                                           xb, n, _ptr(ys), st)
         else:
@@ -159,7 +172,8 @@ class Engine:
         if ws_bytes == 0:
             raise ValueError(f"eval_points_shared: unsupported prefix_bits={prefix_bits} for in_bits={in_bits}")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
-        ys = out if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(scheme, in_bits), "cws")
+        ys = self._need(out, 4 * n, "out") if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
         xb = self._xbytes(xs, in_bits)
         if scheme == DPF:
             rc = L.fss_amd_dpf_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
@@ -168,7 +182,7 @@ class Engine:
             rc = L.fss_amd_dcf_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
                                                   _ptr(ys), prefix_bits, _ptr(ws), ws_bytes, st)
         elif scheme == HT:
-            ocw = self._dev(ocw, torch.int32)
+            ocw = self._dev(self._need(ocw, 4, "ocw"), torch.int32)
             rc = L.fss_amd_ht_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(ocw),
                                                  _ptr(xs), xb, n, _ptr(ys), prefix_bits, _ptr(ws), ws_bytes, st)
         else:
@@ -181,6 +195,8 @@ class Engine:
     def relayout(self, scheme, in_bits, cws):
         """cws: int32[nkeys, slots, 8] key-major raw Cw slots -> LevelMajorKeys."""
         cws = self._dev(cws, torch.int32)
+        if cws.dim() != 3 or cws.shape[1] != self._slots(scheme, in_bits) or cws.shape[2] != 8:
+            raise ValueError(f"relayout: cws must be int32[nkeys, {self._slots(scheme, in_bits)}, 8], got {tuple(cws.shape)}")
         nkeys = cws.shape[0]
         dev, L, st = self.device, self._L, self._stream()
         cw_s = torch.empty((in_bits, nkeys, 4), dtype=torch.int32, device=dev)
@@ -205,6 +221,9 @@ class Engine:
         seeds, xs = self._dev(seeds, torch.int32), self._dev(xs)
         n, nb = keys.nkeys, keys.in_bits
         xb = self._xbytes(xs, nb)
+        self._need(seeds, 4 * n, "seeds"); self._need(xs, n * (2 if xb == 16 else 1), "xs")
+        if out is not None:
+            self._need(out, n if keys.scheme == GROTTO else 4 * n, "out")
         L, st = self._L, self._stream()
         if keys.scheme == GROTTO:
             ys = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=self.device)
@@ -220,7 +239,7 @@ class Engine:
             rc = L.fss_amd_dcf_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.cw_v),
                                          _ptr(keys.out_cw), _ptr(xs), xb, n, _ptr(ys), st)
         else:
-            ocws = self._dev(ocws, torch.int32)
+            ocws = self._dev(self._need(ocws, 4 * n, "ocws"), torch.int32)
             rc = L.fss_amd_ht_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.extra),
                                         _ptr(ocws), _ptr(xs), xb, n, _ptr(ys), st)
         _lib.check(rc, "eval_keys")
@@ -236,6 +255,9 @@ class Engine:
         if ws_bytes == 0:
             raise ValueError(f"eval_all: unsupported block (in_bits={in_bits}, nleaves={nleaves})")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
+        self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(DPF if scheme == GROTTO else scheme, in_bits), "cws")
+        if out is not None:
+            self._need(out, nleaves if scheme == GROTTO else 4 * nleaves, "out")
         if scheme == GROTTO:
             ys = out if out is not None else torch.empty((nleaves,), dtype=torch.uint8, device=self.device)
             rc = L.fss_amd_grotto_eval_all(self._h, in_bits, party, _ptr(seed), _ptr(cws), first_leaf, nleaves,
@@ -249,7 +271,7 @@ class Engine:
                 rc = L.fss_amd_dcf_eval_all(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), first_leaf, nleaves,
                                             _ptr(ys), _ptr(ws), ws_bytes, st)
             else:
-                ocw = self._dev(ocw, torch.int32)
+                ocw = self._dev(self._need(ocw, 4, "ocw"), torch.int32)
                 rc = L.fss_amd_ht_eval_all(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(ocw),
                                            first_leaf, nleaves, _ptr(ys), _ptr(ws), ws_bytes, st)
         _lib.check(rc, "eval_all")
@@ -286,6 +308,7 @@ class Engine:
         s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)
         xb = self._xbytes(alphas, in_bits)
         n = alphas.shape[0] if xb == 16 else alphas.numel()
+        self._need(s0s, 8 * n, "s0s"); self._need(betas, 4 * n, "betas")
         slots = in_bits if scheme == HT else in_bits + 1
         cws = torch.empty((n, slots, 8), dtype=torch.int32, device=self.device)
         L, st = self._L, self._stream()
@@ -308,6 +331,7 @@ class Engine:
         s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)
         xb = self._xbytes(alphas, in_bits)
         n = alphas.shape[0] if xb == 16 else alphas.numel()
+        self._need(s0s, 8 * n, "s0s"); self._need(betas, 4 * n, "betas")
         dev, L, st = self.device, self._L, self._stream()
         cw_s = torch.empty((in_bits, n, 4), dtype=torch.int32, device=dev)
         if scheme in (DPF, GROTTO):

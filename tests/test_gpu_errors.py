@@ -97,3 +97,30 @@ def test_parity_under_forced_tunables(env):
                         "-k", "vs_oracle or kats or subblocks or deep_prefix"],
                        env={**os.environ, **env}, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_engine_refuses_undersized_tensors():
+    """The Python layer checks sizes the raw-pointer ABI cannot."""
+    import fss_amd
+    eng = fss_amd.default_engine(0)
+    z = lambda *shape: torch.zeros(shape, dtype=torch.int32, device="cuda")
+    xs = z(100)
+    with pytest.raises(ValueError, match="cws"):
+        eng.eval_points(fss_amd.DPF, 32, fss_amd.U64, 0, z(4), z(32, 8), xs)          # one slot short
+    with pytest.raises(ValueError, match="seed"):
+        eng.eval_points(fss_amd.DPF, 32, fss_amd.U64, 0, z(3), z(33, 8), xs)
+    with pytest.raises(ValueError, match="ocw"):
+        eng.eval_points(fss_amd.HT, 32, fss_amd.U64, 0, z(4), z(32, 8), xs)           # Half-Tree without ocw
+    with pytest.raises(ValueError, match="out"):
+        eng.eval_points(fss_amd.DPF, 32, fss_amd.U64, 0, z(4), z(33, 8), xs, out=z(99, 4))
+    with pytest.raises(ValueError, match="relayout"):
+        eng.relayout(fss_amd.DCF, 32, z(5, 32, 8))
+    keys = eng.relayout(fss_amd.DPF, 32, z(5, 33, 8))
+    with pytest.raises(ValueError, match="seeds"):
+        eng.eval_keys(keys, fss_amd.U64, 0, z(4, 4), z(5))
+    with pytest.raises(ValueError, match="xs"):
+        eng.eval_keys(keys, fss_amd.U64, 0, z(5, 4), z(4))
+    with pytest.raises(ValueError, match="betas"):
+        eng.gen(fss_amd.DPF, 32, fss_amd.U64, z(5, 2, 4), z(5), z(4, 4))
+    with pytest.raises(ValueError, match="cws"):
+        eng.eval_all(fss_amd.DCF, 10, fss_amd.U64, 0, z(4), z(10, 8))
