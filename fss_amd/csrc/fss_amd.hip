@@ -449,6 +449,41 @@ int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t 
   return FSS_AMD_OK;
 }
 
+// ------------------------------------------------------------------ level-major -> key-major
+}  // extern "C"
+
+template <int SCHEME>
+static int key_major_common(fss_amd_ctx* ctx, int in_bits, const void* cw_s, const void* cw_v, const void* tr_bits,
+                            const void* out_cw, const void* extra, int64_t nkeys, void* cws, void* stream) {
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
+  if (nkeys == 0) return FSS_AMD_OK;
+  if (!cw_s || !cws || (SCHEME == S_DPF && (!tr_bits || !out_cw)) || (SCHEME == S_DCF && (!cw_v || !out_cw)) ||
+      (SCHEME == S_HT && !extra))
+    return FSS_AMD_EINVAL;
+  FSS_ON_DEVICE(ctx);
+  int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 8;
+  hipLaunchKernelGGL(key_major_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, S(stream), in_bits,
+                     reinterpret_cast<const uint4*>(cw_s), reinterpret_cast<const uint4*>(cw_v),
+                     reinterpret_cast<const uint64_t*>(tr_bits), reinterpret_cast<const uint4*>(out_cw),
+                     reinterpret_cast<const uint32_t*>(extra), nkeys, reinterpret_cast<uint4*>(cws));
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+extern "C" {
+
+int fss_amd_dpf_key_major(fss_amd_ctx* ctx, int in_bits, const void* cw_s, const void* tr_bits, const void* out_cw,
+                          int64_t nkeys, void* cws, void* stream) {
+  return key_major_common<S_DPF>(ctx, in_bits, cw_s, nullptr, tr_bits, out_cw, nullptr, nkeys, cws, stream);
+}
+int fss_amd_dcf_key_major(fss_amd_ctx* ctx, int in_bits, const void* cw_s, const void* cw_v, const void* out_cw,
+                          int64_t nkeys, void* cws, void* stream) {
+  return key_major_common<S_DCF>(ctx, in_bits, cw_s, cw_v, nullptr, out_cw, nullptr, nkeys, cws, stream);
+}
+int fss_amd_ht_key_major(fss_amd_ctx* ctx, int in_bits, const void* cw_s, const void* extra, int64_t nkeys, void* cws,
+                         void* stream) {
+  return key_major_common<S_HT>(ctx, in_bits, cw_s, nullptr, nullptr, nullptr, extra, nkeys, cws, stream);
+}
+
 // ------------------------------------------------------------------ point eval, independent keys
 static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seeds,
                        const void* cw_s, const void* cw_v, const void* tr_bits, const void* out_cw, const void* extra,

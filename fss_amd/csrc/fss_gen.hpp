@@ -67,6 +67,32 @@ __global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, 
   }
 }
 
+// Level-major arrays -> key-major raw Cw slots: the inverse of relayout_kernel, for shipping keys generated
+// level-major in the reference's 32-byte-slot format.  One key per lane; whole slots are written (both
+// 16-byte halves, padding zero) as the reference's Gen does (dpf.cuh:147-153).
+template <int SCHEME>
+__global__ __launch_bounds__(256) void key_major_kernel(int in_bits, const uint4* __restrict__ cw_s,
+                                                        const uint4* __restrict__ cw_v,
+                                                        const uint64_t* __restrict__ tr_bits,
+                                                        const uint4* __restrict__ out_cw,
+                                                        const uint32_t* __restrict__ extra, int64_t nkeys,
+                                                        uint4* __restrict__ cws) {
+  const int stride = SCHEME == S_HT ? in_bits : in_bits + 1;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nkeys; k += (int64_t)gridDim.x * blockDim.x) {
+    uint4* slot = cws + k * (int64_t)stride * 2;
+    unsigned long long lo = 0ull, hi = 0ull;
+    if (SCHEME == S_DPF) { lo = tr_bits[k]; hi = in_bits > 64 ? tr_bits[nkeys + k] : 0ull; }
+    for (int i = 0; i < in_bits; ++i) {
+      slot[2 * i] = cw_s[(int64_t)i * nkeys + k];
+      if (SCHEME == S_DCF) slot[2 * i + 1] = cw_v[(int64_t)i * nkeys + k];
+      else if (SCHEME == S_DPF) slot[2 * i + 1] = make_uint4((uint32_t)(((i < 64 ? lo : hi) >> (i & 63)) & 1ull), 0, 0, 0);
+      else slot[2 * i + 1] = make_uint4(i == in_bits - 1 ? (extra[k] & 1u) : 0u, 0, 0, 0);
+    }
+    if (SCHEME == S_DPF) { slot[2 * in_bits] = out_cw[k]; slot[2 * in_bits + 1] = make_uint4(0, 0, 0, 0); }
+    if (SCHEME == S_DCF) { slot[2 * in_bits] = make_uint4(0, 0, 0, 0); slot[2 * in_bits + 1] = out_cw[k]; }
+  }
+}
+
 struct GenArgs {
   int in_bits, group, pred, x_bytes;
   int64_t nkeys;

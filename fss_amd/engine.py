@@ -216,6 +216,23 @@ class Engine:
         _lib.check(L.fss_amd_ht_relayout(self._h, in_bits, _ptr(cws), nkeys, _ptr(cw_s), _ptr(ex), st), "ht_relayout")
         return LevelMajorKeys(scheme, in_bits, nkeys, cw_s, extra=ex)
 
+    def key_major(self, keys):
+        """LevelMajorKeys -> int32[nkeys, slots, 8] key-major raw Cw slots (the inverse of relayout)."""
+        n, nb = keys.nkeys, keys.in_bits
+        scheme = DPF if keys.scheme == GROTTO else keys.scheme
+        cws = torch.empty((n, self._slots(scheme, nb), 8), dtype=torch.int32, device=self.device)
+        L, st = self._L, self._stream()
+        if scheme == DPF:
+            rc = L.fss_amd_dpf_key_major(self._h, nb, _ptr(keys.cw_s), _ptr(keys.tr_bits), _ptr(keys.out_cw), n, _ptr(cws), st)
+        elif scheme == DCF:
+            rc = L.fss_amd_dcf_key_major(self._h, nb, _ptr(keys.cw_s), _ptr(keys.cw_v), _ptr(keys.out_cw), n, _ptr(cws), st)
+        elif scheme == HT:
+            rc = L.fss_amd_ht_key_major(self._h, nb, _ptr(keys.cw_s), _ptr(keys.extra), n, _ptr(cws), st)
+        else:
+            raise ValueError("key_major: DPF, DCF, Half-Tree or Grotto keys")
+        _lib.check(rc, "key_major")
+        return cws
+
     def eval_keys(self, keys, group, party, seeds, xs, ocws=None, out=None):
         """ys[k] = Eval(party, seeds[k], key k, xs[k]) on a LevelMajorKeys batch."""
         seeds, xs = self._dev(seeds, torch.int32), self._dev(xs)

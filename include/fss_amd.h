@@ -144,6 +144,15 @@ int fss_amd_dcf_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t
 int fss_amd_ht_relayout(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *extra,
                         void *stream);
 
+/* The inverse: level-major arrays -> key-major raw Cw slots ((in_bits+1) per key, in_bits for Half-Tree; padding
+ * zero), the format the reference's Gen writes and its CPU Eval / wire transfer read (dpf.cuh:76-81,147-153). */
+int fss_amd_dpf_key_major(fss_amd_ctx *ctx, int in_bits, const void *cw_s, const void *tr_bits, const void *out_cw,
+                          int64_t nkeys, void *cws, void *stream);
+int fss_amd_dcf_key_major(fss_amd_ctx *ctx, int in_bits, const void *cw_s, const void *cw_v, const void *out_cw,
+                          int64_t nkeys, void *cws, void *stream);
+int fss_amd_ht_key_major(fss_amd_ctx *ctx, int in_bits, const void *cw_s, const void *extra, int64_t nkeys, void *cws,
+                         void *stream);
+
 /* ---- point evaluation, independent keys: ys[k] = Eval(party, seeds[k], key k, xs[k]) --
  * Replaces fss::gpu::{Dpf,Dcf,HalfTreeDpf}EvalPointGpu
  * (include/fss/point_eval_gpu.cuh:416-491) on the level-major arrays above. */

@@ -268,6 +268,7 @@ def test_gen_level_major_vs_oracle(engine, O, scheme, n, g, pred):
     else:
         assert (keys.extra.cpu().numpy() == (want[:, n - 1, 4] & 1)).all()
         assert (ocws.cpu().numpy() == want_ocw).all()
+    assert (engine.key_major(keys).cpu().numpy() == want).all()  # and back to the reference's slot format
     ref = engine.relayout(scheme, n, T(want))
     for name in ("cw_s", "cw_v", "tr_bits", "out_cw", "extra"):
         a, b = getattr(keys, name), getattr(ref, name)
