@@ -16,6 +16,10 @@
  *   (2) FIPS-197 appendix C.1 for the AES core, and OpenSSL EVP_aes_128_ecb (the
  *       reference's actual PRG dependency, libcrypto 3.0.2 in this image) block by block,
  *   (3) the reference's property tests (share reconstruction) restated in tests/.
+ * That pins the AES-128-MMO path (the hot path).  The ChaCha PRG and the VDPF / BLAKE3 rows are PARITY UNPINNED
+ * against reference outputs -- none are recorded and none can be produced here: they are pinned to the
+ * published algorithms only (RFC 7539 for the ChaCha permutation, the official BLAKE3 test vectors for the
+ * compression function) and to the reference's source for the constructions around them.
  *
  * Every function cites the reference file:line (under /root/reference) it follows.
  */
