@@ -55,11 +55,9 @@ def hbm_bytes_per_eval(scheme, n, shared):
     return fixed + per_level * n + (4 if n <= 32 else 8)
 
 
-def measured_hbm_traffic(log2_batch):
-    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
-    (profiles/<round>/pmc_summary.json: FETCH_SIZE and WRITE_SIZE in KiB, collected in
-    separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Only valid for the batch the profile was taken on (2^24)."""
+def _headline_pmc(log2_batch):
+    """Counters of the headline kernel (plain DPF walk, shared key) from the committed rocprofv3 PMC passes
+    (profiles/<round>/pmc_summary.json, newest round first).  Only valid for the batch profiled (2^24)."""
     import glob
     if log2_batch != 24:
         return None
@@ -67,11 +65,38 @@ def measured_hbm_traffic(log2_batch):
         try:
             d = json.load(open(f))
             for k, v in d.items():
-                if "eval_points_kernel<0, true" in k and k.rstrip().endswith("false>") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                    return (2 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+                name = k.replace("fssamd::Lds, ", "")
+                if "eval_points_kernel<0, true" in name and name.rstrip().endswith("false>") and "FETCH_SIZE" in v:
+                    return v
         except Exception:
             pass
     return None
+
+
+def measured_hbm_traffic(log2_batch):
+    """HBM bytes per launch: FETCH_SIZE and WRITE_SIZE in KiB, collected in separate passes; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950."""
+    v = _headline_pmc(log2_batch)
+    if not v or "WRITE_SIZE" not in v:
+        return None
+    return (2 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+
+
+def measured_pipe_busy(log2_batch):
+    """LDS- and VALU-busy fractions of the profiled launch (north_star: "VALU-busy against the chip's peak"):
+    SQ_LDS_IDX_ACTIVE per CU, and SQ_ACTIVE_INST_VALU (counted in 4-cycle issue slots) per SIMD, over the
+    kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    v = _headline_pmc(log2_batch)
+    need = ("GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU")
+    if not v or any(k not in v for k in need):
+        return None
+    cyc = v["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
+    out = {"lds_busy": v["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / cyc,
+           "valu_busy": v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / cyc,
+           "valu_wave_instructions_per_launch": v["SQ_INSTS_VALU"]["mean_per_launch"],
+           "clock_ghz_under_profiler": cyc / (v["AverageNs"] * 1e-9) / 1e9 if "AverageNs" in v else None,
+           "source": "profiles/ rocprofv3 --pmc passes of the same command"}
+    return out
 
 
 def time_steps(fn, steps, warmup, dist):
@@ -203,7 +228,7 @@ def run_headline(args, rank, world, dist):
                      "frac": lds_gbs / LDS_PEAK_GBS, "traffic": measured_hbm_traffic(args.log2_batch),
                      "kernel_ms": kernel_ms, "per_gpu_evals_per_s": per_gpu_kernel_rate,
                      "algorithmic": f"{aes} AES blocks/eval x 160 LDS lookups x 4 B; peak = 128 B/clk/CU x 256 CU x 2.4 GHz",
-                     "aes_blocks_per_s": per_gpu_kernel_rate * aes},
+                     "aes_blocks_per_s": per_gpu_kernel_rate * aes, "pipes": measured_pipe_busy(args.log2_batch)},
         "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(args.log2_batch),
                          "algorithmic_bytes_per_launch": hbm_bytes,
