@@ -249,6 +249,71 @@ def run_headline(args, rank, world, dist):
     print(json.dumps(out), flush=True)
 
 
+def run_sharded(args, rank, world, dist):
+    """BASELINE.json configs[3] and configs[4] as multi-GPU workloads with the same one-line contract:
+      evalall_c4: DPF EvalAll kInBits=28; the 2^28-leaf domain is cut into `world` aligned blocks, rank r expands
+                  block r into its own HBM (strong scaling, no collective);
+      ht_c5 / grotto_c5: kInBits=64, 2^24 independent keys x 1 point, key batch split across ranks (strong)."""
+    import fss_amd
+    from fss_amd import shard
+    eng = fss_amd.default_engine(torch.cuda.current_device())
+    G = fss_amd.U64
+    if args.workload == "evalall_c4":
+        n = 28
+        sid, s0s, cws, ocw, _, _ = make_key(eng, "dpf", n, G, 0x5EED0004)
+        first, nleaves = shard.domain_block(n, rank, world)
+        sd, cd = s0s[0].cuda(), cws.cuda()
+        ys = torch.empty((nleaves, 4), dtype=torch.int32, device="cuda")
+        step = lambda: eng.eval_all(sid, n, G, 0, sd, cd, first_leaf=first, nleaves=nleaves, out=ys)
+        units_total, units_rank, unit, aes_per_unit = 1 << n, nleaves, "leaves/s", 2.0
+        desc = (f"DPF full-domain EvalAll kInBits=28 (2^28 outputs), domain-sharded x{world}: "
+                f"2^{nleaves.bit_length() - 1} leaves per GPU, Uint<uint64_t>, party 0")
+        hbm_unit = 16
+    else:
+        n, total = 64, 1 << 24
+        scheme = "ht" if args.workload == "ht_c5" else "grotto"
+        lo, hi = shard.batch_slice(total, rank, world)
+        nk = hi - lo
+        gen = torch.Generator(device="cuda").manual_seed(0x5EED0005 + rank)
+        s0s = torch.randint(-2**31, 2**31, (nk, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
+        betas = torch.randint(-2**31, 2**31, (nk, 4), dtype=torch.int32, device="cuda", generator=gen)
+        alphas = torch.randint(-2**63, 2**63 - 1, (nk,), dtype=torch.int64, device="cuda", generator=gen)
+        xs = torch.randint(-2**63, 2**63 - 1, (nk,), dtype=torch.int64, device="cuda", generator=gen)
+        sid = fss_amd.HT if scheme == "ht" else fss_amd.GROTTO
+        gg = G if scheme == "ht" else fss_amd.BYTES
+        if scheme == "grotto":
+            betas.zero_()
+        keys, ocws = eng.gen_level_major(sid, n, gg, s0s, alphas, betas)  # outside the timed region (src/bench_gpu.cu:616-627)
+        seeds0 = s0s[:, 0].contiguous()
+        del s0s, betas, alphas
+        ys = (torch.empty((nk, 4), dtype=torch.int32, device="cuda") if scheme == "ht"
+              else torch.empty((nk,), dtype=torch.uint8, device="cuda"))
+        step = lambda: eng.eval_keys(keys, gg, 0, seeds0, xs, ocws=ocws, out=ys)
+        units_total, units_rank, unit = total, nk, "evals/s"
+        aes_per_unit = 64.0 if scheme == "ht" else 96.0
+        desc = (f"{'Half-Tree DPF' if scheme == 'ht' else 'Grotto DCF (path walk)'} kInBits=64, 2^24 independent "
+                f"level-major keys x 1 point each, key batch sharded x{world} ({nk} keys per GPU), party 0")
+        hbm_unit = 1084 if scheme == "ht" else 1057
+    wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
+    kname, grid, block = eng.last_kernel()
+    if rank != 0:
+        return
+    rate = units_rank / (kernel_ms * 1e-3)
+    lds_gbs = rate * aes_per_unit * LOOKUP_BYTES_PER_AES / 1e9
+    print(json.dumps({
+        "metric": f"{args.workload}: {unit[:-2]} per second", "value": units_total * args.steps / wall, "unit": unit,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": desc, "kernel": kname, "grid": grid, "block": block,
+                   "parallelism": f"sharded x{world}, no collective"},
+        "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds_gbs / LDS_PEAK_GBS,
+                     "traffic": None, "kernel_ms": kernel_ms,
+                     "algorithmic": f"{aes_per_unit:g} AES blocks per unit x 160 LDS lookups x 4 B (rank 0's share)"},
+        "roofline_hbm": {"bound": "hbm", "achieved": rate * hbm_unit / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": rate * hbm_unit / 1e9 / HBM_PEAK_GBS, "traffic": None},
+    }), flush=True)
+
+
 def run_suite(args):
     """Other BASELINE configs on one GPU (kernel-only rates, HIP events)."""
     import fss_amd
@@ -407,6 +472,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=(1 << 24) if (os.cpu_count() or 1) >= 8 else (1 << 22), help="points of the batch timed on the CPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--suite", action="store_true")
+    ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "evalall_c4", "ht_c5", "grotto_c5"],
+                    help="dpf_points = the headline (BASELINE metric); the others are configs[3] / configs[4], sharded")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -432,7 +499,10 @@ def main():
         print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    run_headline(args, rank, world, dist)
+    if args.workload == "dpf_points":
+        run_headline(args, rank, world, dist)
+    else:
+        run_sharded(args, rank, world, dist)
     if args.suite and world == 1:
         run_suite(args)
     if dist is not None:
