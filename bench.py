@@ -449,6 +449,19 @@ def run_suite(args):
     record("chacha dpf EvalAll n=24", 1 << 24, lambda: ceng.eval_all(sid, 24, G, 0, sd, cd, out=ys), 0, 16, steps=5)
     del ys
 
+    # Grotto DCF full domain: the DPF tree over Bytes with beta = 0, leaf control bits, then the running-XOR scan
+    # (GrottoDcf::EvalAll, grotto_dcf.cuh:151-163); one byte per leaf
+    for n in (24, 26):
+        gen = torch.Generator().manual_seed(77 + n)
+        s0s = torch.randint(-2**31, 2**31, (1, 2, 4), dtype=torch.int32, generator=gen)
+        alpha = torch.randint(0, 2**31, (1,), dtype=torch.int32, generator=gen) & ((1 << n) - 1)
+        cws, _ = eng.gen(fss_amd.DPF, n, fss_amd.BYTES, s0s, alpha, torch.zeros((1, 4), dtype=torch.int32))
+        sd, cd = s0s[0, 0].cuda(), cws[0]
+        yb = torch.empty((1 << n,), dtype=torch.uint8, device="cuda")
+        record(f"grotto EvalAll n={n}", 1 << n,
+               lambda: eng.eval_all(fss_amd.GROTTO, n, fss_amd.BYTES, 0, sd, cd, out=yb), 2, 1, steps=5)
+        del yb
+
     # full domain
     for scheme, n in (("dpf", 24), ("dpf", 26), ("ht", 24)):
         sid, s0s, cws, ocw, _, _ = make_key(eng, scheme, n, G, 7 + n)
