@@ -462,6 +462,23 @@ def run_suite(args):
                lambda: eng.eval_all(fss_amd.GROTTO, n, fss_amd.BYTES, 0, sd, cd, out=yb), 2, 1, steps=5)
         del yb
 
+    # batched full domain (fss::gpu::*EvalAllGpuBatch; the reference's n = 20 rows, README.md:384-385: ChaCha,
+    # DPF 15.43 and Half-Tree 12.09 G outputs/s on RTX PRO 5000)
+    for beng, tag in ((eng, "aes"), (ceng, "chacha")):
+        for scheme, n, nk in (("dpf", 20, 64), ("ht", 20, 64), ("dpf", 14, 4096)):
+            gen = torch.Generator(device="cuda").manual_seed(400 + n)
+            s0s = torch.randint(-2**31, 2**31, (nk, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
+            betas = torch.randint(-2**31, 2**31, (nk, 4), dtype=torch.int32, device="cuda", generator=gen)
+            alphas = torch.randint(0, 1 << n, (nk,), dtype=torch.int32, device="cuda", generator=gen)
+            sid = {"dpf": fss_amd.DPF, "ht": fss_amd.HT}[scheme]
+            cws, ocws = beng.gen(sid, n, G, s0s, alphas, betas)
+            seeds0 = s0s[:, 0].contiguous()
+            yb = torch.empty((nk, 1 << n, 4), dtype=torch.int32, device="cuda")
+            record(f"{tag} {scheme} EvalAll batch n={n} x {nk} keys", nk << n,
+                   lambda: beng.eval_all_batch(sid, n, G, 0, seeds0, cws, ocws=ocws, out=yb),
+                   (2 if scheme == "dpf" else 1.5) if tag == "aes" else 0, 16, steps=5)
+            del yb
+
     # full domain
     for scheme, n in (("dpf", 24), ("dpf", 26), ("ht", 24)):
         sid, s0s, cws, ocw, _, _ = make_key(eng, scheme, n, G, 7 + n)

@@ -47,6 +47,10 @@ PROTOTYPES = {
     "fss_amd_dpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_dcf_gen": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp]),
     "fss_amd_ht_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_eval_all_batch_workspace": (C.c_size_t, [_i, _i, _i64]),
+    "fss_amd_dpf_eval_all_batch": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, C.c_size_t, _vp]),
+    "fss_amd_dcf_eval_all_batch": (_i, [_vp, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, C.c_size_t, _vp]),
+    "fss_amd_ht_eval_all_batch": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, C.c_size_t, _vp]),
     "fss_amd_dpf_key_major": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fss_amd_dcf_key_major": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fss_amd_ht_key_major": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp]),

@@ -35,6 +35,11 @@ struct ExpandArgs {
   uint4* out_v;
   void* ys;             // leaf stage: uint4 per leaf (Grotto: uint8 control bit per leaf)
   int dyn;              // expand_kernel: waves take 64-node chunks from the workgroup's LDS counter (WaveQ)
+  // BATCH kernels (fss::gpu::*EvalAllGpuBatch, eval_all_gpu.cuh:511-535): nkeys trees side by side.  Node f of a
+  // stage whose inputs are at level l belongs to key f >> l; keys are key-major raw slots, `key_slots` per key.
+  int64_t nkeys;
+  int key_slots;
+  const uint4* seeds;   // one per key
 };
 
 // -- one-node expansions ------------------------------------------------------
@@ -114,22 +119,27 @@ __device__ __forceinline__ uint4 ht_convert(const LT& L, const DevCtx* __restric
 // Produces the 2^top nodes at depth level0 = p + top under the subtree root whose
 // path is `prefix` (p bits).  Same walk as point evaluation, but the node (and the
 // DCF running value) is stored instead of converted.
-template <class LT, int SCHEME>
+template <class LT, int SCHEME, bool BATCH = false>
 __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                        const uint32_t* __restrict__ k_seed,
                                                        const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
   const DevCtx* c = first_kernarg(K);
   FSS_PRG_PROLOGUE(LT, te0);
   const int depth = a.level0;  // p + top
-  const int64_t nout = (int64_t)1 << top;
+  const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nout; j += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t path = (top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j;
-    uint32_t s0[4] = {k_seed[0], k_seed[1], k_seed[2], k_seed[3]};
+    // BATCH: lane j walks node j & (2^top - 1) of key j >> top; its correction words are that key's slots
+    const int64_t key = BATCH ? (j >> top) : 0;
+    const uint64_t path = BATCH ? (uint64_t)(j & (((int64_t)1 << top) - 1)) : ((top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j);
+    const uint32_t* kc = BATCH ? k_cws + 8 * key * a.key_slots : k_cws;
+    uint32_t s0[4];
+    if constexpr (BATCH) { uint4 t = a.seeds[key]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+    else { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
     if constexpr (SCHEME == S_DCF) {
       DcfWalk w;
       w.init(s0, a.party, X128{path, 0});
       for (int i = 0; i < depth; ++i) {
-        const uint32_t* p = k_cws + 8 * i;
+        const uint32_t* p = kc + 8 * i;
         CwDcf cw;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { cw.s[q] = p[q]; cw.v[q] = p[4 + q]; }
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
       HtWalk w;
       w.init(s0, a.party, X128{path, 0});
       for (int i = 0; i < depth; ++i) {
-        const uint32_t* p = k_cws + 8 * i;
+        const uint32_t* p = kc + 8 * i;
         uint32_t cw[4] = {p[0], p[1], p[2], p[3]};
         w.level(L, c, depth, i, cw);
       }
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
       DpfWalk w;
       w.init(s0, a.party, X128{path, 0});
       for (int i = 0; i < depth; ++i) {
-        const uint32_t* p = k_cws + 8 * i;
+        const uint32_t* p = kc + 8 * i;
         CwDpf cw{p[0], p[1], p[2], p[3], p[4]};
         w.level(L, c, depth, i, cw);
       }
@@ -170,10 +180,11 @@ template <class LT, int SCHEME, int E>
 struct OuterLevels {
   template <class Body>
   static __device__ __forceinline__ void run(const LT& L, const DevCtx* __restrict__ c, const Grp& g,
-                                             const uint32_t* __restrict__ k_cws, int lvl, const uint32_t node[4],
-                                             const Acc& v, int64_t ob, int sub_log2, Body& body) {
+                                             const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
+                                             int lvl, const uint32_t node[4], const Acc& v, int64_t ob, int sub_log2,
+                                             Body& body) {
     if constexpr (E == 0) {
-      body(node, v, lvl, ob);
+      body(k_cws, k_ocw, node, v, lvl, ob);
     } else {
       uint32_t l[4], r[4];
       Acc vl, vr;
@@ -190,14 +201,14 @@ struct OuterLevels {
           ch[q] = h ? r[q] : l[q];
           if constexpr (SCHEME == S_DCF) cv.v[q] = h ? vr.v[q] : vl.v[q];
         }
-        OuterLevels<LT, SCHEME, E - 1>::run(L, c, g, k_cws, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
+        OuterLevels<LT, SCHEME, E - 1>::run(L, c, g, k_cws, k_ocw, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
                                             sub_log2 - 1, body);
       }
     }
   }
 };
 
-template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0>
+template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0, bool BATCH = false>
 __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                     const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
                                                     const uint32_t* __restrict__ k_ocw,  // Half-Tree
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
 
   constexpr int NN = 1 << D;
   // the D levels expanded in registers, from one node at level `lvl` to outputs ob .. ob + 2^D - 1
-  auto body = [&](const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob) {
+  auto body = [&](const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc, const uint32_t nin[4],
+                  const Acc& vin, int lvl, int64_t ob) {
     uint32_t nodes[NN][4];
     Acc vs[SCHEME == S_DCF ? NN : 1];
     nodes[0][0] = nin[0]; nodes[0][1] = nin[1]; nodes[0][2] = nin[2]; nodes[0][3] = nin[3];
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
     constexpr int DE = (SCHEME == S_HT && LEAF) ? D - 1 : D;
 #pragma unroll
     for (int lev = 0; lev < DE; ++lev) {
-      const uint32_t* cw = k_cws + 8 * (lvl + lev);
+      const uint32_t* cw = kc + 8 * (lvl + lev);
 #pragma unroll
       for (int k = (1 << lev) - 1; k >= 0; --k) {
         uint32_t l[4], r[4];
@@ -243,12 +255,12 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
         if constexpr (SCHEME == S_DCF) a.out_v[ob + k] = make_uint4(vs[k].v[0], vs[k].v[1], vs[k].v[2], vs[k].v[3]);
       }
     } else if constexpr (SCHEME == S_HT) {
-      const uint32_t* cw = k_cws + 8 * (a.in_bits - 1);
+      const uint32_t* cw = kc + 8 * (a.in_bits - 1);
       uint4* ys = reinterpret_cast<uint4*>(a.ys);
 #pragma unroll
       for (int k = 0; k < (1 << DE); ++k) {
-        ys[ob + 2 * k] = ht_convert(L, c, g, party, cw, k_ocw, nodes[k], 0u);
-        ys[ob + 2 * k + 1] = ht_convert(L, c, g, party, cw, k_ocw, nodes[k], 1u);
+        ys[ob + 2 * k] = ht_convert(L, c, g, party, cw, koc, nodes[k], 0u);
+        ys[ob + 2 * k + 1] = ht_convert(L, c, g, party, cw, koc, nodes[k], 1u);
       }
     } else if constexpr (SCHEME == S_GROTTO) {
       uint8_t* ys = reinterpret_cast<uint8_t*>(a.ys);
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
         for (int k = 0; k < NN; ++k) ys[ob + k] = (uint8_t)(nodes[k][3] & 1u);
       }
     } else {
-      const uint32_t* ocp = k_cws + 8 * a.in_bits + (SCHEME == S_DCF ? 4 : 0);
+      const uint32_t* ocp = kc + 8 * a.in_bits + (SCHEME == S_DCF ? 4 : 0);
       uint32_t oc[4] = {ocp[0], ocp[1], ocp[2], ocp[3]};
       uint4* ys = reinterpret_cast<uint4*>(a.ys);
 #pragma unroll
@@ -299,7 +311,11 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
         v0.v[0] = u.x; v0.v[1] = u.y; v0.v[2] = u.z; v0.v[3] = u.w;
       }
     }
-    OuterLevels<LT, SCHEME, E>::run(L, c, g, k_cws, a.level0, n0, v0, j << (E + D), E + D, body);
+    // BATCH: node j belongs to key j >> level0; that key's slots (and Half-Tree ocw) are read per lane
+    const int64_t key = BATCH ? (j >> a.level0) : 0;
+    const uint32_t* kc = BATCH ? k_cws + 8 * key * a.key_slots : k_cws;
+    const uint32_t* koc = (BATCH && k_ocw) ? k_ocw + 4 * key : k_ocw;
+    OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
   }
 }
 

@@ -296,6 +296,35 @@ class Engine:
         ws.record_stream(torch.cuda.current_stream(self.device))
         return ys
 
+    def eval_all_batch(self, scheme, in_bits, group, party, seeds, cws, ocws=None, out=None):
+        """Full domain of every key of a key-major batch: seeds int32[n,4], cws int32[n,slots,8] ->
+        int32[n, 2^in_bits, 4]   (fss::gpu::*EvalAllGpuBatch)."""
+        seeds, cws = self._dev(seeds, torch.int32), self._dev(cws, torch.int32)
+        if cws.dim() != 3 or cws.shape[1] != self._slots(scheme, in_bits) or cws.shape[2] != 8:
+            raise ValueError(f"eval_all_batch: cws must be int32[nkeys, {self._slots(scheme, in_bits)}, 8], got {tuple(cws.shape)}")
+        n = cws.shape[0]
+        self._need(seeds, 4 * n, "seeds")
+        L, st = self._L, self._stream()
+        ws_bytes = L.fss_amd_eval_all_batch_workspace(scheme, in_bits, n)
+        if ws_bytes == 0:
+            raise ValueError(f"eval_all_batch: unsupported (scheme={scheme}, in_bits={in_bits}, nkeys={n})")
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
+        ys = (self._need(out, 4 * n << in_bits, "out") if out is not None
+              else torch.empty((n, 1 << in_bits, 4), dtype=torch.int32, device=self.device))
+        if scheme == DPF:
+            rc = L.fss_amd_dpf_eval_all_batch(self._h, in_bits, group, party, _ptr(seeds), _ptr(cws), n, _ptr(ys), _ptr(ws), ws_bytes, st)
+        elif scheme == DCF:
+            rc = L.fss_amd_dcf_eval_all_batch(self._h, in_bits, group, party, _ptr(seeds), _ptr(cws), n, _ptr(ys), _ptr(ws), ws_bytes, st)
+        elif scheme == HT:
+            ocws = self._dev(self._need(ocws, 4 * n, "ocws"), torch.int32)
+            rc = L.fss_amd_ht_eval_all_batch(self._h, in_bits, group, party, _ptr(seeds), _ptr(cws), _ptr(ocws), n, _ptr(ys),
+                                             _ptr(ws), ws_bytes, st)
+        else:
+            raise ValueError("eval_all_batch: DPF, DCF or Half-Tree")
+        _lib.check(rc, "eval_all_batch")
+        ws.record_stream(torch.cuda.current_stream(self.device))
+        return ys
+
     # ------------------------------------------------------------ Grotto parity table
     def grotto_preprocess(self, in_bits, party, seed, cws):
         """GrottoDcf::Preprocess: uint8[2N-1] parity tree (device)."""

@@ -189,6 +189,19 @@ int fss_amd_ht_eval_all(fss_amd_ctx *ctx, int in_bits, int group, int party, con
                         const void *ocw, int64_t first_leaf, int64_t nleaves, void *ys, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* Many keys, the full domain of each: fss::gpu::DpfEvalAllGpuBatch / HalfTreeDpfEvalAllGpuBatch
+ * (eval_all_gpu.cuh:511-535; DCF added).  seeds: int4[nkeys]; cws: key-major raw slots, (in_bits+1) per key
+ * (in_bits for Half-Tree); ocws: int4[nkeys]; ys[k * 2^in_bits + x] = Eval(party, seeds[k], key k, x).
+ * in_bits <= 40 and nkeys * 2^in_bits <= 2^40; workspace from fss_amd_eval_all_batch_workspace. */
+size_t fss_amd_eval_all_batch_workspace(int scheme, int in_bits, int64_t nkeys);
+int fss_amd_dpf_eval_all_batch(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cws,
+                               int64_t nkeys, void *ys, void *workspace, size_t workspace_bytes, void *stream);
+int fss_amd_dcf_eval_all_batch(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cws,
+                               int64_t nkeys, void *ys, void *workspace, size_t workspace_bytes, void *stream);
+int fss_amd_ht_eval_all_batch(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cws,
+                              const void *ocws, int64_t nkeys, void *ys, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
 /* ---- Grotto DCF (include/fss/grotto_dcf.cuh) -------------------------------------
  * Keys are DPF keys over Bytes with beta = 0 (grotto_dcf.cuh:63-67).
  * eval_all: ys[x] = share of 1[alpha <= x], one byte per point, = GrottoDcf::EvalAll

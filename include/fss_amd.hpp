@@ -432,5 +432,25 @@ void HalfTreeDpfEvalAllGpu(bool b, const int4* d_s0, const typename HalfTreeDpf<
   dpf.EvalAll(b, d_s0, cws, d_ocw, ys, workspace, ws_bytes, 0, int64_t(1) << in_bits, stream);
 }
 
+// :511-520  ys[k * 2^in_bits + x] = Dpf::Eval(b, s0s[k], key k, x); workspace from EvalAllBatchWorkspace
+template <int in_bits, typename Group, typename Prg, typename In>
+void DpfEvalAllGpuBatch(bool b, const int4* d_s0s, const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys,
+                        int4* ys, void* workspace, size_t ws_bytes, const Dpf<in_bits, Group, Prg, In>& dpf,
+                        hipStream_t stream = 0) {
+  Check(fss_amd_dpf_eval_all_batch(dpf.prg.handle(), in_bits, Group::kId, b, d_s0s, cws, nkeys, ys, workspace, ws_bytes,
+                                   stream), "dpf_eval_all_batch");
+}
+// :526-535
+template <int in_bits, typename Group, typename Prg, typename In>
+void HalfTreeDpfEvalAllGpuBatch(bool b, const int4* d_s0s, const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws,
+                                const int4* d_ocws, int64_t nkeys, int4* ys, void* workspace, size_t ws_bytes,
+                                const HalfTreeDpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
+  Check(fss_amd_ht_eval_all_batch(dpf.prg.handle(), in_bits, Group::kId, b, d_s0s, cws, d_ocws, nkeys, ys, workspace,
+                                  ws_bytes, stream), "ht_eval_all_batch");
+}
+inline size_t EvalAllBatchWorkspace(int scheme, int in_bits, int64_t nkeys) {
+  return fss_amd_eval_all_batch_workspace(scheme, in_bits, nkeys);
+}
+
 }  // namespace gpu
 }  // namespace fss

@@ -638,3 +638,32 @@ def test_modular_uint_groups_vs_oracle(O, scheme, n, g, mod):
                 eng.eval_points(scheme, n, g, 0, T(s[0]), T(cws), xs_tensor(xs, n), ocw=None if ocw is None else T(ocw))
     finally:
         O.set_uint_modulus(0)
+
+
+@pytest.mark.parametrize("scheme,n,nkeys,g", [(DPF, 1, 5, G.U64), (DPF, 5, 37, G.BYTES), (DPF, 12, 9, G.U64), (DPF, 14, 3, G.U128),
+                                              (DPF, 9, 300, G.U32), (DCF, 2, 7, G.U64), (DCF, 10, 20, G.BYTES), (DCF, 13, 3, G.U64),
+                                              (HT, 1, 4, G.U64), (HT, 6, 33, G.U64), (HT, 12, 5, G.BYTES), (DPF, 16, 1, G.U64),
+                                              (HT, 3, 1000, G.U64)])
+def test_eval_all_batch_vs_oracle(engine, O, scheme, n, nkeys, g):
+    """fss::gpu::{Dpf,HalfTreeDpf}EvalAllGpuBatch (eval_all_gpu.cuh:511-535; DCF added): the full domain of every
+    key of a key-major batch in one call, ys[k, x] = Eval(party, seeds[k], key k, x)."""
+    rng = SplitMix64(31000 + 100 * scheme + n)
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    betas = np.stack([rng.i4() for _ in range(nkeys)])
+    cws, ocws = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=O.LT, nthreads=4)
+    ref = {DPF: lambda b, k: O.dpf_eval_all(p, n, g, b, s0s[k, b], cws[k]),
+           DCF: lambda b, k: O.dcf_eval_all(p, n, g, b, s0s[k, b], cws[k]),
+           HT: lambda b, k: O.ht_eval_all(p, n, g, b, s0s[k, b], cws[k], ocws[k])}[scheme]
+    check = range(nkeys) if nkeys <= 40 else [0, 1, nkeys // 2, nkeys - 2, nkeys - 1]
+    for b in (0, 1):
+        got = engine.eval_all_batch(scheme, n, g, b, T(np.ascontiguousarray(s0s[:, b])), T(cws),
+                                    ocws=None if ocws is None else T(ocws)).cpu().numpy()
+        assert got.shape == (nkeys, 1 << n, 4)
+        for k in check:
+            assert (got[k] == ref(b, k)).all(), (scheme, n, g, b, k)
+    # one key per call gives the same rows
+    one = engine.eval_all(scheme, n, g, 1, T(s0s[nkeys - 1, 1].copy()), T(cws[nkeys - 1]),
+                          ocw=None if ocws is None else T(ocws[nkeys - 1])).cpu().numpy()
+    assert (got[nkeys - 1] == one).all()
