@@ -17,7 +17,6 @@ include/fss/grotto_dcf.cuh), which the reference does not bind to Python.
 import torch
 
 from . import engine as E
-from ._int import split_uint128  # noqa: F401  (kept for interface parity)
 from ._validate import (validate_alpha, validate_beta, validate_cpu_only, validate_cws, validate_device_match,
                         validate_domain_value, validate_group, validate_in_bits, validate_party, validate_pred,
                         validate_prg, validate_s0, validate_s0s)
