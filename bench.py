@@ -462,6 +462,15 @@ def run_suite(args):
                lambda: eng.eval_all(fss_amd.GROTTO, n, fss_amd.BYTES, 0, sd, cd, out=yb), 2, 1, steps=5)
         del yb
 
+    # raw PRG (Aes128Mmo<mul>::Gen, aes128_mmo.cuh:72-93; the reference's Aes128Soft<2>::Gen: 425.7 M Gen/s on A30,
+    # doc/bench_aes128_soft.md:35-47): 16 B seed in, mul x 16 B out
+    seeds = torch.randint(-2**31, 2**31, (1 << 24, 4), dtype=torch.int32, device="cuda")
+    for beng, tag in ((eng, "aes"), (ceng, "chacha")):
+        for mul in (1, 2, 4):
+            record(f"{tag} prg Gen mul={mul}, 2^24 seeds", 1 << 24, lambda: beng.prg_gen(mul, seeds),
+                   mul if tag == "aes" else 0, 16 + 16 * mul, steps=5)
+    del seeds
+
     # batched full domain (fss::gpu::*EvalAllGpuBatch; the reference's n = 20 rows, README.md:384-385: ChaCha,
     # DPF 15.43 and Half-Tree 12.09 G outputs/s on RTX PRO 5000)
     for beng, tag in ((eng, "aes"), (ceng, "chacha")):

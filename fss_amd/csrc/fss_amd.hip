@@ -368,7 +368,8 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
   int64_t want = (n + bs - 1) / bs;
   int grid = (int)(want < (int64_t)ctx->num_cu ? want : (int64_t)ctx->num_cu);
   FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL(prg_gen_kernel<LT>, dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, mul,
-                                      reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out)));
+                                      reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out),
+                                      use_dyn(n, 64, grid, bs)));
   HIP_TRY(hipGetLastError());
   return FSS_AMD_OK;
 }

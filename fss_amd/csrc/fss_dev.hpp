@@ -737,7 +737,9 @@ __device__ __forceinline__ void prg_hash2(const ChaChaL& L, const DevCtx* __rest
 // Raw PRG outputs for fss_amd_prg_gen: out[j] for j < mul.
 __device__ __forceinline__ void prg_raw(const Lds& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],
                                         uint32_t out[4][4]) {
-  for (int j = 0; j < mul; ++j) aes_mmo<false>(L, c->rk[j], 0, s, out[j]);
+  if (mul == 1) aes_mmo<false>(L, c->rk[0], 0, s, out[0]);
+  else if (mul == 2) prg_gen2(L, c, s, out[0], out[1]);  // two interleaved blocks
+  else prg_gen4(L, c, s, out[0], out[1], out[2], out[3]);
 }
 __device__ __forceinline__ void prg_raw(const ChaChaL& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],
                                         uint32_t out[4][4]) {

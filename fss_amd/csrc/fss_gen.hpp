@@ -10,10 +10,13 @@ namespace fssamd {
 template <class LT>
 __global__ __launch_bounds__(1024) void prg_gen_kernel(const DevCtx K, const uint32_t* __restrict__ te0, int mul,
                                                       const uint4* __restrict__ seeds, int64_t n,
-                                                      uint4* __restrict__ out) {
+                                                      uint4* __restrict__ out, int dyn) {
   const DevCtx* c = first_kernarg(K);
+  FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  WaveQ q(dyn, &waveq_ctr_, n, 1);
+  for (int64_t i; q.next(i);) {
+    if (i >= n) continue;
     uint4 s = seeds[i];
     uint32_t in[4] = {s.x, s.y, s.z, s.w};
     uint32_t o[4][4];
