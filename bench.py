@@ -429,7 +429,9 @@ def run_suite(args):
         del keys, ys
     # verifiable DPF: walk + one keyed-BLAKE3 XorHash per evaluation; the reference's GPU number
     # is ChaCha + BLAKE3 at n = 20 (README.md:389, BM_VdpfEvalPointGpu: 945 M eval/s on RTX PRO 5000)
-    for veng, tag, n, lk in ((ceng, "chacha", 20, 22), (eng, "aes", 32, 22)):
+    seng = fss_amd.Engine(0)  # AES-128-MMO + SHA-256: the pair of the reference's CPU VDPF rows (README.md:354: 2499 ns/eval at n=20)
+    seng.set_hash_sha256([0x11111111, 0x22222222, 0x33333333, 0x44444444])
+    for veng, tag, n, lk in ((ceng, "chacha+blake3", 20, 22), (eng, "aes+blake3", 32, 22), (seng, "aes+sha256", 20, 22)):
         nk = 1 << lk
         gen = torch.Generator(device="cuda").manual_seed(300 + n)
         s0s = torch.randint(-2**31, 2**31, (nk, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
@@ -441,7 +443,7 @@ def run_suite(args):
         outs = (torch.empty((nk, 4), dtype=torch.int32, device="cuda"), torch.empty((nk, 4, 4), dtype=torch.int32, device="cuda"))
         record(f"{tag} vdpf n={n} 2^{lk} independent keys x 1 point (y + pi~)", nk,
                lambda: veng.vdpf_eval_keys(keys, G, 0, seeds0, cs, ocws, xs, out=outs),
-               n if tag == "aes" else 0, 16 + 4 + n * 16 + 8 + 64 + 16 + 16 + 64)
+               n if tag.startswith("aes") else 0, 16 + 4 + n * 16 + 8 + 64 + 16 + 16 + 64)
         del keys, outs
     sid, s0s, cws, ocw, _, _ = make_key(ceng, "dpf", 24, G, 5)
     sd, cd = s0s[0].cuda(), cws.cuda()

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "fss_amd_dcf_key_major": (_i, [_vp, _i, _vp, _vp, _vp, _i64, _vp, _vp]),
     "fss_amd_ht_key_major": (_i, [_vp, _i, _vp, _vp, _i64, _vp, _vp]),
     "fss_amd_ctx_set_hash_iv": (_i, [_vp, _vp]),
+    "fss_amd_ctx_set_hash_sha256": (_i, [_vp, _vp]),
     "fss_amd_ctx_set_uint_modulus": (_i, [_vp, C.c_uint64]),
     "fss_amd_vdpf_gen": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "fss_amd_vdpf_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

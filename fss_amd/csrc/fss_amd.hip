@@ -272,6 +272,7 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   c->host.chacha_nonce[0] = c->host.chacha_nonce[1] = 0;
   c->host.chacha_rounds = 20;
   c->host.uint_mod = 0;
+  c->host.hash_kind = 0;
   {  // default VDPF hash key: the reference bench's kBlake3Iv (src/bench_gpu.cu:27-30)
     const uint32_t iv[8] = {0x11223344u, 0x55667788u, 0x99aabbccu, 0xddeeff00u, 0x00112233u, 0x44556677u, 0x8899aabbu, 0xccddeeffu};
     for (int i = 0; i < 8; ++i) c->host.blake3_iv[i] = iv[i];

@@ -50,6 +50,7 @@ struct DevCtx {
   int chacha_rounds;
   uint32_t blake3_iv[8];     // VDPF: key of the keyed BLAKE3 hashes H and H' (fss::hash::Blake3::iv_)
   uint64_t uint_mod;         // modulus of Uint<T, mod> for T up to 64 bits; 0 = 2^(8 sizeof T)
+  int hash_kind;             // VDPF hash pair: 0 = keyed BLAKE3 (blake3_iv[0..7]), 1 = SHA-256 keyed with blake3_iv[0..3]
 };
 
 
@@ -650,6 +651,93 @@ __device__ __forceinline__ void blake3_xorhash(const DevCtx* __restrict__ c, con
   blake3_compress8(c, m, 32, out);
   m[3] |= 1u;
   blake3_compress8(c, m, 32, out + 8);
+}
+
+// ------------------------------------------------------------------ SHA-256 (VDPF hashes, second pair)
+// fss::hash::Sha256 (include/fss/hash/sha256.cuh:15-62): EVP_Digest(key | message) with a 16-byte key --
+// host-only in the reference; here FIPS 180-4 on the VALU, fully unrolled, 16-word rolling schedule.
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], const uint32_t wi[16]) {
+  constexpr uint32_t Kc[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t w[16], a[8];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = wi[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = h[i];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) {
+    if (i >= 16) {
+      const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+      const uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+      const uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+      w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+    }
+    const uint32_t S1 = xor3(rotr32(a[4], 6), rotr32(a[4], 11), rotr32(a[4], 25));
+    const uint32_t ch = __builtin_amdgcn_bitop3_b32(a[4], a[5], a[6], 0xCA);  // e ? f : g
+    const uint32_t t1 = a[7] + S1 + ch + Kc[i] + w[i & 15];
+    const uint32_t S0 = xor3(rotr32(a[0], 2), rotr32(a[0], 13), rotr32(a[0], 22));
+    const uint32_t mj = __builtin_amdgcn_bitop3_b32(a[0], a[1], a[2], 0xE8);  // majority
+    a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + S0 + mj;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] += a[i];
+}
+__device__ __forceinline__ void sha256_init(uint32_t h[8]) {
+  h[0] = 0x6a09e667u; h[1] = 0xbb67ae85u; h[2] = 0x3c6ef372u; h[3] = 0xa54ff53au;
+  h[4] = 0x510e527fu; h[5] = 0x9b05688cu; h[6] = 0x1f83d9abu; h[7] = 0x5be0cd19u;
+}
+// digest of key | a | b (48 bytes, one block) as 8 little-endian int4 words
+__device__ __forceinline__ void sha256_48(const DevCtx* __restrict__ c, const uint32_t a[4], const uint32_t b[4], uint32_t out[8]) {
+  uint32_t w[16], h[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { w[i] = __builtin_bswap32(c->blake3_iv[i]); w[4 + i] = __builtin_bswap32(a[i]); w[8 + i] = __builtin_bswap32(b[i]); }
+  w[12] = 0x80000000u; w[13] = 0; w[14] = 0; w[15] = 48 * 8;
+  sha256_init(h);
+  sha256_compress(h, w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = __builtin_bswap32(h[i]);
+}
+// digest of key | m[0..15] (80 bytes, two blocks)
+__device__ __forceinline__ void sha256_80(const DevCtx* __restrict__ c, const uint32_t m[16], uint32_t out[8]) {
+  uint32_t w[16], h[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = __builtin_bswap32(c->blake3_iv[i]);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) w[4 + i] = __builtin_bswap32(m[i]);
+  sha256_init(h);
+  sha256_compress(h, w);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = __builtin_bswap32(m[12 + i]);
+  w[4] = 0x80000000u;
+#pragma unroll
+  for (int i = 5; i < 15; ++i) w[i] = 0;
+  w[15] = 80 * 8;
+  sha256_compress(h, w);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = __builtin_bswap32(h[i]);
+}
+
+// The VDPF hashes by the context's hash pair: H(a, b) -> 16 words (XorHashable), H'(m) -> 8 words (Hashable).
+__device__ __forceinline__ void vdpf_xorhash(const DevCtx* __restrict__ c, const uint32_t a[4], const uint32_t b[4],
+                                             uint32_t out[16]) {
+  if (c->hash_kind == 1) {
+    uint32_t a0[4] = {a[0], a[1], a[2], a[3] & ~1u}, a1[4] = {a[0], a[1], a[2], a[3] | 1u};
+    sha256_48(c, a0, b, out);
+    sha256_48(c, a1, b, out + 8);
+  } else {
+    blake3_xorhash(c, a, b, out);
+  }
+}
+__device__ __forceinline__ void vdpf_hash(const DevCtx* __restrict__ c, const uint32_t m[16], uint32_t out[8]) {
+  if (c->hash_kind == 1) sha256_80(c, m, out);
+  else blake3_compress8(c, m, 64, out);
 }
 
 // ------------------------------------------------------------------ PRG interface

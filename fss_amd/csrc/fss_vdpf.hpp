@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
       const uint32_t s[4] = {w[j].st[0], w[j].st[1], w[j].st[2], w[j].st[3] & ~1u};
       const uint32_t tm = lsb_mask(w[j].st[3]);
       uint32_t h[16];
-      blake3_xorhash(c, xb, s, h);
+      vdpf_xorhash(c, xb, s, h);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         uint32_t cq[4];
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(1024) void vdpf_gen_kernel(const DevCtx K, const ui
     // cs = H(a, s0) ^ H(a, s1)   (vdpf.cuh:170-174)
     const uint32_t ab4[4] = {(uint32_t)alpha.lo, (uint32_t)(alpha.lo >> 32), (uint32_t)alpha.hi, (uint32_t)(alpha.hi >> 32)};
     uint32_t h0[16], h1[16];
-    blake3_xorhash(c, ab4, s0, h0);
-    blake3_xorhash(c, ab4, s1, h1);
+    vdpf_xorhash(c, ab4, s0, h0);
+    vdpf_xorhash(c, ab4, s1, h1);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       a.cs[4 * k + q] = make_uint4(h0[4 * q] ^ h1[4 * q], h0[4 * q + 1] ^ h1[4 * q + 1], h0[4 * q + 2] ^ h1[4 * q + 2],
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void vdpf_prove_kernel(const DevCtx K, const u
       for (int q = 0; q < 4; ++q) ld(m + 4 * q, pis[4 * i + q]);
 #pragma unroll
       for (int q = 0; q < 16; ++q) m[q] ^= pi[q];
-      blake3_compress8(c, m, 64, h);
+      vdpf_hash(c, m, h);
 #pragma unroll
       for (int q = 0; q < 8; ++q) pi[q] ^= h[q];
     }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void vdpf_prove_kernel(const DevCtx K, const u
       for (int q = 0; q < 4; ++q) { ld(pi + 4 * q, cs[4 * k + q]); ld(m + 4 * q, pis[4 * k + q]); }
 #pragma unroll
       for (int q = 0; q < 16; ++q) m[q] ^= pi[q];
-      blake3_compress8(c, m, 64, h);
+      vdpf_hash(c, m, h);
 #pragma unroll
       for (int q = 0; q < 8; ++q) pi[q] ^= h[q];
 #pragma unroll

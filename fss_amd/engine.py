@@ -412,6 +412,11 @@ class Engine:
         v = (C.c_int32 * 8)(*[int(np.uint32(int(x) & 0xFFFFFFFF).astype(np.int32)) for x in iv])
         _lib.check(self._L.fss_amd_ctx_set_hash_iv(self._h, v), "fss_amd_ctx_set_hash_iv")
 
+    def set_hash_sha256(self, key):
+        """Use fss::hash::Sha256(key) (4 words) for the VDPF's H and H' instead of keyed BLAKE3."""
+        v = (C.c_int32 * 4)(*[int(np.uint32(int(x) & 0xFFFFFFFF).astype(np.int32)) for x in key])
+        _lib.check(self._L.fss_amd_ctx_set_hash_sha256(self._h, v), "fss_amd_ctx_set_hash_sha256")
+
     def vdpf_gen(self, in_bits, group, s0s, alphas, betas, level_major=False):
         """-> (cws int32[n, in_bits, 8] | LevelMajorKeys, cs int32[n,4,4], ocws int32[n,4], retry int32[n])."""
         s0s, alphas, betas = self._dev(s0s, torch.int32), self._dev(alphas), self._dev(betas, torch.int32)

@@ -257,8 +257,8 @@ int fss_amd_ht_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const v
 
 /* ---- verifiable DPF (include/fss/vdpf.cuh; de Castro-Polychroniadou, EUROCRYPT'22) -------------
  * The DPF walk plus, per evaluation, the verification hash pi~ = H(Pack(x), s) [^ cs when t], with
- * H = H' = fss::hash::Blake3 keyed with the context's 8-word IV (blake3.cuh:13-172; the SHA-256 pair of
- * hash/sha256.cuh is not built).  A key is in_bits raw Cw slots (vdpf.cuh:77-82, same 32-byte {s, tr}
+ * H = H' = fss::hash::Blake3 keyed with the context's 8-word IV (blake3.cuh:13-172), or fss::hash::Sha256
+ * after fss_amd_ctx_set_hash_sha256.  A key is in_bits raw Cw slots (vdpf.cuh:77-82, same 32-byte {s, tr}
  * slot as the DPF, no output slot), cs = int4[4] and ocw = int4.
  *   gen            Vdpf::Gen (vdpf.cuh:103-189), one key per lane; retry[k] = 1 where the reference
  *                  returns 1 (t0 == t1; resample the seeds), may be NULL.
@@ -270,6 +270,10 @@ int fss_amd_ht_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const v
  *   prove_keys     the same fold for nkeys keys with one evaluation each, one key per lane.
  * Vdpf::Verify (vdpf.cuh:287-292) is a 64-byte comparison of the two parties' pi and is left to the caller. */
 int fss_amd_ctx_set_hash_iv(fss_amd_ctx *ctx, const int32_t iv[8]);
+/* The reference's other hash pair, fss::hash::Sha256(key) for both H and H' (include/fss/hash/sha256.cuh:15-62:
+ * SHA-256 of the 16-byte key followed by the message; host-only in the reference, on the device here).  This is
+ * the pair the reference's CPU benchmarks combine with the AES-128-MMO PRG (README.md:354-355). */
+int fss_amd_ctx_set_hash_sha256(fss_amd_ctx *ctx, const int32_t key[4]);
 int fss_amd_vdpf_gen(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas, int x_bytes,
                      const void *betas, int64_t nkeys, void *cws, void *cs, void *ocws, int32_t *retry, void *stream);
 int fss_amd_vdpf_gen_level_major(fss_amd_ctx *ctx, int in_bits, int group, const void *s0s, const void *alphas,

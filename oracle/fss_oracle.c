@@ -814,8 +814,75 @@ static inline fo_i4 words_i4(const uint32_t *w) {
   return v;
 }
 
+/* ---- SHA-256 (FIPS 180-4), the reference's other hash pair: fss::hash::Sha256 (include/fss/hash/sha256.cuh:15-62)
+ * = EVP_Digest(key | message) with a 16-byte key.  Own implementation, checked against OpenSSL in the tests. */
+static const uint32_t kSha256K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static void sha256_block(uint32_t h[8], const uint8_t blk[64]) {
+  uint32_t w[64], a[8];
+  for (int i = 0; i < 16; ++i)
+    w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) | ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
+  for (int i = 16; i < 64; ++i) {
+    uint32_t s0 = rotr_u32(w[i - 15], 7) ^ rotr_u32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+    uint32_t s1 = rotr_u32(w[i - 2], 17) ^ rotr_u32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  for (int i = 0; i < 8; ++i) a[i] = h[i];
+  for (int i = 0; i < 64; ++i) {
+    uint32_t S1 = rotr_u32(a[4], 6) ^ rotr_u32(a[4], 11) ^ rotr_u32(a[4], 25);
+    uint32_t ch = (a[4] & a[5]) ^ (~a[4] & a[6]);
+    uint32_t t1 = a[7] + S1 + ch + kSha256K[i] + w[i];
+    uint32_t S0 = rotr_u32(a[0], 2) ^ rotr_u32(a[0], 13) ^ rotr_u32(a[0], 22);
+    uint32_t mj = (a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]);
+    uint32_t t2 = S0 + mj;
+    a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+  }
+  for (int i = 0; i < 8; ++i) h[i] += a[i];
+}
+void fo_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  uint8_t blk[64];
+  size_t off = 0;
+  for (; off + 64 <= len; off += 64) sha256_block(h, msg + off);
+  size_t rem = len - off;
+  memset(blk, 0, 64);
+  memcpy(blk, msg + off, rem);
+  blk[rem] = 0x80;
+  if (rem >= 56) { sha256_block(h, blk); memset(blk, 0, 64); }
+  uint64_t bits = (uint64_t)len * 8;
+  for (int i = 0; i < 8; ++i) blk[63 - i] = (uint8_t)(bits >> (8 * i));
+  sha256_block(h, blk);
+  for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+
+/* Which hash pair the VDPF functions below use: 0 = keyed BLAKE3 (8-word iv), 1 = SHA-256 (the first 4 words of
+ * `iv` are the 16-byte key).  Process-wide test-infrastructure switch. */
+static int g_hash_kind = 0;
+void fo_set_hash_kind(int kind) { g_hash_kind = kind; }
+
+static void sha_hash(const int32_t key[4], const fo_i4 msg[4], fo_i4 out[2]) { /* sha256.cuh:24-39: 80 bytes */
+  uint8_t buf[80];
+  memcpy(buf, key, 16); memcpy(buf + 16, msg, 64);
+  fo_sha256(buf, 80, (uint8_t *)out);
+}
+static void sha_xorhash(const int32_t key[4], fo_i4 a, fo_i4 b, fo_i4 out[4]) { /* sha256.cuh:41-60: 2 x 48 bytes */
+  uint8_t buf[48];
+  fo_i4 a0 = set_lsb(a, 0), a1 = set_lsb(a, 1);
+  memcpy(buf, key, 16); memcpy(buf + 16, &a0, 16); memcpy(buf + 32, &b, 16);
+  fo_sha256(buf, 48, (uint8_t *)out);
+  memcpy(buf + 16, &a1, 16);
+  fo_sha256(buf, 48, (uint8_t *)out + 32);
+}
+
 /* Hashable: 64-byte message -> 2 int4 (blake3.cuh:151-155). */
 void fo_blake3_hash(const int32_t iv[8], const fo_i4 msg[4], fo_i4 out[2]) {
+  if (g_hash_kind == 1) { sha_hash(iv, msg, out); return; }
   uint32_t m[16], o[16];
   for (int i = 0; i < 4; ++i) i4_words(msg[i], m + 4 * i);
   fo_blake3_compress((const uint32_t *)iv, m, 0, 64, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT | B3_KEYED, o);
@@ -824,6 +891,7 @@ void fo_blake3_hash(const int32_t iv[8], const fo_i4 msg[4], fo_i4 out[2]) {
 
 /* XorHashable: (a, b) -> 4 int4 = H(a with lsb 0 | b) | H(a with lsb 1 | b), block_len 32 (blake3.cuh:157-169). */
 void fo_blake3_xorhash(const int32_t iv[8], fo_i4 a, fo_i4 b, fo_i4 out[4]) {
+  if (g_hash_kind == 1) { sha_xorhash(iv, a, b, out); return; }
   uint32_t m[16] = {0}, o[16];
   const uint32_t fl = B3_CHUNK_START | B3_CHUNK_END | B3_ROOT | B3_KEYED;
   i4_words(set_lsb(a, 0), m); i4_words(b, m + 4);

@@ -128,6 +128,11 @@ int fo_grotto_eval_walk(const fo_prg *p, int in_bits, int b, fo_i4 s0, const fo_
  * zero byte, keyed empty input; tests/test_oracle_kat.py), the construction around it against the source. */
 void fo_blake3_compress(const uint32_t h[8], const uint32_t msg[16], uint64_t counter, uint32_t block_len,
                         uint32_t flags, uint32_t out[16]);
+/* SHA-256 (FIPS 180-4) and the hash-pair switch: 0 = keyed BLAKE3 (default), 1 = fss::hash::Sha256
+ * (include/fss/hash/sha256.cuh:15-62; key = first 4 words of `iv`).  fo_blake3_hash / fo_blake3_xorhash and the
+ * VDPF functions follow the switch. */
+void fo_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+void fo_set_hash_kind(int kind);
 void fo_blake3_hash(const int32_t iv[8], const fo_i4 msg[4], fo_i4 out[2]);
 void fo_blake3_xorhash(const int32_t iv[8], fo_i4 a, fo_i4 b, fo_i4 out[4]);
 int fo_vdpf_gen(const fo_prg *p, const int32_t iv[8], int in_bits, int group, fo_cw *cws /* in_bits */, fo_i4 cs[4],

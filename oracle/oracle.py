@@ -99,6 +99,8 @@ def lib():
         L.fo_vdpf_eval.restype = _I4
         L.fo_vdpf_prove.argtypes = [vp, vp, sz, vp, vp]
         L.fo_set_uint_modulus.argtypes = [u64]
+        L.fo_sha256.argtypes = [vp, sz, vp]
+        L.fo_set_hash_kind.argtypes = [i]
         L.fo_eval_points.argtypes = [P, _I4, i, i, i, i, _I4, vp, _I4, vp, vp, sz, vp, i]
         L.fo_eval_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, sz, vp, vp, vp, sz, vp, i]
         L.fo_gen_keys.argtypes = [P, _I4, i, i, i, i, vp, vp, vp, vp, sz, vp, sz, vp, i]
@@ -298,6 +300,17 @@ BLAKE3_IV = np.array([0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F
 # hash IV of the reference's VDPF tests (src/vdpf_test.cu:35-36)
 HASH_IV = np.array([0x11111111, 0x22222222, 0x33333333, 0x44444444, 0x55555555, 0x66666666, 0x77777777, 0x88888888],
                    dtype=np.uint32).view(np.int32)
+
+
+def sha256(data: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().fo_sha256(C.c_char_p(data), len(data), out)
+    return bytes(out)
+
+
+def set_hash_kind(kind: int):
+    """0 = keyed BLAKE3 (fss::hash::Blake3), 1 = SHA-256 (fss::hash::Sha256, key = first 4 IV words); process-wide."""
+    lib().fo_set_hash_kind(int(kind))
 
 
 def blake3_compress(h, msg, counter=0, block_len=64, flags=0):

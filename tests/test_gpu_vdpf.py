@@ -11,12 +11,21 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["aes128_mmo", "chacha"])
-def veng(request):
+@pytest.fixture(scope="module", params=[("aes128_mmo", "blake3"), ("chacha", "blake3"), ("aes128_mmo", "sha256")],
+                ids=lambda p: "-".join(p))
+def veng(request, O):
+    """An engine per (PRG, hash pair); the oracle's process-wide hash switch follows it for the module's tests."""
     import fss_amd
-    e = fss_amd.Engine(0, prg=request.param)
-    e.set_hash_iv([int(v) & 0xFFFFFFFF for v in HASH_IV_WORDS])
-    return e
+    prg, hname = request.param
+    e = fss_amd.Engine(0, prg=prg)
+    if hname == "sha256":  # fss::hash::Sha256(key): the pair the reference's CPU benchmarks use with the AES PRG
+        e.set_hash_sha256(HASH_IV_WORDS[:4])
+        O.set_hash_kind(1)
+    else:
+        e.set_hash_iv([int(v) & 0xFFFFFFFF for v in HASH_IV_WORDS])
+        O.set_hash_kind(0)
+    yield e
+    O.set_hash_kind(0)
 
 
 HASH_IV_WORDS = [0x11111111, 0x22222222, 0x33333333, 0x44444444, 0x55555555, 0x66666666, 0x77777777, 0x88888888]

@@ -156,3 +156,29 @@ def test_aesni_prg_equals_evp_and_table_aes(O, rng):
         for _ in range(50):
             s = rng.i4(clear_lsb=False)
             assert (a.gen(s) == c.gen(s)).all() and (b.gen(s) == c.gen(s)).all()
+
+
+def test_sha256_against_openssl_and_nist(O):
+    """The oracle's SHA-256 (the reference's fss::hash::Sha256 = OpenSSL EVP_Digest over key | message,
+    hash/sha256.cuh:15-62) against hashlib (OpenSSL) at every padding edge, the FIPS 180-4 "abc" vector, and the two
+    Hash overloads as digests of the concatenations the reference builds."""
+    import hashlib
+    assert O.sha256(b"abc").hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    for n in (0, 1, 47, 48, 55, 56, 63, 64, 79, 80, 119, 120, 200):
+        m = bytes((7 * i + n) & 0xFF for i in range(n))
+        assert O.sha256(m) == hashlib.sha256(m).digest(), n
+    key = O.HASH_IV[:4].copy()
+    a = np.array([0x01020305, 7, 8, 9], dtype=np.int32)
+    b = np.array([11, 12, 13, 14], dtype=np.int32)
+    O.set_hash_kind(1)
+    try:
+        a0, a1 = a.copy(), a.copy()
+        a0[3] &= ~1
+        a1[3] |= 1
+        want = (hashlib.sha256(key.tobytes() + a0.tobytes() + b.tobytes()).digest()
+                + hashlib.sha256(key.tobytes() + a1.tobytes() + b.tobytes()).digest())
+        assert O.blake3_xorhash(O.HASH_IV, a, b).tobytes() == want
+        msg = np.arange(16, dtype=np.int32).reshape(4, 4)
+        assert O.blake3_hash(O.HASH_IV, msg).tobytes() == hashlib.sha256(key.tobytes() + msg.tobytes()).digest()
+    finally:
+        O.set_hash_kind(0)
