@@ -5,28 +5,43 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.path.join(_HERE, "libfss_amd.so")
-SOURCES = ["fss_amd.hip", "fss_dev.hpp", "fss_point.hpp", "fss_evalall.hpp", "fss_gen.hpp", "fss_vdpf.hpp", "fss_abi_rest.inc",
-           "fss_abi_vdpf.inc"]
+UNITS = ["fss_amd.hip", "fss_abi_evalall.hip", "fss_abi_gen.hip"]  # compiled in parallel, linked into one .so
+HEADERS = ["fss_dev.hpp", "fss_point.hpp", "fss_evalall.hpp", "fss_gen.hpp", "fss_vdpf.hpp", "fss_host.hpp"]
+OBJDIR = os.path.join(_HERE, "csrc", "build")
+
+
+def _deps_mtime():
+    deps = [os.path.join(CSRC, s) for s in UNITS + HEADERS] + [os.path.join(_HERE, "..", "include", "fss_amd.h")]
+    return max(os.path.getmtime(d) for d in deps)
 
 
 def _stale():
-    if not os.path.exists(SO):
-        return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(_HERE, "..", "include", "fss_amd.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not os.path.exists(SO) or os.path.getmtime(SO) < _deps_mtime()
 
 
 def build(force=False, verbose=False):
-    """Compile fss_amd/csrc/fss_amd.hip -> fss_amd/libfss_amd.so for gfx950."""
+    """Compile fss_amd/csrc/*.hip for gfx950 (one hipcc per unit, in parallel) and link fss_amd/libfss_amd.so."""
     if not force and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", SO,
-           os.path.join(CSRC, "fss_amd.hip")]
+    os.makedirs(OBJDIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    procs = []
+    for u in UNITS:
+        obj = os.path.join(OBJDIR, u.replace(".hip", ".o"))
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, u), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, obj, subprocess.Popen(cmd)))
+    objs = []
+    for cmd, obj, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return SO
 
 

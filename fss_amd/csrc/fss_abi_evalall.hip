@@ -1,4 +1,8 @@
-// Included at the end of fss_amd.hip: full-domain evaluation, Grotto, key generation.
+// libfss_amd.so, second unit: full-domain evaluation (single key, sub-blocks, batches of keys), the shared-prefix
+// point walks that are built on its stages, and Grotto DCF.
+#include "fss_host.hpp"
+#include "fss_evalall.hpp"
+
 
 namespace {
 
@@ -553,89 +557,6 @@ int fss_amd_ht_eval_all_batch(fss_amd_ctx* ctx, int in_bits, int group, int part
                               void* stream) {
   return eval_all_batch_impl<S_HT>(ctx, in_bits, group, party, seeds, cws, ocws, nkeys, ys, workspace, workspace_bytes,
                                    S(stream));
-}
-
-// ------------------------------------------------------------------ key generation
-}  // extern "C"
-
-struct LevelMajorOut {
-  void *cw_s = nullptr, *cw_v = nullptr, *tr_bits = nullptr, *out_cw = nullptr, *extra = nullptr;
-};
-
-template <bool LM>
-static int gen_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int pred, const void* s0s,
-                      const void* alphas, int x_bytes, const void* betas, int64_t nkeys, void* cws, void* ocws,
-                      const LevelMajorOut& lm, void* stream) {
-  if (!ctx || nkeys < 0 || !group_ok(ctx, group) || !x_ok(in_bits, x_bytes) || (pred != 0 && pred != 1)) return FSS_AMD_EINVAL;
-  if (nkeys == 0) return FSS_AMD_OK;
-  if (!s0s || !alphas || (scheme == S_HT && !ocws)) return FSS_AMD_EINVAL;  // betas may be null: beta = 0
-  if (!LM && !cws) return FSS_AMD_EINVAL;
-  if (LM && (!lm.cw_s || (scheme == S_DPF && (!lm.tr_bits || !lm.out_cw)) ||
-             (scheme == S_DCF && (!lm.cw_v || !lm.out_cw)) || (scheme == S_HT && !lm.extra)))
-    return FSS_AMD_EINVAL;
-  FSS_ON_DEVICE(ctx);
-  GenArgs a{};
-  a.in_bits = in_bits; a.group = group; a.pred = pred; a.x_bytes = x_bytes; a.nkeys = nkeys;
-  a.s0s = reinterpret_cast<const uint4*>(s0s);
-  a.alphas = alphas;
-  a.betas = reinterpret_cast<const uint4*>(betas);
-  a.cws = reinterpret_cast<uint4*>(cws);
-  a.ocws = reinterpret_cast<uint4*>(ocws);
-  a.cw_s = reinterpret_cast<uint4*>(lm.cw_s);
-  a.cw_v = reinterpret_cast<uint4*>(lm.cw_v);
-  a.tr_bits = reinterpret_cast<uint64_t*>(lm.tr_bits);
-  a.out_cw = reinterpret_cast<uint4*>(lm.out_cw);
-  a.extra = reinterpret_cast<uint32_t*>(lm.extra);
-  int bs = nkeys <= 64 ? 64 : (nkeys <= 256 ? 256 : 1024);
-  int64_t want = (nkeys + bs - 1) / bs;
-  int64_t cap = (int64_t)ctx->num_cu;
-  int grid = (int)(want < cap ? want : cap);
-  a.dyn = use_dyn(nkeys, 64, grid, bs);
-  if (scheme == S_DPF)
-    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((gen_kernel<LT, S_DPF, LM>), dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, a));
-  else if (scheme == S_DCF)
-    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((gen_kernel<LT, S_DCF, LM>), dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, a));
-  else
-    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((ht_gen_kernel<LT, LM>), dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, a));
-  HIP_TRY(hipGetLastError());
-  return FSS_AMD_OK;
-}
-
-extern "C" {
-
-int fss_amd_dpf_gen(fss_amd_ctx* ctx, int in_bits, int group, const void* s0s, const void* alphas, int x_bytes,
-                    const void* betas, int64_t nkeys, void* cws, void* stream) {
-  return gen_common<false>(ctx, S_DPF, in_bits, group, 0, s0s, alphas, x_bytes, betas, nkeys, cws, nullptr, {}, stream);
-}
-int fss_amd_dcf_gen(fss_amd_ctx* ctx, int in_bits, int group, int pred, const void* s0s, const void* alphas,
-                    int x_bytes, const void* betas, int64_t nkeys, void* cws, void* stream) {
-  return gen_common<false>(ctx, S_DCF, in_bits, group, pred, s0s, alphas, x_bytes, betas, nkeys, cws, nullptr, {}, stream);
-}
-int fss_amd_ht_gen(fss_amd_ctx* ctx, int in_bits, int group, const void* s0s, const void* alphas, int x_bytes,
-                   const void* betas, int64_t nkeys, void* cws, void* ocws, void* stream) {
-  return gen_common<false>(ctx, S_HT, in_bits, group, 0, s0s, alphas, x_bytes, betas, nkeys, cws, ocws, {}, stream);
-}
-
-int fss_amd_dpf_gen_level_major(fss_amd_ctx* ctx, int in_bits, int group, const void* s0s, const void* alphas,
-                                int x_bytes, const void* betas, int64_t nkeys, void* cw_s, void* tr_bits,
-                                void* out_cw, void* stream) {
-  LevelMajorOut lm;
-  lm.cw_s = cw_s; lm.tr_bits = tr_bits; lm.out_cw = out_cw;
-  return gen_common<true>(ctx, S_DPF, in_bits, group, 0, s0s, alphas, x_bytes, betas, nkeys, nullptr, nullptr, lm, stream);
-}
-int fss_amd_dcf_gen_level_major(fss_amd_ctx* ctx, int in_bits, int group, int pred, const void* s0s,
-                                const void* alphas, int x_bytes, const void* betas, int64_t nkeys, void* cw_s,
-                                void* cw_v, void* out_cw, void* stream) {
-  LevelMajorOut lm;
-  lm.cw_s = cw_s; lm.cw_v = cw_v; lm.out_cw = out_cw;
-  return gen_common<true>(ctx, S_DCF, in_bits, group, pred, s0s, alphas, x_bytes, betas, nkeys, nullptr, nullptr, lm, stream);
-}
-int fss_amd_ht_gen_level_major(fss_amd_ctx* ctx, int in_bits, int group, const void* s0s, const void* alphas,
-                               int x_bytes, const void* betas, int64_t nkeys, void* cw_s, void* extra, void* ocws,
-                               void* stream) {
-  LevelMajorOut lm;
-  lm.cw_s = cw_s; lm.extra = extra;
-  return gen_common<true>(ctx, S_HT, in_bits, group, 0, s0s, alphas, x_bytes, betas, nkeys, nullptr, ocws, lm, stream);
 }
 
 }  // extern "C"

@@ -1,66 +1,10 @@
-// libfss_amd.so -- C ABI (include/fss_amd.h) over the gfx950 kernels.
-// Host side: context (AES key schedule, Te0 table), argument checks, launches.
-#include "../../include/fss_amd.h"
-
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <unordered_map>
-
-#include "fss_dev.hpp"
-#include "fss_evalall.hpp"
+// libfss_amd.so -- C ABI (include/fss_amd.h) over the gfx950 kernels.  This unit: context, raw PRG, point
+// evaluation (shared key and independent keys), relayout.  fss_abi_evalall.hip: full-domain evaluation,
+// shared-prefix walks, Grotto.  fss_abi_gen.hip: key generation, verifiable DPF.
+#include "fss_host.hpp"
 #include "fss_gen.hpp"
-#include "fss_point.hpp"
-#include "fss_vdpf.hpp"
-
-using namespace fssamd;
-
-// ------------------------------------------------------------------ context
-struct fss_amd_ctx {
-  int device;
-  int num_cu;
-  uint32_t* te0;  // device: Te0 table, 1 KiB, followed by the device copy of `host`
-  DevCtx host;    // round keys etc., passed to kernels by value
-  int prg;        // FSS_AMD_PRG_AES128_MMO or FSS_AMD_PRG_CHACHA
-  const char* last_kernel;
-  int last_grid, last_block;
-};
-
-static thread_local int g_last_hip = 0;
-
-#define HIP_TRY(expr)                    \
-  do {                                   \
-    hipError_t e_ = (expr);              \
-    if (e_ != hipSuccess) {              \
-      g_last_hip = (int)e_;              \
-      return FSS_AMD_EHIP;               \
-    }                                    \
-  } while (0)
 
 namespace {
-
-// The entry points run on the context's device and leave the caller's current device as they found it.
-struct DeviceGuard {
-  int prev = -1;
-  hipError_t err = hipSuccess;
-  explicit DeviceGuard(int dev) {
-    err = hipGetDevice(&prev);
-    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
-    else if (err == hipSuccess) prev = -1;  // nothing to restore
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-#define FSS_ON_DEVICE(ctx)             \
-  DeviceGuard guard_((ctx)->device);   \
-  HIP_TRY(guard_.err)
-
-// FIPS-197 S-box from the field inverse and the affine map.
 void make_sbox(uint8_t sbox[256]) {
   uint8_t p = 1, q = 1;
   do {
@@ -96,155 +40,6 @@ void expand_key(const uint8_t sbox[256], const uint8_t key[16], uint32_t rk[44])
   for (int i = 0; i < 44; ++i)
     rk[i] = (uint32_t)w[4 * i] | ((uint32_t)w[4 * i + 1] << 8) | ((uint32_t)w[4 * i + 2] << 16) |
             ((uint32_t)w[4 * i + 3] << 24);
-}
-
-inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-// group id in range and, for Uint<T, mod> with a context modulus, the modulus representable in T
-bool group_ok(const fss_amd_ctx* ctx, int g) {
-  if (g < 0 || g > 5) return false;
-  const uint64_t m = ctx->host.uint_mod;
-  if (m == 0 || g < G_U8 || g > G_U32) return true;
-  return m <= (1ull << (g == G_U8 ? 8 : (g == G_U16 ? 16 : 32)));
-}
-bool x_ok(int in_bits, int x_bytes) {
-  if (in_bits < 1) return false;
-  if (x_bytes == 1) return in_bits <= 8;
-  if (x_bytes == 2) return in_bits <= 16;
-  if (x_bytes == 4) return in_bits <= 32;
-  if (x_bytes == 8) return in_bits <= 64;
-  if (x_bytes == 16) return in_bits <= 128;  // two little-endian uint64 per value (__uint128_t)
-  return false;
-}
-
-// Tunables (env, read once): FSS_AMD_ILP in {1,2}, FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU.
-struct Tune {
-  int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
-  bool ilp_set = false;  // FSS_AMD_ILP given: do not second-guess it for small batches
-  int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
-  int rot_prio = -1;  // FSS_AMD_ROTPRIO: 1 / 0 force; default: on for static launches
-  Tune() {
-    if (const char* e = getenv("FSS_AMD_ROTPRIO")) rot_prio = atoi(e) != 0;
-    if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
-    if (const char* e = getenv("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
-    if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
-    if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
-    if (ilp != 1 && ilp != 2) ilp = 2;
-    if (bs != 256 && bs != 512 && bs != 1024) bs = 1024;
-  }
-};
-const Tune& tune() {
-  static Tune t;
-  return t;
-}
-
-// Grid of a persistent launch: one workgroup per resident slot, fewer when the batch is smaller.
-template <typename K>
-int persistent_grid(fss_amd_ctx* ctx, K kernel, int bs, int64_t threads_needed, int* grid) {
-  // resident workgroups per CU of this kernel at this block size: asked once per (kernel, block size)
-  static std::mutex mu;
-  static std::unordered_map<uint64_t, int> cache;
-  const uint64_t key = (uint64_t)reinterpret_cast<uintptr_t>(reinterpret_cast<const void*>(kernel)) * 4099u + (uint64_t)bs;
-  int occ = 0;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(key);
-    if (it != cache.end()) occ = it->second;
-  }
-  if (occ == 0) {
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, bs, 0));
-    if (occ < 1) occ = 1;
-    std::lock_guard<std::mutex> lk(mu);
-    cache[key] = occ;
-  }
-  if (tune().wgs_per_cu > 0 && tune().wgs_per_cu < occ) occ = tune().wgs_per_cu;
-  int64_t want = (threads_needed + bs - 1) / bs;
-  int64_t cap = (int64_t)ctx->num_cu * occ;
-  *grid = (int)(want < cap ? want : cap);
-  if (*grid < 1) *grid = 1;
-  return FSS_AMD_OK;
-}
-
-// Dynamic (per-workgroup LDS counter, WaveQ in fss_dev.hpp) or static distribution of `units` units taken
-// `per_chunk` at a time over `grid` workgroups of `bs` lanes: dynamic when a wave gets at least 4 chunks.
-int use_dyn(int64_t units, int per_chunk, int grid, int bs) {
-  if (tune().dyn >= 0) return tune().dyn;
-  const int64_t nchunks = (units + per_chunk - 1) / per_chunk, waves = (int64_t)grid * (bs / 64);
-  return nchunks >= 4 * waves ? 1 : 0;
-}
-
-template <typename K, typename... Args>
-int launch_grid(fss_amd_ctx* ctx, K kernel, const char* name, int grid, int bs, hipStream_t st, Args... args) {
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(bs), 0, st, args...);
-  HIP_TRY(hipGetLastError());
-  ctx->last_kernel = name;
-  ctx->last_grid = grid;
-  ctx->last_block = bs;
-  return FSS_AMD_OK;
-}
-
-template <typename K, typename... Args>
-int launch_persistent(fss_amd_ctx* ctx, K kernel, const char* name, int bs, int64_t threads_needed, hipStream_t st,
-                      Args... args) {
-  int grid = 0;
-  int rc = persistent_grid(ctx, kernel, bs, threads_needed, &grid);
-  if (rc != FSS_AMD_OK) return rc;
-  return launch_grid(ctx, kernel, name, grid, bs, st, args...);
-}
-
-// Instantiate CALL once per PRG (LT = Lds: AES-128-MMO with LDS tables; LT = ChaChaL) and run the one
-// the context is set to.
-#define FSS_BY_PRG(ctx, CALL)                                  \
-  ((ctx)->prg == FSS_AMD_PRG_CHACHA ? [&] { using LT = ChaChaL; return CALL; }() \
-                                    : [&] { using LT = Lds; return CALL; }())
-
-#define FSS_BY_PRG_DO(ctx, ...)                      \
-  do {                                               \
-    if ((ctx)->prg == FSS_AMD_PRG_CHACHA) {          \
-      using LT = ChaChaL;                            \
-      __VA_ARGS__;                                   \
-    } else {                                         \
-      using LT = Lds;                                \
-      __VA_ARGS__;                                   \
-    }                                                \
-  } while (0)
-
-struct SharedKey {
-  const uint32_t *seed = nullptr, *cws = nullptr, *ocw = nullptr;
-};
-
-template <typename K>
-int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int bs, const SharedKey& k, EvalArgs a,
-                    hipStream_t st) {
-  int grid = 0;
-  int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
-  if (rc != FSS_AMD_OK) return rc;
-  a.dyn = use_dyn(a.n, 64 * ilp, grid, bs);
-  a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : !a.dyn;
-  return launch_grid(ctx, kernel, name, grid, bs, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a);
-}
-
-template <int SCHEME, bool SHARED, bool PREFIX = false>
-int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
-  if (a.n == 0) return FSS_AMD_OK;
-  const int bs = PREFIX ? 1024 : tune().bs;  // the shared-prefix walk is built for 1024 only
-  int ilp = tune().ilp;
-  // two evaluations per lane only pay when there are enough to give every resident wave a chunk of 128
-  // (2^18 points: 0.10 ms with one per lane, 0.17 ms with two and half of the waves idle)
-  const int64_t resident_waves = (int64_t)ctx->num_cu * (ctx->prg == FSS_AMD_PRG_CHACHA ? 2 : 1) * (bs / 64);
-  if (!tune().ilp_set && a.n < 128 * resident_waves) ilp = 1;
-#define FSS_L(I, B) \
-  if (ilp == I && bs == B)                                                                                      \
-  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st)))
-  FSS_L(1, 1024);
-  FSS_L(2, 1024);
-  if constexpr (PREFIX) return FSS_AMD_EINVAL;
-  FSS_L(1, 512);
-  FSS_L(2, 512);
-  FSS_L(1, 256);
-  FSS_L(2, 256);
-#undef FSS_L
-  return FSS_AMD_EINVAL;
 }
 
 }  // namespace
@@ -534,5 +329,3 @@ int fss_amd_ht_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, co
 
 }  // extern "C"
 
-#include "fss_abi_rest.inc"
-#include "fss_abi_vdpf.inc"
