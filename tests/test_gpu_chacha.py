@@ -137,3 +137,25 @@ def test_chacha_grotto_and_python_surface(ceng, O):
     assert (torch.bitwise_xor(y0, y1) == beta).all()
     assert (torch.bitwise_xor(d.eval(0, s0s[0], c, 50), d.eval(1, s0s[1], c, 50)) == 0).all()
     assert d.eval_all(0, s0s[0], c).shape == (1 << 16, 4)
+
+
+@pytest.mark.parametrize("scheme,n,nkeys", [(DPF, 9, 21), (DCF, 7, 5), (HT, 10, 64)])
+def test_chacha_eval_all_batch_and_key_major(ceng, O, scheme, n, nkeys):
+    """Batched full-domain evaluation and the level-major -> key-major conversion with the ChaCha PRG."""
+    g = G.U64
+    rng = SplitMix64(6100 + 10 * scheme + n)
+    p = cprg(O, {DPF: 2, DCF: 4, HT: 1}[scheme])
+    s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    betas = np.stack([rng.i4() for _ in range(nkeys)])
+    cws, ocws = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=O.LT, nthreads=4)
+    keys, docws = ceng.gen_level_major(scheme, n, g, T(s0s), xs_tensor(list(map(int, alphas)), n), T(betas))
+    km = ceng.key_major(keys)
+    assert (km.cpu().numpy() == cws).all()
+    ref = {DPF: lambda b, k: O.dpf_eval_all(p, n, g, b, s0s[k, b], cws[k]),
+           DCF: lambda b, k: O.dcf_eval_all(p, n, g, b, s0s[k, b], cws[k]),
+           HT: lambda b, k: O.ht_eval_all(p, n, g, b, s0s[k, b], cws[k], ocws[k])}[scheme]
+    for b in (0, 1):
+        got = ceng.eval_all_batch(scheme, n, g, b, T(np.ascontiguousarray(s0s[:, b])), km, ocws=docws).cpu().numpy()
+        for k in range(0, nkeys, max(1, nkeys // 7)):
+            assert (got[k] == ref(b, k)).all(), (scheme, n, b, k)
