@@ -235,6 +235,15 @@ def run_headline(args, rank, world, dist):
                          "algorithmic": "4 B x + 16 B y per eval (key resident on chip); traffic = PMC bytes per "
                                         "launch from profiles/ (FETCH_SIZE x2 + WRITE_SIZE)"},
     }
+    pipes = measured_pipe_busy(args.log2_batch)
+    if pipes:
+        # third roof SURVEY 8(d) asks for: VALU issue.  Peak = 256 CU x 4 SIMD x one wave64 instruction per 2 clk x
+        # 2.4 GHz (the fast-class rate); this kernel's instruction mix issues at ~4 clk, so the
+        # pipe is ~0.9 busy at less than half of that peak.
+        valu_rate = pipes["valu_wave_instructions_per_launch"] / (kernel_ms * 1e-3)
+        out["roofline_valu"] = {"bound": "valu", "achieved": valu_rate / 1e12, "peak": 1.2288, "unit": "T wave64-instr/s",
+                                "frac": valu_rate / 1.2288e12, "busy_frac_pmc": pipes["valu_busy"],
+                                "instructions_per_launch": pipes["valu_wave_instructions_per_launch"]}
     out["shared_prefix"] = {
         "value": batch * world * args.steps / wall_sp, "unit": "evals/s", "ms_per_step": wall_sp / args.steps * 1e3,
         "kernel_ms": kernel_ms_sp, "identical_to_plain_walk": same,
