@@ -139,7 +139,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   if (!make_plan(SCHEME, in_bits, first_leaf, nleaves, &pl)) return FSS_AMD_EINVAL;
   size_t need = plan_workspace(SCHEME, pl, nleaves);
   if (!workspace || ws_bytes < need) return FSS_AMD_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(ys) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return FSS_AMD_EINVAL;
+  if (!aligned16(seed, cws, ocw, ys, workspace)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
 
   const size_t per = (SCHEME == S_DCF) ? 32 : 16;
@@ -257,7 +257,7 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   if (!make_batch_plan(SCHEME, in_bits, nkeys, &bp)) return FSS_AMD_EINVAL;
   const Plan& pl = bp.pl;
   if (!workspace || ws_bytes < batch_workspace(SCHEME, bp)) return FSS_AMD_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(ys) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return FSS_AMD_EINVAL;
+  if (!aligned16(seeds, cws, ocws, ys, workspace)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
 
   const size_t per = (SCHEME == S_DCF) ? 32 : 16;
@@ -357,8 +357,8 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
   if (SCHEME == S_HT && !ocw) return FSS_AMD_EINVAL;
   PrefixPlan pl;
   if (!make_prefix_plan(SCHEME, in_bits, k, &pl)) return FSS_AMD_EINVAL;
-  if (!workspace || ws_bytes < prefix_workspace(SCHEME, pl, k) || (reinterpret_cast<uintptr_t>(workspace) & 15))
-    return FSS_AMD_EINVAL;
+  if (!workspace || ws_bytes < prefix_workspace(SCHEME, pl, k)) return FSS_AMD_EINVAL;
+  if (!aligned16(seed, cws, ocw, ys, workspace) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
   FSS_ON_DEVICE(ctx);
 
@@ -502,7 +502,7 @@ int fss_amd_grotto_eval_table(fss_amd_ctx* ctx, int in_bits, const void* pt, con
                               int64_t npoints, void* ys_bytes, void* stream) {
   if (!ctx || !pt || npoints < 0 || in_bits < 1 || in_bits > 32 || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
   if (npoints == 0) return FSS_AMD_OK;
-  if (!xs || !ys_bytes) return FSS_AMD_EINVAL;
+  if (!xs || !ys_bytes || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   int64_t want = (npoints + 255) / 256;
   int grid = (int)(want < (int64_t)ctx->num_cu * 16 ? want : (int64_t)ctx->num_cu * 16);
@@ -519,6 +519,7 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
   if (!ctx || nkeys < 0 || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes) || in_bits > 64) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!seeds || !cw_s || !tr_bits || !xs || !ys_bytes) return FSS_AMD_EINVAL;
+  if (!aligned16(seeds, cw_s) || !aligned_to(tr_bits, 8) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   EvalArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = G_BYTES; a.x_bytes = x_bytes; a.n = nkeys;

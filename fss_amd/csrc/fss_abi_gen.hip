@@ -20,6 +20,9 @@ static int gen_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int 
   if (LM && (!lm.cw_s || (scheme == S_DPF && (!lm.tr_bits || !lm.out_cw)) ||
              (scheme == S_DCF && (!lm.cw_v || !lm.out_cw)) || (scheme == S_HT && !lm.extra)))
     return FSS_AMD_EINVAL;
+  if (!aligned16(s0s, betas, cws, ocws, lm.cw_s, lm.cw_v, lm.out_cw) || !aligned_to(alphas, x_bytes) ||
+      !aligned_to(lm.tr_bits, 8) || !aligned_to(lm.extra, 4))
+    return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   GenArgs a{};
   a.in_bits = in_bits; a.group = group; a.pred = pred; a.x_bytes = x_bytes; a.nkeys = nkeys;
@@ -133,6 +136,9 @@ static int vdpf_gen_common(fss_amd_ctx* ctx, int in_bits, int group, const void*
   if (nkeys == 0) return FSS_AMD_OK;
   if (!s0s || !alphas || !cs || !ocws) return FSS_AMD_EINVAL;
   if (LM ? (!cw_s || !tr_bits) : !cws) return FSS_AMD_EINVAL;
+  if (!aligned16(s0s, betas, cws, cw_s, cs, ocws) || !aligned_to(alphas, x_bytes) || !aligned_to(tr_bits, 8) ||
+      !aligned_to(retry, 4))
+    return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   VdpfGenArgs a{};
   a.in_bits = in_bits; a.group = group; a.x_bytes = x_bytes; a.nkeys = nkeys;
@@ -173,6 +179,7 @@ int fss_amd_vdpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_
   if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !tr_bits) return FSS_AMD_EINVAL;
+  if (!aligned16(cws, cw_s) || !aligned_to(tr_bits, 8)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_DPF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s), (uint4*)nullptr,
@@ -188,6 +195,7 @@ int fss_amd_vdpf_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party
       !x_ok(in_bits, x_bytes))
     return FSS_AMD_EINVAL;
   if (npoints > 0 && (!xs || !ys || !pi_tildes)) return FSS_AMD_EINVAL;
+  if (!aligned16(seed, cws, cs, ocw, ys, pi_tildes) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   VdpfArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = npoints;
@@ -203,6 +211,8 @@ int fss_amd_vdpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, 
   if (!ctx || nkeys < 0 || !group_ok(ctx, group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!seeds || !cw_s || !tr_bits || !cs || !ocws || !xs || !ys || !pi_tildes) return FSS_AMD_EINVAL;
+  if (!aligned16(seeds, cw_s, cs, ocws, ys, pi_tildes) || !aligned_to(tr_bits, 8) || !aligned_to(xs, x_bytes))
+    return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   VdpfArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = nkeys;
@@ -217,6 +227,7 @@ int fss_amd_vdpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, 
 
 int fss_amd_vdpf_prove(fss_amd_ctx* ctx, const void* pi_tildes, int64_t npoints, const void* cs, void* pi, void* stream) {
   if (!ctx || npoints < 0 || !cs || !pi || (npoints > 0 && !pi_tildes)) return FSS_AMD_EINVAL;
+  if (!aligned16(pi_tildes, cs, pi)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(vdpf_prove_kernel<true>, dim3(1), dim3(64), 0, S(stream), ctx->host,
                      reinterpret_cast<const uint4*>(pi_tildes), reinterpret_cast<const uint4*>(cs), npoints,
@@ -230,6 +241,7 @@ int fss_amd_vdpf_prove_keys(fss_amd_ctx* ctx, const void* pi_tildes, const void*
   if (!ctx || nkeys < 0) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!pi_tildes || !cs || !pis) return FSS_AMD_EINVAL;
+  if (!aligned16(pi_tildes, cs, pis)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 8;
   hipLaunchKernelGGL(vdpf_prove_kernel<false>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, S(stream),

@@ -157,6 +157,7 @@ const char* fss_amd_last_kernel(const fss_amd_ctx* ctx, int* grid, int* block) {
 // ------------------------------------------------------------------ raw PRG
 int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, void* out, void* stream) {
   if (!ctx || !seeds || !out || n < 0 || (mul != 1 && mul != 2 && mul != 4)) return FSS_AMD_EINVAL;
+  if (!aligned16(seeds, out)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
   FSS_ON_DEVICE(ctx);
   // one wave per workgroup for tiny batches (the LDS fill is per workgroup), 1024 lanes otherwise
@@ -178,6 +179,7 @@ static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, i
     return FSS_AMD_EINVAL;
   if (n > 0 && (!xs || !ys)) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !ocw) return FSS_AMD_EINVAL;
+  if (!aligned16(seed, cws, ocw, ys) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   EvalArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;
@@ -212,6 +214,7 @@ int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
   if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !tr_bits || !out_cw) return FSS_AMD_EINVAL;
+  if (!aligned16(cws, cw_s, out_cw) || !aligned_to(tr_bits, 8)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_DPF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
@@ -225,6 +228,7 @@ int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
   if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !cw_v || !out_cw) return FSS_AMD_EINVAL;
+  if (!aligned16(cws, cw_s, cw_v, out_cw)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_DCF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
@@ -238,6 +242,7 @@ int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t 
   if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !extra) return FSS_AMD_EINVAL;
+  if (!aligned16(cws, cw_s) || !aligned_to(extra, 4)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   hipLaunchKernelGGL(relayout_kernel<S_HT>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
@@ -257,6 +262,7 @@ static int key_major_common(fss_amd_ctx* ctx, int in_bits, const void* cw_s, con
   if (!cw_s || !cws || (SCHEME == S_DPF && (!tr_bits || !out_cw)) || (SCHEME == S_DCF && (!cw_v || !out_cw)) ||
       (SCHEME == S_HT && !extra))
     return FSS_AMD_EINVAL;
+  if (!aligned16(cw_s, cw_v, out_cw, cws) || !aligned_to(tr_bits, 8) || !aligned_to(extra, 4)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 8;
   hipLaunchKernelGGL(key_major_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, S(stream), in_bits,
@@ -291,6 +297,8 @@ static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int
   if (scheme == S_DPF && !tr_bits) return FSS_AMD_EINVAL;
   if (scheme == S_DCF && !cw_v) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !extra) return FSS_AMD_EINVAL;
+  if (!aligned16(seeds, cw_s, cw_v, out_cw, ys) || !aligned_to(tr_bits, 8) || !aligned_to(extra, 4) || !aligned_to(xs, x_bytes))
+    return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   EvalArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;

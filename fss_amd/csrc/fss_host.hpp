@@ -60,7 +60,6 @@ struct DeviceGuard {
   DeviceGuard guard_((ctx)->device);   \
   HIP_TRY(guard_.err)
 
-// FIPS-197 S-box from the field inverse and the affine map.
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // group id in range and, for Uint<T, mod> with a context modulus, the modulus representable in T
@@ -70,6 +69,12 @@ bool group_ok(const fss_amd_ctx* ctx, int g) {
   if (m == 0 || g < G_U8 || g > G_U32) return true;
   return m <= (1ull << (g == G_U8 ? 8 : (g == G_U16 ? 16 : 32)));
 }
+// Every int4 array of the interface is read and written with 16-byte accesses; null (optional) pointers pass.
+template <typename... P>
+bool aligned16(const P*... p) {
+  return (((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ...);
+}
+inline bool aligned_to(const void* p, int bytes) { return (reinterpret_cast<uintptr_t>(p) & (uintptr_t)(bytes - 1)) == 0; }
 bool x_ok(int in_bits, int x_bytes) {
   if (in_bits < 1) return false;
   if (x_bytes == 1) return in_bits <= 8;

@@ -17,6 +17,9 @@
  *    they enqueue kernels on `stream` (a hipStream_t passed as void*, NULL =
  *    default stream) and return, like the reference launchers
  *    (include/fss/point_eval_gpu.cuh:448-460).
+ *  - Alignment: every int4 / Cw array (seeds, cws, cw_s, cw_v, out_cw, ocws, cs, betas, ys, pi, workspaces)
+ *    must be 16-byte aligned (the reference's int4 is; its Cw is alignas(32)), tr_bits 8-byte, extra 4-byte,
+ *    xs / alphas sizeof(In)-aligned.  A misaligned pointer is FSS_AMD_EINVAL, never a device fault.
  *  - Return value: 0 on success, a negative FSS_AMD_E* code otherwise.  No
  *    exceptions cross the ABI.  There is no CPU fallback: without a usable HIP
  *    device fss_amd_ctx_create fails with FSS_AMD_EHIP.

@@ -51,6 +51,29 @@ def test_eval_all_argument_errors(raw):
     assert call(0, 256, ys=C.c_void_p(bufs["ys"].data_ptr() + 4)) == EINVAL  # misaligned output
 
 
+def test_misaligned_pointers_are_einval(raw):
+    """int4 arrays are 16-byte accessed, x arrays sizeof(In)-accessed (include/fss_amd.h, Conventions): a
+    misaligned pointer is refused on the host instead of faulting on the device."""
+    L, h, p, bufs = raw
+    off = lambda k, b: C.c_void_p(bufs[k].data_ptr() + b)
+    pts = lambda **kw: L.fss_amd_dpf_eval_points(h, 32, 4, 0, kw.get("seed", p["seed"]), kw.get("cws", p["cws"]),
+                                                 kw.get("xs", p["xs"]), kw.get("xb", 4), 8, kw.get("ys", p["ys"]), None)
+    assert pts(seed=off("seed", 16), cws=off("cws", 32), xs=off("xs", 4), ys=off("ys", 16)) == 0
+    for bad in (dict(seed=off("seed", 4)), dict(cws=off("cws", 8)), dict(ys=off("ys", 8)), dict(xs=off("xs", 2)),
+                dict(xs=off("xs", 4), xb=8)):
+        assert pts(**bad) == EINVAL, bad
+    keys = lambda **kw: L.fss_amd_dpf_eval_keys(h, 32, 4, 0, kw.get("seeds", p["seed"]), kw.get("cw_s", p["cws"]),
+                                                kw.get("tr", p["xs"]), kw.get("ocw", p["ocw"]), p["xs"], 4, 8,
+                                                kw.get("ys", p["ys"]), None)
+    assert keys() == 0
+    for bad in (dict(seeds=off("seed", 8)), dict(cw_s=off("cws", 4)), dict(tr=off("xs", 4)), dict(ocw=off("ocw", 4)),
+                dict(ys=off("ys", 12))):
+        assert keys(**bad) == EINVAL, bad
+    assert L.fss_amd_dpf_gen(h, 32, 4, p["seed"], p["xs"], 4, p["ocw"], 4, off("cws", 8), None) == EINVAL
+    assert L.fss_amd_prg_gen(h, 2, off("seed", 4), 4, p["ys"], None) == EINVAL
+    assert L.fss_amd_dpf_relayout(h, 32, p["cws"], 4, p["ws"], off("xs", 4), p["ocw"], None) == EINVAL
+
+
 def test_keys_gen_and_misc_argument_errors(raw):
     L, h, p, _ = raw
     assert L.fss_amd_dpf_eval_keys(h, 32, 4, 0, p["seed"], p["cws"], p["xs"], p["ocw"], p["xs"], 4, 8, p["ys"], None) == 0
