@@ -1,17 +1,22 @@
 """Randomised parity sweep: scheme x in_bits x group x party x batch size drawn from a seeded stream, HIP path
 against the oracle bit for bit (shared key, shared prefix, independent keys through device Gen + level-major
-relayout).  Complements the fixed matrices of test_gpu_parity.py with the sizes in between."""
+relayout), and the same for EvalAll (whole domains, aligned sub-blocks, key batches).  Complements the fixed
+matrices of test_gpu_parity.py with the sizes in between.  FSS_AMD_FUZZ_CASES=N widens every sweep to N seeded
+cases (48 / 40 by default; a 2000-case run is part of the round's GPU log)."""
+import os
+
 import numpy as np
 import pytest
 
 import groups as G
 from conftest import SplitMix64
-from test_gpu_parity import DCF, DPF, HT, T, rand_below, xs_tensor
+from test_gpu_parity import DCF, DPF, GROTTO, HT, T, rand_below, xs_tensor
 
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 GROUPS = [G.BYTES, G.U8, G.U16, G.U32, G.U64, G.U128]
+CASES = int(os.environ.get("FSS_AMD_FUZZ_CASES", "0"))
 
 
 def draw(rng):
@@ -22,7 +27,7 @@ def draw(rng):
     return scheme, n, g, count
 
 
-@pytest.mark.parametrize("case", range(48))
+@pytest.mark.parametrize("case", range(CASES or 48))
 def test_random_configuration_vs_oracle(engine, O, case):
     rng = SplitMix64(0xF5500000 + case)
     scheme, n, g, count = draw(rng)
@@ -59,3 +64,57 @@ def test_random_configuration_vs_oracle(engine, O, case):
         want = O.eval_points(p, scheme, n, g, b, s[b], cws, xs_np[:m] if n <= 64 else xs[:m], ocw=ocw, nthreads=4)
         got = engine.eval_keys(keys, g, b, T(np.ascontiguousarray(s0s[:, b])), xs_tensor(xs[:m], n), ocws=ocws).cpu().numpy()
         assert (got == want).all(), (scheme, n, g, b, m)
+
+
+def oracle_tree(O, p, scheme, n, g, b, s0, cws, ocw):
+    if scheme == DPF:
+        return O.dpf_eval_all(p, n, g, b, s0, cws)
+    if scheme == DCF:
+        return O.dcf_eval_all(p, n, g, b, s0, cws)
+    if scheme == HT:
+        return O.ht_eval_all(p, n, g, b, s0, cws, ocw)
+    return O.grotto_eval_all(p, n, b, s0, cws)
+
+
+@pytest.mark.parametrize("case", range(CASES or 40))
+def test_random_eval_all_vs_oracle(engine, O, case):
+    """Whole domain and one random aligned power-of-two block of it, both parties; every third case a key batch."""
+    rng = SplitMix64(0xEA110000 + case)
+    scheme = [DPF, DCF, HT, GROTTO][rng.next() % 4]
+    n = 1 + rng.next() % 17
+    g = G.BYTES if scheme == GROTTO else GROUPS[rng.next() % len(GROUPS)]
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1, GROTTO: 2}[scheme])
+    pred = rng.next() & 1
+    s = [rng.i4(clear_lsb=bool(rng.next() & 1)), rng.i4(clear_lsb=bool(rng.next() & 1))]
+    alpha, beta = rng.below(n), rng.i4(clear_lsb=False)
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, pred, s, alpha, beta)
+    elif scheme == HT:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    else:
+        cws = O.grotto_gen(p, n, s, alpha)
+    lo = 1 if scheme == HT else 0  # a Half-Tree block holds whole sibling pairs
+    r = lo + rng.next() % (n - lo + 1)
+    first = (rng.next() % (1 << (n - r))) << r
+    for b in (0, 1):
+        want = oracle_tree(O, p, scheme, n, g, b, s[b], cws, ocw)
+        dev = lambda **kw: engine.eval_all(scheme, n, g, b, T(s[b]), T(cws), ocw=None if ocw is None else T(ocw),
+                                           **kw).cpu().numpy()
+        assert (dev() == want).all(), (scheme, n, g, b)
+        if scheme != GROTTO:  # Grotto blocks need the carry of the blocks before them (test_grotto_eval_all_sharded_*)
+            assert (dev(first_leaf=first, nleaves=1 << r) == want[first:first + (1 << r)]).all(), (scheme, n, g, b, first, r)
+    if case % 3 == 0 and scheme != GROTTO and n <= 12:
+        nkeys = 1 + rng.next() % 70
+        s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
+        alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+        betas = np.stack([rng.i4() for _ in range(nkeys)])
+        kc, ko = O.gen_keys(p, scheme, n, g, s0s, alphas, betas, pred=pred, nthreads=4)
+        b = rng.next() & 1
+        got = engine.eval_all_batch(scheme, n, g, b, T(np.ascontiguousarray(s0s[:, b])), T(kc),
+                                    ocws=None if ko is None else T(ko)).cpu().numpy()
+        for k in {0, nkeys // 2, nkeys - 1}:
+            want = oracle_tree(O, p, scheme, n, g, b, s0s[k, b], kc[k], None if ko is None else ko[k])
+            assert (got[k] == want).all(), (scheme, n, g, b, nkeys, k)
