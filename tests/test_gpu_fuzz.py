@@ -2,7 +2,7 @@
 against the oracle bit for bit (shared key, shared prefix, independent keys through device Gen + level-major
 relayout), and the same for EvalAll (whole domains, aligned sub-blocks, key batches).  Complements the fixed
 matrices of test_gpu_parity.py with the sizes in between.  FSS_AMD_FUZZ_CASES=N widens every sweep to N seeded
-cases (48 / 40 by default; a 2000-case run is part of the round's GPU log)."""
+cases (48 / 40 by default; the 20000-case run is recorded in DESIGN.md section 2)."""
 import os
 
 import numpy as np
