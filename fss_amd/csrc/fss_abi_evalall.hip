@@ -39,6 +39,17 @@ inline int leaf_extra(int scheme) {
   return v >= 0 ? v : (scheme == S_HT ? 0 : 2);
 }
 
+// Extra rolled levels of the stages between the frontier and the leaf stage (FSS_AMD_MID_E = 0 .. 2): fewer,
+// deeper launches above the leaf stage.
+inline int mid_extra() {
+  static int v = [] {
+    const char* e = getenv("FSS_AMD_MID_E");
+    int t = e ? atoi(e) : 0;
+    return (t < 0 || t > 2) ? 0 : t;
+  }();
+  return v;
+}
+
 bool make_plan(int scheme, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl) {
   if (in_bits < 1 || in_bits > 62 || nleaves < 1 || first_leaf < 0) return false;
   if (nleaves & (nleaves - 1)) return false;
@@ -62,8 +73,9 @@ bool make_plan(int scheme, int in_bits, int64_t first_leaf, int64_t nleaves, Pla
   } else {
     const int leaf = rem < dm + leaf_extra(scheme) ? rem : dm + leaf_extra(scheme);
     rem -= leaf;
-    if (rem % dm) pl->D[pl->nstages++] = rem % dm;
-    for (int i = 0; i < rem / dm; ++i) pl->D[pl->nstages++] = dm;
+    const int mid = dm + mid_extra();  // shallowest stage first: it runs on the fewest nodes
+    if (rem % mid) pl->D[pl->nstages++] = rem % mid;
+    for (int i = 0; i < rem / mid; ++i) pl->D[pl->nstages++] = mid;
     pl->D[pl->nstages++] = leaf;
   }
   int64_t f = (int64_t)1 << top;
