@@ -127,6 +127,17 @@ def time_steps(fn, steps, warmup, dist):
     return wall, kernel_ms
 
 
+def time_steady(fn, steps=10, min_ms=150.0, warm_ms=60.0):
+    """Kernel-only rate of a short launch at steady clocks: the chip needs tens of milliseconds of continuous work
+    to reach its sustained clock (a 0.3 ms kernel timed over 10 launches runs 15 % below what it sustains), so warm
+    up for `warm_ms` of device time and time at least `min_ms` of back-to-back launches (>= `steps`)."""
+    _, est = time_steps(fn, 3, 1, None)
+    est = max(est, 1e-3)
+    warm = min(5000, max(2, int(warm_ms / est) + 1))
+    k = min(20000, max(steps, int(min_ms / est) + 1))
+    return time_steps(fn, k, warm, None)
+
+
 def make_key(eng, scheme, n, group_id, seed_val):
     """One valid key from fixed seeds, generated by the product's device Gen."""
     import fss_amd
@@ -330,7 +341,7 @@ def run_suite(args):
     res = []
 
     def record(name, units, fn, aes_per_unit, hbm_per_unit, steps=10):
-        wall, kms = time_steps(fn, steps, 2, None)
+        wall, kms = time_steady(fn, steps)
         rate = units / (kms * 1e-3)
         res.append({"config": name, "units_per_launch": units, "kernel_ms": kms, "units_per_s": rate,
                     "aes_blocks_per_s": rate * aes_per_unit,
@@ -516,8 +527,8 @@ def run_suite(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-batch", type=int, default=24)
     ap.add_argument("--cpu-sample", type=int, default=(1 << 24) if (os.cpu_count() or 1) >= 8 else (1 << 22), help="points of the batch timed on the CPU")
     ap.add_argument("--no-cpu", action="store_true")

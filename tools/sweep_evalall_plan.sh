@@ -5,5 +5,5 @@ for sch in ${SCHEMES:-dpf ht dcf}; do
 for cfg in "24 24" "26 26" "28 25"; do set -- $cfg
 for top in ${TOPS:-13 15 16}; do for mid in ${MIDS:-0 1 2}; do
   echo -n "$sch n=$1 leaves=2^$2 TOPMAX=$top MID_E=$mid: "
-  FSS_AMD_TOPMAX=$top FSS_AMD_MID_E=$mid python3 $R/tools/bench_evalall.py --scheme $sch --n $1 --log2-leaves $2 --steps 20 | tail -1
+  FSS_AMD_TOPMAX=$top FSS_AMD_MID_E=$mid python3 $R/tools/bench_evalall.py --scheme $sch --n $1 --log2-leaves $2 --steady | tail -1
 done; done; done; done
