@@ -539,13 +539,19 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
   a.seeds = reinterpret_cast<const uint4*>(seeds);
   a.cw_s = reinterpret_cast<const uint4*>(cw_s);
   a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
-  const int bs = 512;
+  static const int bs = [] {
+    const char* e = getenv("FSS_AMD_GROTTO_BS");
+    return (e && atoi(e) == 512) ? 512 : 1024;
+  }();
   return FSS_BY_PRG(ctx, ([&] {
-    int grid = 0;
-    int rc = persistent_grid(ctx, grotto_walk_kernel<LT, 512>, bs, nkeys, &grid);
-    if (rc != FSS_AMD_OK) return rc;
-    a.dyn = use_dyn(nkeys, 64, grid, bs);
-    return launch_grid(ctx, grotto_walk_kernel<LT, 512>, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
+    auto go = [&](auto kernel) {
+      int grid = 0;
+      int rc = persistent_grid(ctx, kernel, bs, nkeys, &grid);
+      if (rc != FSS_AMD_OK) return rc;
+      a.dyn = use_dyn(nkeys, 64, grid, bs);
+      return launch_grid(ctx, kernel, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
+    };
+    return bs == 512 ? go(grotto_walk_kernel<LT, 512>) : go(grotto_walk_kernel<LT, 1024>);
   }()));
 }
 
