@@ -551,6 +551,17 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
       a.dyn = use_dyn(nkeys, 64, grid, bs);
       return launch_grid(ctx, kernel, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
     };
+    // AES: taken child per level, siblings deferred to dense batches (FSS_AMD_GROTTO_DEFER=0: both children per level)
+    if constexpr (std::is_same_v<LT, Lds>) {
+      static const bool defer = [] { const char* e = getenv("FSS_AMD_GROTTO_DEFER"); return !(e && atoi(e) == 0); }();
+      if (defer && bs == 1024) {
+        int grid = 0;
+        int rc = persistent_grid(ctx, grotto_walk_defer_kernel<1024>, bs, (nkeys + 1) / 2, &grid);
+        if (rc != FSS_AMD_OK) return rc;
+        a.dyn = use_dyn(nkeys, 128, grid, bs);
+        return launch_grid(ctx, grotto_walk_defer_kernel<1024>, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
+      }
+    }
     return bs == 512 ? go(grotto_walk_kernel<LT, 512>) : go(grotto_walk_kernel<LT, 1024>);
   }()));
 }

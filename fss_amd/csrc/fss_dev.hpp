@@ -239,7 +239,10 @@ __device__ __forceinline__ const uint32_t* round_key(const Lds& L, const uint32_
 #endif
 }
 
-template <bool SEL>
+// LSB3: only bit 0 of out[3] (the control bit of a child) is wanted; out[3]'s other bits and out[0..2] are
+// unspecified.  That bit comes from one S-box lookup of the last round, which needs one column of round 9:
+// 133 lookups instead of 160 (the unused ones of the two last rounds disappear as dead code).
+template <bool SEL, bool LSB3 = false>
 __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict__ key, uint32_t mask,
                                         const uint32_t in[4], uint32_t out[4]) {
   constexpr int RS = SEL ? 8 : 4;  // key words per round
@@ -267,7 +270,7 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
     uint32_t d0 = lk<3, 3>(L, s3), d1 = lk<3, 3>(L, s0), d2 = lk<3, 3>(L, s1), d3 = lk<3, 3>(L, s2);
     // The next round's key load is anchored on a looked-up value: it is issued right after
     // this round's LDS wait, and has the whole VALU phase plus the next LDS phase to land.
-    const uint32_t* kn = round_key(L, key, RS * (r + 1), a0);
+    const uint32_t* kn = round_key(L, key, RS * (r + 1), (LSB3 && r == 9) ? a3 : a0);
     uint32_t knx[RS];
 #pragma unroll
     for (int j = 0; j < RS; ++j) knx[j] = kn[j];
@@ -290,7 +293,11 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
     for (int j = 0; j < RS; ++j) kc[j] = knx[j];
   }
   // Last round: S-box only, ShiftRows, AddRoundKey, then ^ in.
-  {
+  if constexpr (LSB3 && FSS_T4) {
+    static_assert(!SEL || !LSB3, "control-bit-only blocks use one key");
+    out[0] = out[1] = out[2] = 0u;
+    out[3] = xor3(lk<0, 2>(L, s3), in[3], kc[3]);  // byte 0 of word 3 = S(byte 0 of s3) ^ k ^ in
+  } else {
     const uint32_t* k = kc;
 #if FSS_T4
     // T2 has S in byte 0, T3 in byte 1, T0 in byte 2, T1 in byte 3: each lookup already
@@ -402,9 +409,14 @@ __device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k,
   }
 }
 
-template <bool SEL>
+template <bool SEL, bool LSB3 = false>
 __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], const uint32_t* k, const uint32_t* kd,
                                         uint32_t mask, const uint32_t in[4], uint32_t out[4]) {
+  if constexpr (LSB3 && FSS_T4) {  // see aes_mmo: v[3] = the last-round lookup of byte 0 of s3
+    out[0] = out[1] = out[2] = 0u;
+    out[3] = xor3(v[3], in[3], k[3]);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #if FSS_T4
@@ -430,7 +442,7 @@ __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], cons
 // maskA / maskB as for aes_mmo<SEL>; they may be the same or different key schedules.
 // RESD (two-key schedules only, keyA == keyB): the 44 (rkA ^ rkB) words come from `kdv`, registers
 // loaded once per kernel, so half of the key operands are VGPRs (2-cycle issue instead of 4).
-template <bool SEL, bool RESD = false>
+template <bool SEL, bool RESD = false, bool LSB3 = false>
 __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restrict__ keyA,
                                          const uint32_t* __restrict__ keyB, uint32_t maskA, uint32_t maskB,
                                          const uint32_t inA[4], const uint32_t inB[4], uint32_t outA[4],
@@ -473,7 +485,7 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
     else aes_addr16<true>(L, sA, vA);
     FSS_DRAIN_LGKM();  // B's round-r lookups and keys
     {
-      const uint32_t* kn = round_key(L, keyA, RS * (r + 1), sA[0]);
+      const uint32_t* kn = round_key(L, keyA, RS * (r + 1), sA[(LSB3 && r == 9) ? 3 : 0]);
       aes_load16(L, vA, vA);
 #pragma unroll
       for (int j = 0; j < RL; ++j) kA[j] = kn[j];
@@ -486,15 +498,15 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
   uint32_t kLA[RS], kLB[RS];  // last-round keys, all RS words from the scalar copy
   FSS_DRAIN_LGKM();  // A's last-round lookups
   {
-    const uint32_t* kn = round_key(L, keyB, RS * 10, sB[0]);
-    const uint32_t* kna = round_key(L, keyA, RS * 10, sB[1]);
+    const uint32_t* kn = round_key(L, keyB, RS * 10, sB[LSB3 ? 3 : 0]);
+    const uint32_t* kna = round_key(L, keyA, RS * 10, sB[LSB3 ? 3 : 1]);
     aes_load16(L, vB, vB);
 #pragma unroll
     for (int j = 0; j < RS; ++j) { kLB[j] = kn[j]; kLA[j] = kna[j]; }
   }
   FSS_DRAIN_LGKM();
-  aes_fin<SEL>(L, vA, kLA, kLA + 4, maskA, inA, outA);
-  aes_fin<SEL>(L, vB, kLB, kLB + 4, maskB, inB, outB);
+  aes_fin<SEL, LSB3>(L, vA, kLA, kLA + 4, maskA, inA, outA);
+  aes_fin<SEL, LSB3>(L, vB, kLB, kLB + 4, maskB, inB, outB);
 }
 
 // The DevCtx a kernel received by value as its FIRST argument, addressed in the kernarg segment
@@ -774,6 +786,19 @@ __device__ __forceinline__ void prg_hash2(const Lds& L, const DevCtx* __restrict
                                           const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
   aes_mmo2<false>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
 }
+// Control bits only (Grotto: leaves of the tree, left siblings of the path walk): bit 0 of the results is
+// bit 0 of word 3 of Gen(s)[0] / Gen(s)[1]; the other bits are unspecified.
+__device__ __forceinline__ uint32_t prg_tbit_left(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4]) {
+  uint32_t o[4];
+  aes_mmo<false, true>(L, c->rk[0], 0, s, o);
+  return o[3];
+}
+__device__ __forceinline__ void prg_tbits2(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t& tl,
+                                           uint32_t& tr) {
+  uint32_t l[4], r[4];
+  aes_mmo2<false, false, true>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
+  tl = l[3]; tr = r[3];
+}
 
 __device__ __forceinline__ void prg_gen2(const ChaChaL&, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t l[4],
                                          uint32_t r[4]) {
@@ -821,6 +846,12 @@ __device__ __forceinline__ void prg_hash2(const ChaChaL& L, const DevCtx* __rest
                                           const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
   prg_hash(L, c, ia, ha);
   prg_hash(L, c, ib, hb);
+}
+__device__ __forceinline__ void prg_tbits2(const ChaChaL& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t& tl,
+                                           uint32_t& tr) {
+  uint32_t l[4], r[4];
+  prg_gen2(L, c, s, l, r);
+  tl = l[3]; tr = r[3];
 }
 // Raw PRG outputs for fss_amd_prg_gen: out[j] for j < mul.
 __device__ __forceinline__ void prg_raw(const Lds& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],

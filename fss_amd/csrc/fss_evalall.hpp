@@ -57,6 +57,17 @@ __device__ __forceinline__ void dpf_expand(const LT& L, const DevCtx* __restrict
   left[3] = and_xor(tm, wl, left[3]);      right[3] = and_xor(tm, wr, right[3]);
 }
 
+// Grotto, last level: only the children's control bits (bit 0 of tl / tr; grotto_dcf.cuh:194-198).
+template <class LT>
+__device__ __forceinline__ void grotto_leaf_bits(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
+                                                 const uint32_t st[4], uint32_t& tl, uint32_t& tr) {
+  uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+  uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
+  prg_tbits2(L, c, in, tl, tr);
+  tl = and_xor(tm, cw[3], tl);
+  tr = and_xor(tm, cw[4], tr);
+}
+
 // DCF node (dcf.cuh:331-366): children plus their running values (positive terms;
 // the party sign is applied at the leaf).
 template <class LT>
@@ -241,6 +252,13 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
           vs[2 * k] = vl; vs[2 * k + 1] = vr;
         } else if constexpr (SCHEME == S_HT) {
           ht_expand(L, c, cw, nodes[k], l, r);
+        } else if constexpr (SCHEME == S_GROTTO && LEAF) {
+          if (lev == DE - 1) {  // the leaves are control bits: partial blocks
+            l[0] = l[1] = l[2] = r[0] = r[1] = r[2] = 0u;
+            grotto_leaf_bits(L, c, cw, nodes[k], l[3], r[3]);
+          } else {
+            dpf_expand(L, c, cw, nodes[k], l, r);
+          }
         } else {
           dpf_expand(L, c, cw, nodes[k], l, r);
         }

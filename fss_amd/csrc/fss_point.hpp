@@ -475,4 +475,112 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
   }
 }
 
+// The same walk with the siblings deferred (AES tables only).  A level needs the taken child of every lane
+// but the left sibling -- and of it only the control bit -- just where e's bit is 1: computing both children
+// everywhere is 2n blocks for the 1.5n the walk needs.  So a level computes the taken child only (per-lane
+// key select, two keys per lane interleaved) and lanes whose bit is 1 append (parent seed, owner) to a
+// per-wave queue in LDS; whenever 64 jobs are queued the wave runs one dense AES over them (key 0, every
+// lane busy) and XORs each job's control bit into its owner's accumulator with an LDS atomic (XOR commutes,
+// so the order of delivery is free).  The correction of the sibling's bit (t & cw.tl) is the owner's own.
+// A short queue is flushed at the end of the chunk (one partly filled AES per 128 keys x n levels).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int BS>
+__global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
+  const DevCtx* c = first_kernarg(K);
+  FSS_WAVEQ_PROLOGUE();
+  FSS_PRG_PROLOGUE(Lds, te0);
+  constexpr int NW = BS / 64;
+  __shared__ uint4 q_seed[NW][64];
+  __shared__ uint32_t q_own[NW][64];   // lane + 64 * j of the key that waits for the bit
+  __shared__ uint32_t q_acc[NW][128];  // per key of the chunk: XOR of the delivered bits
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  q_acc[wv][lane] = 0u;
+  q_acc[wv][lane + 64] = 0u;
+  const int n = a.in_bits;
+  uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
+  // one dense AES over the first `count` queued jobs of this wave
+  auto flush = [&](int count) {
+    wave_lds_sync();
+    if (lane < count) {
+      const uint4 s4 = q_seed[wv][lane];
+      const uint32_t own = q_own[wv][lane];
+      uint32_t in[4] = {s4.x, s4.y, s4.z, s4.w};
+      // key 0 = the left child (aes128_mmo.cuh:79-89); in[3]'s control bit is clear; control bit only
+      atomicXor(&q_acc[wv][own], prg_tbit_left(L, c, in) & 1u);
+    }
+    wave_lds_sync();
+  };
+  WaveQ q(a.dyn, &waveq_ctr_, a.n, 2);
+  for (int64_t base; q.next(base);) {
+    int64_t k[2];
+    bool valid[2], whole[2];
+    uint64_t e[2], trb[2];
+    uint32_t st[2][4], pi[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      valid[j] = base + 64 * j < a.n;
+      k[j] = valid[j] ? base + 64 * j : 0;  // idle lanes walk key 0 and drop the result
+      e[j] = load_x(a.xs, a.x_bytes, k[j]).lo + 1;
+      whole[j] = n == 64 ? (e[j] == 0) : (e[j] == (1ull << n));
+      const uint4 s4 = a.seeds[k[j]];
+      st[j][0] = s4.x; st[j][1] = s4.y; st[j][2] = s4.z; st[j][3] = (s4.w & ~1u) | (uint32_t)a.party;
+      trb[j] = a.tr_bits[k[j]];
+    }
+    int pending = 0;  // jobs queued by this wave (wave-uniform)
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+      uint4 t[2];
+      uint32_t m[2], tm[2], in[2][4], o[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        t[j] = FSS_LD_STREAM(a.cw_s + (int64_t)i * a.n + k[j]);
+        m[j] = bit_mask(e[j], n - 1 - i);
+        tm[j] = lsb_mask(st[j][3]);
+        in[j][0] = st[j][0]; in[j][1] = st[j][1]; in[j][2] = st[j][2]; in[j][3] = st[j][3] & ~1u;
+      }
+      prg_take2x2(L, c, m[0], m[1], in[0], in[1], o[0], o[1]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint32_t wl = t[j].w, wr = (t[j].w & ~1u) | ((uint32_t)(trb[j] >> i) & 1u);
+        st[j][0] = and_xor(tm[j], t[j].x, o[j][0]);
+        st[j][1] = and_xor(tm[j], t[j].y, o[j][1]);
+        st[j][2] = and_xor(tm[j], t[j].z, o[j][2]);
+        st[j][3] = and_xor(tm[j], m[j] ? wr : wl, o[j][3]);
+        pi[j] ^= m[j] & tm[j] & wl & 1u;  // the sibling's correction; its PRG bit arrives through the queue
+        const bool has = valid[j] && m[j] != 0u;
+        const uint64_t bal = __ballot(has);
+        const int cnt = __builtin_amdgcn_readfirstlane(__popcll(bal));
+        const int pos = pending + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (has && pos < 64) {
+          q_seed[wv][pos] = make_uint4(in[j][0], in[j][1], in[j][2], in[j][3]);
+          q_own[wv][pos] = (uint32_t)(lane + 64 * j);
+        }
+        if (pending + cnt >= 64) {
+          flush(64);
+          if (has && pos >= 64) {
+            q_seed[wv][pos - 64] = make_uint4(in[j][0], in[j][1], in[j][2], in[j][3]);
+            q_own[wv][pos - 64] = (uint32_t)(lane + 64 * j);
+          }
+          pending += cnt - 64;
+        } else {
+          pending += cnt;
+        }
+      }
+    }
+    if (pending > 0) flush(pending);
+    else wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      pi[j] ^= q_acc[wv][lane + 64 * j];
+      q_acc[wv][lane + 64 * j] = 0u;
+      if (valid[j]) ys[k[j]] = (uint8_t)(whole[j] ? (uint32_t)a.party : pi[j]);
+    }
+    wave_lds_sync();
+  }
+}
+
 }  // namespace fssamd

@@ -431,10 +431,9 @@ def test_grotto_preprocess_and_table_eval_vs_oracle(engine, O, n):
         assert ((sh[0] ^ sh[1]) == (xs >= alpha)).all()
 
 
-@pytest.mark.parametrize("n", [1, 16, 32, 64])
-def test_grotto_eval_keys_vs_oracle_walk(engine, O, n):
-    rng = SplitMix64(901 + n)
-    nkeys = 200
+@pytest.mark.parametrize("n,nkeys", [(1, 200), (16, 200), (32, 200), (64, 200), (64, 1), (64, 63), (64, 129), (37, 4099)])
+def test_grotto_eval_keys_vs_oracle_walk(engine, O, n, nkeys):
+    rng = SplitMix64(901 + n + 7 * nkeys)
     p = O.Prg(2)
     s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
     alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
@@ -529,6 +528,28 @@ def test_full_size_half_tree_keys_reconstruct(engine, O):
     want0 = O.eval_keys(p, HT, n, g, 0, s0s[:, 0].numpy()[idx], cws.cpu().numpy()[idx],
                         xs.numpy().view(np.uint64)[idx], ocws=ocws.cpu().numpy()[idx], nthreads=4)
     assert (y[0].cpu().numpy()[idx] == want0).all()
+
+
+def test_full_size_grotto_keys_reconstruct(engine, O):
+    """configs[4] shape, Grotto half (n=64, independent keys, path walk) at 2^20 keys generated on the device: the
+    two shares XOR to 1[alpha <= x] (unsigned) for every key; a sample equals the oracle's walk bit for bit."""
+    n, nkeys = 64, 1 << 20
+    gen = torch.Generator().manual_seed(77)
+    s0s = torch.randint(-2**31, 2**31, (nkeys, 2, 4), dtype=torch.int32, generator=gen)
+    alphas = torch.randint(-2**63, 2**63 - 1, (nkeys,), dtype=torch.int64, generator=gen)
+    xs = torch.randint(-2**63, 2**63 - 1, (nkeys,), dtype=torch.int64, generator=gen)
+    xs[0::5] = alphas[0::5]
+    xs[1::5] = alphas[1::5] - 1  # wraps at alpha = 0, like the unsigned domain
+    xs[2] = -1                   # x = 2^64 - 1: the whole-domain case
+    keys, _ = engine.gen_level_major(GROTTO, n, G.BYTES, s0s.cuda(), alphas.cuda(),
+                                      torch.zeros((nkeys, 4), dtype=torch.int32, device="cuda"))
+    sh = [engine.eval_keys(keys, G.BYTES, b, s0s[:, b].contiguous().cuda(), xs.cuda()).cpu().numpy() for b in (0, 1)]
+    au, xu = alphas.numpy().view(np.uint64), xs.numpy().view(np.uint64)
+    assert ((sh[0] ^ sh[1]) == (au <= xu)).all()
+    idx = np.arange(0, nkeys, 4093)
+    cws = engine.key_major(keys).cpu().numpy()[idx]
+    want0 = O.eval_keys(O.Prg(2), GROTTO, n, G.BYTES, 0, s0s[:, 0].numpy()[idx], cws, xu[idx], nthreads=4)[:, 0].astype(np.uint8)
+    assert (sh[0][idx] == want0).all()
 
 
 def test_cxx_sample_self_check():
