@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time fss_amd EvalAll for one scheme/size (used under rocprofv3 to see the per-stage split)."""
-import argparse, os, sys, time
+import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, fss_amd
 from bench import make_key, time_steady, time_steps
