@@ -340,13 +340,13 @@ def run_suite(args):
     eng = fss_amd.default_engine(0)
     res = []
 
-    def record(name, units, fn, aes_per_unit, hbm_per_unit, steps=10):
+    def record(name, units, fn, aes_per_unit, hbm_per_unit, steps=10, e=None):
         wall, kms = time_steady(fn, steps)
         rate = units / (kms * 1e-3)
         res.append({"config": name, "units_per_launch": units, "kernel_ms": kms, "units_per_s": rate,
                     "aes_blocks_per_s": rate * aes_per_unit,
                     "lds_frac": rate * aes_per_unit * LOOKUP_BYTES_PER_AES / 1e9 / LDS_PEAK_GBS,
-                    "hbm_gbs_algorithmic": rate * hbm_per_unit / 1e9, "kernel": eng.last_kernel()})
+                    "hbm_gbs_algorithmic": rate * hbm_per_unit / 1e9, "kernel": (e or eng).last_kernel()})
         print(json.dumps(res[-1]), file=sys.stderr, flush=True)
 
     G = fss_amd.U64
@@ -432,7 +432,7 @@ def run_suite(args):
         od = None if ocw is None else ocw.cuda()
         ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
         record(f"chacha {scheme} n={n} 1 key x 2^{lb} points", batch,
-               lambda: ceng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys), 0, hbm_bytes_per_eval(scheme, n, True))
+               lambda: ceng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys), 0, hbm_bytes_per_eval(scheme, n, True), e=ceng)
     for scheme, n, lk in (("dpf", 20, 22), ("dcf", 20, 21), ("ht", 20, 22)):
         nk = 1 << lk
         gen = torch.Generator(device="cuda").manual_seed(200 + n)
@@ -445,7 +445,7 @@ def run_suite(args):
         seeds0 = s0s[:, 0].contiguous()
         ys = torch.empty((nk, 4), dtype=torch.int32, device="cuda")
         record(f"chacha {scheme} n={n} 2^{lk} independent keys x 1 point", nk,
-               lambda: ceng.eval_keys(keys, G, 0, seeds0, xs, ocws=ocws, out=ys), 0, hbm_bytes_per_eval(scheme, n, False))
+               lambda: ceng.eval_keys(keys, G, 0, seeds0, xs, ocws=ocws, out=ys), 0, hbm_bytes_per_eval(scheme, n, False), e=ceng)
         del keys, ys
     # verifiable DPF: walk + one keyed-BLAKE3 XorHash per evaluation; the reference's GPU number
     # is ChaCha + BLAKE3 at n = 20 (README.md:389, BM_VdpfEvalPointGpu: 945 M eval/s on RTX PRO 5000)
@@ -463,12 +463,12 @@ def run_suite(args):
         outs = (torch.empty((nk, 4), dtype=torch.int32, device="cuda"), torch.empty((nk, 4, 4), dtype=torch.int32, device="cuda"))
         record(f"{tag} vdpf n={n} 2^{lk} independent keys x 1 point (y + pi~)", nk,
                lambda: veng.vdpf_eval_keys(keys, G, 0, seeds0, cs, ocws, xs, out=outs),
-               n if tag.startswith("aes") else 0, 16 + 4 + n * 16 + 8 + 64 + 16 + 16 + 64)
+               n if tag.startswith("aes") else 0, 16 + 4 + n * 16 + 8 + 64 + 16 + 16 + 64, e=veng)
         del keys, outs
     sid, s0s, cws, ocw, _, _ = make_key(ceng, "dpf", 24, G, 5)
     sd, cd = s0s[0].cuda(), cws.cuda()
     ys = torch.empty((1 << 24, 4), dtype=torch.int32, device="cuda")
-    record("chacha dpf EvalAll n=24", 1 << 24, lambda: ceng.eval_all(sid, 24, G, 0, sd, cd, out=ys), 0, 16, steps=5)
+    record("chacha dpf EvalAll n=24", 1 << 24, lambda: ceng.eval_all(sid, 24, G, 0, sd, cd, out=ys), 0, 16, steps=5, e=ceng)
     del ys
 
     # Grotto DCF full domain: the DPF tree over Bytes with beta = 0, leaf control bits, then the running-XOR scan
@@ -490,8 +490,22 @@ def run_suite(args):
     for beng, tag in ((eng, "aes"), (ceng, "chacha")):
         for mul in (1, 2, 4):
             record(f"{tag} prg Gen mul={mul}, 2^24 seeds", 1 << 24, lambda: beng.prg_gen(mul, seeds),
-                   mul if tag == "aes" else 0, 16 + 16 * mul, steps=5)
+                   mul if tag == "aes" else 0, 16 + 16 * mul, steps=5, e=beng)
     del seeds
+
+    # key-major <-> level-major transpositions (fss::gpu::*RelayoutGpu, point_eval_gpu.cuh:324-375, and the inverse):
+    # pure copies, HBM-bound (hbm_gbs_algorithmic / 8000 is their roofline fraction); one-time work in the
+    # reference's benches (src/bench_gpu.cu:618-619)
+    for scheme, n in (("dpf", 32), ("dcf", 32), ("ht", 64)):
+        nk = 1 << 22
+        sid = {"dpf": fss_amd.DPF, "dcf": fss_amd.DCF, "ht": fss_amd.HT}[scheme]
+        slots = n if scheme == "ht" else n + 1
+        km = torch.randint(-2**31, 2**31, (nk, slots, 8), dtype=torch.int32, device="cuda")
+        moved = slots * 32 + n * (32 if scheme == "dcf" else 16) + 24
+        record(f"{scheme} relayout n={n}, 2^22 keys (key-major -> level-major)", nk, lambda: eng.relayout(sid, n, km), 0, moved, steps=5)
+        lm = eng.relayout(sid, n, km)
+        record(f"{scheme} key_major n={n}, 2^22 keys (level-major -> key-major)", nk, lambda: eng.key_major(lm), 0, moved, steps=5)
+        del km, lm
 
     # batched full domain (fss::gpu::*EvalAllGpuBatch; the reference's n = 20 rows, README.md:384-385: ChaCha,
     # DPF 15.43 and Half-Tree 12.09 G outputs/s on RTX PRO 5000)
@@ -507,7 +521,7 @@ def run_suite(args):
             yb = torch.empty((nk, 1 << n, 4), dtype=torch.int32, device="cuda")
             record(f"{tag} {scheme} EvalAll batch n={n} x {nk} keys", nk << n,
                    lambda: beng.eval_all_batch(sid, n, G, 0, seeds0, cws, ocws=ocws, out=yb),
-                   (2 if scheme == "dpf" else 1.5) if tag == "aes" else 0, 16, steps=5)
+                   (2 if scheme == "dpf" else 1.5) if tag == "aes" else 0, 16, steps=5, e=beng)
             del yb
 
     # full domain

@@ -48,6 +48,9 @@ static int gen_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int 
   else
     FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((ht_gen_kernel<LT, LM>), dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, a));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = scheme == S_DPF ? "dpf_gen" : (scheme == S_DCF ? "dcf_gen" : "ht_gen");
+  ctx->last_grid = grid;
+  ctx->last_block = bs;
   return FSS_AMD_OK;
 }
 
@@ -157,6 +160,9 @@ static int vdpf_gen_common(fss_amd_ctx* ctx, int in_bits, int group, const void*
   a.dyn = use_dyn(nkeys, 64, grid, bs);
   FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((vdpf_gen_kernel<LT, LM>), dim3(grid), dim3(bs), 0, S(stream), ctx->host, ctx->te0, a));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "vdpf_gen";
+  ctx->last_grid = grid;
+  ctx->last_block = bs;
   return FSS_AMD_OK;
 }
 
@@ -185,6 +191,9 @@ int fss_amd_vdpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s), (uint4*)nullptr,
                      reinterpret_cast<uint64_t*>(tr_bits), (uint4*)nullptr, (uint32_t*)nullptr);
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "relayout";
+  ctx->last_grid = (int)((nkeys + 63) / 64);
+  ctx->last_block = 256;
   return FSS_AMD_OK;
 }
 
@@ -233,6 +242,9 @@ int fss_amd_vdpf_prove(fss_amd_ctx* ctx, const void* pi_tildes, int64_t npoints,
                      reinterpret_cast<const uint4*>(pi_tildes), reinterpret_cast<const uint4*>(cs), npoints,
                      reinterpret_cast<uint4*>(pi));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "vdpf_prove";
+  ctx->last_grid = 1;
+  ctx->last_block = 64;
   return FSS_AMD_OK;
 }
 
@@ -248,6 +260,9 @@ int fss_amd_vdpf_prove_keys(fss_amd_ctx* ctx, const void* pi_tildes, const void*
                      ctx->host, reinterpret_cast<const uint4*>(pi_tildes), reinterpret_cast<const uint4*>(cs), nkeys,
                      reinterpret_cast<uint4*>(pis));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "vdpf_prove_keys";
+  ctx->last_grid = (int)(want < cap ? want : cap);
+  ctx->last_block = 256;
   return FSS_AMD_OK;
 }
 

@@ -168,6 +168,9 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
                                       reinterpret_cast<const uint4*>(seeds), n, reinterpret_cast<uint4*>(out),
                                       use_dyn(n, 64, grid, bs)));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "prg_gen";
+  ctx->last_grid = grid;
+  ctx->last_block = bs;
   return FSS_AMD_OK;
 }
 
@@ -221,6 +224,9 @@ int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
                      (uint4*)nullptr, reinterpret_cast<uint64_t*>(tr_bits), reinterpret_cast<uint4*>(out_cw),
                      (uint32_t*)nullptr);
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "relayout";
+  ctx->last_grid = (int)((nkeys + 63) / 64);
+  ctx->last_block = 256;
   return FSS_AMD_OK;
 }
 int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* cw_v,
@@ -235,6 +241,9 @@ int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
                      reinterpret_cast<uint4*>(cw_v), (uint64_t*)nullptr, reinterpret_cast<uint4*>(out_cw),
                      (uint32_t*)nullptr);
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "relayout";
+  ctx->last_grid = (int)((nkeys + 63) / 64);
+  ctx->last_block = 256;
   return FSS_AMD_OK;
 }
 int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* extra,
@@ -248,6 +257,9 @@ int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t 
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      (uint4*)nullptr, (uint64_t*)nullptr, (uint4*)nullptr, reinterpret_cast<uint32_t*>(extra));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "relayout";
+  ctx->last_grid = (int)((nkeys + 63) / 64);
+  ctx->last_block = 256;
   return FSS_AMD_OK;
 }
 
@@ -270,6 +282,9 @@ static int key_major_common(fss_amd_ctx* ctx, int in_bits, const void* cw_s, con
                      reinterpret_cast<const uint64_t*>(tr_bits), reinterpret_cast<const uint4*>(out_cw),
                      reinterpret_cast<const uint32_t*>(extra), nkeys, reinterpret_cast<uint4*>(cws));
   HIP_TRY(hipGetLastError());
+  ctx->last_kernel = "key_major";
+  ctx->last_grid = (int)(want < cap ? want : cap);
+  ctx->last_block = 256;
   return FSS_AMD_OK;
 }
 extern "C" {

@@ -603,6 +603,14 @@ struct WaveQ {
   }
 };
 
+// Orders this wave's LDS accesses around a hand-over between its lanes (the LDS executes a wave's
+// instructions in order; this keeps the compiler from moving them across the hand-over).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Rotating wave priority, for launches too small for WaveQ's dynamic distribution: the four waves that
 // share a SIMD take turns, level by level, at being preferred by the instruction arbiter instead of the
 // oldest always winning, so they finish closer together (+6 % at 2^20 points, +9 % at 2^24 when static;

@@ -483,11 +483,6 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
 // lane busy) and XORs each job's control bit into its owner's accumulator with an LDS atomic (XOR commutes,
 // so the order of delivery is free).  The correction of the sibling's bit (t & cw.tl) is the owner's own.
 // A short queue is flushed at the end of the chunk (one partly filled AES per 128 keys x n levels).
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 template <int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
   const DevCtx* c = first_kernarg(K);
