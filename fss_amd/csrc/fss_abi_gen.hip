@@ -187,7 +187,7 @@ int fss_amd_vdpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_
   if (!cws || !cw_s || !tr_bits) return FSS_AMD_EINVAL;
   if (!aligned16(cws, cw_s) || !aligned_to(tr_bits, 8)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
-  hipLaunchKernelGGL(relayout_kernel<S_DPF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+  launch_relayout<S_DPF>(ctx, S(stream), in_bits,
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s), (uint4*)nullptr,
                      reinterpret_cast<uint64_t*>(tr_bits), (uint4*)nullptr, (uint32_t*)nullptr);
   HIP_TRY(hipGetLastError());

@@ -219,7 +219,7 @@ int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
   if (!cws || !cw_s || !tr_bits || !out_cw) return FSS_AMD_EINVAL;
   if (!aligned16(cws, cw_s, out_cw) || !aligned_to(tr_bits, 8)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
-  hipLaunchKernelGGL(relayout_kernel<S_DPF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+  launch_relayout<S_DPF>(ctx, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      (uint4*)nullptr, reinterpret_cast<uint64_t*>(tr_bits), reinterpret_cast<uint4*>(out_cw),
                      (uint32_t*)nullptr);
@@ -236,7 +236,7 @@ int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t
   if (!cws || !cw_s || !cw_v || !out_cw) return FSS_AMD_EINVAL;
   if (!aligned16(cws, cw_s, cw_v, out_cw)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
-  hipLaunchKernelGGL(relayout_kernel<S_DCF>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+  launch_relayout<S_DCF>(ctx, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      reinterpret_cast<uint4*>(cw_v), (uint64_t*)nullptr, reinterpret_cast<uint4*>(out_cw),
                      (uint32_t*)nullptr);
@@ -253,7 +253,7 @@ int fss_amd_ht_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t 
   if (!cws || !cw_s || !extra) return FSS_AMD_EINVAL;
   if (!aligned16(cws, cw_s) || !aligned_to(extra, 4)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
-  hipLaunchKernelGGL(relayout_kernel<S_HT>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, S(stream), in_bits,
+  launch_relayout<S_HT>(ctx, S(stream), in_bits,
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      (uint4*)nullptr, (uint64_t*)nullptr, (uint4*)nullptr, reinterpret_cast<uint32_t*>(extra));
   HIP_TRY(hipGetLastError());

@@ -70,6 +70,70 @@ __global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, 
   }
 }
 
+// The same transposition staged through LDS, the mirror image of key_major_kernel below: a wave owns 64 keys
+// and moves them four levels at a time; on the key-major side eight lanes read the 128 contiguous bytes (four
+// slots) of one key, on the level-major side a store instruction is 64 keys x 16 B of one level.
+template <int SCHEME>
+__global__ __launch_bounds__(256) void relayout_tiled_kernel(int in_bits, int stride, const uint4* __restrict__ cws,
+                                                             int64_t nkeys, uint4* __restrict__ cw_s,
+                                                             uint4* __restrict__ cw_v, uint64_t* __restrict__ tr_bits,
+                                                             uint4* __restrict__ out_cw, uint32_t* __restrict__ extra) {
+  __shared__ uint4 tile[4][8][65];  // [wave][level-in-group * 2 + half][key], padded: the eight lanes of a key hit different banks
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t ntiles = (nkeys + 63) / 64;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wv; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t k0 = t * 64, k = k0 + lane;
+    const bool mine = k < nkeys;
+    unsigned long long lo = 0ull, hi = 0ull;
+    for (int ig = 0; ig < stride; ig += 4) {
+#pragma unroll
+      for (int pass = 0; pass < 8; ++pass) {
+        const int kk = pass * 8 + (lane >> 3), part = lane & 7, i = ig + (part >> 1);
+        if (k0 + kk < nkeys && i < stride) tile[wv][part][kk] = cws[(k0 + kk) * (int64_t)stride * 2 + 2 * ig + part];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = ig + j;
+        if (!mine || i >= stride) continue;
+        const uint4 s4 = tile[wv][2 * j][lane], v4 = tile[wv][2 * j + 1][lane];
+        if (i < in_bits) {
+          cw_s[(int64_t)i * nkeys + k] = s4;
+          if (SCHEME == S_DCF) cw_v[(int64_t)i * nkeys + k] = v4;
+          if (SCHEME == S_DPF) {
+            if (i < 64) lo |= (unsigned long long)(v4.x & 1u) << i;
+            else hi |= (unsigned long long)(v4.x & 1u) << (i - 64);
+          }
+          if (SCHEME == S_HT && i == in_bits - 1) extra[k] = v4.x & 1u;
+        } else {  // slot in_bits of a DPF / DCF key
+          if (SCHEME == S_DPF && out_cw) out_cw[k] = s4;
+          if (SCHEME == S_DCF) out_cw[k] = v4;
+        }
+      }
+      wave_lds_sync();
+    }
+    if (SCHEME == S_DPF && mine) {
+      tr_bits[k] = lo;
+      if (in_bits > 64) tr_bits[nkeys + k] = hi;
+    }
+  }
+}
+
+// Host side: the tiled kernel by default, FSS_AMD_RELAYOUT=0 selects the one-key-per-lane kernel (A/B).
+template <int SCHEME, class Ctx>
+void launch_relayout(Ctx* ctx, hipStream_t st, int in_bits, int stride, const uint4* cws, int64_t nkeys, uint4* cw_s,
+                     uint4* cw_v, uint64_t* tr_bits, uint4* out_cw, uint32_t* extra) {
+  static const bool tiled = [] { const char* e = getenv("FSS_AMD_RELAYOUT"); return !(e && atoi(e) == 0); }();
+  if (tiled) {
+    const int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 4;
+    hipLaunchKernelGGL(relayout_tiled_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, in_bits,
+                       stride, cws, nkeys, cw_s, cw_v, tr_bits, out_cw, extra);
+  } else {
+    hipLaunchKernelGGL(relayout_kernel<SCHEME>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, st, in_bits, stride, cws,
+                       nkeys, cw_s, cw_v, tr_bits, out_cw, extra);
+  }
+}
+
 // Level-major arrays -> key-major raw Cw slots: the inverse of relayout_kernel, for shipping keys generated
 // level-major in the reference's 32-byte-slot format; whole slots are written (both 16-byte halves, padding
 // zero) as the reference's Gen does (dpf.cuh:147-153).  A wave owns 64 keys and moves them four levels at a
@@ -84,8 +148,8 @@ __global__ __launch_bounds__(256) void key_major_kernel(int in_bits, const uint4
                                                         const uint32_t* __restrict__ extra, int64_t nkeys,
                                                         uint4* __restrict__ cws) {
   constexpr bool kV = SCHEME == S_DCF;
-  __shared__ uint4 tile_s[4][4][64];
-  __shared__ uint4 tile_v[kV ? 4 : 1][4][64];
+  __shared__ uint4 tile_s[4][4][65];  // padded: lanes reading different levels of one key hit different banks
+  __shared__ uint4 tile_v[kV ? 4 : 1][4][65];
   __shared__ unsigned long long bits[4][2][64];  // DPF: tr bits (two planes); Half-Tree: extra
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int stride = SCHEME == S_HT ? in_bits : in_bits + 1;  // slots per key
