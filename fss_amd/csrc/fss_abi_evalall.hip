@@ -6,19 +6,23 @@
 
 namespace {
 
-// The first frontier comes from independent point walks (taken child only): 2^15 lanes x ~15 AES is
-// ~20 us of chip time, cheaper than the tiny expansion launches it replaces (~35 us each:
-// launch, 128 KiB LDS fill per workgroup, drain).
-constexpr int kTopMaxDefault = 15;
-inline int top_max() {
+// The first frontier comes from independent point walks (taken child only): cheaper than the tiny expansion
+// launches they replace (each a launch, a 128 KiB LDS fill per workgroup and a drain: >= 10 us for almost no
+// work).  DPF / Grotto walks cost one block per level and pay up to 2^18 lanes x 18 levels (every wave of the
+// chip busy, ~40 us) -- measured optimum, tools/sweep_evalall_small.sh: n = 20 in 76 us instead of 93 (15
+// levels), n = 24 +5 %; at 19 levels the walk itself dominates.  DCF (two blocks per level) and Half-Tree are
+// best at 15, and so is every scheme with the ChaCha PRG, whose walk level costs a whole permutation (`aes` =
+// the context uses the AES tables).  FSS_AMD_TOPMAX overrides (A/B).  The workspace queries have no context
+// and return the larger of the two plans' needs.
+inline int top_max(int scheme, bool aes) {
   static int v = [] {
     const char* e = getenv("FSS_AMD_TOPMAX");
-    int t = e ? atoi(e) : kTopMaxDefault;
-    return (t < 0 || t > 20) ? kTopMaxDefault : t;
+    int t = e ? atoi(e) : -1;
+    return (t < 0 || t > 20) ? -1 : t;
   }();
-  return v;
+  if (v >= 0) return v;
+  return (aes && (scheme == S_DPF || scheme == S_GROTTO)) ? 18 : 15;
 }
-#define kTopMax top_max()
 
 struct Plan {
   int r, p, top, nstages;
@@ -30,13 +34,21 @@ inline int dmax_for(int scheme) { return scheme == S_DCF ? 1 : 2; }  // levels e
 // Extra levels the last stage of a plan walks depth-first above those (expand_kernel's E): the deeper the
 // last stage, the smaller and fewer the launches above it.  FSS_AMD_LEAF_E = 0 .. 2.
 // Measured at 2^24 leaves: DPF +3 %, DCF +5 % with two extra levels, Half-Tree -7 % (its nodes cost one AES).
-inline int leaf_extra(int scheme) {
+// A deep leaf stage needs enough input nodes to give every wave of the chip a chunk (64 nodes x 4096 waves =
+// 2^18): below that the launch is a latency chain run by a fraction of the waves, and a shallower last stage
+// on more nodes is faster (DPF n = 20: 136 -> 94 us with E = 0, tools/sweep_evalall_small.sh).
+// log2_leaves = log2 of the leaves the stage produces in total (all keys of a batch).
+inline int leaf_extra(int scheme, int log2_leaves) {
   static int v = [] {
     const char* e = getenv("FSS_AMD_LEAF_E");
     int t = e ? atoi(e) : -1;
     return (t < 0 || t > 2) ? -1 : t;
   }();
-  return v >= 0 ? v : (scheme == S_HT ? 0 : 2);
+  if (v >= 0) return v;
+  int e = scheme == S_HT ? 0 : 2;
+  const int room = log2_leaves - dmax_for(scheme) - 18;
+  if (e > room) e = room < 0 ? 0 : room;
+  return e;
 }
 
 // Extra rolled levels of the stages between the frontier and the leaf stage (FSS_AMD_MID_E = 0 .. 2): fewer,
@@ -50,7 +62,7 @@ inline int mid_extra() {
   return v;
 }
 
-bool make_plan(int scheme, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl) {
+bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl) {
   if (in_bits < 1 || in_bits > 62 || nleaves < 1 || first_leaf < 0) return false;
   if (nleaves & (nleaves - 1)) return false;
   int r = 0;
@@ -62,7 +74,7 @@ bool make_plan(int scheme, int in_bits, int64_t first_leaf, int64_t nleaves, Pla
   pl->r = r;
   pl->p = in_bits - r;
   int top = r - (scheme == S_HT ? 1 : 0);
-  if (top > kTopMax) top = kTopMax;
+  if (top > top_max(scheme, aes)) top = top_max(scheme, aes);
   pl->top = top;
   int rem = r - top;
   const int dm = dmax_for(scheme);
@@ -71,7 +83,8 @@ bool make_plan(int scheme, int in_bits, int64_t first_leaf, int64_t nleaves, Pla
   if (rem == 0) {
     pl->D[pl->nstages++] = 0;  // leaf conversion only
   } else {
-    const int leaf = rem < dm + leaf_extra(scheme) ? rem : dm + leaf_extra(scheme);
+    const int le = leaf_extra(scheme, r);
+    const int leaf = rem < dm + le ? rem : dm + le;
     rem -= leaf;
     const int mid = dm + mid_extra();  // shallowest stage first: it runs on the fewest nodes
     if (rem % mid) pl->D[pl->nstages++] = rem % mid;
@@ -148,7 +161,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   if (!ctx || !seed || !cws || !ys || !group_ok(ctx, group) || (party != 0 && party != 1)) return FSS_AMD_EINVAL;
   if (SCHEME == S_HT && !ocw) return FSS_AMD_EINVAL;
   Plan pl;
-  if (!make_plan(SCHEME, in_bits, first_leaf, nleaves, &pl)) return FSS_AMD_EINVAL;
+  if (!make_plan(SCHEME, ctx->prg != FSS_AMD_PRG_CHACHA, in_bits, first_leaf, nleaves, &pl)) return FSS_AMD_EINVAL;
   size_t need = plan_workspace(SCHEME, pl, nleaves);
   if (!workspace || ws_bytes < need) return FSS_AMD_EINVAL;
   if (!aligned16(seed, cws, ocw, ys, workspace)) return FSS_AMD_EINVAL;
@@ -217,7 +230,7 @@ struct BatchPlan {
   int64_t nkeys;
 };
 
-bool make_batch_plan(int scheme, int in_bits, int64_t nkeys, BatchPlan* bp) {
+bool make_batch_plan(int scheme, bool aes, int in_bits, int64_t nkeys, BatchPlan* bp) {
   if (nkeys < 1 || in_bits < 1 || in_bits > 40) return false;
   if (nkeys > ((int64_t)1 << 40) >> in_bits) return false;  // at most 2^40 leaves in one call
   Plan& pl = bp->pl;
@@ -227,7 +240,7 @@ bool make_batch_plan(int scheme, int in_bits, int64_t nkeys, BatchPlan* bp) {
   int lk = 0;
   while (((int64_t)1 << lk) < nkeys) ++lk;
   int top = in_bits - (scheme == S_HT ? 1 : 0);
-  int want = kTopMax - lk;
+  int want = top_max(scheme, aes) - lk;
   if (want < 0) want = 0;
   if (top > want) top = want;
   pl.top = top;
@@ -237,7 +250,8 @@ bool make_batch_plan(int scheme, int in_bits, int64_t nkeys, BatchPlan* bp) {
   if (rem == 0) {
     pl.D[pl.nstages++] = 0;
   } else {
-    const int leaf = rem < dm + leaf_extra(scheme) ? rem : dm + leaf_extra(scheme);
+    const int le = leaf_extra(scheme, in_bits + lk);
+    const int leaf = rem < dm + le ? rem : dm + le;
     rem -= leaf;
     if (rem % dm) pl.D[pl.nstages++] = rem % dm;
     for (int i = 0; i < rem / dm; ++i) pl.D[pl.nstages++] = dm;
@@ -266,7 +280,7 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   if (nkeys == 0) return FSS_AMD_OK;
   if (!seeds || !cws || !ys || (SCHEME == S_HT && !ocws)) return FSS_AMD_EINVAL;
   BatchPlan bp;
-  if (!make_batch_plan(SCHEME, in_bits, nkeys, &bp)) return FSS_AMD_EINVAL;
+  if (!make_batch_plan(SCHEME, ctx->prg != FSS_AMD_PRG_CHACHA, in_bits, nkeys, &bp)) return FSS_AMD_EINVAL;
   const Plan& pl = bp.pl;
   if (!workspace || ws_bytes < batch_workspace(SCHEME, bp)) return FSS_AMD_EINVAL;
   if (!aligned16(seeds, cws, ocws, ys, workspace)) return FSS_AMD_EINVAL;
@@ -326,17 +340,18 @@ struct PrefixPlan {
   int64_t cap_a, cap_b;  // intermediate frontiers (the last stage writes the node table itself)
 };
 
-bool make_prefix_plan(int scheme, int in_bits, int k, PrefixPlan* pl) {
+bool make_prefix_plan(int scheme, bool aes, int in_bits, int k, PrefixPlan* pl) {
   if (k < 1 || k > kPrefixMax || k > in_bits) return false;
   if (scheme == S_HT && k > in_bits - 1) return false;
   if (scheme != S_DPF && scheme != S_DCF && scheme != S_HT) return false;
-  int top = k < kTopMax ? k : kTopMax;
+  int top = k < top_max(scheme, aes) ? k : top_max(scheme, aes);
   pl->top = top;
   int rem = k - top;
   const int dm = dmax_for(scheme);
   pl->nstages = 0;
   if (rem > 0) {
-    const int last = rem < dm + leaf_extra(scheme) ? rem : dm + leaf_extra(scheme);
+    const int le = leaf_extra(scheme, k);
+    const int last = rem < dm + le ? rem : dm + le;
     rem -= last;
     if (rem % dm) pl->D[pl->nstages++] = rem % dm;
     for (int i = 0; i < rem / dm; ++i) pl->D[pl->nstages++] = dm;
@@ -368,7 +383,7 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
   if (n > 0 && (!xs || !ys)) return FSS_AMD_EINVAL;
   if (SCHEME == S_HT && !ocw) return FSS_AMD_EINVAL;
   PrefixPlan pl;
-  if (!make_prefix_plan(SCHEME, in_bits, k, &pl)) return FSS_AMD_EINVAL;
+  if (!make_prefix_plan(SCHEME, ctx->prg != FSS_AMD_PRG_CHACHA, in_bits, k, &pl)) return FSS_AMD_EINVAL;
   if (!workspace || ws_bytes < prefix_workspace(SCHEME, pl, k)) return FSS_AMD_EINVAL;
   if (!aligned16(seed, cws, ocw, ys, workspace) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
@@ -431,8 +446,13 @@ extern "C" {
 
 size_t fss_amd_eval_points_workspace(int scheme, int in_bits, int prefix_bits) {
   PrefixPlan pl;
-  if (!make_prefix_plan(scheme, in_bits, prefix_bits, &pl)) return 0;
-  return prefix_workspace(scheme, pl, prefix_bits);
+  size_t need = 0;
+  for (int aes = 0; aes < 2; ++aes) {
+    if (!make_prefix_plan(scheme, aes != 0, in_bits, prefix_bits, &pl)) return 0;
+    const size_t b = prefix_workspace(scheme, pl, prefix_bits);
+    if (b > need) need = b;
+  }
+  return need;
 }
 
 int fss_amd_dpf_eval_points_shared(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed,
@@ -457,8 +477,13 @@ int fss_amd_ht_eval_points_shared(fss_amd_ctx* ctx, int in_bits, int group, int 
 size_t fss_amd_eval_all_workspace(int scheme, int in_bits, int64_t nleaves) {
   Plan pl;
   if (scheme < 0 || scheme > 3) return 0;
-  if (!make_plan(scheme, in_bits, 0, nleaves, &pl)) return 0;
-  return plan_workspace(scheme, pl, nleaves);
+  size_t need = 0;
+  for (int aes = 0; aes < 2; ++aes) {
+    if (!make_plan(scheme, aes != 0, in_bits, 0, nleaves, &pl)) return 0;
+    const size_t b = plan_workspace(scheme, pl, nleaves);
+    if (b > need) need = b;
+  }
+  return need;
 }
 
 int fss_amd_dpf_eval_all(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
@@ -569,8 +594,14 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
 // ------------------------------------------------------------------ batched full-domain evaluation
 size_t fss_amd_eval_all_batch_workspace(int scheme, int in_bits, int64_t nkeys) {
   BatchPlan bp;
-  if ((scheme != S_DPF && scheme != S_DCF && scheme != S_HT) || !make_batch_plan(scheme, in_bits, nkeys, &bp)) return 0;
-  return batch_workspace(scheme, bp);
+  if (scheme != S_DPF && scheme != S_DCF && scheme != S_HT) return 0;
+  size_t need = 0;
+  for (int aes = 0; aes < 2; ++aes) {
+    if (!make_batch_plan(scheme, aes != 0, in_bits, nkeys, &bp)) return 0;
+    const size_t b = batch_workspace(scheme, bp);
+    if (b > need) need = b;
+  }
+  return need;
 }
 int fss_amd_dpf_eval_all_batch(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cws,
                                int64_t nkeys, void* ys, void* workspace, size_t workspace_bytes, void* stream) {
