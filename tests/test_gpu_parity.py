@@ -309,6 +309,35 @@ def test_eval_all_vs_oracle(engine, O, scheme, n, g):
         assert (got == ref(b)).all(), (scheme, n, g, b)
 
 
+@pytest.mark.parametrize("scheme,n", [(DPF, 18), (DPF, 19), (DPF, 20), (DPF, 21), (DPF, 22), (GROTTO, 19), (GROTTO, 21),
+                                      (DCF, 17), (DCF, 19), (DCF, 20), (DCF, 21), (HT, 17), (HT, 18), (HT, 19), (HT, 21)])
+def test_eval_all_planner_shapes_vs_oracle(engine, O, scheme, n):
+    """Domains around the planner's thresholds (frontier depth 15 / 18, leaf-stage depth sized by the domain:
+    fss_abi_evalall.hip top_max / leaf_extra), whole and as the second quarter, bit for bit."""
+    rng = SplitMix64(5150 + 100 * scheme + n)
+    g = G.BYTES if scheme == GROTTO else G.U64
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1, GROTTO: 2}[scheme])
+    s = [rng.i4(), rng.i4()]
+    alpha, beta, ocw = rng.below(n), beta_for(rng), None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+        want = O.dpf_eval_all(p, n, g, 1, s[1], cws)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 0, s, alpha, beta)
+        want = O.dcf_eval_all(p, n, g, 1, s[1], cws)
+    elif scheme == HT:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+        want = O.ht_eval_all(p, n, g, 1, s[1], cws, ocw)
+    else:
+        cws = O.grotto_gen(p, n, s, alpha)
+        want = O.grotto_eval_all(p, n, 1, s[1], cws)
+    dev = lambda **kw: engine.eval_all(scheme, n, g, 1, T(s[1]), T(cws), ocw=None if ocw is None else T(ocw), **kw).cpu().numpy()
+    assert (dev() == want).all()
+    if scheme != GROTTO:
+        q = 1 << (n - 2)
+        assert (dev(first_leaf=q, nleaves=q) == want[q:2 * q]).all()
+
+
 @pytest.mark.parametrize("scheme", [DPF, DCF, HT])
 def test_eval_all_subblocks(engine, O, scheme):
     """Domain sharding: aligned power-of-two blocks reproduce the slices of the whole."""
