@@ -118,3 +118,26 @@ def test_random_eval_all_vs_oracle(engine, O, case):
         for k in {0, nkeys // 2, nkeys - 1}:
             want = oracle_tree(O, p, scheme, n, g, b, s0s[k, b], kc[k], None if ko is None else ko[k])
             assert (got[k] == want).all(), (scheme, n, g, b, nkeys, k)
+
+
+@pytest.mark.parametrize("case", range(CASES or 24))
+def test_random_grotto_walk_vs_oracle(engine, O, case):
+    """Grotto path walk (fss_amd_grotto_eval_keys: taken child per level, siblings batched through the per-wave
+    queue) against the oracle's walk and the predicate, random domain sizes and ragged key counts."""
+    rng = SplitMix64(0x6A077000 + case)
+    n = 1 + rng.next() % 64
+    nkeys = [1, 2, 63, 64, 65, 127, 128, 129, 200, 1000][rng.next() % 10]
+    p = O.Prg(2)
+    s0s = np.stack([np.stack([rng.i4(clear_lsb=bool(rng.next() & 1)), rng.i4()]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    cws, _ = O.gen_keys(p, GROTTO, n, G.BYTES, s0s, alphas, np.zeros((nkeys, 4), np.int32), nthreads=4)
+    top = (1 << n) - 1
+    xs = np.array([[alphas[i], top, 0, rng.below(n), (int(alphas[i]) - 1) & top][i % 5] for i in range(nkeys)], dtype=np.uint64)
+    keys = engine.relayout(GROTTO, n, T(cws))
+    sh = []
+    for b in (0, 1):
+        want = O.eval_keys(p, GROTTO, n, G.BYTES, b, s0s[:, b], cws, xs, nthreads=4)[:, 0].astype(np.uint8)
+        got = engine.eval_keys(keys, G.BYTES, b, T(s0s[:, b].copy()), xs_tensor(xs, n)).cpu().numpy()
+        assert (got == want).all(), (n, nkeys, b)
+        sh.append(got)
+    assert ((sh[0] ^ sh[1]) == (alphas <= xs)).all(), (n, nkeys)
