@@ -14,6 +14,14 @@ namespace {
 // best at 15, and so is every scheme with the ChaCha PRG, whose walk level costs a whole permutation (`aes` =
 // the context uses the AES tables).  FSS_AMD_TOPMAX overrides (A/B).  The workspace queries have no context
 // and return the larger of the two plans' needs.
+// DPF / Grotto / Half-Tree with the AES tables walk the frontier one block per QUAD of lanes
+// (frontier_quad_kernel, FSS_AMD_QUAD_FRONTIER=0: one walk per lane): a level costs ~0.9 us instead of ~2.2,
+// and the optimum is 16 levels (DPF n = 20: 60 us, n = 24: +5 % over 18 per-lane levels; Half-Tree n = 20:
+// 75 -> 49 us, n = 24: +7 %).
+inline bool quad_frontier() {
+  static const bool v = [] { const char* e = getenv("FSS_AMD_QUAD_FRONTIER"); return !(e && atoi(e) == 0); }();
+  return v;
+}
 inline int top_max(int scheme, bool aes) {
   static int v = [] {
     const char* e = getenv("FSS_AMD_TOPMAX");
@@ -21,7 +29,9 @@ inline int top_max(int scheme, bool aes) {
     return (t < 0 || t > 20) ? -1 : t;
   }();
   if (v >= 0) return v;
-  return (aes && (scheme == S_DPF || scheme == S_GROTTO)) ? 18 : 15;
+  if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return quad_frontier() ? 16 : 18;
+  if (aes && scheme == S_HT) return quad_frontier() ? 16 : 15;
+  return 15;
 }
 
 struct Plan {
@@ -154,6 +164,31 @@ int launch_stage(fss_amd_ctx* ctx, int T, bool leaf, const SharedKey& k, const E
   return FSS_AMD_EINVAL;
 }
 
+// The first frontier: one walk per lane, or -- DPF / Grotto / Half-Tree with the AES tables -- one walk per quad of lanes
+// (frontier_quad_kernel; FSS_AMD_QUAD_FRONTIER=0 selects the per-lane kernel).
+template <int SCHEME, bool BATCH>
+int launch_frontier(fss_amd_ctx* ctx, hipStream_t st, int64_t nout, const uint32_t* seed, const uint32_t* cws,
+                    const ExpandArgs& a, int top) {
+  constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
+  if constexpr (WS == S_DPF || WS == S_HT) if (ctx->prg != FSS_AMD_PRG_CHACHA && quad_frontier()) {
+    const int64_t lanes = nout * 4;
+    const int fbs = lanes >= 65536 ? 1024 : (lanes >= 256 ? 256 : 64);
+    const int64_t want = (lanes + fbs - 1) / fbs, cap = (int64_t)ctx->num_cu * (1024 / fbs);
+    hipLaunchKernelGGL((frontier_quad_kernel<WS, BATCH>), dim3((unsigned)(want < cap ? want : cap)), dim3(fbs), 0, st, ctx->host,
+                       ctx->te0, seed, cws, a, top);
+    HIP_TRY(hipGetLastError());
+    return FSS_AMD_OK;
+  }
+  {
+    const int fbs = nout >= 65536 ? 1024 : (nout >= 256 ? 256 : 64);  // few walks: spread them over CUs
+    const int64_t want = (nout + fbs - 1) / fbs, cap = BATCH ? (int64_t)ctx->num_cu * (1024 / fbs) * 4 : want;
+    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((frontier_kernel<LT, WS, BATCH>), dim3((unsigned)(want < cap ? want : cap)), dim3(fbs),
+                                        0, st, ctx->host, ctx->te0, seed, cws, a, top));
+  }
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+
 template <int SCHEME>
 int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
                   const void* ocw, int64_t first_leaf, int64_t nleaves, void* ys, void* workspace, size_t ws_bytes,
@@ -186,12 +221,8 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   a.out_nodes = bufn[0];
   a.out_v = bufv[0];
   {
-    int64_t nout = (int64_t)1 << pl.top;
-    int fbs = nout >= 65536 ? 1024 : (nout >= 256 ? 256 : 64);  // few walks: spread them over CUs
-    int grid = (int)((nout + fbs - 1) / fbs);
-    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((frontier_kernel<LT, SCHEME == S_GROTTO ? S_DPF : SCHEME>), dim3(grid), dim3(fbs),
-                                        0, st, ctx->host, ctx->te0, k.seed, k.cws, a, pl.top));
-    HIP_TRY(hipGetLastError());
+    int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, k.seed, k.cws, a, pl.top);
+    if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = (int64_t)1 << pl.top;
   int level = pl.p + pl.top;
@@ -306,13 +337,8 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   a.out_nodes = bufn[0];
   a.out_v = bufv[0];
   {
-    int64_t nout = nkeys << pl.top;
-    int fbs = nout >= 65536 ? 1024 : (nout >= 256 ? 256 : 64);
-    int64_t want = (nout + fbs - 1) / fbs, cap = (int64_t)ctx->num_cu * (1024 / fbs) * 4;
-    int grid = (int)(want < cap ? want : cap);
-    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((frontier_kernel<LT, SCHEME, true>), dim3(grid), dim3(fbs), 0, st, ctx->host,
-                                        ctx->te0, (const uint32_t*)nullptr, k.cws, a, pl.top));
-    HIP_TRY(hipGetLastError());
+    int rc = launch_frontier<SCHEME, true>(ctx, st, nkeys << pl.top, nullptr, k.cws, a, pl.top);
+    if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = nkeys << pl.top;
   int level = pl.top, cur = 0;
@@ -410,12 +436,8 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
   e.out_nodes = pl.nstages ? bufn[0] : tab_n;
   e.out_v = pl.nstages ? bufv[0] : tab_v;
   {
-    int64_t nout = (int64_t)1 << pl.top;
-    int fbs = nout >= 65536 ? 1024 : (nout >= 256 ? 256 : 64);
-    int grid = (int)((nout + fbs - 1) / fbs);
-    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((frontier_kernel<LT, SCHEME>), dim3(grid), dim3(fbs), 0, st, ctx->host, ctx->te0,
-                                        key.seed, key.cws, e, pl.top));
-    HIP_TRY(hipGetLastError());
+    int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, key.seed, key.cws, e, pl.top);
+    if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = (int64_t)1 << pl.top;
   int level = pl.top, cur = 0;

@@ -16,6 +16,7 @@
 // (include/fss/grotto_dcf.cuh:190-238); replaces the kernels of
 // include/fss/eval_all_gpu.cuh:207-268, :62-150.
 #pragma once
+#include <cstddef>
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
 
@@ -177,6 +178,87 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
       }
       a.out_nodes[j] = make_uint4(w.st[0], w.st[1], w.st[2], w.st[3]);
     }
+  }
+}
+
+// -- frontier, DPF / Grotto with the AES tables: one walk per QUAD of lanes ---------------------------------
+// The frontier is a latency chain: `depth` blocks one after the other, and a lone wave issues a VALU op only
+// every ~7 clk, so a block costs ~2 us however few walks there are.  Here four adjacent lanes
+// share one walk, a state column each: per round a lane does the four table lookups of ITS column's bytes
+// (T0[b0], T1[b1], T2[b2], T3[b3]) and column q of the next state is A(q) ^ B(q+1) ^ C(q+2) ^ D(q+3), the
+// three foreign terms fetched with DPP quad_perm moves -- ~10 VALU and 4 lookups per round on the critical
+// path instead of ~36 and 16.  Same lookups in total, a quarter of the chain.  The lane's column of the
+// two-key schedule {rkA, rkA ^ rkB} (DevCtx::sel01) sits in 22 VGPRs.
+#define FSS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_get(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+// Column q of AES_k(in) for the quad's block; SEL: k = key A where m == 0, key B where m == ~0 (ka = rkA,
+// kd = rkA ^ rkB, this lane's column of every round).
+template <bool SEL>
+__device__ __forceinline__ uint32_t quad_aes(const Lds& L, uint32_t in, uint32_t m, const uint32_t ka[11], const uint32_t kd[11]) {
+  uint32_t s = SEL ? xor3(in, ka[0], m & kd[0]) : (in ^ ka[0]);
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    const uint32_t A = lk<0, 0>(L, s), B = lk<1, 1>(L, s), C = lk<2, 2>(L, s), D = lk<3, 3>(L, s);
+    const uint32_t x = xor3(A, quad_get<FSS_QP(1, 2, 3, 0)>(B), quad_get<FSS_QP(2, 3, 0, 1)>(C));
+    s = xor3(x, quad_get<FSS_QP(3, 0, 1, 2)>(D), SEL ? and_xor(m, kd[r], ka[r]) : ka[r]);
+  }
+  // last round: the tables that hold S in the output byte position (aes_mmo)
+  const uint32_t A = lk<0, 2>(L, s), B = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, s)),
+                 C = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, s)), D = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, s));
+  const uint32_t pcol = (A & 0xffu) | (B & 0xff00u) | (C & 0xff0000u) | (D & 0xff000000u);
+  return pcol ^ (SEL ? and_xor(m, kd[10], ka[10]) : ka[10]);
+}
+
+template <int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto) or S_HT
+__global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                            const uint32_t* __restrict__ k_seed,
+                                                            const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
+  static_assert(SCHEME == S_DPF || SCHEME == S_HT, "quad frontier: DPF / Grotto / Half-Tree");
+  const DevCtx* c = first_kernarg(K);
+  FSS_PRG_PROLOGUE(Lds, te0);
+  const int q = threadIdx.x & 3;
+  const uint32_t is3 = q == 3 ? ~0u : 0u;
+  uint32_t ka[11], kd[11];
+  {
+    const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01) : offsetof(DevCtx, rk)) / 4;
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+      ka[r] = SCHEME == S_DPF ? gk[8 * r + q] : gk[4 * r + q];  // Half-Tree hashes with key 0 (half_tree_dpf.cuh:195)
+      kd[r] = SCHEME == S_DPF ? gk[8 * r + 4 + q] : 0u;
+    }
+  }
+  const uint32_t hk = SCHEME == S_HT ? (c->self_dev + offsetof(DevCtx, hash_key) / 4)[q] : 0u;
+  const int depth = a.level0;  // p + top
+  const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;
+  const int64_t nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
+  for (int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; j < nout; j += nquads) {
+    const int64_t key = BATCH ? (j >> top) : 0;
+    const uint64_t path = BATCH ? (uint64_t)(j & (((int64_t)1 << top) - 1)) : ((top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j);
+    const uint32_t* kc = BATCH ? k_cws + 8 * key * a.key_slots : k_cws;
+    uint32_t st = BATCH ? reinterpret_cast<const uint32_t*>(a.seeds + key)[q] : k_seed[q];
+    st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);  // dpf.cuh:171-173, half_tree_dpf.cuh:188
+#pragma unroll 1
+    for (int i = 0; i < depth; ++i) {
+      const uint32_t m = bit_mask(path, depth - 1 - i);  // the same for the four lanes of a walk
+      const uint32_t w = kc[8 * i + q];
+      const uint32_t tm = lsb_mask(quad_get<FSS_QP(3, 3, 3, 3)>(st));
+      if constexpr (SCHEME == S_DPF) {
+        const uint32_t trw = kc[8 * i + 4];
+        const uint32_t in = st & ~(is3 & 1u);
+        const uint32_t o = quad_aes<true>(L, in, m, ka, kd) ^ in;
+        // correction (DpfWalk::apply): word 3 carries tl_cw / tr_cw in bit 0
+        const uint32_t cwq = w ^ (is3 & m & ((w ^ trw) & 1u));
+        st = and_xor(tm, cwq, o);
+      } else {
+        const uint32_t in = st ^ hk;
+        const uint32_t h = quad_aes<false>(L, in, 0u, ka, kd) ^ in;  // HtWalk::level
+        st = and_xor(m, st, and_xor(tm, w, h));
+      }
+    }
+    reinterpret_cast<uint32_t*>(a.out_nodes)[4 * j + q] = st;
   }
 }
 
