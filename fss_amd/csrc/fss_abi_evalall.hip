@@ -14,10 +14,10 @@ namespace {
 // best at 15, and so is every scheme with the ChaCha PRG, whose walk level costs a whole permutation (`aes` =
 // the context uses the AES tables).  FSS_AMD_TOPMAX overrides (A/B).  The workspace queries have no context
 // and return the larger of the two plans' needs.
-// DPF / Grotto / Half-Tree with the AES tables walk the frontier one block per QUAD of lanes
+// With the AES tables every scheme walks the frontier one block per QUAD of lanes
 // (frontier_quad_kernel, FSS_AMD_QUAD_FRONTIER=0: one walk per lane): a level costs ~0.9 us instead of ~2.2,
 // and the optimum is 16 levels (DPF n = 20: 60 us, n = 24: +5 % over 18 per-lane levels; Half-Tree n = 20:
-// 75 -> 49 us, n = 24: +7 %).
+// 75 -> 49 us, n = 24: +7 %; DCF, two blocks and a group addition per level: n = 20 146 -> 132 us, n = 24 +3 %).
 inline bool quad_frontier() {
   static const bool v = [] { const char* e = getenv("FSS_AMD_QUAD_FRONTIER"); return !(e && atoi(e) == 0); }();
   return v;
@@ -29,8 +29,8 @@ inline int top_max(int scheme, bool aes) {
     return (t < 0 || t > 20) ? -1 : t;
   }();
   if (v >= 0) return v;
-  if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return quad_frontier() ? 16 : 18;
-  if (aes && scheme == S_HT) return quad_frontier() ? 16 : 15;
+  if (aes && quad_frontier()) return 16;
+  if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return 18;
   return 15;
 }
 
@@ -164,13 +164,13 @@ int launch_stage(fss_amd_ctx* ctx, int T, bool leaf, const SharedKey& k, const E
   return FSS_AMD_EINVAL;
 }
 
-// The first frontier: one walk per lane, or -- DPF / Grotto / Half-Tree with the AES tables -- one walk per quad of lanes
+// The first frontier: one walk per lane (ChaCha), or -- with the AES tables -- one walk per quad of lanes
 // (frontier_quad_kernel; FSS_AMD_QUAD_FRONTIER=0 selects the per-lane kernel).
 template <int SCHEME, bool BATCH>
 int launch_frontier(fss_amd_ctx* ctx, hipStream_t st, int64_t nout, const uint32_t* seed, const uint32_t* cws,
                     const ExpandArgs& a, int top) {
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
-  if constexpr (WS == S_DPF || WS == S_HT) if (ctx->prg != FSS_AMD_PRG_CHACHA && quad_frontier()) {
+  if (ctx->prg != FSS_AMD_PRG_CHACHA && quad_frontier()) {
     const int64_t lanes = nout * 4;
     const int fbs = lanes >= 65536 ? 1024 : (lanes >= 256 ? 256 : 64);
     const int64_t want = (lanes + fbs - 1) / fbs, cap = (int64_t)ctx->num_cu * (1024 / fbs);

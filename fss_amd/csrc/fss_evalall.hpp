@@ -212,24 +212,50 @@ __device__ __forceinline__ uint32_t quad_aes(const Lds& L, uint32_t in, uint32_t
   return pcol ^ (SEL ? and_xor(m, kd[10], ka[10]) : ka[10]);
 }
 
-template <int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto) or S_HT
+// Two blocks of the same input under two selected keys (DCF: seed and value of the taken side), their
+// rounds interleaved so that the lookups of one fly during the exchanges of the other.
+__device__ __forceinline__ void quad_aes_pair(const Lds& L, uint32_t in, uint32_t m, const uint32_t ka[11], const uint32_t kd[11],
+                                              const uint32_t kb[11], const uint32_t ke[11], uint32_t& oa, uint32_t& ob) {
+  uint32_t s = xor3(in, ka[0], m & kd[0]), t = xor3(in, kb[0], m & ke[0]);
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    const uint32_t A = lk<0, 0>(L, s), B = lk<1, 1>(L, s), C = lk<2, 2>(L, s), D = lk<3, 3>(L, s);
+    const uint32_t E = lk<0, 0>(L, t), F = lk<1, 1>(L, t), G = lk<2, 2>(L, t), H = lk<3, 3>(L, t);
+    const uint32_t x = xor3(A, quad_get<FSS_QP(1, 2, 3, 0)>(B), quad_get<FSS_QP(2, 3, 0, 1)>(C));
+    const uint32_t y = xor3(E, quad_get<FSS_QP(1, 2, 3, 0)>(F), quad_get<FSS_QP(2, 3, 0, 1)>(G));
+    s = xor3(x, quad_get<FSS_QP(3, 0, 1, 2)>(D), and_xor(m, kd[r], ka[r]));
+    t = xor3(y, quad_get<FSS_QP(3, 0, 1, 2)>(H), and_xor(m, ke[r], kb[r]));
+  }
+  const uint32_t A = lk<0, 2>(L, s), B = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, s)),
+                 C = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, s)), D = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, s));
+  const uint32_t E = lk<0, 2>(L, t), F = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, t)),
+                 G = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, t)), H = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, t));
+  oa = ((A & 0xffu) | (B & 0xff00u) | (C & 0xff0000u) | (D & 0xff000000u)) ^ and_xor(m, kd[10], ka[10]);
+  ob = ((E & 0xffu) | (F & 0xff00u) | (G & 0xff0000u) | (H & 0xff000000u)) ^ and_xor(m, ke[10], kb[10]);
+}
+
+template <int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
 __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
                                                             const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
-  static_assert(SCHEME == S_DPF || SCHEME == S_HT, "quad frontier: DPF / Grotto / Half-Tree");
+  static_assert(SCHEME == S_DPF || SCHEME == S_DCF || SCHEME == S_HT, "quad frontier: DPF / Grotto / DCF / Half-Tree");
   const DevCtx* c = first_kernarg(K);
   FSS_PRG_PROLOGUE(Lds, te0);
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
   uint32_t ka[11], kd[11];
+  uint32_t kb[SCHEME == S_DCF ? 11 : 1], ke[SCHEME == S_DCF ? 11 : 1];  // DCF: the value block's keys 1 / 3 (dcf.cuh:223)
   {
-    const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01) : offsetof(DevCtx, rk)) / 4;
+    const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01) : (SCHEME == S_DCF ? offsetof(DevCtx, sel02) : offsetof(DevCtx, rk))) / 4;
+    const uint32_t* gv = c->self_dev + offsetof(DevCtx, sel13) / 4;
 #pragma unroll
     for (int r = 0; r < 11; ++r) {
-      ka[r] = SCHEME == S_DPF ? gk[8 * r + q] : gk[4 * r + q];  // Half-Tree hashes with key 0 (half_tree_dpf.cuh:195)
-      kd[r] = SCHEME == S_DPF ? gk[8 * r + 4 + q] : 0u;
+      ka[r] = SCHEME == S_HT ? gk[4 * r + q] : gk[8 * r + q];  // Half-Tree hashes with key 0 (half_tree_dpf.cuh:195)
+      kd[r] = SCHEME == S_HT ? 0u : gk[8 * r + 4 + q];
+      if constexpr (SCHEME == S_DCF) { kb[r] = gv[8 * r + q]; ke[r] = gv[8 * r + 4 + q]; }
     }
   }
+  const Grp g = make_grp(a.group, c);
   const uint32_t hk = SCHEME == S_HT ? (c->self_dev + offsetof(DevCtx, hash_key) / 4)[q] : 0u;
   const int depth = a.level0;  // p + top
   const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;
@@ -240,6 +266,7 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
     const uint32_t* kc = BATCH ? k_cws + 8 * key * a.key_slots : k_cws;
     uint32_t st = BATCH ? reinterpret_cast<const uint32_t*>(a.seeds + key)[q] : k_seed[q];
     st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);  // dpf.cuh:171-173, half_tree_dpf.cuh:188
+    Acc v;  // DCF: the running value, kept whole (and identical) in the four lanes
 #pragma unroll 1
     for (int i = 0; i < depth; ++i) {
       const uint32_t m = bit_mask(path, depth - 1 - i);  // the same for the four lanes of a walk
@@ -252,6 +279,19 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
         // correction (DpfWalk::apply): word 3 carries tl_cw / tr_cw in bit 0
         const uint32_t cwq = w ^ (is3 & m & ((w ^ trw) & 1u));
         st = and_xor(tm, cwq, o);
+      } else if constexpr (SCHEME == S_DCF) {  // DcfWalk::level
+        const uint32_t in = st & ~(is3 & 1u);
+        uint32_t os, ovq;
+        quad_aes_pair(L, in, m, ka, kd, kb, ke, os, ovq);
+        os ^= in; ovq ^= in;
+        uint32_t ov[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(ovq), quad_get<FSS_QP(1, 1, 1, 1)>(ovq), quad_get<FSS_QP(2, 2, 2, 2)>(ovq),
+                          quad_get<FSS_QP(3, 3, 3, 3)>(ovq) & ~1u};
+        v.add(g, ov);
+        const uint32_t v3 = kc[8 * i + 7];
+        uint32_t vcw[4] = {kc[8 * i + 4], kc[8 * i + 5], kc[8 * i + 6], v3 & ~1u};
+        v.add_if(g, tm, vcw);
+        const uint32_t cwq = w ^ (is3 & m & ((w ^ v3) & 1u));  // word 3: tl_cw in s.w, tr_cw in v.w
+        st = and_xor(tm, cwq, os);
       } else {
         const uint32_t in = st ^ hk;
         const uint32_t h = quad_aes<false>(L, in, 0u, ka, kd) ^ in;  // HtWalk::level
@@ -259,6 +299,7 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
       }
     }
     reinterpret_cast<uint32_t*>(a.out_nodes)[4 * j + q] = st;
+    if constexpr (SCHEME == S_DCF) reinterpret_cast<uint32_t*>(a.out_v)[4 * j + q] = v.v[q];
   }
 }
 
