@@ -33,9 +33,19 @@ inline int top_max(int scheme, bool aes) {
   if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return 18;
   return 15;
 }
+// Levels of the frontier that its kernel expands in registers after the walk (frontier_quad_kernel's tail): the
+// quad's node -> its four grandchildren, i.e. the first and thinnest expansion stage without a launch.
+// `walked` levels come from the walk, `room` more levels exist above the leaf stage's reach: the tail is used
+// when the walk was capped (it then replaces a launch; below the cap walking two more levels is cheaper).
+inline int frontier_tail(int scheme, bool aes, bool capped, int room) {
+  static const bool on = [] { const char* e = getenv("FSS_AMD_FRONTIER_TAIL"); return !(e && atoi(e) == 0); }();
+  if (!on || !aes || !quad_frontier() || scheme == S_DCF || !capped || room < 2) return 0;
+  return 2;
+}
 
 struct Plan {
   int r, p, top, nstages;
+  int tail;  // levels of `top` the frontier kernel expands in registers after its walk (frontier_tail)
   int D[64];
   int64_t cap_a, cap_b;  // nodes in the two frontier buffers
 };
@@ -83,8 +93,10 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
   if (scheme == S_HT && r < 1) return false;  // the last Half-Tree level always yields two leaves
   pl->r = r;
   pl->p = in_bits - r;
-  int top = r - (scheme == S_HT ? 1 : 0);
-  if (top > top_max(scheme, aes)) top = top_max(scheme, aes);
+  const int limit = r - (scheme == S_HT ? 1 : 0);
+  int top = limit < top_max(scheme, aes) ? limit : top_max(scheme, aes);
+  pl->tail = frontier_tail(scheme, aes, top < limit, limit - top);
+  top += pl->tail;
   pl->top = top;
   int rem = r - top;
   const int dm = dmax_for(scheme);
@@ -168,17 +180,18 @@ int launch_stage(fss_amd_ctx* ctx, int T, bool leaf, const SharedKey& k, const E
 // (frontier_quad_kernel; FSS_AMD_QUAD_FRONTIER=0 selects the per-lane kernel).
 template <int SCHEME, bool BATCH>
 int launch_frontier(fss_amd_ctx* ctx, hipStream_t st, int64_t nout, const uint32_t* seed, const uint32_t* cws,
-                    const ExpandArgs& a, int top) {
+                    const ExpandArgs& a, int top, int tail) {
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
   if (ctx->prg != FSS_AMD_PRG_CHACHA && quad_frontier()) {
-    const int64_t lanes = nout * 4;
+    const int64_t lanes = (nout >> tail) * 4;  // a quad per walk
     const int fbs = lanes >= 65536 ? 1024 : (lanes >= 256 ? 256 : 64);
     const int64_t want = (lanes + fbs - 1) / fbs, cap = (int64_t)ctx->num_cu * (1024 / fbs);
     hipLaunchKernelGGL((frontier_quad_kernel<WS, BATCH>), dim3((unsigned)(want < cap ? want : cap)), dim3(fbs), 0, st, ctx->host,
-                       ctx->te0, seed, cws, a, top);
+                       ctx->te0, seed, cws, a, top, tail);
     HIP_TRY(hipGetLastError());
     return FSS_AMD_OK;
   }
+  if (tail != 0) return FSS_AMD_EINVAL;  // only the quad kernel has a tail (frontier_tail)
   {
     const int fbs = nout >= 65536 ? 1024 : (nout >= 256 ? 256 : 64);  // few walks: spread them over CUs
     const int64_t want = (nout + fbs - 1) / fbs, cap = BATCH ? (int64_t)ctx->num_cu * (1024 / fbs) * 4 : want;
@@ -221,7 +234,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   a.out_nodes = bufn[0];
   a.out_v = bufv[0];
   {
-    int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, k.seed, k.cws, a, pl.top);
+    int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, k.seed, k.cws, a, pl.top, pl.tail);
     if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = (int64_t)1 << pl.top;
@@ -270,10 +283,12 @@ bool make_batch_plan(int scheme, bool aes, int in_bits, int64_t nkeys, BatchPlan
   pl.p = 0;
   int lk = 0;
   while (((int64_t)1 << lk) < nkeys) ++lk;
-  int top = in_bits - (scheme == S_HT ? 1 : 0);
-  int want = top_max(scheme, aes) - lk;
+  const int limit = in_bits - (scheme == S_HT ? 1 : 0);
+  int want = top_max(scheme, aes) - lk;  // about 2^top_max walks over all keys
   if (want < 0) want = 0;
-  if (top > want) top = want;
+  int top = limit < want ? limit : want;
+  pl.tail = frontier_tail(scheme, aes, top < limit, limit - top);
+  top += pl.tail;
   pl.top = top;
   int rem = in_bits - top;
   const int dm = dmax_for(scheme);
@@ -337,7 +352,7 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   a.out_nodes = bufn[0];
   a.out_v = bufv[0];
   {
-    int rc = launch_frontier<SCHEME, true>(ctx, st, nkeys << pl.top, nullptr, k.cws, a, pl.top);
+    int rc = launch_frontier<SCHEME, true>(ctx, st, nkeys << pl.top, nullptr, k.cws, a, pl.top, pl.tail);
     if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = nkeys << pl.top;
@@ -361,7 +376,7 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
 constexpr int kPrefixMax = 26;
 
 struct PrefixPlan {
-  int top, nstages;
+  int top, nstages, tail;
   int D[32];
   int64_t cap_a, cap_b;  // intermediate frontiers (the last stage writes the node table itself)
 };
@@ -371,6 +386,8 @@ bool make_prefix_plan(int scheme, bool aes, int in_bits, int k, PrefixPlan* pl) 
   if (scheme == S_HT && k > in_bits - 1) return false;
   if (scheme != S_DPF && scheme != S_DCF && scheme != S_HT) return false;
   int top = k < top_max(scheme, aes) ? k : top_max(scheme, aes);
+  pl->tail = frontier_tail(scheme, aes, top < k, k - top);
+  top += pl->tail;
   pl->top = top;
   int rem = k - top;
   const int dm = dmax_for(scheme);
@@ -436,7 +453,7 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
   e.out_nodes = pl.nstages ? bufn[0] : tab_n;
   e.out_v = pl.nstages ? bufv[0] : tab_v;
   {
-    int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, key.seed, key.cws, e, pl.top);
+    int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, key.seed, key.cws, e, pl.top, pl.tail);
     if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = (int64_t)1 << pl.top;

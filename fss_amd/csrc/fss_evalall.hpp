@@ -214,37 +214,44 @@ __device__ __forceinline__ uint32_t quad_aes(const Lds& L, uint32_t in, uint32_t
 
 // Two blocks of the same input under two selected keys (DCF: seed and value of the taken side), their
 // rounds interleaved so that the lookups of one fly during the exchanges of the other.
+// SEL = false: plain keys ka / kb (kd, ke unused).
+template <bool SEL>
 __device__ __forceinline__ void quad_aes_pair(const Lds& L, uint32_t in, uint32_t m, const uint32_t ka[11], const uint32_t kd[11],
                                               const uint32_t kb[11], const uint32_t ke[11], uint32_t& oa, uint32_t& ob) {
-  uint32_t s = xor3(in, ka[0], m & kd[0]), t = xor3(in, kb[0], m & ke[0]);
+  uint32_t s = SEL ? xor3(in, ka[0], m & kd[0]) : (in ^ ka[0]), t = SEL ? xor3(in, kb[0], m & ke[0]) : (in ^ kb[0]);
 #pragma unroll
   for (int r = 1; r < 10; ++r) {
     const uint32_t A = lk<0, 0>(L, s), B = lk<1, 1>(L, s), C = lk<2, 2>(L, s), D = lk<3, 3>(L, s);
     const uint32_t E = lk<0, 0>(L, t), F = lk<1, 1>(L, t), G = lk<2, 2>(L, t), H = lk<3, 3>(L, t);
     const uint32_t x = xor3(A, quad_get<FSS_QP(1, 2, 3, 0)>(B), quad_get<FSS_QP(2, 3, 0, 1)>(C));
     const uint32_t y = xor3(E, quad_get<FSS_QP(1, 2, 3, 0)>(F), quad_get<FSS_QP(2, 3, 0, 1)>(G));
-    s = xor3(x, quad_get<FSS_QP(3, 0, 1, 2)>(D), and_xor(m, kd[r], ka[r]));
-    t = xor3(y, quad_get<FSS_QP(3, 0, 1, 2)>(H), and_xor(m, ke[r], kb[r]));
+    s = xor3(x, quad_get<FSS_QP(3, 0, 1, 2)>(D), SEL ? and_xor(m, kd[r], ka[r]) : ka[r]);
+    t = xor3(y, quad_get<FSS_QP(3, 0, 1, 2)>(H), SEL ? and_xor(m, ke[r], kb[r]) : kb[r]);
   }
   const uint32_t A = lk<0, 2>(L, s), B = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, s)),
                  C = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, s)), D = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, s));
   const uint32_t E = lk<0, 2>(L, t), F = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, t)),
                  G = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, t)), H = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, t));
-  oa = ((A & 0xffu) | (B & 0xff00u) | (C & 0xff0000u) | (D & 0xff000000u)) ^ and_xor(m, kd[10], ka[10]);
-  ob = ((E & 0xffu) | (F & 0xff00u) | (G & 0xff0000u) | (H & 0xff000000u)) ^ and_xor(m, ke[10], kb[10]);
+  oa = ((A & 0xffu) | (B & 0xff00u) | (C & 0xff0000u) | (D & 0xff000000u)) ^ (SEL ? and_xor(m, kd[10], ka[10]) : ka[10]);
+  ob = ((E & 0xffu) | (F & 0xff00u) | (G & 0xff0000u) | (H & 0xff000000u)) ^ (SEL ? and_xor(m, ke[10], kb[10]) : kb[10]);
 }
 
 template <int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
 __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
-                                                            const uint32_t* __restrict__ k_cws, ExpandArgs a, int top) {
+                                                            const uint32_t* __restrict__ k_cws, ExpandArgs a, int top,
+                                                            int tail) {
+  // `top` levels are produced per key: top - tail walked, then (tail = 2, DPF / Grotto / Half-Tree) the quad expands
+  // its node two levels in registers and stores the four grandchildren -- the first, thinnest expansion stage
+  // without its launch.  a.level0 = depth of the stored nodes.
   static_assert(SCHEME == S_DPF || SCHEME == S_DCF || SCHEME == S_HT, "quad frontier: DPF / Grotto / DCF / Half-Tree");
   const DevCtx* c = first_kernarg(K);
   FSS_PRG_PROLOGUE(Lds, te0);
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
   uint32_t ka[11], kd[11];
-  uint32_t kb[SCHEME == S_DCF ? 11 : 1], ke[SCHEME == S_DCF ? 11 : 1];  // DCF: the value block's keys 1 / 3 (dcf.cuh:223)
+  // DCF: the value block's keys 1 / 3 (dcf.cuh:223); DPF: key 1 alone, for the tail's both-children expansions
+  uint32_t kb[SCHEME == S_HT ? 1 : 11], ke[SCHEME == S_DCF ? 11 : 1];
   {
     const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01) : (SCHEME == S_DCF ? offsetof(DevCtx, sel02) : offsetof(DevCtx, rk))) / 4;
     const uint32_t* gv = c->self_dev + offsetof(DevCtx, sel13) / 4;
@@ -253,13 +260,34 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
       ka[r] = SCHEME == S_HT ? gk[4 * r + q] : gk[8 * r + q];  // Half-Tree hashes with key 0 (half_tree_dpf.cuh:195)
       kd[r] = SCHEME == S_HT ? 0u : gk[8 * r + 4 + q];
       if constexpr (SCHEME == S_DCF) { kb[r] = gv[8 * r + q]; ke[r] = gv[8 * r + 4 + q]; }
+      if constexpr (SCHEME == S_DPF) kb[r] = ka[r] ^ kd[r];
     }
   }
   const Grp g = make_grp(a.group, c);
   const uint32_t hk = SCHEME == S_HT ? (c->self_dev + offsetof(DevCtx, hash_key) / 4)[q] : 0u;
-  const int depth = a.level0;  // p + top
-  const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;
+  const int depth = a.level0 - tail;  // levels walked: p + top - tail
+  top -= tail;
+  const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;  // walks
   const int64_t nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
+  // one node -> both children at tree level lv (dpf_expand / ht_expand), a column per lane
+  auto expand = [&](const uint32_t* kc, int lv, uint32_t node, uint32_t& left, uint32_t& right) {
+    const uint32_t w = kc[8 * lv + q];
+    const uint32_t tm = lsb_mask(quad_get<FSS_QP(3, 3, 3, 3)>(node));
+    if constexpr (SCHEME == S_DPF) {
+      const uint32_t trw = kc[8 * lv + 4];
+      const uint32_t in = node & ~(is3 & 1u);
+      uint32_t l, r;
+      quad_aes_pair<false>(L, in, 0u, ka, kd, kb, ke, l, r);
+      left = and_xor(tm, w, l ^ in);
+      right = and_xor(tm, w ^ (is3 & ((w ^ trw) & 1u)), r ^ in);
+    } else if constexpr (SCHEME == S_HT) {
+      const uint32_t in = node ^ hk;
+      left = and_xor(tm, w, quad_aes<false>(L, in, 0u, ka, kd) ^ in);
+      right = left ^ node;
+    } else {
+      left = right = node;  // no tail for DCF
+    }
+  };
   for (int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; j < nout; j += nquads) {
     const int64_t key = BATCH ? (j >> top) : 0;
     const uint64_t path = BATCH ? (uint64_t)(j & (((int64_t)1 << top) - 1)) : ((top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j);
@@ -282,7 +310,7 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
       } else if constexpr (SCHEME == S_DCF) {  // DcfWalk::level
         const uint32_t in = st & ~(is3 & 1u);
         uint32_t os, ovq;
-        quad_aes_pair(L, in, m, ka, kd, kb, ke, os, ovq);
+        quad_aes_pair<true>(L, in, m, ka, kd, kb, ke, os, ovq);
         os ^= in; ovq ^= in;
         uint32_t ov[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(ovq), quad_get<FSS_QP(1, 1, 1, 1)>(ovq), quad_get<FSS_QP(2, 2, 2, 2)>(ovq),
                           quad_get<FSS_QP(3, 3, 3, 3)>(ovq) & ~1u};
@@ -298,8 +326,21 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
         st = and_xor(m, st, and_xor(tm, w, h));
       }
     }
-    reinterpret_cast<uint32_t*>(a.out_nodes)[4 * j + q] = st;
-    if constexpr (SCHEME == S_DCF) reinterpret_cast<uint32_t*>(a.out_v)[4 * j + q] = v.v[q];
+    uint32_t* out = reinterpret_cast<uint32_t*>(a.out_nodes);
+    if (tail == 2 && SCHEME != S_DCF) {
+      uint32_t c1[2];
+      expand(kc, depth, st, c1[0], c1[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t g0, g1;
+        expand(kc, depth + 1, c1[h], g0, g1);
+        out[4 * ((j << 2) + 2 * h) + q] = g0;
+        out[4 * ((j << 2) + 2 * h + 1) + q] = g1;
+      }
+    } else {
+      out[4 * j + q] = st;
+      if constexpr (SCHEME == S_DCF) reinterpret_cast<uint32_t*>(a.out_v)[4 * j + q] = v.v[q];
+    }
   }
 }
 

@@ -106,7 +106,7 @@ def test_python_layer_raises(raw):
 
 
 @pytest.mark.parametrize("env", [{"FSS_AMD_DYN": "1"}, {"FSS_AMD_DYN": "0", "FSS_AMD_ROTPRIO": "0"},
-                                 {"FSS_AMD_ILP": "1", "FSS_AMD_BS": "256"}, {"FSS_AMD_LEAF_E": "1", "FSS_AMD_TOPMAX": "3"},
+                                 {"FSS_AMD_ILP": "1", "FSS_AMD_BS": "256", "FSS_AMD_FRONTIER_TAIL": "0"}, {"FSS_AMD_LEAF_E": "1", "FSS_AMD_TOPMAX": "3"},
                                  {"FSS_AMD_MID_E": "2", "FSS_AMD_GROTTO_DEFER": "0", "FSS_AMD_RELAYOUT": "0", "FSS_AMD_QUAD_FRONTIER": "0"}])
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
