@@ -268,7 +268,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
 // ---- many keys, full domain each (fss::gpu::{Dpf,HalfTreeDpf}EvalAllGpuBatch, eval_all_gpu.cuh:511-535) -------
 // The same frontier + stage kernels over nkeys trees side by side (BATCH): node f of a level-l frontier belongs
 // to key f >> l, ys[k * 2^in_bits + x].  The frontier depth shrinks with the number of keys so that the first
-// launch has about 2^15 walks in total.
+// launch has about 2^top_max walks in total (2^16 with the quad-lane frontier).
 struct BatchPlan {
   Plan pl;
   int64_t nkeys;
