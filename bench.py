@@ -155,6 +155,25 @@ def make_key(eng, scheme, n, group_id, seed_val):
     return sid, s0s[0].cpu(), cws[0].cpu(), (None if ocws is None else ocws[0].cpu()), alpha, beta
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs under a 16-CPU quota: 256 threads there run at 8.5 M evals/s, 16 threads at 19.7)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(scheme, n, s0s, cws, ocw, xs_sample, gpu_sample, threads):
     """Oracle = restatement of the reference CPU path with the OpenSSL EVP PRG, timed on a
     bounded sample of the workload's own points; also the parity gate for this run."""
@@ -165,18 +184,22 @@ def cpu_baseline(scheme, n, s0s, cws, ocw, xs_sample, gpu_sample, threads):
     xs64 = xs_sample.astype(np.uint64)
     oc = None if ocw is None else ocw.numpy()
     O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64[:1024], ocw=oc, nthreads=1)  # warm
-    t0 = time.perf_counter()
-    ys = O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64, ocw=oc, nthreads=threads)
-    dt = time.perf_counter() - t0
-    n1 = max(1024, len(xs64) // max(threads, 1) // 2)
+    # about 10 s of CPU work in all: the all-threads pass repeated until >= 6 s, a ~3 s single-thread sample, one AES-NI pass
+    reps, dt = 0, 0.0
+    while dt < 6.0 and reps < 64:
+        t0 = time.perf_counter()
+        ys = O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64, ocw=oc, nthreads=threads)
+        dt += time.perf_counter() - t0
+        reps += 1
+    n1 = min(len(xs64), max(1024, 1 << 20))
     t1 = time.perf_counter()
     O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64[:n1], ocw=oc, nthreads=1)
     dt1 = time.perf_counter() - t1
     parity = bool((ys == gpu_sample).all())
     out = {
-        "value": len(xs64) / dt, "unit": "evals/s", "cores": threads, "kind": "port",
-        "sample": f"first {len(xs64)} points of the timed batch, party 0, oracle with OpenSSL EVP AES-128-ECB PRG "
-                  f"(reference call pattern), {threads} OpenMP threads, {dt:.1f} s",
+        "value": reps * len(xs64) / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+        "sample": f"first {len(xs64)} points of the timed batch x {reps} passes, party 0, oracle with OpenSSL EVP AES-128-ECB "
+                  f"PRG (reference call pattern), {threads} OpenMP threads, {dt:.1f} s; single thread: {n1} points",
         "single_thread_value": n1 / dt1,
         "gpu_matches_oracle_on_sample": parity,
     }
@@ -262,7 +285,7 @@ def run_headline(args, rank, world, dist):
                 "then (in_bits - log2(batch)) levels per point; ~10 AES blocks executed per eval instead of 32",
     }
     if world == 1 and not args.no_cpu:
-        threads = os.cpu_count() or 1
+        threads = usable_cores()
         m = min(batch, args.cpu_sample)
         out["cpu_baseline"] = cpu_baseline(scheme, n, s0s, cws, ocw, xs[:m].cpu().numpy().view(np.uint32),
                                            ys[:m].cpu().numpy(), threads)
