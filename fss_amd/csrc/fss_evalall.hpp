@@ -19,6 +19,7 @@
 #include <cstddef>
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
+#include "fss_quad.hpp"
 
 namespace fssamd {
 
@@ -181,61 +182,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
   }
 }
 
-// -- frontier, DPF / Grotto with the AES tables: one walk per QUAD of lanes ---------------------------------
-// The frontier is a latency chain: `depth` blocks one after the other, and a lone wave issues a VALU op only
-// every ~7 clk, so a block costs ~2 us however few walks there are.  Here four adjacent lanes
-// share one walk, a state column each: per round a lane does the four table lookups of ITS column's bytes
-// (T0[b0], T1[b1], T2[b2], T3[b3]) and column q of the next state is A(q) ^ B(q+1) ^ C(q+2) ^ D(q+3), the
-// three foreign terms fetched with DPP quad_perm moves -- ~10 VALU and 4 lookups per round on the critical
-// path instead of ~36 and 16.  Same lookups in total, a quarter of the chain.  The lane's column of the
-// two-key schedule {rkA, rkA ^ rkB} (DevCtx::sel01) sits in 22 VGPRs.
-#define FSS_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
-template <int CTRL>
-__device__ __forceinline__ uint32_t quad_get(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
-}
-// Column q of AES_k(in) for the quad's block; SEL: k = key A where m == 0, key B where m == ~0 (ka = rkA,
-// kd = rkA ^ rkB, this lane's column of every round).
-template <bool SEL>
-__device__ __forceinline__ uint32_t quad_aes(const Lds& L, uint32_t in, uint32_t m, const uint32_t ka[11], const uint32_t kd[11]) {
-  uint32_t s = SEL ? xor3(in, ka[0], m & kd[0]) : (in ^ ka[0]);
-#pragma unroll
-  for (int r = 1; r < 10; ++r) {
-    const uint32_t A = lk<0, 0>(L, s), B = lk<1, 1>(L, s), C = lk<2, 2>(L, s), D = lk<3, 3>(L, s);
-    const uint32_t x = xor3(A, quad_get<FSS_QP(1, 2, 3, 0)>(B), quad_get<FSS_QP(2, 3, 0, 1)>(C));
-    s = xor3(x, quad_get<FSS_QP(3, 0, 1, 2)>(D), SEL ? and_xor(m, kd[r], ka[r]) : ka[r]);
-  }
-  // last round: the tables that hold S in the output byte position (aes_mmo)
-  const uint32_t A = lk<0, 2>(L, s), B = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, s)),
-                 C = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, s)), D = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, s));
-  const uint32_t pcol = (A & 0xffu) | (B & 0xff00u) | (C & 0xff0000u) | (D & 0xff000000u);
-  return pcol ^ (SEL ? and_xor(m, kd[10], ka[10]) : ka[10]);
-}
-
-// Two blocks of the same input under two selected keys (DCF: seed and value of the taken side), their
-// rounds interleaved so that the lookups of one fly during the exchanges of the other.
-// SEL = false: plain keys ka / kb (kd, ke unused).
-template <bool SEL>
-__device__ __forceinline__ void quad_aes_pair(const Lds& L, uint32_t in, uint32_t m, const uint32_t ka[11], const uint32_t kd[11],
-                                              const uint32_t kb[11], const uint32_t ke[11], uint32_t& oa, uint32_t& ob) {
-  uint32_t s = SEL ? xor3(in, ka[0], m & kd[0]) : (in ^ ka[0]), t = SEL ? xor3(in, kb[0], m & ke[0]) : (in ^ kb[0]);
-#pragma unroll
-  for (int r = 1; r < 10; ++r) {
-    const uint32_t A = lk<0, 0>(L, s), B = lk<1, 1>(L, s), C = lk<2, 2>(L, s), D = lk<3, 3>(L, s);
-    const uint32_t E = lk<0, 0>(L, t), F = lk<1, 1>(L, t), G = lk<2, 2>(L, t), H = lk<3, 3>(L, t);
-    const uint32_t x = xor3(A, quad_get<FSS_QP(1, 2, 3, 0)>(B), quad_get<FSS_QP(2, 3, 0, 1)>(C));
-    const uint32_t y = xor3(E, quad_get<FSS_QP(1, 2, 3, 0)>(F), quad_get<FSS_QP(2, 3, 0, 1)>(G));
-    s = xor3(x, quad_get<FSS_QP(3, 0, 1, 2)>(D), SEL ? and_xor(m, kd[r], ka[r]) : ka[r]);
-    t = xor3(y, quad_get<FSS_QP(3, 0, 1, 2)>(H), SEL ? and_xor(m, ke[r], kb[r]) : kb[r]);
-  }
-  const uint32_t A = lk<0, 2>(L, s), B = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, s)),
-                 C = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, s)), D = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, s));
-  const uint32_t E = lk<0, 2>(L, t), F = quad_get<FSS_QP(1, 2, 3, 0)>(lk<1, 3>(L, t)),
-                 G = quad_get<FSS_QP(2, 3, 0, 1)>(lk<2, 0>(L, t)), H = quad_get<FSS_QP(3, 0, 1, 2)>(lk<3, 1>(L, t));
-  oa = ((A & 0xffu) | (B & 0xff00u) | (C & 0xff0000u) | (D & 0xff000000u)) ^ (SEL ? and_xor(m, kd[10], ka[10]) : ka[10]);
-  ob = ((E & 0xffu) | (F & 0xff00u) | (G & 0xff0000u) | (H & 0xff000000u)) ^ (SEL ? and_xor(m, ke[10], kb[10]) : kb[10]);
-}
-
+// -- frontier with the AES tables: one walk per quad of lanes (fss_quad.hpp) ---------------------------------
 template <int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
 __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
@@ -249,22 +196,11 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
   FSS_PRG_PROLOGUE(Lds, te0);
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
-  uint32_t ka[11], kd[11];
+  uint32_t ka[11], kd[11], hk;
   // DCF: the value block's keys 1 / 3 (dcf.cuh:223); DPF: key 1 alone, for the tail's both-children expansions
   uint32_t kb[SCHEME == S_HT ? 1 : 11], ke[SCHEME == S_DCF ? 11 : 1];
-  {
-    const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01) : (SCHEME == S_DCF ? offsetof(DevCtx, sel02) : offsetof(DevCtx, rk))) / 4;
-    const uint32_t* gv = c->self_dev + offsetof(DevCtx, sel13) / 4;
-#pragma unroll
-    for (int r = 0; r < 11; ++r) {
-      ka[r] = SCHEME == S_HT ? gk[4 * r + q] : gk[8 * r + q];  // Half-Tree hashes with key 0 (half_tree_dpf.cuh:195)
-      kd[r] = SCHEME == S_HT ? 0u : gk[8 * r + 4 + q];
-      if constexpr (SCHEME == S_DCF) { kb[r] = gv[8 * r + q]; ke[r] = gv[8 * r + 4 + q]; }
-      if constexpr (SCHEME == S_DPF) kb[r] = ka[r] ^ kd[r];
-    }
-  }
+  quad_keys<SCHEME>(c, q, ka, kd, kb, ke, hk);
   const Grp g = make_grp(a.group, c);
-  const uint32_t hk = SCHEME == S_HT ? (c->self_dev + offsetof(DevCtx, hash_key) / 4)[q] : 0u;
   const int depth = a.level0 - tail;  // levels walked: p + top - tail
   top -= tail;
   const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;  // walks
@@ -298,33 +234,7 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
 #pragma unroll 1
     for (int i = 0; i < depth; ++i) {
       const uint32_t m = bit_mask(path, depth - 1 - i);  // the same for the four lanes of a walk
-      const uint32_t w = kc[8 * i + q];
-      const uint32_t tm = lsb_mask(quad_get<FSS_QP(3, 3, 3, 3)>(st));
-      if constexpr (SCHEME == S_DPF) {
-        const uint32_t trw = kc[8 * i + 4];
-        const uint32_t in = st & ~(is3 & 1u);
-        const uint32_t o = quad_aes<true>(L, in, m, ka, kd) ^ in;
-        // correction (DpfWalk::apply): word 3 carries tl_cw / tr_cw in bit 0
-        const uint32_t cwq = w ^ (is3 & m & ((w ^ trw) & 1u));
-        st = and_xor(tm, cwq, o);
-      } else if constexpr (SCHEME == S_DCF) {  // DcfWalk::level
-        const uint32_t in = st & ~(is3 & 1u);
-        uint32_t os, ovq;
-        quad_aes_pair<true>(L, in, m, ka, kd, kb, ke, os, ovq);
-        os ^= in; ovq ^= in;
-        uint32_t ov[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(ovq), quad_get<FSS_QP(1, 1, 1, 1)>(ovq), quad_get<FSS_QP(2, 2, 2, 2)>(ovq),
-                          quad_get<FSS_QP(3, 3, 3, 3)>(ovq) & ~1u};
-        v.add(g, ov);
-        const uint32_t v3 = kc[8 * i + 7];
-        uint32_t vcw[4] = {kc[8 * i + 4], kc[8 * i + 5], kc[8 * i + 6], v3 & ~1u};
-        v.add_if(g, tm, vcw);
-        const uint32_t cwq = w ^ (is3 & m & ((w ^ v3) & 1u));  // word 3: tl_cw in s.w, tr_cw in v.w
-        st = and_xor(tm, cwq, os);
-      } else {
-        const uint32_t in = st ^ hk;
-        const uint32_t h = quad_aes<false>(L, in, 0u, ka, kd) ^ in;  // HtWalk::level
-        st = and_xor(m, st, and_xor(tm, w, h));
-      }
+      quad_level<SCHEME>(L, g, kc, i, m, q, is3, ka, kd, kb, ke, hk, st, v);
     }
     uint32_t* out = reinterpret_cast<uint32_t*>(a.out_nodes);
     if (tail == 2 && SCHEME != S_DCF) {

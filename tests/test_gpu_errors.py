@@ -105,7 +105,7 @@ def test_python_layer_raises(raw):
         d.eval(2, s0, cws, 1)
 
 
-@pytest.mark.parametrize("env", [{"FSS_AMD_DYN": "1"}, {"FSS_AMD_DYN": "0", "FSS_AMD_ROTPRIO": "0"},
+@pytest.mark.parametrize("env", [{"FSS_AMD_DYN": "1"}, {"FSS_AMD_DYN": "0", "FSS_AMD_ROTPRIO": "0", "FSS_AMD_QUAD_POINTS_MAX": "0"},
                                  {"FSS_AMD_ILP": "1", "FSS_AMD_BS": "256", "FSS_AMD_FRONTIER_TAIL": "0"}, {"FSS_AMD_LEAF_E": "1", "FSS_AMD_TOPMAX": "3"},
                                  {"FSS_AMD_MID_E": "2", "FSS_AMD_GROTTO_DEFER": "0", "FSS_AMD_RELAYOUT": "0", "FSS_AMD_QUAD_FRONTIER": "0"}])
 def test_parity_under_forced_tunables(env):
