@@ -373,7 +373,7 @@ def run_suite(args):
         print(json.dumps(res[-1]), file=sys.stderr, flush=True)
 
     G = fss_amd.U64
-    for scheme, n, lb in (("dpf", 32, 20), ("dcf", 32, 20), ("dpf", 16, 24), ("dpf", 64, 24), ("dcf", 16, 24),
+    for scheme, n, lb in (("dpf", 32, 10), ("dpf", 32, 16), ("dcf", 32, 16), ("dpf", 32, 20), ("dcf", 32, 20), ("dpf", 16, 24), ("dpf", 64, 24), ("dcf", 16, 24),
                           ("dcf", 32, 24), ("dcf", 64, 24), ("ht", 64, 24)):
         sid, s0s, cws, ocw, _, _ = make_key(eng, scheme, n, G, 1 + n)
         batch = 1 << lb
