@@ -8,8 +8,8 @@
 
 namespace fssamd {
 
-// -- frontier, DPF / Grotto with the AES tables: one walk per QUAD of lanes ---------------------------------
-// The frontier is a latency chain: `depth` blocks one after the other, and a lone wave issues a VALU op only
+// -- one AES block per quad ------------------------------------------------------------------------------
+// A short walk is a latency chain: `depth` blocks one after the other, and a lone wave issues a VALU op only
 // every ~7 clk, so a block costs ~2 us however few walks there are.  Here four adjacent lanes
 // share one walk, a state column each: per round a lane does the four table lookups of ITS column's bytes
 // (T0[b0], T1[b1], T2[b2], T3[b3]) and column q of the next state is A(q) ^ B(q+1) ^ C(q+2) ^ D(q+3), the
