@@ -178,6 +178,13 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
 // ------------------------------------------------------------------ point eval, shared key
 // DPF n = 32: 30 us per launch up to 2^16 points (a per-lane walk: 85 us up to 2^18), 56 us at 2^17, 109 us at 2^18
 constexpr int kQuadPointsMax = 131072;
+static int64_t quad_points_max() {
+  static const int64_t v = [] {
+    const char* e = getenv("FSS_AMD_QUAD_POINTS_MAX");
+    return e ? (int64_t)atoll(e) : (int64_t)kQuadPointsMax;
+  }();
+  return v;
+}
 static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seed,
                          const void* cws, const void* ocw, const void* xs, int x_bytes, int64_t n, void* ys,
                          void* stream) {
@@ -196,11 +203,7 @@ static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, i
   k.ocw = reinterpret_cast<const uint32_t*>(ocw);
   // Small batches are latency chains run by lone waves: one walk per quad of lanes (points_quad_kernel) runs a
   // level in ~0.9 us instead of ~2.2.  FSS_AMD_QUAD_POINTS_MAX = largest batch that takes it (0: never).
-  static const int64_t quad_max = [] {
-    const char* e = getenv("FSS_AMD_QUAD_POINTS_MAX");
-    return e ? (int64_t)atoll(e) : (int64_t)kQuadPointsMax;
-  }();
-  if (ctx->prg != FSS_AMD_PRG_CHACHA && n > 0 && n <= quad_max) {
+  if (ctx->prg != FSS_AMD_PRG_CHACHA && n > 0 && n <= quad_points_max()) {
     const int64_t lanes = n * 4;
     const int bs = lanes >= 65536 ? 1024 : 256;
     const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
@@ -349,6 +352,22 @@ static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int
   a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
   a.out_cw = reinterpret_cast<const uint4*>(out_cw);
   a.extra = reinterpret_cast<const uint32_t*>(extra);
+  if (ctx->prg != FSS_AMD_PRG_CHACHA && n <= quad_points_max()) {  // small batch: a quad of lanes per key (points_common)
+    const int64_t lanes = n * 4;
+    const int bs = lanes >= 65536 ? 1024 : 256;
+    const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
+    const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
+    switch (scheme) {
+      case S_DPF: hipLaunchKernelGGL(keys_quad_kernel<S_DPF>, grid, block, 0, S(stream), ctx->host, ctx->te0, a); break;
+      case S_DCF: hipLaunchKernelGGL(keys_quad_kernel<S_DCF>, grid, block, 0, S(stream), ctx->host, ctx->te0, a); break;
+      default: hipLaunchKernelGGL(keys_quad_kernel<S_HT>, grid, block, 0, S(stream), ctx->host, ctx->te0, a); break;
+    }
+    HIP_TRY(hipGetLastError());
+    ctx->last_kernel = scheme == S_DPF ? "dpf_eval_keys" : (scheme == S_DCF ? "dcf_eval_keys" : "ht_eval_keys");
+    ctx->last_grid = (int)grid.x;
+    ctx->last_block = bs;
+    return FSS_AMD_OK;
+  }
   switch (scheme) {
     case S_DPF: return launch_points<S_DPF, false>(ctx, "dpf_eval_keys", SharedKey{}, a, S(stream));
     case S_DCF: return launch_points<S_DCF, false>(ctx, "dcf_eval_keys", SharedKey{}, a, S(stream));

@@ -65,14 +65,15 @@ __device__ __forceinline__ void quad_aes_pair(const Lds& L, uint32_t in, uint32_
 
 // One level of a quad's walk (DpfWalk / DcfWalk / HtWalk ::level, a column per lane): m = the path bit (0 / ~0,
 // the same in the four lanes), st = this lane's word of the node, v = DCF's running value (whole in every lane).
+// The level's correction word: w = this lane's word of cw.s; aux = the word whose bit 0 is tr_cw (DPF: the tr
+// byte, DCF: v.w); vcw = DCF's value words.
 template <int SCHEME>
-__device__ __forceinline__ void quad_level(const Lds& L, const Grp& g, const uint32_t* __restrict__ kc, int i, uint32_t m, int q,
-                                           uint32_t is3, const uint32_t ka[11], const uint32_t kd[11], const uint32_t* kb,
-                                           const uint32_t* ke, uint32_t hk, uint32_t& st, Acc& v) {
-  const uint32_t w = kc[8 * i + q];
+__device__ __forceinline__ void quad_level_cw(const Lds& L, const Grp& g, uint32_t w, uint32_t aux, const uint32_t* vcw_in,
+                                              uint32_t m, uint32_t is3, const uint32_t ka[11], const uint32_t kd[11],
+                                              const uint32_t* kb, const uint32_t* ke, uint32_t hk, uint32_t& st, Acc& v) {
   const uint32_t tm = lsb_mask(quad_get<FSS_QP(3, 3, 3, 3)>(st));
   if constexpr (SCHEME == S_DPF) {
-    const uint32_t trw = kc[8 * i + 4];
+    const uint32_t trw = aux;
     const uint32_t in = st & ~(is3 & 1u);
     const uint32_t o = quad_aes<true>(L, in, m, ka, kd) ^ in;
     // correction (DpfWalk::apply): word 3 carries tl_cw / tr_cw in bit 0
@@ -86,8 +87,8 @@ __device__ __forceinline__ void quad_level(const Lds& L, const Grp& g, const uin
     uint32_t ov[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(ovq), quad_get<FSS_QP(1, 1, 1, 1)>(ovq), quad_get<FSS_QP(2, 2, 2, 2)>(ovq),
                       quad_get<FSS_QP(3, 3, 3, 3)>(ovq) & ~1u};
     v.add(g, ov);
-    const uint32_t v3 = kc[8 * i + 7];
-    uint32_t vcw[4] = {kc[8 * i + 4], kc[8 * i + 5], kc[8 * i + 6], v3 & ~1u};
+    const uint32_t v3 = aux;
+    uint32_t vcw[4] = {vcw_in[0], vcw_in[1], vcw_in[2], v3 & ~1u};
     v.add_if(g, tm, vcw);
     const uint32_t cwq = w ^ (is3 & m & ((w ^ v3) & 1u));  // word 3: tl_cw in s.w, tr_cw in v.w
     st = and_xor(tm, cwq, os);
@@ -95,6 +96,20 @@ __device__ __forceinline__ void quad_level(const Lds& L, const Grp& g, const uin
     const uint32_t in = st ^ hk;
     const uint32_t h = quad_aes<false>(L, in, 0u, ka, kd) ^ in;  // HtWalk::level
     st = and_xor(m, st, and_xor(tm, w, h));
+  }
+}
+
+// The same with the correction word read from a key's raw 32-byte slots (kc = the key, level i).
+template <int SCHEME>
+__device__ __forceinline__ void quad_level(const Lds& L, const Grp& g, const uint32_t* __restrict__ kc, int i, uint32_t m, int q,
+                                           uint32_t is3, const uint32_t ka[11], const uint32_t kd[11], const uint32_t* kb,
+                                           const uint32_t* ke, uint32_t hk, uint32_t& st, Acc& v) {
+  const uint32_t* p = kc + 8 * i;
+  if constexpr (SCHEME == S_DCF) {
+    const uint32_t vcw[3] = {p[4], p[5], p[6]};
+    quad_level_cw<SCHEME>(L, g, p[q], p[7], vcw, m, is3, ka, kd, kb, ke, hk, st, v);
+  } else {
+    quad_level_cw<SCHEME>(L, g, p[q], SCHEME == S_DPF ? p[4] : 0u, nullptr, m, is3, ka, kd, kb, ke, hk, st, v);
   }
 }
 
@@ -168,6 +183,67 @@ __global__ __launch_bounds__(1024) void points_quad_kernel(const DevCtx K, const
       y = w.finish(L, c, g, a.party, cw, p[4], oc);
     }
     ys[4 * j + q] = q == 0 ? y.x : (q == 1 ? y.y : (q == 2 ? y.z : y.w));
+  }
+}
+
+// Small batches of independent level-major keys (fss::gpu::*EvalPointGpu's inputs): a quad per key.
+template <int SCHEME>
+__global__ __launch_bounds__(1024) void keys_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
+  static_assert(SCHEME == S_DPF || SCHEME == S_DCF || SCHEME == S_HT, "quad key walk: DPF / DCF / Half-Tree");
+  const DevCtx* c = first_kernarg(K);
+  FSS_PRG_PROLOGUE(Lds, te0);
+  const int q = threadIdx.x & 3;
+  const uint32_t is3 = q == 3 ? ~0u : 0u;
+  uint32_t ka[11], kd[11], hk;
+  uint32_t kb[SCHEME == S_HT ? 1 : 11], ke[SCHEME == S_DCF ? 11 : 1];
+  quad_keys<SCHEME>(c, q, ka, kd, kb, ke, hk);
+  const Grp g = make_grp(a.group, c);
+  const int n = a.in_bits, depth = SCHEME == S_HT ? n - 1 : n;
+  const int64_t nk = a.n, nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
+  uint32_t* __restrict__ ys = reinterpret_cast<uint32_t*>(a.ys);
+  for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; k < nk; k += nquads) {
+    const X128 x = load_x(a.xs, a.x_bytes, k);
+    uint32_t st = reinterpret_cast<const uint32_t*>(a.seeds + k)[q];
+    st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);
+    uint64_t trb = 0, trbh = 0;
+    if constexpr (SCHEME == S_DPF) { trb = a.tr_bits[k]; trbh = n > 64 ? a.tr_bits[nk + k] : 0ull; }
+    Acc v;
+#pragma unroll 1
+    for (int i = 0; i < depth; ++i) {
+      const uint32_t m = bit_mask(x, n - 1 - i);
+      const uint32_t w = reinterpret_cast<const uint32_t*>(a.cw_s + (int64_t)i * nk + k)[q];
+      if constexpr (SCHEME == S_DCF) {
+        const uint4 cv = a.cw_v[(int64_t)i * nk + k];
+        const uint32_t vcw[3] = {cv.x, cv.y, cv.z};
+        quad_level_cw<SCHEME>(L, g, w, cv.w, vcw, m, is3, ka, kd, kb, ke, hk, st, v);
+      } else {
+        const uint32_t tr = SCHEME == S_DPF ? (uint32_t)(((i < 64 ? trb : trbh) >> (i & 63)) & 1ull) : 0u;
+        quad_level_cw<SCHEME>(L, g, w, tr, nullptr, m, is3, ka, kd, kb, ke, hk, st, v);
+      }
+    }
+    const uint32_t node[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(st), quad_get<FSS_QP(1, 1, 1, 1)>(st), quad_get<FSS_QP(2, 2, 2, 2)>(st),
+                              quad_get<FSS_QP(3, 3, 3, 3)>(st)};
+    uint4 y;
+    if constexpr (SCHEME == S_HT) {
+      HtWalk w;
+      w.resume(make_uint4(node[0], node[1], node[2], node[3]), x);
+      const uint4 t = a.cw_s[(int64_t)(n - 1) * nk + k], u = a.out_cw[k];
+      const uint32_t cw[4] = {t.x, t.y, t.z, t.w}, oc[4] = {u.x, u.y, u.z, u.w};
+      y = w.finish(L, c, g, a.party, cw, a.extra[k], oc);
+    } else {
+      const uint4 u = a.out_cw[k];
+      const uint32_t oc[4] = {u.x, u.y, u.z, u.w};
+      if constexpr (SCHEME == S_DPF) {
+        DpfWalk w;
+        w.resume(make_uint4(node[0], node[1], node[2], node[3]), x);
+        y = w.finish(g, a.party, oc);
+      } else {
+        DcfWalk w;
+        w.resume(make_uint4(node[0], node[1], node[2], node[3]), make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]), x);
+        y = w.finish(g, a.party, oc);
+      }
+    }
+    ys[4 * k + q] = q == 0 ? y.x : (q == 1 ? y.y : (q == 2 ? y.z : y.w));
   }
 }
 
