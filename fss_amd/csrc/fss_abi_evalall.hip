@@ -7,17 +7,14 @@
 namespace {
 
 // The first frontier comes from independent point walks (taken child only): cheaper than the tiny expansion
-// launches they replace (each a launch, a 128 KiB LDS fill per workgroup and a drain: >= 10 us for almost no
-// work).  DPF / Grotto walks cost one block per level and pay up to 2^18 lanes x 18 levels (every wave of the
-// chip busy, ~40 us) -- measured optimum, tools/sweep_evalall_small.sh: n = 20 in 76 us instead of 93 (15
-// levels), n = 24 +5 %; at 19 levels the walk itself dominates.  DCF (two blocks per level) and Half-Tree are
-// best at 15, and so is every scheme with the ChaCha PRG, whose walk level costs a whole permutation (`aes` =
-// the context uses the AES tables).  FSS_AMD_TOPMAX overrides (A/B).  The workspace queries have no context
-// and return the larger of the two plans' needs.
-// With the AES tables every scheme walks the frontier one block per QUAD of lanes
-// (frontier_quad_kernel, FSS_AMD_QUAD_FRONTIER=0: one walk per lane): a level costs ~0.9 us instead of ~2.2,
-// and the optimum is 16 levels (DPF n = 20: 60 us, n = 24: +5 % over 18 per-lane levels; Half-Tree n = 20:
-// 75 -> 49 us, n = 24: +7 %; DCF, two blocks and a group addition per level: n = 20 146 -> 132 us, n = 24 +3 %).
+// launches they replace (each a launch, a table fill per workgroup and a drain: >= 10 us for almost no work).
+// Every scheme and PRG walks it one PRG call per QUAD of lanes (frontier_quad_kernel, fss_quad.hpp): a level
+// costs ~0.9 us instead of 2.2 (AES) or 1.6 (ChaCha), and the optimum is 16 levels plus the in-register tail
+// (frontier_tail) -- DPF n = 20: 136 -> 44 us, 2^24 leaves +13 %; Half-Tree n = 20: 75 -> 39 us; DCF, two
+// blocks and a group addition per level: 146 -> 120 us; ChaCha DPF n = 20: 88 -> 62 us.
+// FSS_AMD_QUAD_FRONTIER=0 selects one walk per lane (then DPF / Grotto with the AES tables walk up to 2^18
+// lanes x 18 levels, every wave of the chip busy, the rest 15).  FSS_AMD_TOPMAX overrides (A/B).  The workspace
+// queries have no context and return the larger of the plans' needs.
 inline bool quad_frontier() {
   static const bool v = [] { const char* e = getenv("FSS_AMD_QUAD_FRONTIER"); return !(e && atoi(e) == 0); }();
   return v;
@@ -29,7 +26,7 @@ inline int top_max(int scheme, bool aes) {
     return (t < 0 || t > 20) ? -1 : t;
   }();
   if (v >= 0) return v;
-  if (aes && quad_frontier()) return 16;
+  if (quad_frontier()) return 16;
   if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return 18;
   return 15;
 }
@@ -39,7 +36,8 @@ inline int top_max(int scheme, bool aes) {
 // when the walk was capped (it then replaces a launch; below the cap walking two more levels is cheaper).
 inline int frontier_tail(int scheme, bool aes, bool capped, int room) {
   static const bool on = [] { const char* e = getenv("FSS_AMD_FRONTIER_TAIL"); return !(e && atoi(e) == 0); }();
-  if (!on || !aes || !quad_frontier() || scheme == S_DCF || !capped || room < 2) return 0;
+  (void)aes;
+  if (!on || !quad_frontier() || scheme == S_DCF || !capped || room < 2) return 0;
   return 2;
 }
 
@@ -182,12 +180,12 @@ template <int SCHEME, bool BATCH>
 int launch_frontier(fss_amd_ctx* ctx, hipStream_t st, int64_t nout, const uint32_t* seed, const uint32_t* cws,
                     const ExpandArgs& a, int top, int tail) {
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
-  if (ctx->prg != FSS_AMD_PRG_CHACHA && quad_frontier()) {
+  if (quad_frontier()) {
     const int64_t lanes = (nout >> tail) * 4;  // a quad per walk
     const int fbs = lanes >= 65536 ? 1024 : (lanes >= 256 ? 256 : 64);
     const int64_t want = (lanes + fbs - 1) / fbs, cap = (int64_t)ctx->num_cu * (1024 / fbs);
-    hipLaunchKernelGGL((frontier_quad_kernel<WS, BATCH>), dim3((unsigned)(want < cap ? want : cap)), dim3(fbs), 0, st, ctx->host,
-                       ctx->te0, seed, cws, a, top, tail);
+    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((frontier_quad_kernel<LT, WS, BATCH>), dim3((unsigned)(want < cap ? want : cap)), dim3(fbs),
+                                        0, st, ctx->host, ctx->te0, seed, cws, a, top, tail));
     HIP_TRY(hipGetLastError());
     return FSS_AMD_OK;
   }

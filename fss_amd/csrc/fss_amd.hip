@@ -203,15 +203,15 @@ static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, i
   k.ocw = reinterpret_cast<const uint32_t*>(ocw);
   // Small batches are latency chains run by lone waves: one walk per quad of lanes (points_quad_kernel) runs a
   // level in ~0.9 us instead of ~2.2.  FSS_AMD_QUAD_POINTS_MAX = largest batch that takes it (0: never).
-  if (ctx->prg != FSS_AMD_PRG_CHACHA && n > 0 && n <= quad_points_max()) {
+  if (n > 0 && n <= quad_points_max()) {
     const int64_t lanes = n * 4;
     const int bs = lanes >= 65536 ? 1024 : 256;
     const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
     const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
     switch (scheme) {
-      case S_DPF: hipLaunchKernelGGL(points_quad_kernel<S_DPF>, grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a); break;
-      case S_DCF: hipLaunchKernelGGL(points_quad_kernel<S_DCF>, grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a); break;
-      default: hipLaunchKernelGGL(points_quad_kernel<S_HT>, grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a); break;
+      case S_DPF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, S_DPF>), grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)); break;
+      case S_DCF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, S_DCF>), grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)); break;
+      default: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, S_HT>), grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)); break;
     }
     HIP_TRY(hipGetLastError());
     ctx->last_kernel = scheme == S_DPF ? "dpf_eval_points" : (scheme == S_DCF ? "dcf_eval_points" : "ht_eval_points");
@@ -352,15 +352,15 @@ static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int
   a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
   a.out_cw = reinterpret_cast<const uint4*>(out_cw);
   a.extra = reinterpret_cast<const uint32_t*>(extra);
-  if (ctx->prg != FSS_AMD_PRG_CHACHA && n <= quad_points_max()) {  // small batch: a quad of lanes per key (points_common)
+  if (n <= quad_points_max()) {  // small batch: a quad of lanes per key (points_common)
     const int64_t lanes = n * 4;
     const int bs = lanes >= 65536 ? 1024 : 256;
     const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
     const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
     switch (scheme) {
-      case S_DPF: hipLaunchKernelGGL(keys_quad_kernel<S_DPF>, grid, block, 0, S(stream), ctx->host, ctx->te0, a); break;
-      case S_DCF: hipLaunchKernelGGL(keys_quad_kernel<S_DCF>, grid, block, 0, S(stream), ctx->host, ctx->te0, a); break;
-      default: hipLaunchKernelGGL(keys_quad_kernel<S_HT>, grid, block, 0, S(stream), ctx->host, ctx->te0, a); break;
+      case S_DPF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_DPF>), grid, block, 0, S(stream), ctx->host, ctx->te0, a)); break;
+      case S_DCF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_DCF>), grid, block, 0, S(stream), ctx->host, ctx->te0, a)); break;
+      default: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_HT>), grid, block, 0, S(stream), ctx->host, ctx->te0, a)); break;
     }
     HIP_TRY(hipGetLastError());
     ctx->last_kernel = scheme == S_DPF ? "dpf_eval_keys" : (scheme == S_DCF ? "dcf_eval_keys" : "ht_eval_keys");

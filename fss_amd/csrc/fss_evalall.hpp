@@ -183,7 +183,7 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
 }
 
 // -- frontier with the AES tables: one walk per quad of lanes (fss_quad.hpp) ---------------------------------
-template <int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
+template <class LT, int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
 __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
                                                             const uint32_t* __restrict__ k_cws, ExpandArgs a, int top,
@@ -193,32 +193,28 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
   // without its launch.  a.level0 = depth of the stored nodes.
   static_assert(SCHEME == S_DPF || SCHEME == S_DCF || SCHEME == S_HT, "quad frontier: DPF / Grotto / DCF / Half-Tree");
   const DevCtx* c = first_kernarg(K);
-  FSS_PRG_PROLOGUE(Lds, te0);
+  FSS_PRG_PROLOGUE(LT, te0);
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
-  uint32_t ka[11], kd[11], hk;
-  // DCF: the value block's keys 1 / 3 (dcf.cuh:223); DPF: key 1 alone, for the tail's both-children expansions
-  uint32_t kb[SCHEME == S_HT ? 1 : 11], ke[SCHEME == S_DCF ? 11 : 1];
-  quad_keys<SCHEME>(c, q, ka, kd, kb, ke, hk);
+  QuadPrg<LT, SCHEME> P;
+  P.init(L, c, q);
   const Grp g = make_grp(a.group, c);
   const int depth = a.level0 - tail;  // levels walked: p + top - tail
   top -= tail;
   const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;  // walks
   const int64_t nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
-  // one node -> both children at tree level lv (dpf_expand / ht_expand), a column per lane
+  // one node -> both children at tree level lv (dpf_expand / ht_expand), a word per lane
   auto expand = [&](const uint32_t* kc, int lv, uint32_t node, uint32_t& left, uint32_t& right) {
     const uint32_t w = kc[8 * lv + q];
     const uint32_t tm = lsb_mask(quad_get<FSS_QP(3, 3, 3, 3)>(node));
     if constexpr (SCHEME == S_DPF) {
       const uint32_t trw = kc[8 * lv + 4];
-      const uint32_t in = node & ~(is3 & 1u);
       uint32_t l, r;
-      quad_aes_pair<false>(L, in, 0u, ka, kd, kb, ke, l, r);
-      left = and_xor(tm, w, l ^ in);
-      right = and_xor(tm, w ^ (is3 & ((w ^ trw) & 1u)), r ^ in);
+      P.both(node & ~(is3 & 1u), l, r);
+      left = and_xor(tm, w, l);
+      right = and_xor(tm, w ^ (is3 & ((w ^ trw) & 1u)), r);
     } else if constexpr (SCHEME == S_HT) {
-      const uint32_t in = node ^ hk;
-      left = and_xor(tm, w, quad_aes<false>(L, in, 0u, ka, kd) ^ in);
+      left = and_xor(tm, w, P.hash(node ^ P.hk));
       right = left ^ node;
     } else {
       left = right = node;  // no tail for DCF
@@ -232,10 +228,7 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
     st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);  // dpf.cuh:171-173, half_tree_dpf.cuh:188
     Acc v;  // DCF: the running value, kept whole (and identical) in the four lanes
 #pragma unroll 1
-    for (int i = 0; i < depth; ++i) {
-      const uint32_t m = bit_mask(path, depth - 1 - i);  // the same for the four lanes of a walk
-      quad_level<SCHEME>(L, g, kc, i, m, q, is3, ka, kd, kb, ke, hk, st, v);
-    }
+    for (int i = 0; i < depth; ++i) quad_level(P, g, kc, i, bit_mask(path, depth - 1 - i), q, is3, st, v);
     uint32_t* out = reinterpret_cast<uint32_t*>(a.out_nodes);
     if (tail == 2 && SCHEME != S_DCF) {
       uint32_t c1[2];
