@@ -118,7 +118,8 @@ def test_parity_under_forced_tunables(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_vdpf.py"),
-                        "-k", "vs_oracle or kats or subblocks or deep_prefix"],
+                        os.path.join(root, "tests", "test_gpu_chacha.py"),
+                        "-k", "vs_oracle or kats or subblocks or deep_prefix or chacha"],
                        env={**os.environ, **env}, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
