@@ -428,6 +428,17 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
   if (!workspace || ws_bytes < prefix_workspace(SCHEME, pl, k)) return FSS_AMD_EINVAL;
   if (!aligned16(seed, cws, ocw, ys, workspace) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
+  if (n <= quad_points_max()) {  // too few points to amortise a node table: the plain quad-lane walk (same outputs)
+    FSS_ON_DEVICE(ctx);
+    EvalArgs q{};
+    q.in_bits = in_bits; q.party = party; q.group = group; q.x_bytes = x_bytes; q.n = n;
+    q.xs = xs; q.ys = ys;
+    SharedKey sk;
+    sk.seed = reinterpret_cast<const uint32_t*>(seed);
+    sk.cws = reinterpret_cast<const uint32_t*>(cws);
+    sk.ocw = reinterpret_cast<const uint32_t*>(ocw);
+    return launch_points_quad<SCHEME>(ctx, name, sk, q, st);
+  }
   FSS_ON_DEVICE(ctx);
 
   const size_t per = (SCHEME == S_DCF) ? 32 : 16;

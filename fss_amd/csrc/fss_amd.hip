@@ -3,7 +3,6 @@
 // shared-prefix walks, Grotto.  fss_abi_gen.hip: key generation, verifiable DPF.
 #include "fss_host.hpp"
 #include "fss_gen.hpp"
-#include "fss_quad.hpp"
 
 namespace {
 void make_sbox(uint8_t sbox[256]) {
@@ -176,15 +175,6 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
 }
 
 // ------------------------------------------------------------------ point eval, shared key
-// DPF n = 32: 30 us per launch up to 2^16 points (a per-lane walk: 85 us up to 2^18), 56 us at 2^17, 109 us at 2^18
-constexpr int kQuadPointsMax = 131072;
-static int64_t quad_points_max() {
-  static const int64_t v = [] {
-    const char* e = getenv("FSS_AMD_QUAD_POINTS_MAX");
-    return e ? (int64_t)atoll(e) : (int64_t)kQuadPointsMax;
-  }();
-  return v;
-}
 static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seed,
                          const void* cws, const void* ocw, const void* xs, int x_bytes, int64_t n, void* ys,
                          void* stream) {
@@ -201,23 +191,12 @@ static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, i
   k.seed = reinterpret_cast<const uint32_t*>(seed);
   k.cws = reinterpret_cast<const uint32_t*>(cws);
   k.ocw = reinterpret_cast<const uint32_t*>(ocw);
-  // Small batches are latency chains run by lone waves: one walk per quad of lanes (points_quad_kernel) runs a
-  // level in ~0.9 us instead of ~2.2.  FSS_AMD_QUAD_POINTS_MAX = largest batch that takes it (0: never).
-  if (n > 0 && n <= quad_points_max()) {
-    const int64_t lanes = n * 4;
-    const int bs = lanes >= 65536 ? 1024 : 256;
-    const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
-    const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
+  if (n > 0 && n <= quad_points_max()) {  // small batch: one walk per quad of lanes
     switch (scheme) {
-      case S_DPF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, S_DPF>), grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)); break;
-      case S_DCF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, S_DCF>), grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)); break;
-      default: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, S_HT>), grid, block, 0, S(stream), ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a)); break;
+      case S_DPF: return launch_points_quad<S_DPF>(ctx, "dpf_eval_points", k, a, S(stream));
+      case S_DCF: return launch_points_quad<S_DCF>(ctx, "dcf_eval_points", k, a, S(stream));
+      default: return launch_points_quad<S_HT>(ctx, "ht_eval_points", k, a, S(stream));
     }
-    HIP_TRY(hipGetLastError());
-    ctx->last_kernel = scheme == S_DPF ? "dpf_eval_points" : (scheme == S_DCF ? "dcf_eval_points" : "ht_eval_points");
-    ctx->last_grid = (int)grid.x;
-    ctx->last_block = bs;
-    return FSS_AMD_OK;
   }
   switch (scheme) {
     case S_DPF: return launch_points<S_DPF, true>(ctx, "dpf_eval_points", k, a, S(stream));

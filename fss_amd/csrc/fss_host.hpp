@@ -15,6 +15,7 @@
 
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
+#include "fss_quad.hpp"
 
 using namespace fssamd;
 
@@ -213,6 +214,31 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   FSS_L(2, 256);
 #undef FSS_L
   return FSS_AMD_EINVAL;
+}
+
+// Small shared-key batches: one walk per quad of lanes (points_quad_kernel, fss_quad.hpp) runs a level in ~0.9 us
+// instead of the 2 - 3 us of a lone wave.  DPF n = 32: 30 us per launch up to 2^16 points (a per-lane walk: 85 us up
+// to 2^18), 56 us at 2^17, 109 us at 2^18.  FSS_AMD_QUAD_POINTS_MAX = largest batch that takes it (0: never).
+constexpr int kQuadPointsMax = 131072;
+inline int64_t quad_points_max() {
+  static const int64_t v = [] {
+    const char* e = getenv("FSS_AMD_QUAD_POINTS_MAX");
+    return e ? (int64_t)atoll(e) : (int64_t)kQuadPointsMax;
+  }();
+  return v;
+}
+template <int SCHEME>
+int launch_points_quad(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
+  const int64_t lanes = a.n * 4;
+  const int bs = lanes >= 65536 ? 1024 : 256;
+  const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
+  const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
+  FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, SCHEME>), grid, block, 0, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a));
+  HIP_TRY(hipGetLastError());
+  ctx->last_kernel = name;
+  ctx->last_grid = (int)grid.x;
+  ctx->last_block = bs;
+  return FSS_AMD_OK;
 }
 
 }  // namespace
