@@ -37,6 +37,16 @@ def _xs_tensor(values, in_bits, device):
     return torch.tensor([[s64(v & ((1 << 64) - 1)), s64(v >> 64)] for v in values], dtype=torch.int64, device=device)
 
 
+def _x_tensor(x, in_bits, device):
+    """One evaluation point for the per-point `eval` methods, created on the engine's device by a fill (no
+    host-to-device copy, which would synchronise) for in_bits <= 64."""
+    if in_bits > 64 or torch.device(device).type != "cuda":
+        return _xs_tensor([x], in_bits, "cpu")
+    if in_bits <= 32:
+        return torch.full((1,), x - (1 << 32) if x >= (1 << 31) else x, dtype=torch.int32, device=device)
+    return torch.full((1,), x - (1 << 64) if x >= (1 << 63) else x, dtype=torch.int64, device=device)
+
+
 def _check_group(group):
     """'bytes' / 'uint' as the reference; 'u8' .. 'u128' name one Uint<T> explicitly."""
     if group not in E.GROUP_IDS:
@@ -107,7 +117,7 @@ class Dpf(_Base):
         validate_device_match(s0, cws)
         validate_domain_value("x", x, self.in_bits)
         ys = self.engine.eval_points(self.scheme, self.in_bits, self._g, party, s0, cws,
-                                     _xs_tensor([x], self.in_bits, "cpu"))
+                                     _x_tensor(x, self.in_bits, self.engine.device))
         return self._back(ys[0], s0)
 
     def eval_points(self, party, s0, cws, xs):
@@ -189,7 +199,7 @@ class HalfTreeDpf(_Base):
         validate_cws(cws, self.in_bits, slots=self.in_bits)
         validate_domain_value("x", x, self.in_bits)
         ys = self.engine.eval_points(self.scheme, self.in_bits, self._g, party, s0, cws,
-                                     _xs_tensor([x], self.in_bits, "cpu"), ocw=ocw)
+                                     _x_tensor(x, self.in_bits, self.engine.device), ocw=ocw)
         return self._back(ys[0], s0)
 
     def eval_points(self, party, s0, cws, ocw, xs):
@@ -286,7 +296,7 @@ class Vdpf(_Base):
         validate_s0(s0)
         validate_domain_value("x", x, self.in_bits)
         ys, pis = self.engine.vdpf_eval_points(self.in_bits, self._g, party, s0, cws, cs, ocw,
-                                               _xs_tensor([x], self.in_bits, "cpu"))
+                                               _x_tensor(x, self.in_bits, self.engine.device))
         return self._back(ys[0], s0), self._back(pis[0], s0)
 
     def eval_points(self, party, s0, cws, cs, ocw, xs):
