@@ -94,7 +94,7 @@ def measured_pipe_busy(log2_batch):
     out = {"lds_busy": v["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / cyc,
            "valu_busy": v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / cyc,
            "valu_wave_instructions_per_launch": v["SQ_INSTS_VALU"]["mean_per_launch"],
-           "clock_ghz_under_profiler": cyc / (v["AverageNs"] * 1e-9) / 1e9 if "AverageNs" in v else None,
+           "clock_ghz_in_pmc_run": cyc / (v["AverageNs"] * 1e-9) / 1e9 if "AverageNs" in v else None,
            "source": "profiles/ rocprofv3 --pmc passes of the same command"}
     return out
 
