@@ -98,6 +98,22 @@ class Engine:
             raise ValueError(f"{what}: expected at least {numel} elements, got {have}")
         return t
 
+    def _out(self, out, nbytes, what, dtypes=(torch.int32,)):
+        """A caller-supplied output tensor is handed to the kernels as a raw pointer: it must live on this engine's
+        device, be contiguous, have the element type the kernel writes and hold at least `nbytes` bytes."""
+        if not isinstance(out, torch.Tensor):
+            raise TypeError(f"{what}: expected a torch.Tensor, got {type(out).__name__}")
+        if out.device != self.device:
+            raise ValueError(f"{what}: must be on {self.device}, got {out.device}")
+        if not out.is_contiguous():
+            raise ValueError(f"{what}: must be contiguous")
+        if out.dtype not in dtypes:
+            raise ValueError(f"{what}: dtype must be {' or '.join(str(d) for d in dtypes)}, got {out.dtype}")
+        have = out.element_size() * out.numel()
+        if have < nbytes:
+            raise ValueError(f"{what}: expected at least {nbytes} bytes, got {have} ({tuple(out.shape)} {out.dtype})")
+        return out
+
     @staticmethod
     def _slots(scheme, in_bits):
         return in_bits if scheme in (HT, VDPF) else in_bits + 1
@@ -140,7 +156,7 @@ class Engine:
         xb = self._xbytes(xs, in_bits)
         n = xs.shape[0] if xb == 16 else xs.numel()
         self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(scheme, in_bits), "cws")
-        ys = self._need(out, 4 * n, "out") if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        ys = self._out(out, 16 * n, "out") if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
         L, st = self._L, self._stream()
         if scheme == DPF:
             rc = L.fss_amd_dpf_eval_points(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
@@ -161,6 +177,9 @@ class Engine:
         """eval_points with the shared top of the tree expanded once per launch (same outputs).
         prefix_bits=None picks ~log2(len(xs)), capped by in_bits and 26."""
         seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
+        xb = self._xbytes(xs, in_bits)
+        if xb == 16:
+            raise ValueError("eval_points_shared covers in_bits <= 64: pass int32 / int64 xs, not (n, 2) pairs")
         n = xs.numel()
         cap = min(in_bits - (1 if scheme == HT else 0), 26)
         if prefix_bits is None:
@@ -173,8 +192,7 @@ class Engine:
             raise ValueError(f"eval_points_shared: unsupported prefix_bits={prefix_bits} for in_bits={in_bits}")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
         self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(scheme, in_bits), "cws")
-        ys = self._need(out, 4 * n, "out") if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
-        xb = self._xbytes(xs, in_bits)
+        ys = self._out(out, 16 * n, "out") if out is not None else torch.empty((n, 4), dtype=torch.int32, device=self.device)
         if scheme == DPF:
             rc = L.fss_amd_dpf_eval_points_shared(self._h, in_bits, group, party, _ptr(seed), _ptr(cws), _ptr(xs), xb, n,
                                                   _ptr(ys), prefix_bits, _ptr(ws), ws_bytes, st)
@@ -220,6 +238,7 @@ class Engine:
         """LevelMajorKeys -> int32[nkeys, slots, 8] key-major raw Cw slots (the inverse of relayout)."""
         n, nb = keys.nkeys, keys.in_bits
         scheme = DPF if keys.scheme == GROTTO else keys.scheme
+        self._check_keys(keys)
         cws = torch.empty((n, self._slots(scheme, nb), 8), dtype=torch.int32, device=self.device)
         L, st = self._L, self._stream()
         if scheme == DPF:
@@ -233,14 +252,34 @@ class Engine:
         _lib.check(rc, "key_major")
         return cws
 
+    def _check_keys(self, keys):
+        """Sizes of the level-major arrays of a LevelMajorKeys batch (they reach the kernels as raw pointers)."""
+        n, nb = keys.nkeys, keys.in_bits
+        self._need(keys.cw_s, 4 * nb * n, "keys.cw_s")
+        if keys.scheme == DCF:
+            self._need(keys.cw_v, 4 * nb * n, "keys.cw_v")
+        if keys.scheme in (DPF, GROTTO, VDPF):
+            self._need(keys.tr_bits, (nb + 63) // 64 * n, "keys.tr_bits")
+        if keys.scheme in (DPF, DCF, GROTTO):
+            self._need(keys.out_cw, 4 * n, "keys.out_cw")
+        if keys.scheme == HT:
+            self._need(keys.extra, n, "keys.extra")
+
     def eval_keys(self, keys, group, party, seeds, xs, ocws=None, out=None):
-        """ys[k] = Eval(party, seeds[k], key k, xs[k]) on a LevelMajorKeys batch."""
+        """ys[k] = Eval(party, seeds[k], key k, xs[k]) on a LevelMajorKeys batch.
+        Grotto keys: the path-walk evaluator for domains with no table.  It reconstructs 1[alpha <= x], but its
+        per-party share is NOT the share of eval_all / grotto_eval_table / the reference's GrottoDcf::Eval (they
+        differ by a party-independent mask): both parties must use eval_keys for the same (key, x)."""
         seeds, xs = self._dev(seeds, torch.int32), self._dev(xs)
         n, nb = keys.nkeys, keys.in_bits
+        self._check_keys(keys)
         xb = self._xbytes(xs, nb)
         self._need(seeds, 4 * n, "seeds"); self._need(xs, n * (2 if xb == 16 else 1), "xs")
         if out is not None:
-            self._need(out, n if keys.scheme == GROTTO else 4 * n, "out")
+            if keys.scheme == GROTTO:
+                self._out(out, n, "out", (torch.uint8, torch.bool))
+            else:
+                self._out(out, 16 * n, "out")
         L, st = self._L, self._stream()
         if keys.scheme == GROTTO:
             ys = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=self.device)
@@ -274,7 +313,10 @@ class Engine:
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
         self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(DPF if scheme == GROTTO else scheme, in_bits), "cws")
         if out is not None:
-            self._need(out, nleaves if scheme == GROTTO else 4 * nleaves, "out")
+            if scheme == GROTTO:
+                self._out(out, nleaves, "out", (torch.uint8, torch.bool))
+            else:
+                self._out(out, 16 * nleaves, "out")
         if scheme == GROTTO:
             ys = out if out is not None else torch.empty((nleaves,), dtype=torch.uint8, device=self.device)
             rc = L.fss_amd_grotto_eval_all(self._h, in_bits, party, _ptr(seed), _ptr(cws), first_leaf, nleaves,
@@ -309,7 +351,7 @@ class Engine:
         if ws_bytes == 0:
             raise ValueError(f"eval_all_batch: unsupported (scheme={scheme}, in_bits={in_bits}, nkeys={n})")
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=self.device)
-        ys = (self._need(out, 4 * n << in_bits, "out") if out is not None
+        ys = (self._out(out, 16 * n << in_bits, "out") if out is not None
               else torch.empty((n, 1 << in_bits, 4), dtype=torch.int32, device=self.device))
         if scheme == DPF:
             rc = L.fss_amd_dpf_eval_all_batch(self._h, in_bits, group, party, _ptr(seeds), _ptr(cws), n, _ptr(ys), _ptr(ws), ws_bytes, st)
@@ -341,10 +383,16 @@ class Engine:
 
     def grotto_eval_table(self, in_bits, pt, xs, out=None):
         """GrottoDcf::Eval over a batch: uint8[n]."""
+        if in_bits > 40:
+            raise ValueError("grotto_eval_table: the parity table has 2^(in_bits+1) - 1 bytes; in_bits <= 40")
         pt, xs = self._dev(pt, torch.uint8), self._dev(xs)
+        xb = self._xbytes(xs, in_bits)
+        if xb == 16:
+            raise ValueError("grotto_eval_table covers in_bits <= 64: pass int32 / int64 xs")
         n = xs.numel()
-        ys = out if out is not None else torch.empty((n,), dtype=torch.uint8, device=self.device)
-        _lib.check(self._L.fss_amd_grotto_eval_table(self._h, in_bits, _ptr(pt), _ptr(xs), self._xbytes(xs, in_bits), n,
+        self._need(pt, (2 << in_bits) - 1, "pt")
+        ys = self._out(out, n, "out", (torch.uint8, torch.bool)) if out is not None else torch.empty((n,), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.fss_amd_grotto_eval_table(self._h, in_bits, _ptr(pt), _ptr(xs), xb, n,
                                                      _ptr(ys), self._stream()), "grotto_eval_table")
         return ys
 
@@ -441,6 +489,8 @@ class Engine:
 
     def vdpf_relayout(self, in_bits, cws):
         cws = self._dev(cws, torch.int32)
+        if cws.dim() != 3 or cws.shape[1] != in_bits or cws.shape[2] != 8:
+            raise ValueError(f"vdpf_relayout: cws must be int32[nkeys, {in_bits}, 8], got {tuple(cws.shape)}")
         n = cws.shape[0]
         cw_s = torch.empty((in_bits, n, 4), dtype=torch.int32, device=self.device)
         tr = torch.empty(((in_bits + 63) // 64 * n,), dtype=torch.int64, device=self.device)
@@ -454,6 +504,7 @@ class Engine:
                                 self._dev(ocw, torch.int32), self._dev(xs))
         xb = self._xbytes(xs, in_bits)
         n = xs.shape[0] if xb == 16 else xs.numel()
+        self._need(s0, 4, "s0"); self._need(cws, 8 * in_bits, "cws"); self._need(cs, 16, "cs"); self._need(ocw, 4, "ocw")
         ys = torch.empty((n, 4), dtype=torch.int32, device=self.device)
         pis = torch.empty((n, 4, 4), dtype=torch.int32, device=self.device)
         rc = self._L.fss_amd_vdpf_eval_points(self._h, in_bits, group, party, _ptr(s0), _ptr(cws), _ptr(cs), _ptr(ocw),
@@ -467,8 +518,14 @@ class Engine:
                                self._dev(xs))
         n, nb = keys.nkeys, keys.in_bits
         xb = self._xbytes(xs, nb)
-        ys, pis = out if out is not None else (torch.empty((n, 4), dtype=torch.int32, device=self.device),
-                                                torch.empty((n, 4, 4), dtype=torch.int32, device=self.device))
+        self._check_keys(keys)
+        self._need(seeds, 4 * n, "seeds"); self._need(cs, 16 * n, "cs"); self._need(ocws, 4 * n, "ocws")
+        self._need(xs, n * (2 if xb == 16 else 1), "xs")
+        if out is not None:
+            ys, pis = self._out(out[0], 16 * n, "out[0]"), self._out(out[1], 64 * n, "out[1]")
+        else:
+            ys, pis = (torch.empty((n, 4), dtype=torch.int32, device=self.device),
+                       torch.empty((n, 4, 4), dtype=torch.int32, device=self.device))
         rc = self._L.fss_amd_vdpf_eval_keys(self._h, nb, group, party, _ptr(seeds), _ptr(keys.cw_s), _ptr(keys.tr_bits),
                                             _ptr(cs), _ptr(ocws), _ptr(xs), xb, n, _ptr(ys), _ptr(pis), self._stream())
         _lib.check(rc, "vdpf_eval_keys")
@@ -477,6 +534,7 @@ class Engine:
     def vdpf_prove(self, pi_tildes, cs):
         """Vdpf::Prove over the hashes of ONE key (sequential chain) -> int32[4,4]."""
         pis, cs = self._dev(pi_tildes, torch.int32), self._dev(cs, torch.int32)
+        self._need(cs, 16, "cs")
         out = torch.empty((4, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._L.fss_amd_vdpf_prove(self._h, _ptr(pis), pis.numel() // 16, _ptr(cs), _ptr(out), self._stream()),
                    "vdpf_prove")
@@ -486,6 +544,7 @@ class Engine:
         """Per key, one evaluation each -> int32[n,4,4]."""
         pis, cs = self._dev(pi_tildes, torch.int32), self._dev(cs, torch.int32)
         n = pis.numel() // 16
+        self._need(cs, 16 * n, "cs")
         out = torch.empty((n, 4, 4), dtype=torch.int32, device=self.device)
         _lib.check(self._L.fss_amd_vdpf_prove_keys(self._h, _ptr(pis), _ptr(cs), n, _ptr(out), self._stream()),
                    "vdpf_prove_keys")

@@ -256,10 +256,16 @@ class GrottoDcf(_Base):
         """= GrottoDcf::Eval (grotto_dcf.cuh:116-135) for a batch of x: uint8[n] shares of 1[alpha <= x]."""
         return self.engine.grotto_eval_table(self.in_bits, pt, xs)
 
-    def eval_keys(self, party, seeds, keys, xs):
-        """Path-walk shares for independent keys (any in_bits <= 64); see include/fss_amd.h."""
+    def eval_keys_pathwalk(self, party, seeds, keys, xs):
+        """Path-walk shares for independent keys, one point each (any in_bits <= 64; the reference has no evaluator
+        for domains too large for a table, grotto_dcf.cuh:117).  The two parties' shares XOR to 1[alpha <= x], but a
+        party's share is NOT the one `eval` / `eval_all` (= the reference's GrottoDcf::Eval / EvalAll) give for the
+        same key and x: they differ by a party-independent mask.  BOTH parties must use this method for a given
+        (key, x); mixing it with `eval` or `eval_all` on the other side reconstructs a wrong bit half of the time."""
         validate_party(party)
         return self.engine.eval_keys(keys, E.BYTES, party, seeds, xs)
+
+    eval_keys = eval_keys_pathwalk  # older name; same incompatibility caveat
 
 
 class Vdpf(_Base):

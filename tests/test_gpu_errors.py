@@ -149,3 +149,74 @@ def test_engine_refuses_undersized_tensors():
         eng.gen(fss_amd.DPF, 32, fss_amd.U64, z(5, 2, 4), z(5), z(4, 4))
     with pytest.raises(ValueError, match="cws"):
         eng.eval_all(fss_amd.DCF, 10, fss_amd.U64, 0, z(4), z(10, 8))
+
+
+def test_engine_refuses_unusable_out_tensors():
+    """A caller-supplied `out` reaches the kernels as a raw pointer: wrong element size (numel alone would pass),
+    wrong device, a strided view or a wrong dtype must be ValueError, never a device heap overflow."""
+    import fss_amd
+    eng = fss_amd.default_engine(0)
+    z = lambda *shape, dt=torch.int32: torch.zeros(shape, dtype=dt, device="cuda")
+    xs, seed, cws = z(100), z(4), z(33, 8)
+    ev = lambda out: eng.eval_points(fss_amd.DPF, 32, fss_amd.U64, 0, seed, cws, xs, out=out)
+    with pytest.raises(ValueError, match="dtype"):
+        ev(torch.zeros(4 * 100, dtype=torch.uint8, device="cuda"))       # 400 elements but 400 bytes, not 1600
+    with pytest.raises(ValueError, match="must be on"):
+        ev(torch.zeros((100, 4), dtype=torch.int32))                     # host memory
+    with pytest.raises(ValueError, match="contiguous"):
+        ev(z(100, 8)[:, ::2])
+    with pytest.raises(ValueError, match="bytes"):
+        ev(z(99, 4))
+    assert ev(z(100, 4)).shape == (100, 4)
+    with pytest.raises(ValueError, match="dtype"):
+        eng.eval_points_shared(fss_amd.DPF, 32, fss_amd.U64, 0, seed, cws, xs, out=z(100, 4, dt=torch.int16))
+    with pytest.raises(ValueError, match="dtype"):
+        eng.eval_all(fss_amd.DPF, 10, fss_amd.U64, 0, seed, z(11, 8), out=z(1024 * 4, dt=torch.uint8))
+    with pytest.raises(ValueError, match="dtype"):
+        eng.eval_all(fss_amd.GROTTO, 10, fss_amd.BYTES, 0, seed, z(11, 8), out=z(1024))   # Grotto writes bytes
+    with pytest.raises(ValueError, match="bytes"):
+        eng.eval_all_batch(fss_amd.DPF, 6, fss_amd.U64, 0, z(3, 4), z(3, 7, 8), out=z(3, 63, 4))
+    keys = eng.relayout(fss_amd.DPF, 32, z(5, 33, 8))
+    with pytest.raises(ValueError, match="dtype"):
+        eng.eval_keys(keys, fss_amd.U64, 0, z(5, 4), z(5), out=z(20, dt=torch.int8))
+    # (n, 2) int64 pairs are __uint128_t points: the shared-prefix path (in_bits <= 64) refuses them instead of
+    # reading 2n 16-byte values from an n-element buffer
+    with pytest.raises(ValueError, match="pairs"):
+        eng.eval_points_shared(fss_amd.DPF, 32, fss_amd.U64, 0, seed, cws, torch.zeros((50, 2), dtype=torch.int64, device="cuda"))
+    # short parity table / short VDPF key material
+    with pytest.raises(ValueError, match="pt"):
+        eng.grotto_eval_table(10, torch.zeros(2047 - 1, dtype=torch.uint8, device="cuda"), z(5))
+    vk = fss_amd.engine.LevelMajorKeys(fss_amd.engine.VDPF, 16, 8, z(16, 8, 4), tr_bits=torch.zeros(8, dtype=torch.int64, device="cuda"))
+    with pytest.raises(ValueError, match="cs"):
+        eng.vdpf_eval_keys(vk, fss_amd.U64, 0, z(8, 4), z(7, 4, 4), z(8, 4), z(8))
+    with pytest.raises(ValueError, match="ocws"):
+        eng.vdpf_eval_keys(vk, fss_amd.U64, 0, z(8, 4), z(8, 4, 4), z(7, 4), z(8))
+    short = fss_amd.engine.LevelMajorKeys(fss_amd.DPF, 32, 5, z(31, 5, 4), tr_bits=keys.tr_bits, out_cw=keys.out_cw)
+    with pytest.raises(ValueError, match="cw_s"):
+        eng.key_major(short)
+
+
+def test_grotto_pathwalk_reconstructs_only_with_itself():
+    """The n = 64-capable path walk and the table / EvalAll evaluators give different per-party shares of the same
+    predicate (include/fss_amd.h, schemes.GrottoDcf.eval_keys_pathwalk): each reconstructs with itself; mixing
+    them across the two parties does not."""
+    import numpy as np
+    import fss_amd
+    n, nkeys = 10, 256
+    g = fss_amd.GrottoDcf(n)
+    gen = torch.Generator().manual_seed(5)
+    s0s = torch.randint(-2**31, 2**31, (nkeys, 2, 4), dtype=torch.int32, generator=gen)
+    alphas = torch.randint(0, 1 << n, (nkeys,), dtype=torch.int32, generator=gen)
+    xs = torch.randint(0, 1 << n, (nkeys,), dtype=torch.int32, generator=gen)
+    cws = g.gen_batch(s0s, alphas)
+    keys = g.relayout(cws)
+    walk = [g.eval_keys_pathwalk(b, s0s[:, b].contiguous(), keys, xs).cpu().numpy() for b in (0, 1)]
+    want = (alphas <= xs).numpy().astype(np.uint8)
+    assert ((walk[0] ^ walk[1]) == want).all()
+    table = []
+    for b in (0, 1):
+        row = [int(g.eval(g.preprocess(b, s0s[k, b], cws[k].cpu()), xs[k:k + 1])[0]) for k in range(nkeys)]
+        table.append(np.array(row, dtype=np.uint8))
+    assert ((table[0] ^ table[1]) == want).all()
+    mixed = walk[0] ^ table[1]
+    assert (mixed != want).any(), "walk and table shares are documented as incompatible"
