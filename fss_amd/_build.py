@@ -57,6 +57,23 @@ def build_sample(force=False):
             and os.path.getmtime(SAMPLE_BIN) >= max(os.path.getmtime(f) for f in [SAMPLE_SRC, SO] + hdrs)):
         return SAMPLE_BIN
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I" + os.path.join(_HERE, "..", "include"),
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20", "-I" + os.path.join(_HERE, "..", "include"),
                            SAMPLE_SRC, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../fss_amd", "-o", SAMPLE_BIN])
     return SAMPLE_BIN
+
+
+DROPIN_SRC = os.path.join(_HERE, "..", "tests", "cxx", "dropin_test.cpp")
+DROPIN_BIN = os.path.join(_HERE, "..", "tests", "cxx", "dropin_test")
+
+
+def build_dropin_test(force=False):
+    """Compile tests/cxx/dropin_test.cpp: caller code in the reference's own call syntax against include/fss_amd.hpp."""
+    build()
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("fss_amd.h", "fss_amd.hpp")]
+    if (not force and os.path.exists(DROPIN_BIN)
+            and os.path.getmtime(DROPIN_BIN) >= max(os.path.getmtime(f) for f in [DROPIN_SRC, SO] + hdrs)):
+        return DROPIN_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20", "-I" + os.path.join(_HERE, "..", "include"),
+                           DROPIN_SRC, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../../fss_amd", "-o", DROPIN_BIN])
+    return DROPIN_BIN

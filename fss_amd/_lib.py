@@ -68,6 +68,10 @@ PROTOTYPES = {
     "fss_amd_dcf_gen_level_major": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_ht_gen_level_major": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_last_kernel": (C.c_char_p, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "fss_amd_dpf_relayout_u32": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "fss_amd_dpf_eval_keys_u32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_ctx_scratch": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "fss_amd_upload": (_i, [_vp, _vp, _vp, _sz, _vp]),
 }
 
 

@@ -110,7 +110,57 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
 void fss_amd_ctx_destroy(fss_amd_ctx* ctx) {
   if (!ctx) return;
   if (ctx->te0) (void)hipFree(ctx->te0);
+  for (auto& kv : ctx->scratch)
+    if (kv.second.p) (void)hipFree(kv.second.p);
   delete ctx;
+}
+
+int fss_amd_ctx_scratch(fss_amd_ctx* ctx, void* stream, size_t bytes, void** out) {
+  if (!ctx || !out) return FSS_AMD_EINVAL;
+  *out = nullptr;
+  FSS_ON_DEVICE(ctx);
+  std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+  fss_amd_ctx::Scratch& s = ctx->scratch[stream];
+  if (s.bytes < bytes || !s.p) {
+    // hipFree waits for the device, so work still queued on the old buffer has finished before it goes away
+    if (s.p) HIP_TRY(hipFree(s.p));
+    s.p = nullptr;
+    s.bytes = 0;
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    HIP_TRY(hipMalloc(&s.p, want));
+    s.bytes = want;
+  }
+  *out = s.p;
+  return FSS_AMD_OK;
+}
+
+}  // extern "C"
+namespace {
+struct UploadBlob { uint32_t w[512]; };  // 2 KiB of kernel arguments per launch
+__global__ void upload_kernel(uint8_t* dst, const UploadBlob b, int bytes) {
+  const uint8_t* src = reinterpret_cast<const uint8_t*>(b.w);
+  if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+    for (int i = threadIdx.x; i < bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(dst)[i] = b.w[i];
+    for (int i = (bytes & ~3) + threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
+  } else {
+    for (int i = threadIdx.x; i < bytes; i += blockDim.x) dst[i] = src[i];
+  }
+}
+}  // namespace
+extern "C" {
+
+int fss_amd_upload(fss_amd_ctx* ctx, void* dst, const void* src_host, size_t bytes, void* stream) {
+  if (!ctx || (bytes && (!dst || !src_host)) || bytes > (1u << 20)) return FSS_AMD_EINVAL;
+  if (bytes == 0) return FSS_AMD_OK;
+  FSS_ON_DEVICE(ctx);
+  for (size_t off = 0; off < bytes; off += sizeof(UploadBlob)) {
+    UploadBlob b;
+    const size_t m = bytes - off < sizeof(UploadBlob) ? bytes - off : sizeof(UploadBlob);
+    memcpy(b.w, static_cast<const uint8_t*>(src_host) + off, m);  // the bytes travel as kernel arguments
+    hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(256), 0, S(stream), static_cast<uint8_t*>(dst) + off, b, (int)m);
+    HIP_TRY(hipGetLastError());
+  }
+  return FSS_AMD_OK;
 }
 
 int fss_amd_ctx_device(const fss_amd_ctx* ctx) { return ctx ? ctx->device : -1; }
@@ -219,22 +269,30 @@ int fss_amd_ht_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, 
 }
 
 // ------------------------------------------------------------------ relayout
-int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
-                         void* out_cw, void* stream) {
-  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
+static int dpf_relayout_common(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
+                               void* out_cw, int tr32, void* stream) {
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > (tr32 ? 32 : 128)) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !tr_bits || !out_cw) return FSS_AMD_EINVAL;
-  if (!aligned16(cws, cw_s, out_cw) || !aligned_to(tr_bits, 8)) return FSS_AMD_EINVAL;
+  if (!aligned16(cws, cw_s, out_cw) || !aligned_to(tr_bits, tr32 ? 4 : 8)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   launch_relayout<S_DPF>(ctx, S(stream), in_bits,
                      in_bits + 1, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s),
                      (uint4*)nullptr, reinterpret_cast<uint64_t*>(tr_bits), reinterpret_cast<uint4*>(out_cw),
-                     (uint32_t*)nullptr);
+                     (uint32_t*)nullptr, tr32);
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = "relayout";
   ctx->last_grid = (int)((nkeys + 63) / 64);
   ctx->last_block = 256;
   return FSS_AMD_OK;
+}
+int fss_amd_dpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
+                         void* out_cw, void* stream) {
+  return dpf_relayout_common(ctx, in_bits, cws, nkeys, cw_s, tr_bits, out_cw, 0, stream);
+}
+int fss_amd_dpf_relayout_u32(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* extra,
+                             void* out_cw, void* stream) {
+  return dpf_relayout_common(ctx, in_bits, cws, nkeys, cw_s, extra, out_cw, 1, stream);
 }
 int fss_amd_dcf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* cw_v,
                          void* out_cw, void* stream) {
@@ -312,14 +370,16 @@ int fss_amd_ht_key_major(fss_amd_ctx* ctx, int in_bits, const void* cw_s, const 
 // ------------------------------------------------------------------ point eval, independent keys
 static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seeds,
                        const void* cw_s, const void* cw_v, const void* tr_bits, const void* out_cw, const void* extra,
-                       const void* xs, int x_bytes, int64_t n, void* ys, void* stream) {
+                       const void* xs, int x_bytes, int64_t n, void* ys, void* stream, int tr32 = 0) {
   if (!ctx || n < 0 || !group_ok(ctx, group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
+  if (tr32 && in_bits > 32) return FSS_AMD_EINVAL;
   if (n == 0) return FSS_AMD_OK;
   if (!seeds || !cw_s || !xs || !ys || !out_cw) return FSS_AMD_EINVAL;
   if (scheme == S_DPF && !tr_bits) return FSS_AMD_EINVAL;
   if (scheme == S_DCF && !cw_v) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !extra) return FSS_AMD_EINVAL;
-  if (!aligned16(seeds, cw_s, cw_v, out_cw, ys) || !aligned_to(tr_bits, 8) || !aligned_to(extra, 4) || !aligned_to(xs, x_bytes))
+  if (!aligned16(seeds, cw_s, cw_v, out_cw, ys) || !aligned_to(tr_bits, tr32 ? 4 : 8) || !aligned_to(extra, 4) ||
+      !aligned_to(xs, x_bytes))
     return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   EvalArgs a{};
@@ -329,6 +389,7 @@ static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int
   a.cw_s = reinterpret_cast<const uint4*>(cw_s);
   a.cw_v = reinterpret_cast<const uint4*>(cw_v);
   a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
+  a.tr32 = tr32;
   a.out_cw = reinterpret_cast<const uint4*>(out_cw);
   a.extra = reinterpret_cast<const uint32_t*>(extra);
   if (n <= quad_points_max()) {  // small batch: a quad of lanes per key (points_common)
@@ -359,6 +420,12 @@ int fss_amd_dpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, c
                           void* stream) {
   return keys_common(ctx, S_DPF, in_bits, group, party, seeds, cw_s, nullptr, tr_bits, out_cw, nullptr, xs, x_bytes,
                      nkeys, ys, stream);
+}
+int fss_amd_dpf_eval_keys_u32(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                              const void* extra, const void* out_cw, const void* xs, int x_bytes, int64_t nkeys, void* ys,
+                              void* stream) {
+  return keys_common(ctx, S_DPF, in_bits, group, party, seeds, cw_s, nullptr, extra, out_cw, nullptr, xs, x_bytes,
+                     nkeys, ys, stream, 1);
 }
 int fss_amd_dcf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
                           const void* cw_v, const void* out_cw, const void* xs, int x_bytes, int64_t nkeys, void* ys,

@@ -34,7 +34,8 @@ template <int SCHEME>
 __global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, const uint4* __restrict__ cws,
                                                        int64_t nkeys, uint4* __restrict__ cw_s,
                                                        uint4* __restrict__ cw_v, uint64_t* __restrict__ tr_bits,
-                                                       uint4* __restrict__ out_cw, uint32_t* __restrict__ extra) {
+                                                       uint4* __restrict__ out_cw, uint32_t* __restrict__ extra,
+                                                       int tr32) {
   __shared__ unsigned long long bits[2][64];  // levels 0..63 / 64..127
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t k = (int64_t)blockIdx.x * 64 + lane;
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(256) void relayout_kernel(int in_bits, int stride, 
   if (wave == 0 && k < nkeys) {
     const uint4* slot = cws + k * (int64_t)stride * 2;
     if (SCHEME == S_DPF) {
-      tr_bits[k] = bits[0][lane];
+      if (tr32) reinterpret_cast<uint32_t*>(tr_bits)[k] = (uint32_t)bits[0][lane];  // the reference's `extra`
+      else tr_bits[k] = bits[0][lane];
       if (in_bits > 64) tr_bits[nkeys + k] = bits[1][lane];
       if (out_cw) out_cw[k] = slot[2 * in_bits];  // VDPF keys (stride in_bits) have no such slot
     } else if (SCHEME == S_DCF) {
@@ -77,7 +79,8 @@ template <int SCHEME>
 __global__ __launch_bounds__(256) void relayout_tiled_kernel(int in_bits, int stride, const uint4* __restrict__ cws,
                                                              int64_t nkeys, uint4* __restrict__ cw_s,
                                                              uint4* __restrict__ cw_v, uint64_t* __restrict__ tr_bits,
-                                                             uint4* __restrict__ out_cw, uint32_t* __restrict__ extra) {
+                                                             uint4* __restrict__ out_cw, uint32_t* __restrict__ extra,
+                                                             int tr32) {
   __shared__ uint4 tile[4][8][65];  // [wave][level-in-group * 2 + half][key], padded: the eight lanes of a key hit different banks
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t ntiles = (nkeys + 63) / 64;
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(256) void relayout_tiled_kernel(int in_bits, int st
       wave_lds_sync();
     }
     if (SCHEME == S_DPF && mine) {
-      tr_bits[k] = lo;
+      if (tr32) reinterpret_cast<uint32_t*>(tr_bits)[k] = (uint32_t)lo;  // the reference's `extra`
+      else tr_bits[k] = lo;
       if (in_bits > 64) tr_bits[nkeys + k] = hi;
     }
   }
@@ -122,15 +126,15 @@ __global__ __launch_bounds__(256) void relayout_tiled_kernel(int in_bits, int st
 // Host side: the tiled kernel by default, FSS_AMD_RELAYOUT=0 selects the one-key-per-lane kernel (A/B).
 template <int SCHEME, class Ctx>
 void launch_relayout(Ctx* ctx, hipStream_t st, int in_bits, int stride, const uint4* cws, int64_t nkeys, uint4* cw_s,
-                     uint4* cw_v, uint64_t* tr_bits, uint4* out_cw, uint32_t* extra) {
+                     uint4* cw_v, uint64_t* tr_bits, uint4* out_cw, uint32_t* extra, int tr32 = 0) {
   static const bool tiled = [] { const char* e = getenv("FSS_AMD_RELAYOUT"); return !(e && atoi(e) == 0); }();
   if (tiled) {
     const int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 4;
     hipLaunchKernelGGL(relayout_tiled_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, in_bits,
-                       stride, cws, nkeys, cw_s, cw_v, tr_bits, out_cw, extra);
+                       stride, cws, nkeys, cw_s, cw_v, tr_bits, out_cw, extra, tr32);
   } else {
     hipLaunchKernelGGL(relayout_kernel<SCHEME>, dim3((unsigned)((nkeys + 63) / 64)), dim3(256), 0, st, in_bits, stride, cws,
-                       nkeys, cw_s, cw_v, tr_bits, out_cw, extra);
+                       nkeys, cw_s, cw_v, tr_bits, out_cw, extra, tr32);
   }
 }
 

@@ -28,6 +28,10 @@ struct fss_amd_ctx {
   int prg;        // FSS_AMD_PRG_AES128_MMO or FSS_AMD_PRG_CHACHA
   const char* last_kernel;
   int last_grid, last_block;
+  // fss_amd_ctx_scratch: one grow-only device buffer per stream that asked for one
+  struct Scratch { void* p = nullptr; size_t bytes = 0; };
+  std::mutex scratch_mu;
+  std::unordered_map<void*, Scratch> scratch;
 };
 
 inline thread_local int g_last_hip = 0;  // one instance across the translation units

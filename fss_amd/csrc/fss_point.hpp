@@ -54,7 +54,13 @@ struct EvalArgs {
   const uint4* pre_v;       // DCF: running group value of every node
   int dyn;                  // waves take chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
   int rot_prio;             // statically distributed launches: rotate the wave priority every level (rotate_prio)
+  int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
 };
+
+// tr bits of key i: uint64_t per key, or the reference's 32-bit packing (wave-uniform choice)
+__device__ __forceinline__ uint64_t load_tr(const uint64_t* tr_bits, int tr32, int64_t i) {
+  return tr32 ? (uint64_t)reinterpret_cast<const uint32_t*>(tr_bits)[i] : tr_bits[i];
+}
 
 // An evaluation point / alpha of up to 128 bits (In = uint32_t, uint64_t or __uint128_t in the reference).
 struct X128 {
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       if constexpr (!SHARED) {
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
-          trb[j] = a.tr_bits[idx[j]];
+          trb[j] = load_tr(a.tr_bits, a.tr32, idx[j]);
           trbh[j] = in_bits > 64 ? a.tr_bits[n + idx[j]] : 0ull;
         }
       }
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
     const bool whole = n == 64 ? (e == 0) : (e == (1ull << n));
     uint4 s4 = a.seeds[k];
     uint32_t st[4] = {s4.x, s4.y, s4.z, (s4.w & ~1u) | (uint32_t)a.party};
-    const uint64_t trb = a.tr_bits[k];
+    const uint64_t trb = load_tr(a.tr_bits, a.tr32, k);
     uint32_t pi = 0;
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
       whole[j] = n == 64 ? (e[j] == 0) : (e[j] == (1ull << n));
       const uint4 s4 = a.seeds[k[j]];
       st[j][0] = s4.x; st[j][1] = s4.y; st[j][2] = s4.z; st[j][3] = (s4.w & ~1u) | (uint32_t)a.party;
-      trb[j] = a.tr_bits[k[j]];
+      trb[j] = load_tr(a.tr_bits, a.tr32, k[j]);
     }
     int pending = 0;  // jobs queued by this wave (wave-uniform)
 #pragma unroll 1

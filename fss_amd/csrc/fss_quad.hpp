@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void keys_quad_kernel(const DevCtx K, const u
     uint32_t st = reinterpret_cast<const uint32_t*>(a.seeds + k)[q];
     st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);
     uint64_t trb = 0, trbh = 0;
-    if constexpr (SCHEME == S_DPF) { trb = a.tr_bits[k]; trbh = n > 64 ? a.tr_bits[nk + k] : 0ull; }
+    if constexpr (SCHEME == S_DPF) { trb = load_tr(a.tr_bits, a.tr32, k); trbh = n > 64 ? a.tr_bits[nk + k] : 0ull; }
     Acc v;
 #pragma unroll 1
     for (int i = 0; i < depth; ++i) {

@@ -19,6 +19,7 @@ struct VdpfArgs {
   const uint4* cs;          // 4 per key
   const uint4* ocws;
   int dyn;                  // WaveQ: chunks of 64 * ILP evaluations from the workgroup's LDS counter
+  int tr32;                 // tr_bits is the reference's uint32_t `extra` (in_bits <= 32)
 };
 
 // fss::Vdpf::Eval (vdpf.cuh:204-257) for a batch; fss::gpu::VdpfEvalPointKernel (point_eval_gpu.cuh:254-308).
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
       else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
       w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
       if constexpr (!SHARED) {
-        trb[j] = a.tr_bits[idx[j]];
+        trb[j] = load_tr(a.tr_bits, a.tr32, idx[j]);
         trbh[j] = in_bits > 64 ? a.tr_bits[n + idx[j]] : 0ull;
       }
     }

@@ -294,6 +294,31 @@ int fss_amd_vdpf_prove(fss_amd_ctx *ctx, const void *pi_tildes, int64_t npoints,
 int fss_amd_vdpf_prove_keys(fss_amd_ctx *ctx, const void *pi_tildes, const void *cs, int64_t nkeys, void *pis,
                             void *stream);
 
+/* ---- the reference's 32-bit `extra` packing of the DPF tr bits ---------------------------
+ * fss::gpu::DpfRelayoutGpu / DpfEvalPointGpu take `uint32_t* extra` (bit i = tr of level i,
+ * include/fss/point_eval_gpu.cuh:57-62,346-353,448-460), which stops at in_bits = 32.  These two are
+ * fss_amd_dpf_relayout / fss_amd_dpf_eval_keys on that layout (extra: uint32[nkeys], 4-byte aligned;
+ * in_bits <= 32), so a caller's existing `extra` buffers keep their type and size. */
+int fss_amd_dpf_relayout_u32(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *extra,
+                             void *out_cw, void *stream);
+int fss_amd_dpf_eval_keys_u32(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
+                              const void *extra, const void *out_cw, const void *xs, int x_bytes, int64_t nkeys,
+                              void *ys, void *stream);
+
+/* ---- host conveniences for layers that keep the reference's call signatures ------------------
+ * The reference's launchers take the party seed BY VALUE and no workspace
+ * (fss::gpu::DpfEvalAllGpu(bool b, int4 s0, const Cw* cws, int4* ys, const Dpf&, cudaStream_t),
+ * include/fss/eval_all_gpu.cuh:478-488); its scheme methods take host buffers (dpf.cuh:93,170,232).
+ *   fss_amd_ctx_scratch  device scratch owned by the context, one grow-only buffer per stream: *out is valid
+ *                        until a later call for the same (ctx, stream) asks for more, or the context is destroyed.
+ *                        Growing frees the old buffer with hipFree (which waits for the device first).
+ *                        This is the only call after creation that allocates.  Thread-safe.
+ *   fss_amd_upload       stream-ordered copy of a small host value (<= 1 MiB; meant for seeds and single keys) to
+ *                        device memory.  The bytes travel as kernel arguments, so `src_host` may be pageable and
+ *                        may be reused as soon as the call returns; nothing synchronises. */
+int fss_amd_ctx_scratch(fss_amd_ctx *ctx, void *stream, size_t bytes, void **out);
+int fss_amd_upload(fss_amd_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);
+
 /* ---- tuning / introspection -------------------------------------------------------- */
 /* Name and launch geometry of the kernel the last eval call on this ctx launched
  * (for bench.py / profiles). */

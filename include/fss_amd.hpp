@@ -1,35 +1,67 @@
-// fss_amd.hpp -- C++ host layer over the C ABI (fss_amd.h), spelled like the reference's
-// template surface so that code written against myl7/fss's batched GPU launchers ports by
-// changing includes.  Header-only; link with libfss_amd.so and the HIP runtime.
+// fss_amd.hpp -- the myl7/fss C++ surface (scheme templates, PRG hook, fss::gpu launchers) over the C ABI
+// of libfss_amd.so (fss_amd.h).  Header-only, C++20 (the reference is C++20 too); compile with hipcc and
+// link with -lfss_amd.  A caller of the reference changes its includes, cuda* -> hip* runtime names and
+// cuda::std::{array,span} -> std::{array,span}; the fss:: spellings below are the reference's own:
 //
-//   fss::prg::Aes128Mmo<mul>          <- include/fss/prg/aes128_mmo.cuh:27-95 (key material; here it
-//                                        owns the engine context instead of OpenSSL EVP contexts)
-//   fss::prg::ChaCha<mul, rounds>     <- include/fss/prg/chacha.cuh:24-128 (nonce in the context)
-//   fss::group::Bytes / Uint<T, mod>  <- include/fss/group/bytes.cuh, uint.cuh (type tags: the group
-//                                        arithmetic runs in the kernels)
-//   fss::Dpf / Dcf / HalfTreeDpf      <- include/fss/dpf.cuh:61-81, dcf.cuh:74-96,
-//                                        half_tree_dpf.cuh:39-57 (same template parameters, `prg`
-//                                        member, 32-byte `Cw`; methods are the batched device forms)
-//   fss::GrottoDcf                    <- include/fss/grotto_dcf.cuh:46-238
-//   fss::Vdpf + fss::hash::Blake3     <- include/fss/vdpf.cuh:57-404, include/fss/hash/blake3.cuh
-//   fss::gpu::*RelayoutGpu, *EvalPointGpu, *EvalAllGpu
-//                                     <- include/fss/point_eval_gpu.cuh:324-491,
-//                                        include/fss/eval_all_gpu.cuh:451-535
-// Differences from the reference, all forced by the engine: every pointer is a device pointer;
-// the DPF tr bits are uint64_t per key (the reference packs 32 levels into uint32_t); EvalAll
-// takes a workspace; errors throw fss::Error instead of being ignored.
+//   Prgable / Groupable (global concepts)  <- include/fss/prg.cuh:20-23, include/fss/group.cuh:39-45
+//   fss::util::Xor/SetLsb/GetLsb/Pack      <- include/fss/util.cuh:16-64
+//   fss::group::Bytes / Uint<T, mod>       <- include/fss/group/bytes.cuh:19-43, group/uint.cuh:27-88
+//   fss::prg::Aes128Mmo<mul>               <- include/fss/prg/aes128_mmo.cuh:27-95: span constructor, CreateCtxs,
+//                                             FreeCtxs, Gen(int4) -> array<int4, mul>; the "cipher contexts" carry
+//                                             the AES key bytes (AesKeyCtx) instead of OpenSSL EVP state
+//   fss::prg::ChaCha<mul, rounds>          <- include/fss/prg/chacha.cuh:24-128 (constructor from the nonce pointer)
+//   fss::Dpf / Dcf / HalfTreeDpf / GrottoDcf
+//                                          <- include/fss/dpf.cuh:61-303, dcf.cuh:74-385, half_tree_dpf.cuh:39-354,
+//                                             grotto_dcf.cuh:45-238: same template parameters (incl. par_depth, accepted
+//                                             and unused: the GPU expands the whole tree in parallel), public `prg`
+//                                             (and `hash_key`) members, aggregate initialisation, 32-byte `Cw`, and the
+//                                             reference's Gen / Eval / EvalAll signatures.  They are HOST functions:
+//                                             every one is computed by the engine's kernels (buffers staged through a
+//                                             context-owned pool; a device pointer is used in place).  Next to them
+//                                             are the batched device forms the engine is built for (GenBatch,
+//                                             GenLevelMajor, EvalPoints, EvalAllBlock).
+//   fss::gpu::*RelayoutGpu / *EvalPointGpu / *EvalAllGpu[Batch]
+//                                          <- include/fss/point_eval_gpu.cuh:324-491, include/fss/eval_all_gpu.cuh:451-535:
+//                                             the reference's template-parameter order (leading `unroll`, `z, b1, bs`;
+//                                             accepted and ignored: the engine plans its own launches), uint32_t `extra`
+//                                             and uint32_t `xs` for in_bits <= 32, the seed by value and no workspace
+//                                             argument; plus overloads with uint64_t tr bits and `In` points for
+//                                             in_bits > 32, where the reference's launchers stop.
+// What does not carry over: calling Gen / Eval per thread inside a user's own kernel (the reference's members are
+// __host__ __device__; src/bench_gpu.cu:85-95) -- that per-thread walk is what this engine replaces, see the batched
+// forms -- and user-defined Groupable / Prgable types, which the prebuilt kernels cannot execute: Group must be
+// Bytes or Uint, Prg must be Aes128Mmo or ChaCha (static_assert).  Errors throw fss::Error (the reference asserts).
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
+#include <concepts>
 #include <cstdint>
 #include <cstring>
-#include <memory>
+#include <map>
+#include <mutex>
+#include <span>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <utility>
 
 #include "fss_amd.h"
+
+// include/fss/prg.cuh:20-23
+template <typename Prg, int mul>
+concept Prgable = requires(Prg prg, int4 seed) {
+  { prg.Gen(seed) } -> std::same_as<std::array<int4, mul>>;
+};
+
+// include/fss/group.cuh:39-45
+template <typename Group>
+concept Groupable = std::is_default_constructible_v<Group> && requires(Group lhs, Group rhs, int4 buf) {
+  { lhs + rhs } -> std::same_as<Group>;
+  { -lhs } -> std::same_as<Group>;
+  { Group::From(buf) } -> std::same_as<Group>;
+  { lhs.Into() } -> std::same_as<int4>;
+};
 
 namespace fss {
 
@@ -40,265 +72,732 @@ struct Error : std::runtime_error {
 inline void Check(int rc, const char* what) {
   if (rc != FSS_AMD_OK) throw Error(what, rc);
 }
+inline void CheckHip(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw Error((std::string(what) + ": " + hipGetErrorString(e)).c_str(), FSS_AMD_EHIP);
+}
 
+// ---------------------------------------------------------------- util (include/fss/util.cuh:16-64)
+namespace util {
+__host__ __device__ inline int4 Xor(int4 a, int4 b) { return int4{a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
+template <size_t N>
+__host__ __device__ inline std::array<int4, N> Xor(std::span<const int4, N> a, std::span<const int4, N> b) {
+  std::array<int4, N> r;
+  for (size_t i = 0; i < N; ++i) r[i] = Xor(a[i], b[i]);
+  return r;
+}
+// the control ("clamped") bit is bit 0 of w
+__host__ __device__ inline int4 SetLsb(int4 v, bool bit) {
+  v.w = (v.w & ~1) | (bit ? 1 : 0);
+  return v;
+}
+__host__ __device__ inline bool GetLsb(int4 v) { return v.w & 1; }
+template <typename In>
+__host__ __device__ inline int4 Pack(In val) {
+  const unsigned __int128 v = static_cast<unsigned __int128>(val);
+  int4 r{static_cast<int>(static_cast<uint32_t>(v)), 0, 0, 0};
+  if constexpr (sizeof(In) > 4) r.y = static_cast<int>(static_cast<uint32_t>(v >> 32));
+  if constexpr (sizeof(In) > 8) {
+    r.z = static_cast<int>(static_cast<uint32_t>(v >> 64));
+    r.w = static_cast<int>(static_cast<uint32_t>(v >> 96));
+  }
+  return r;
+}
+}  // namespace util
+
+// ---------------------------------------------------------------- groups
 namespace group {
+// include/fss/group/bytes.cuh:19-43: 16 bytes under XOR
 struct Bytes {
+  int4 val;
+  __host__ __device__ Bytes() : val{0, 0, 0, 0} {}
+  __host__ __device__ Bytes operator+(Bytes o) const { return Bytes(util::Xor(val, o.val)); }
+  __host__ __device__ Bytes operator-() const { return *this; }
+  __host__ __device__ static Bytes From(int4 buf) { return Bytes(buf); }
+  __host__ __device__ int4 Into() const { return val; }
   static constexpr int kId = FSS_AMD_GROUP_BYTES;
+  static constexpr uint64_t kMod = 0;
+
+ private:
+  __host__ __device__ explicit Bytes(int4 b) : val(b) {}
 };
-template <typename T, unsigned __int128 mod = 0>
+
+// include/fss/group/uint.cuh:27-88: the low sizeof(T) bytes of the buffer as an integer, wrapping or modulo `mod`;
+// T = __uint128_t keeps 127 bits (bit 0 of w is the clamped bit, so the top word is stored shifted left by one).
+template <typename T, T mod = 0>
+  requires((std::is_unsigned_v<T> || std::is_same_v<T, unsigned __int128>) && sizeof(T) <= 16 &&
+           (sizeof(T) < 16 || (mod > 0 && mod <= static_cast<T>(1) << 127)))
 struct Uint {
-  static_assert(std::is_unsigned_v<T> || std::is_same_v<T, unsigned __int128>);
-  static_assert(sizeof(T) < 16 || mod == (static_cast<unsigned __int128>(1) << 127),
-                "Uint<__uint128_t> is built for mod = 2^127 only");
-  // mod != 0 below 128 bits: fss_amd_ctx_set_uint_modulus(prg.handle(), kMod) before using the scheme object
-  static constexpr uint64_t kMod = sizeof(T) == 16 ? 0 : (uint64_t)mod;
+  T val;
+  __host__ __device__ Uint() : val(0) {}
+  __host__ __device__ Uint operator+(Uint o) const {
+    const T wrapped = static_cast<T>(val + o.val);
+    if constexpr (mod == 0) return Uint(wrapped);
+    else return Uint(val >= static_cast<T>(mod - o.val) ? static_cast<T>(wrapped - mod) : wrapped);
+  }
+  __host__ __device__ Uint operator-() const {
+    if constexpr (mod == 0) return Uint(static_cast<T>(0 - val));
+    else return Uint(val == 0 ? T(0) : static_cast<T>(mod - val));
+  }
+  __host__ __device__ static Uint From(int4 buf) {
+    const uint32_t w[4] = {static_cast<uint32_t>(buf.x), static_cast<uint32_t>(buf.y), static_cast<uint32_t>(buf.z),
+                           static_cast<uint32_t>(buf.w)};
+    T v;
+    if constexpr (sizeof(T) <= 4) v = static_cast<T>(w[0]);
+    else if constexpr (sizeof(T) == 8) v = static_cast<T>(w[0]) | static_cast<T>(w[1]) << 32;
+    else v = static_cast<T>(w[0]) | static_cast<T>(w[1]) << 32 | static_cast<T>(w[2]) << 64 | static_cast<T>(w[3] >> 1) << 96;
+    if constexpr (mod != 0) v = static_cast<T>(v % mod);
+    return Uint(v);
+  }
+  __host__ __device__ int4 Into() const {
+    int4 r{0, 0, 0, 0};
+    if constexpr (sizeof(T) <= 4) {
+      r.x = static_cast<int>(val);
+    } else {
+      r.x = static_cast<int>(static_cast<uint32_t>(val));
+      r.y = static_cast<int>(static_cast<uint32_t>(val >> 32));
+      if constexpr (sizeof(T) == 16) {
+        r.z = static_cast<int>(static_cast<uint32_t>(val >> 64));
+        r.w = static_cast<int>(static_cast<uint32_t>(val >> 96) << 1);
+      }
+    }
+    return r;
+  }
+  // the engine's name for this group: enum fss_amd_group + the context's modulus (fss_amd_ctx_set_uint_modulus)
+  static_assert(sizeof(T) < 16 || mod == (static_cast<T>(1) << 127), "Uint<__uint128_t> is built for mod = 2^127 only");
   static constexpr int kId = sizeof(T) == 1   ? FSS_AMD_GROUP_U8
                              : sizeof(T) == 2 ? FSS_AMD_GROUP_U16
                              : sizeof(T) == 4 ? FSS_AMD_GROUP_U32
                              : sizeof(T) == 8 ? FSS_AMD_GROUP_U64
                                               : FSS_AMD_GROUP_U128_M127;
+  static constexpr uint64_t kMod = sizeof(T) == 16 ? 0 : static_cast<uint64_t>(mod);
+
+ private:
+  __host__ __device__ explicit Uint(T v) : val(v) {}
 };
+static_assert(Groupable<Bytes> && Groupable<Uint<uint8_t>> && Groupable<Uint<uint32_t>> && Groupable<Uint<uint64_t>> &&
+              Groupable<Uint<unsigned __int128, static_cast<unsigned __int128>(1) << 127>>);
 }  // namespace group
 
 enum class DcfPred { kLt = FSS_AMD_PRED_LT, kGt = FSS_AMD_PRED_GT };  // include/fss/dcf.cuh:58-61
 
-namespace prg {
-// AES-128-MMO key material.  mul = number of PRG outputs a scheme uses (DPF/Grotto 2, DCF 4,
-// Half-Tree 1); key i produces output i.  Copyable handle (shared ownership of the context).
-template <int mul>
-class Aes128Mmo {
-  static_assert(mul == 1 || mul == 2 || mul == 4);
-
- public:
-  // keys: mul pointers to 16-byte AES keys, as Aes128Mmo::CreateCtxs takes them (aes128_mmo.cuh:49).
-  explicit Aes128Mmo(const unsigned char* const keys[mul], int device = 0, const int32_t hash_key[4] = nullptr) {
-    uint8_t k[64] = {};
-    for (int i = 0; i < mul; ++i) std::memcpy(k + 16 * i, keys[i], 16);
-    fss_amd_ctx* c = nullptr;
-    Check(fss_amd_ctx_create(&c, device, k, hash_key), "fss_amd_ctx_create");
-    ctx_ = std::shared_ptr<fss_amd_ctx>(c, fss_amd_ctx_destroy);
-  }
-  fss_amd_ctx* handle() const { return ctx_.get(); }
-  // out[i * mul + j] = AES_{key j}(seeds[i]) ^ seeds[i]   (Aes128Mmo::Gen, aes128_mmo.cuh:72-93)
-  void Gen(const int4* d_seeds, int64_t n, int4* d_out, hipStream_t stream = 0) const {
-    Check(fss_amd_prg_gen(handle(), mul, d_seeds, n, d_out, stream), "fss_amd_prg_gen");
-  }
-
- private:
-  std::shared_ptr<fss_amd_ctx> ctx_;
-};
-
-// ChaCha PRG (include/fss/prg/chacha.cuh:24-128): one permutation of [constant | seed | seed | 0,0,nonce]
-// per Gen.  The nonce the reference keeps in __constant__ memory (chacha.cuh:93) lives in the context.
-template <int mul, int rounds = 20>
-class ChaCha {
-  static_assert(mul == 1 || mul == 2 || mul == 4);
-  static_assert(rounds > 0 && rounds % 2 == 0);
-
- public:
-  explicit ChaCha(const int32_t nonce[2], int device = 0, const int32_t hash_key[4] = nullptr) {
-    const uint8_t unused_aes_keys[64] = {};
-    fss_amd_ctx* c = nullptr;
-    Check(fss_amd_ctx_create(&c, device, unused_aes_keys, hash_key), "fss_amd_ctx_create");
-    ctx_ = std::shared_ptr<fss_amd_ctx>(c, fss_amd_ctx_destroy);
-    Check(fss_amd_ctx_set_prg(c, FSS_AMD_PRG_CHACHA, nonce, rounds), "fss_amd_ctx_set_prg");
-  }
-  fss_amd_ctx* handle() const { return ctx_.get(); }
-  // out[i * mul + j] = output j of ChaCha::Gen(seeds[i])   (chacha.cuh:95-127)
-  void Gen(const int4* d_seeds, int64_t n, int4* d_out, hipStream_t stream = 0) const {
-    Check(fss_amd_prg_gen(handle(), mul, d_seeds, n, d_out, stream), "fss_amd_prg_gen");
-  }
-
- private:
-  std::shared_ptr<fss_amd_ctx> ctx_;
-};
-}  // namespace prg
-
+// ---------------------------------------------------------------- engine contexts behind the value types
 namespace detail {
+// Everything a fss_amd_ctx is made from.  The reference's PRG / scheme objects are small values that are copied
+// around freely (point_eval_gpu.cuh:455 passes them to kernels by value); here they stay values too, and the engine
+// context they stand for is looked up -- created on first use -- by this description.
+struct Spec {
+  int device = 0;
+  int prg = FSS_AMD_PRG_AES128_MMO;
+  uint8_t aes[64] = {};
+  int32_t hash_key[4] = {};
+  int32_t nonce[2] = {};
+  int rounds = 20;
+  uint64_t mod = 0;
+  int has_iv = 0;
+  int32_t iv[8] = {};
+};
+inline std::string KeyOf(const Spec& s) {
+  std::string k;
+  auto put = [&k](const void* p, size_t n) { k.append(static_cast<const char*>(p), n); };
+  put(&s.device, sizeof s.device); put(&s.prg, sizeof s.prg); put(s.aes, sizeof s.aes);
+  put(s.hash_key, sizeof s.hash_key); put(s.nonce, sizeof s.nonce); put(&s.rounds, sizeof s.rounds);
+  put(&s.mod, sizeof s.mod); put(&s.has_iv, sizeof s.has_iv); put(s.iv, sizeof s.iv);
+  return k;
+}
+struct Registry {
+  std::mutex mu;
+  std::map<std::string, fss_amd_ctx*> ctxs;
+  std::mutex stage_mu;  // the host-buffer methods share one staging area per context: one at a time
+};
+inline Registry& Reg() {
+  static Registry* r = new Registry;  // never destroyed: contexts must not outlive the HIP runtime's own teardown
+  return *r;
+}
+inline fss_amd_ctx* Engine(Spec s) {
+  CheckHip(hipGetDevice(&s.device), "hipGetDevice");
+  const std::string key = KeyOf(s);
+  Registry& r = Reg();
+  std::lock_guard<std::mutex> lk(r.mu);
+  auto it = r.ctxs.find(key);
+  if (it != r.ctxs.end()) return it->second;
+  fss_amd_ctx* c = nullptr;
+  Check(fss_amd_ctx_create(&c, s.device, s.aes, s.hash_key), "fss_amd_ctx_create");
+  int rc = s.prg == FSS_AMD_PRG_CHACHA ? fss_amd_ctx_set_prg(c, s.prg, s.nonce, s.rounds) : FSS_AMD_OK;
+  if (rc == FSS_AMD_OK && s.mod) rc = fss_amd_ctx_set_uint_modulus(c, s.mod);
+  if (rc == FSS_AMD_OK && s.has_iv) rc = fss_amd_ctx_set_hash_iv(c, s.iv);
+  if (rc != FSS_AMD_OK) {
+    fss_amd_ctx_destroy(c);
+    Check(rc, "fss_amd_ctx setup");
+  }
+  r.ctxs.emplace(key, c);
+  return c;
+}
+// Drop every context (and its scratch) the value types created so far, e.g. before hipDeviceReset.
+inline void ReleaseEngines() {
+  Registry& r = Reg();
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (auto& kv : r.ctxs) fss_amd_ctx_destroy(kv.second);
+  r.ctxs.clear();
+}
+
 template <typename In>
 constexpr int XBytes() {
   static_assert(sizeof(In) == 1 || sizeof(In) == 2 || sizeof(In) == 4 || sizeof(In) == 8 || sizeof(In) == 16,
                 "In must be an unsigned integer of 1, 2, 4 or 8 bytes or __uint128_t");
-  return (int)sizeof(In);
+  return static_cast<int>(sizeof(In));
+}
+template <typename In>
+concept InType = std::is_unsigned_v<In> || std::is_same_v<In, unsigned __int128>;
+
+// Is p usable by a kernel as it stands?  Plain (and pinned) host memory is staged instead.
+inline bool OnDevice(const void* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an unregistered host pointer is reported as an error: not one
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeUnified;
+}
+
+// Staging area for the host-buffer (reference-signature) methods: slices of the context's scratch for the null
+// stream.  Blocking copies on the null stream keep the reference's synchronous semantics.
+class Stage {
+ public:
+  Stage(fss_amd_ctx* ctx, size_t bytes) : lock_(Reg().stage_mu) {
+    Check(fss_amd_ctx_scratch(ctx, nullptr, bytes + 256, &base_), "fss_amd_ctx_scratch");  // + alignment slack
+  }
+  // the next `bytes` of the area (32-byte aligned)
+  void* Take(size_t bytes) {
+    void* p = static_cast<char*>(base_) + off_;
+    off_ += (bytes + 31) & ~size_t(31);
+    return p;
+  }
+  // device copy of host data, or the pointer itself when it already is device memory
+  template <typename T>
+  const T* Load(const T* src, size_t count) {
+    if (OnDevice(src)) return src;
+    void* d = Take(count * sizeof(T));
+    CheckHip(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy (stage in)");
+    return static_cast<const T*>(d);
+  }
+  template <typename T>
+  const T* Value(const T& v) {
+    void* d = Take(sizeof(T));
+    CheckHip(hipMemcpy(d, &v, sizeof(T), hipMemcpyHostToDevice), "hipMemcpy (stage in)");
+    return static_cast<const T*>(d);
+  }
+  // device buffer for an output: the destination itself when it is device memory
+  template <typename T>
+  T* Out(T* dst, size_t count) {
+    if (OnDevice(dst)) return dst;
+    return static_cast<T*>(Take(count * sizeof(T)));
+  }
+  template <typename T>
+  void Back(T* dst, const T* dev, size_t count) {
+    if (static_cast<const void*>(dst) == static_cast<const void*>(dev)) {
+      CheckHip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+      return;
+    }
+    CheckHip(hipMemcpy(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy (stage out)");
+  }
+
+ private:
+  std::lock_guard<std::mutex> lock_;
+  void* base_ = nullptr;
+  size_t off_ = 0;
+};
+
+// Scratch of (ctx, stream) for the asynchronous launchers: [0, 256) small by-value arguments, then the workspace.
+struct Scratch {
+  char* base;
+  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) {
+    void* p = nullptr;
+    Check(fss_amd_ctx_scratch(ctx, stream, ws_bytes + 256, &p), "fss_amd_ctx_scratch");
+    base = static_cast<char*>(p);
+  }
+  void* Small(int slot) const { return base + 32 * slot; }
+  void* Workspace() const { return base + 256; }
+};
+inline const int4* PutInt4(fss_amd_ctx* ctx, const Scratch& s, int slot, int4 v, hipStream_t stream) {
+  Check(fss_amd_upload(ctx, s.Small(slot), &v, sizeof v, stream), "fss_amd_upload");
+  return static_cast<const int4*>(s.Small(slot));
 }
 }  // namespace detail
 
-// ---------------------------------------------------------------- DPF
-template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
+using detail::ReleaseEngines;
+
+namespace detail {
+template <typename P>
+auto GenOne(const P& prg, int4 seed) -> std::array<int4, P::kMul>;  // one PRG call on the engine (below)
+}
+
+// ---------------------------------------------------------------- PRG hook
+namespace prg {
+// What CreateCtxs hands out where the reference hands out EVP_CIPHER_CTX* (aes128_mmo.cuh:49-64): the key itself.
+struct AesKeyCtx {
+  unsigned char key[16];
+};
+
+// AES-128 in Matyas-Meyer-Oseas mode as the PRG: out[i] = AES_{key i}(seed) ^ seed (aes128_mmo.cuh:72-93).
+// mul outputs per call (Half-Tree 1, DPF / Grotto 2, DCF 4).  A plain value (the key bytes); copies are free.
+template <int mul>
+class Aes128Mmo {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+  unsigned char keys_[mul][16];
+
+ public:
+  // ctxs: from CreateCtxs(); only read here, the caller frees them with FreeCtxs()  (aes128_mmo.cuh:40-42)
+  Aes128Mmo(std::span<AesKeyCtx*, mul> ctxs) {
+    for (int i = 0; i < mul; ++i) std::memcpy(keys_[i], ctxs[i]->key, 16);
+  }
+  // the key bytes directly (no context objects to manage)
+  explicit Aes128Mmo(const unsigned char* const keys[mul]) {
+    for (int i = 0; i < mul; ++i) std::memcpy(keys_[i], keys[i], 16);
+  }
+  static std::array<AesKeyCtx*, mul> CreateCtxs(const unsigned char* keys[mul]) {
+    std::array<AesKeyCtx*, mul> ctxs;
+    for (int i = 0; i < mul; ++i) {
+      ctxs[i] = new AesKeyCtx;
+      std::memcpy(ctxs[i]->key, keys[i], 16);
+    }
+    return ctxs;
+  }
+  static void FreeCtxs(std::span<AesKeyCtx*, mul> ctxs) {
+    for (AesKeyCtx* c : ctxs) delete c;
+  }
+  // One seed through the engine (a batch of one on the GPU; fss_amd_prg_gen is the batched form).
+  std::array<int4, mul> Gen(int4 seed) const { return detail::GenOne(*this, seed); }
+
+  static constexpr int kMul = mul;
+  void Describe(detail::Spec& s) const {
+    s.prg = FSS_AMD_PRG_AES128_MMO;
+    std::memcpy(s.aes, keys_, sizeof keys_);
+  }
+};
+
+// ChaCha as the PRG (chacha.cuh:24-128): one permutation of [constant | seed | seed | 0, 0, nonce] per Gen.
+template <int mul, int rounds = 20>
+  requires(rounds % 2 == 0 && rounds > 0 && (mul == 1 || mul == 2 || mul == 4))
+class ChaCha {
+  int nonce_[2];
+
+ public:
+  // nonce: two ints, read here (the reference keeps the pointer, chacha.cuh:93; a host-readable pointer is needed)
+  ChaCha(const int* nonce) : nonce_{nonce[0], nonce[1]} {}
+  std::array<int4, mul> Gen(int4 seed) const { return detail::GenOne(*this, seed); }
+
+  static constexpr int kMul = mul;
+  void Describe(detail::Spec& s) const {
+    s.prg = FSS_AMD_PRG_CHACHA;
+    s.nonce[0] = nonce_[0];
+    s.nonce[1] = nonce_[1];
+    s.rounds = rounds;
+  }
+};
+}  // namespace prg
+
+namespace detail {
+template <typename P>
+concept EnginePrg = requires(const P& p, Spec& s) {
+  { p.Describe(s) };
+  { P::kMul } -> std::convertible_to<int>;
+};
+template <typename G>
+concept EngineGroup = Groupable<G> && requires {
+  { G::kId } -> std::convertible_to<int>;
+  { G::kMod } -> std::convertible_to<uint64_t>;
+};
+
+template <typename Prg>
+fss_amd_ctx* CtxOf(const Prg& prg, uint64_t mod = 0, const int4* hash_key = nullptr, const int32_t* iv = nullptr) {
+  static_assert(EnginePrg<Prg>, "the engine runs fss::prg::Aes128Mmo and fss::prg::ChaCha; other Prgable types cannot "
+                                "be executed by its prebuilt kernels");
+  Spec s;
+  prg.Describe(s);
+  s.mod = mod;
+  if (hash_key) std::memcpy(s.hash_key, hash_key, sizeof s.hash_key);
+  if (iv) {
+    s.has_iv = 1;
+    std::memcpy(s.iv, iv, sizeof s.iv);
+  }
+  return Engine(s);
+}
+
+template <typename Prg>
+auto GenOne(const Prg& prg, int4 seed) -> std::array<int4, Prg::kMul> {
+  fss_amd_ctx* ctx = CtxOf(prg);
+  Stage st(ctx, 16 + 16 * Prg::kMul);
+  const int4* d_seed = st.Value(seed);
+  int4* d_out = static_cast<int4*>(st.Take(16 * Prg::kMul));
+  Check(fss_amd_prg_gen(ctx, Prg::kMul, d_seed, 1, d_out, nullptr), "fss_amd_prg_gen");
+  std::array<int4, Prg::kMul> out;
+  st.Back(out.data(), static_cast<const int4*>(d_out), Prg::kMul);
+  return out;
+}
+}  // namespace detail
+
+namespace prg {
+static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Aes128Mmo<4>, 4>);
+static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
+}  // namespace prg
+
+// ---------------------------------------------------------------- DPF (include/fss/dpf.cuh:61-303)
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t, int par_depth = -1>
+  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 2>)
 class Dpf {
-  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+  static_assert(detail::EngineGroup<Group>, "Group must be fss::group::Bytes or fss::group::Uint<T, mod>");
 
  public:
   Prg prg;
-  struct alignas(32) Cw {  // include/fss/dpf.cuh:76-81
+  struct alignas(32) Cw {  // dpf.cuh:76-81
     int4 s;
     bool tr;
   };
   static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits + 1;
+  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod); }
 
-  // nkeys keys at once: s0s[2k], s0s[2k+1] are the party seeds of key k; cws is key-major,
-  // kSlots slots per key (Dpf::Gen, dpf.cuh:93-159, one key per GPU lane).
-  void Gen(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
-           hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
-                          d_cws, stream), "fss_amd_dpf_gen");
+  // ---- the reference's signatures; buffers on the host (or the device), computed on the GPU, synchronous
+  // dpf.cuh:93: cws[in_bits + 1] out; s0s: the two party seeds; a: alpha; b_buf: beta (clamped)
+  void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {
+    fss_amd_ctx* ctx = handle();
+    detail::Stage st(ctx, 32 + 32 + 32 + sizeof(Cw) * kSlots);
+    const int4* d_s0s = st.Load(s0s, 2);
+    const In* d_a = st.Value(a);
+    const int4* d_b = st.Value(b_buf);
+    Cw* d_cws = st.Out(cws, kSlots);
+    GenBatch(d_cws, d_s0s, d_a, d_b, 1);
+    st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
+  }
+  // dpf.cuh:170: party b's share of f(x)
+  int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {
+    fss_amd_ctx* ctx = handle();
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + 32);
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    const In* d_x = st.Value(x);
+    int4* d_y = static_cast<int4*>(st.Take(sizeof(int4)));
+    EvalPoints(b, d_s0, d_cws, d_x, d_y, 1);
+    int4 y;
+    st.Back(&y, static_cast<const int4*>(d_y), 1);
+    return y;
+  }
+  // dpf.cuh:232: ys[x] = Eval(b, s0, cws, x) for every x of the domain, in index order
+  void EvalAll(bool b, int4 s0, const Cw cws[], int4 ys[]) const {
+    static_assert(in_bits <= 40, "a full-domain output of 2^in_bits int4s");
+    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
+    fss_amd_ctx* ctx = handle();
+    const bool direct = detail::OnDevice(ys);
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    void* d_ws = st.Take(ws);
+    int4* d_ys = st.Out(ys, n);
+    EvalAllBlock(b, d_s0, d_cws, d_ys, d_ws, ws);
+    st.Back(ys, static_cast<const int4*>(d_ys), n);
+  }
+
+  // ---- batched device forms (every pointer a device pointer; asynchronous on `stream`)
+  // nkeys keys at once, one per GPU lane: s0s[2k], s0s[2k+1] the party seeds of key k; cws key-major, kSlots per key.
+  void GenBatch(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+                hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
+                          stream), "fss_amd_dpf_gen");
   }
   // The same keys written level-major (what gpu::DpfRelayoutGpu would make of d_cws), no intermediate.
   void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* out_cw, const int4* d_s0s, const In* d_alphas,
                      const int4* d_betas, int64_t nkeys, hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_gen_level_major(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(),
-                                      d_betas, nkeys, cw_s, tr_bits, out_cw, stream), "fss_amd_dpf_gen_level_major");
+    Check(fss_amd_dpf_gen_level_major(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
+                                      nkeys, cw_s, tr_bits, out_cw, stream), "fss_amd_dpf_gen_level_major");
   }
-  // ys[i] = Eval(b, *d_s0, d_cws, xs[i])   (Dpf::Eval, dpf.cuh:170-214, for a whole batch of x)
+  // ys[i] = Eval(b, *d_s0, d_cws, xs[i]): one key, a whole batch of points
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n,
-                                  d_ys, stream), "fss_amd_dpf_eval_points");
+    Check(fss_amd_dpf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n, d_ys,
+                                  stream), "fss_amd_dpf_eval_points");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_DPF, in_bits, nleaves);
   }
-  // ys[j] = Eval(b, *d_s0, d_cws, first_leaf + j)   (Dpf::EvalAll, dpf.cuh:232-303)
-  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, int4* d_ys, void* d_workspace, size_t ws_bytes,
-               int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, first_leaf, nleaves, d_ys,
-                               d_workspace, ws_bytes, stream), "fss_amd_dpf_eval_all");
+  // ys[j] = Eval(b, *d_s0, d_cws, first_leaf + j): an aligned power-of-two block of the domain (a GPU's share)
+  void EvalAllBlock(bool b, const int4* d_s0, const Cw* d_cws, int4* d_ys, void* d_workspace, size_t ws_bytes,
+                    int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_eval_all(handle(), in_bits, Group::kId, b, d_s0, d_cws, first_leaf, nleaves, d_ys, d_workspace,
+                               ws_bytes, stream), "fss_amd_dpf_eval_all");
   }
 };
 
-// ---------------------------------------------------------------- DCF
-template <int in_bits, typename Group, typename Prg, typename In = uint32_t, DcfPred pred = DcfPred::kLt>
+// ---------------------------------------------------------------- DCF (include/fss/dcf.cuh:74-385)
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t, DcfPred pred = DcfPred::kLt,
+          int par_depth = -1>
+  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 4>)
 class Dcf {
-  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+  static_assert(detail::EngineGroup<Group>, "Group must be fss::group::Bytes or fss::group::Uint<T, mod>");
 
  public:
   Prg prg;
-  struct alignas(32) Cw {  // include/fss/dcf.cuh:91-96
+  struct alignas(32) Cw {  // dcf.cuh:91-96
     int4 s;
     int4 v;
   };
   static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits + 1;
+  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod); }
 
-  void Gen(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
-           hipStream_t stream = 0) const {
-    Check(fss_amd_dcf_gen(prg.handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
-                          nkeys, d_cws, stream), "fss_amd_dcf_gen");
+  void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {  // dcf.cuh:108
+    fss_amd_ctx* ctx = handle();
+    detail::Stage st(ctx, 32 + 32 + 32 + sizeof(Cw) * kSlots);
+    const int4* d_s0s = st.Load(s0s, 2);
+    const In* d_a = st.Value(a);
+    const int4* d_b = st.Value(b_buf);
+    Cw* d_cws = st.Out(cws, kSlots);
+    GenBatch(d_cws, d_s0s, d_a, d_b, 1);
+    st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
+  }
+  int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {  // dcf.cuh:205
+    fss_amd_ctx* ctx = handle();
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + 32);
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    const In* d_x = st.Value(x);
+    int4* d_y = static_cast<int4*>(st.Take(sizeof(int4)));
+    EvalPoints(b, d_s0, d_cws, d_x, d_y, 1);
+    int4 y;
+    st.Back(&y, static_cast<const int4*>(d_y), 1);
+    return y;
+  }
+  void EvalAll(bool b, int4 s0, const Cw cws[], int4 ys[]) const {  // dcf.cuh:294
+    static_assert(in_bits <= 40, "a full-domain output of 2^in_bits int4s");
+    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
+    fss_amd_ctx* ctx = handle();
+    const bool direct = detail::OnDevice(ys);
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    void* d_ws = st.Take(ws);
+    int4* d_ys = st.Out(ys, n);
+    EvalAllBlock(b, d_s0, d_cws, d_ys, d_ws, ws);
+    st.Back(ys, static_cast<const int4*>(d_ys), n);
+  }
+
+  void GenBatch(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+                hipStream_t stream = 0) const {
+    Check(fss_amd_dcf_gen(handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
+                          d_cws, stream), "fss_amd_dcf_gen");
   }
   void GenLevelMajor(int4* cw_s, int4* cw_v, int4* out_cw, const int4* d_s0s, const In* d_alphas, const int4* d_betas,
                      int64_t nkeys, hipStream_t stream = 0) const {
-    Check(fss_amd_dcf_gen_level_major(prg.handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas,
-                                      detail::XBytes<In>(), d_betas, nkeys, cw_s, cw_v, out_cw, stream),
-          "fss_amd_dcf_gen_level_major");
+    Check(fss_amd_dcf_gen_level_major(handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(),
+                                      d_betas, nkeys, cw_s, cw_v, out_cw, stream), "fss_amd_dcf_gen_level_major");
   }
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
-    Check(fss_amd_dcf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n,
-                                  d_ys, stream), "fss_amd_dcf_eval_points");
+    Check(fss_amd_dcf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n, d_ys,
+                                  stream), "fss_amd_dcf_eval_points");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_DCF, in_bits, nleaves);
   }
-  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, int4* d_ys, void* d_workspace, size_t ws_bytes,
-               int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
-    Check(fss_amd_dcf_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, first_leaf, nleaves, d_ys,
-                               d_workspace, ws_bytes, stream), "fss_amd_dcf_eval_all");
+  void EvalAllBlock(bool b, const int4* d_s0, const Cw* d_cws, int4* d_ys, void* d_workspace, size_t ws_bytes,
+                    int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
+    Check(fss_amd_dcf_eval_all(handle(), in_bits, Group::kId, b, d_s0, d_cws, first_leaf, nleaves, d_ys, d_workspace,
+                               ws_bytes, stream), "fss_amd_dcf_eval_all");
   }
 };
 
-// ---------------------------------------------------------------- Half-Tree DPF
-template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
+// ---------------------------------------------------------------- Half-Tree DPF (include/fss/half_tree_dpf.cuh:39-354)
+template <int in_bits, typename Group, typename Prg, typename In = uint32_t, int par_depth = -1>
+  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 1>)
 class HalfTreeDpf {
-  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
+  static_assert(detail::EngineGroup<Group>, "Group must be fss::group::Bytes or fss::group::Uint<T, mod>");
 
  public:
-  Prg prg;  // its context carries hash_key (HalfTreeDpf::hash_key, half_tree_dpf.cuh:45)
-  struct alignas(32) Cw {  // include/fss/half_tree_dpf.cuh:53-57
+  Prg prg;
+  int4 hash_key;           // half_tree_dpf.cuh:45
+  struct alignas(32) Cw {  // half_tree_dpf.cuh:53-57
     int4 s;
     bool extra;
   };
   static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits;
+  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod, &hash_key); }
 
-  void Gen(Cw* d_cws, int4* d_ocws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
-           hipStream_t stream = 0) const {
-    Check(fss_amd_ht_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
-                         d_cws, d_ocws, stream), "fss_amd_ht_gen");
+  void Gen(Cw cws[], int4& ocw, const int4 s0s[2], In a, int4 b_buf) const {  // half_tree_dpf.cuh:68
+    fss_amd_ctx* ctx = handle();
+    detail::Stage st(ctx, 32 + 32 + 32 + sizeof(Cw) * kSlots + 32);
+    const int4* d_s0s = st.Load(s0s, 2);
+    const In* d_a = st.Value(a);
+    const int4* d_b = st.Value(b_buf);
+    Cw* d_cws = st.Out(cws, kSlots);
+    int4* d_ocw = static_cast<int4*>(st.Take(sizeof(int4)));
+    GenBatch(d_cws, d_ocw, d_s0s, d_a, d_b, 1);
+    st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
+    st.Back(&ocw, static_cast<const int4*>(d_ocw), 1);
+  }
+  int4 Eval(bool b, int4 s0, const Cw cws[], int4 ocw, In x) const {  // half_tree_dpf.cuh:187
+    fss_amd_ctx* ctx = handle();
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + 32 + 32);
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    const int4* d_ocw = st.Value(ocw);
+    const In* d_x = st.Value(x);
+    int4* d_y = static_cast<int4*>(st.Take(sizeof(int4)));
+    EvalPoints(b, d_s0, d_cws, d_ocw, d_x, d_y, 1);
+    int4 y;
+    st.Back(&y, static_cast<const int4*>(d_y), 1);
+    return y;
+  }
+  void EvalAll(bool b, int4 s0, const Cw cws[], int4 ocw, int4 ys[]) const {  // half_tree_dpf.cuh:246
+    static_assert(in_bits <= 40, "a full-domain output of 2^in_bits int4s");
+    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
+    fss_amd_ctx* ctx = handle();
+    const bool direct = detail::OnDevice(ys);
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + ws + 32 + (direct ? 0 : n * sizeof(int4)));
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    const int4* d_ocw = st.Value(ocw);
+    void* d_ws = st.Take(ws);
+    int4* d_ys = st.Out(ys, n);
+    EvalAllBlock(b, d_s0, d_cws, d_ocw, d_ys, d_ws, ws);
+    st.Back(ys, static_cast<const int4*>(d_ys), n);
+  }
+
+  void GenBatch(Cw* d_cws, int4* d_ocws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+                hipStream_t stream = 0) const {
+    Check(fss_amd_ht_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
+                         d_ocws, stream), "fss_amd_ht_gen");
   }
   void GenLevelMajor(int4* cw_s, uint32_t* extra, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
                      const int4* d_betas, int64_t nkeys, hipStream_t stream = 0) const {
-    Check(fss_amd_ht_gen_level_major(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
+    Check(fss_amd_ht_gen_level_major(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
                                      nkeys, cw_s, extra, d_ocws, stream), "fss_amd_ht_gen_level_major");
   }
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
-    Check(fss_amd_ht_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, d_xs, detail::XBytes<In>(),
-                                 n, d_ys, stream), "fss_amd_ht_eval_points");
+    Check(fss_amd_ht_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, d_xs, detail::XBytes<In>(), n,
+                                 d_ys, stream), "fss_amd_ht_eval_points");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_HT, in_bits, nleaves);
   }
-  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, int4* d_ys, void* d_workspace,
-               size_t ws_bytes, int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits,
-               hipStream_t stream = 0) const {
-    Check(fss_amd_ht_eval_all(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, first_leaf, nleaves, d_ys,
+  void EvalAllBlock(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, int4* d_ys, void* d_workspace,
+                    size_t ws_bytes, int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits,
+                    hipStream_t stream = 0) const {
+    Check(fss_amd_ht_eval_all(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, first_leaf, nleaves, d_ys,
                               d_workspace, ws_bytes, stream), "fss_amd_ht_eval_all");
   }
 };
 
-// ---------------------------------------------------------------- Grotto DCF
-// include/fss/grotto_dcf.cuh:46-238: keys are DPF keys over Bytes with beta = 0; shares are bools (1 byte).
-template <int in_bits, typename Prg, typename In = uint32_t>
+// ---------------------------------------------------------------- Grotto DCF (include/fss/grotto_dcf.cuh:45-238)
+// Keys are DPF keys over Bytes with beta = 0; shares are bools.
+template <int in_bits, typename Prg, typename In = uint32_t, int par_depth = -1>
+  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Prgable<Prg, 2>)
 class GrottoDcf {
-  static_assert(in_bits >= 1 && in_bits <= 64 && in_bits <= (int)sizeof(In) * 8);
+  using DpfType = Dpf<in_bits, group::Bytes, Prg, In, par_depth>;
+  static_assert(sizeof(bool) == 1);
 
  public:
+  using Cw = typename DpfType::Cw;
   Prg prg;
-  using Cw = typename Dpf<in_bits, group::Bytes, Prg, In>::Cw;
   static constexpr int kSlots = in_bits + 1;
+  fss_amd_ctx* handle() const { return detail::CtxOf(prg); }
 
-  // GrottoDcf::Gen (grotto_dcf.cuh:63-67), nkeys keys at once.
-  void Gen(Cw* d_cws, const int4* d_s0s, const In* d_alphas, int64_t nkeys, hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_gen(prg.handle(), in_bits, group::Bytes::kId, d_s0s, d_alphas, detail::XBytes<In>(), nullptr,
-                          nkeys, d_cws, stream), "fss_amd_dpf_gen");
+  // grotto_dcf.cuh:63-67
+  void Gen(Cw cws[], const int4 s0s[2], In a) const { DpfType{prg}.Gen(cws, s0s, a, int4{0, 0, 0, 0}); }
+
+  // grotto_dcf.cuh:76-84: p = 2N-1 bools, level order (root p[0], leaf x at p[x + N - 1]); b = the party
+  struct ParityTree {
+    bool* p;
+    bool b;
+  };
+  static constexpr size_t ParityTreeBytes() { return (size_t(2) << in_bits) - 1; }
+
+  // grotto_dcf.cuh:94-104.  pt.p: 2N-1 bools on the host or on the device, pt.b set by the caller.
+  void Preprocess(ParityTree& pt, int4 s0, const Cw cws[]) const {
+    static_assert(in_bits <= 40, "a parity table of 2^(in_bits + 1) bytes");
+    fss_amd_ctx* ctx = handle();
+    const size_t ws = PreprocessWorkspace();
+    const bool direct = detail::OnDevice(pt.p);
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 64 + (direct ? 0 : ParityTreeBytes()));
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    void* d_ws = st.Take(ws);
+    bool* d_pt = st.Out(pt.p, ParityTreeBytes());
+    PreprocessDevice(pt.b, reinterpret_cast<uint8_t*>(d_pt), d_s0, d_cws, d_ws, ws);
+    st.Back(pt.p, static_cast<const bool*>(d_pt), ParityTreeBytes());
+  }
+  // grotto_dcf.cuh:116-135: the share of 1[alpha <= x] -- no PRG call, a walk down the finished table: XOR of the
+  // left children where e = x + 1 has a 1 bit.  Runs where it is called, on the table it is given.
+  __host__ __device__ static bool Eval(const ParityTree& pt, In x) {
+    const unsigned __int128 e = static_cast<unsigned __int128>(x) + 1;
+    if (e >> in_bits) return pt.p[0];  // x = N - 1: the whole domain
+    bool share = false;
+    size_t node = 0;
+    for (int level = in_bits - 1; level >= 0; --level) {
+      const size_t left = 2 * node + 1;
+      if ((e >> level) & 1) {
+        share ^= pt.p[left];
+        node = left + 1;
+      } else {
+        node = left;
+      }
+    }
+    return share;
+  }
+  // grotto_dcf.cuh:151-163: ys[x] = party b's share of 1[alpha <= x] for the whole domain
+  void EvalAll(bool b, int4 s0, const Cw cws[], bool ys[]) const {
+    static_assert(in_bits <= 40, "a full-domain output of 2^in_bits bools");
+    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
+    fss_amd_ctx* ctx = handle();
+    const bool direct = detail::OnDevice(ys);
+    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 64 + (direct ? 0 : n));
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws, kSlots);
+    void* d_ws = st.Take(ws);
+    bool* d_ys = st.Out(ys, n);
+    EvalAllBlock(b, d_s0, d_cws, reinterpret_cast<uint8_t*>(d_ys), d_ws, ws);
+    st.Back(ys, static_cast<const bool*>(d_ys), n);
+  }
+
+  // ---- batched device forms
+  void GenBatch(Cw* d_cws, const int4* d_s0s, const In* d_alphas, int64_t nkeys, hipStream_t stream = 0) const {
+    Check(fss_amd_dpf_gen(handle(), in_bits, group::Bytes::kId, d_s0s, d_alphas, detail::XBytes<In>(), nullptr, nkeys,
+                          d_cws, stream), "fss_amd_dpf_gen");
   }
   void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* out_cw, const int4* d_s0s, const In* d_alphas, int64_t nkeys,
                      hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_gen_level_major(prg.handle(), in_bits, group::Bytes::kId, d_s0s, d_alphas, detail::XBytes<In>(),
+    Check(fss_amd_dpf_gen_level_major(handle(), in_bits, group::Bytes::kId, d_s0s, d_alphas, detail::XBytes<In>(),
                                       nullptr, nkeys, cw_s, tr_bits, out_cw, stream), "fss_amd_dpf_gen_level_major");
   }
-  // ParityTree::p = 2N-1 bytes (grotto_dcf.cuh:76-84); workspace >= PreprocessWorkspace() bytes.
-  static size_t ParityTreeBytes() { return (size_t(2) << in_bits) - 1; }
   static size_t PreprocessWorkspace() {
     return fss_amd_eval_all_workspace(FSS_AMD_GROTTO, in_bits, int64_t(1) << in_bits) + (size_t(1) << in_bits);
   }
-  // GrottoDcf::Preprocess (grotto_dcf.cuh:94-104)
-  void Preprocess(bool b, uint8_t* d_pt, const int4* d_s0, const Cw* d_cws, void* d_workspace, size_t ws_bytes,
-                  hipStream_t stream = 0) const {
-    Check(fss_amd_grotto_preprocess(prg.handle(), in_bits, b, d_s0, d_cws, d_pt, d_workspace, ws_bytes, stream),
+  void PreprocessDevice(bool b, uint8_t* d_pt, const int4* d_s0, const Cw* d_cws, void* d_workspace, size_t ws_bytes,
+                        hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_preprocess(handle(), in_bits, b, d_s0, d_cws, d_pt, d_workspace, ws_bytes, stream),
           "fss_amd_grotto_preprocess");
   }
-  // GrottoDcf::Eval (grotto_dcf.cuh:116-135) for a batch of x against one parity tree
-  void Eval(const uint8_t* d_pt, const In* d_xs, uint8_t* d_ys, int64_t n, hipStream_t stream = 0) const {
-    Check(fss_amd_grotto_eval_table(prg.handle(), in_bits, d_pt, d_xs, detail::XBytes<In>(), n, d_ys, stream),
+  // GrottoDcf::Eval for a batch of x against one parity table on the device
+  void EvalPoints(const uint8_t* d_pt, const In* d_xs, uint8_t* d_ys, int64_t n, hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_eval_table(handle(), in_bits, d_pt, d_xs, detail::XBytes<In>(), n, d_ys, stream),
           "fss_amd_grotto_eval_table");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_GROTTO, in_bits, nleaves);
   }
-  // GrottoDcf::EvalAll (grotto_dcf.cuh:151-163); a sub-block needs the carry of the blocks before it
-  // (fss_amd/shard.py: grotto_fix_shard).
-  void EvalAll(bool b, const int4* d_s0, const Cw* d_cws, uint8_t* d_ys, void* d_workspace, size_t ws_bytes,
-               int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
-    Check(fss_amd_grotto_eval_all(prg.handle(), in_bits, b, d_s0, d_cws, first_leaf, nleaves, d_ys, d_workspace,
-                                  ws_bytes, stream), "fss_amd_grotto_eval_all");
+  // a sub-block needs the carry of the blocks before it (fss_amd/shard.py: grotto_fix_shard)
+  void EvalAllBlock(bool b, const int4* d_s0, const Cw* d_cws, uint8_t* d_ys, void* d_workspace, size_t ws_bytes,
+                    int64_t first_leaf = 0, int64_t nleaves = int64_t(1) << in_bits, hipStream_t stream = 0) const {
+    Check(fss_amd_grotto_eval_all(handle(), in_bits, b, d_s0, d_cws, first_leaf, nleaves, d_ys, d_workspace, ws_bytes,
+                                  stream), "fss_amd_grotto_eval_all");
   }
-  // Path-walk evaluator on level-major keys, one point per key (domains with no table, in_bits up to 64):
-  // reconstructs the predicate; the per-party share is not the table share (see fss_amd.h).
+  // Path-walk evaluator on level-major keys, one point per key, for domains with no table (in_bits up to 64).
+  // Reconstructs the predicate, but a party's share is NOT the table share of Eval / EvalAll: both parties must
+  // use this evaluator for a given (key, x) (see fss_amd.h).
   void EvalKeysWalk(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const In* xs, uint8_t* ys,
                     int64_t nkeys, hipStream_t stream = 0) const {
-    Check(fss_amd_grotto_eval_keys(prg.handle(), in_bits, b, seeds, cw_s, tr_bits, xs, detail::XBytes<In>(), nkeys, ys,
+    static_assert(in_bits <= 64);
+    Check(fss_amd_grotto_eval_keys(handle(), in_bits, b, seeds, cw_s, tr_bits, xs, detail::XBytes<In>(), nkeys, ys,
                                    stream), "fss_amd_grotto_eval_keys");
   }
 };
@@ -306,150 +805,215 @@ class GrottoDcf {
 // ---------------------------------------------------------------- verifiable DPF
 namespace hash {
 // fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): the 8-word key of the keyed BLAKE3 hashes.
-// A tag carrying the IV; the hashing runs in the kernels (Vdpf installs the IV in its PRG's context).
+// A tag carrying the IV; the hashing runs in the kernels.
 struct Blake3 {
   int32_t iv[8];
+  explicit Blake3(std::span<const int4, 2> iv2) { std::memcpy(iv, iv2.data(), sizeof(iv)); }
   explicit Blake3(const int4 iv2[2]) { std::memcpy(iv, iv2, sizeof(iv)); }
 };
 }  // namespace hash
 
-// include/fss/vdpf.cuh:57-404 with XorHash = Hash = hash::Blake3 (one IV for both, as the reference's
-// tests and benches use them).  A key = kSlots Cw slots + cs (4 int4) + ocw.
+// include/fss/vdpf.cuh:57-404 with XorHash = Hash = hash::Blake3 (one IV for both, as the reference's tests and
+// benches use them).  A key = kSlots Cw slots + cs (4 int4) + ocw.  Batched device forms only.
 template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
+  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 2>)
 class Vdpf {
-  static_assert(in_bits >= 1 && in_bits <= (int)sizeof(In) * 8);
-
  public:
   Prg prg;
-  Vdpf(Prg p, const hash::Blake3& h) : prg(std::move(p)) {
-    Check(fss_amd_ctx_set_hash_iv(prg.handle(), h.iv), "fss_amd_ctx_set_hash_iv");
-  }
+  hash::Blake3 xor_hash;
   using Cw = typename Dpf<in_bits, Group, Prg, In>::Cw;  // vdpf.cuh:77-82
   static constexpr int kSlots = in_bits;
+  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod, nullptr, xor_hash.iv); }
 
   // Vdpf::Gen (vdpf.cuh:103-189) for nkeys keys; d_retry[k] = its return value (may be null).
   void Gen(Cw* d_cws, int4* d_cs /* 4 per key */, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
            const int4* d_betas, int64_t nkeys, int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_gen(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
-                           d_cws, d_cs, d_ocws, d_retry, stream), "fss_amd_vdpf_gen");
+    Check(fss_amd_vdpf_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
+                           d_cs, d_ocws, d_retry, stream), "fss_amd_vdpf_gen");
   }
   void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* d_cs, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
                      const int4* d_betas, int64_t nkeys, int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_gen_level_major(prg.handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(),
-                                       d_betas, nkeys, cw_s, tr_bits, d_cs, d_ocws, d_retry, stream),
+    Check(fss_amd_vdpf_gen_level_major(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
+                                       nkeys, cw_s, tr_bits, d_cs, d_ocws, d_retry, stream),
           "fss_amd_vdpf_gen_level_major");
   }
   // Vdpf::Eval (vdpf.cuh:204-257) of one key at n points: ys[i], pi_tildes[4i..4i+3]
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_cs, const int4* d_ocw, const In* d_xs,
                   int4* d_ys, int4* d_pi_tildes, int64_t n, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_eval_points(prg.handle(), in_bits, Group::kId, b, d_s0, d_cws, d_cs, d_ocw, d_xs,
+    Check(fss_amd_vdpf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_cs, d_ocw, d_xs,
                                    detail::XBytes<In>(), n, d_ys, d_pi_tildes, stream), "fss_amd_vdpf_eval_points");
   }
   // Vdpf::Prove (vdpf.cuh:268-278) over the n hashes of one key (a sequential chain)
   void Prove(const int4* d_pi_tildes, int64_t n, const int4* d_cs, int4* d_pi, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_prove(prg.handle(), d_pi_tildes, n, d_cs, d_pi, stream), "fss_amd_vdpf_prove");
+    Check(fss_amd_vdpf_prove(handle(), d_pi_tildes, n, d_cs, d_pi, stream), "fss_amd_vdpf_prove");
   }
   // ... and for nkeys keys with one evaluation each
   void ProveKeys(const int4* d_pi_tildes, const int4* d_cs, int64_t nkeys, int4* d_pis, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_prove_keys(prg.handle(), d_pi_tildes, d_cs, nkeys, d_pis, stream), "fss_amd_vdpf_prove_keys");
+    Check(fss_amd_vdpf_prove_keys(handle(), d_pi_tildes, d_cs, nkeys, d_pis, stream), "fss_amd_vdpf_prove_keys");
   }
   // Vdpf::Verify (vdpf.cuh:287-292), host copies of the two proofs
   static bool Verify(const int4 pi0[4], const int4 pi1[4]) { return std::memcmp(pi0, pi1, 4 * sizeof(int4)) == 0; }
 };
 
 // ---------------------------------------------------------------- fss::gpu launchers
+// Device pointers owned by the caller, asynchronous on `stream`, nothing synchronises (the reference's contract,
+// point_eval_gpu.cuh / eval_all_gpu.cuh).  `unroll`, `z`, `b1`, `bs` are accepted so existing call sites compile;
+// the engine sizes its own launches.  A failed launch throws fss::Error where the reference would leave it to
+// cudaPeekAtLastError.
 namespace gpu {
+namespace detail_gpu {
+// relayout needs no key material: any context of the current device will do
+inline fss_amd_ctx* AnyCtx() { return detail::Engine(detail::Spec{}); }
+}  // namespace detail_gpu
 
-// include/fss/point_eval_gpu.cuh:346-353 (extra -> 64-bit tr_bits)
+// point_eval_gpu.cuh:324-331
+template <int in_bits, typename Group, typename Prg, typename In>
+void HalfTreeDpfRelayoutGpu(const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws, int nkeys, int4* cw_s,
+                            uint32_t* extra, hipStream_t stream = 0) {
+  Check(fss_amd_ht_relayout(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, extra, stream), "fss_amd_ht_relayout");
+}
+// point_eval_gpu.cuh:346-353: extra[k] bit i = tr of level i (in_bits <= 32, as the reference)
+template <int in_bits, typename Group, typename Prg, typename In>
+void DpfRelayoutGpu(const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int nkeys, int4* cw_s, uint32_t* extra,
+                    int4* out_cw, hipStream_t stream = 0) {
+  static_assert(in_bits <= 32, "uint32_t extra holds 32 levels; pass uint64_t* tr_bits for in_bits > 32");
+  Check(fss_amd_dpf_relayout_u32(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, extra, out_cw, stream),
+        "fss_amd_dpf_relayout_u32");
+}
+// ... with 64 tr bits per key (two planes of nkeys for in_bits > 64): any in_bits
 template <int in_bits, typename Group, typename Prg, typename In>
 void DpfRelayoutGpu(const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s, uint64_t* tr_bits,
-                    int4* out_cw, const Dpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
-  Check(fss_amd_dpf_relayout(dpf.prg.handle(), in_bits, cws, nkeys, cw_s, tr_bits, out_cw, stream), "dpf_relayout");
+                    int4* out_cw, hipStream_t stream = 0) {
+  Check(fss_amd_dpf_relayout(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, tr_bits, out_cw, stream),
+        "fss_amd_dpf_relayout");
 }
-// :368-375
-template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred>
-void DcfRelayoutGpu(const typename Dcf<in_bits, Group, Prg, In, pred>::Cw* cws, int64_t nkeys, int4* cw_s, int4* cw_v,
-                    int4* out_cw, const Dcf<in_bits, Group, Prg, In, pred>& dcf, hipStream_t stream = 0) {
-  Check(fss_amd_dcf_relayout(dcf.prg.handle(), in_bits, cws, nkeys, cw_s, cw_v, out_cw, stream), "dcf_relayout");
-}
-// :324-331
-template <int in_bits, typename Group, typename Prg, typename In>
-void HalfTreeDpfRelayoutGpu(const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s,
-                            uint32_t* extra, const HalfTreeDpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
-  Check(fss_amd_ht_relayout(dpf.prg.handle(), in_bits, cws, nkeys, cw_s, extra, stream), "ht_relayout");
+// point_eval_gpu.cuh:368-375
+template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred = DcfPred::kLt>
+void DcfRelayoutGpu(const typename Dcf<in_bits, Group, Prg, In, pred>::Cw* cws, int nkeys, int4* cw_s, int4* cw_v,
+                    int4* out_cw, hipStream_t stream = 0) {
+  Check(fss_amd_dcf_relayout(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, cw_v, out_cw, stream),
+        "fss_amd_dcf_relayout");
 }
 
-// :448-460  ys[k] = Dpf::Eval(b, seeds[k], key k, xs[k])
-template <int in_bits, typename Group, typename Prg, typename In>
-void DpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* out_cw,
-                     const In* xs, int4* ys, int64_t nkeys, const Dpf<in_bits, Group, Prg, In>& dpf,
-                     hipStream_t stream = 0) {
-  Check(fss_amd_dpf_eval_keys(dpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, out_cw, xs,
-                              detail::XBytes<In>(), nkeys, ys, stream), "dpf_eval_keys");
-}
-// :479-491
-template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred>
-void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw_v, const int4* out_cw, const In* xs,
-                     int4* ys, int64_t nkeys, const Dcf<in_bits, Group, Prg, In, pred>& dcf, hipStream_t stream = 0) {
-  Check(fss_amd_dcf_eval_keys(dcf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs,
-                              detail::XBytes<In>(), nkeys, ys, stream), "dcf_eval_keys");
-}
-// :416-429
-template <int in_bits, typename Group, typename Prg, typename In>
+// point_eval_gpu.cuh:416-429  ys[k] = HalfTreeDpf::Eval(b, seeds[k], key k, ocws[k], xs[k])
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
 void HalfTreeDpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra, const int4* ocws,
-                             const In* xs, int4* ys, int64_t nkeys, const HalfTreeDpf<in_bits, Group, Prg, In>& dpf,
-                             hipStream_t stream = 0) {
-  Check(fss_amd_ht_eval_keys(dpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs,
-                             detail::XBytes<In>(), nkeys, ys, stream), "ht_eval_keys");
+                             const uint32_t* xs, int4* ys, int nkeys,
+                             const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
+  static_assert(in_bits <= 32, "uint32_t xs cover in_bits <= 32; pass const In* xs");
+  Check(fss_amd_ht_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs, 4, nkeys, ys, stream),
+        "fss_amd_ht_eval_keys");
+}
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+  requires(!std::is_same_v<In, uint32_t>)
+void HalfTreeDpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra, const int4* ocws,
+                             const In* xs, int4* ys, int64_t nkeys,
+                             const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
+  Check(fss_amd_ht_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs, detail::XBytes<In>(),
+                             nkeys, ys, stream), "fss_amd_ht_eval_keys");
+}
+// point_eval_gpu.cuh:448-460  ys[k] = Dpf::Eval(b, seeds[k], key k, xs[k])
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+void DpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra, const int4* out_cw,
+                     const uint32_t* xs, int4* ys, int nkeys, const Dpf<in_bits, Group, Prg, In, par_depth>& dpf,
+                     hipStream_t stream = 0) {
+  static_assert(in_bits <= 32, "uint32_t extra / xs cover in_bits <= 32; pass uint64_t* tr_bits and const In* xs");
+  Check(fss_amd_dpf_eval_keys_u32(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, out_cw, xs, 4, nkeys, ys,
+                                  stream), "fss_amd_dpf_eval_keys_u32");
+}
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+void DpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* out_cw,
+                     const In* xs, int4* ys, int64_t nkeys, const Dpf<in_bits, Group, Prg, In, par_depth>& dpf,
+                     hipStream_t stream = 0) {
+  Check(fss_amd_dpf_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, out_cw, xs,
+                              detail::XBytes<In>(), nkeys, ys, stream), "fss_amd_dpf_eval_keys");
+}
+// point_eval_gpu.cuh:479-491
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int par_depth>
+void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw_v, const int4* out_cw,
+                     const uint32_t* xs, int4* ys, int nkeys, const Dcf<in_bits, Group, Prg, In, pred, par_depth>& dcf,
+                     hipStream_t stream = 0) {
+  static_assert(in_bits <= 32, "uint32_t xs cover in_bits <= 32; pass const In* xs");
+  Check(fss_amd_dcf_eval_keys(dcf.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs, 4, nkeys, ys, stream),
+        "fss_amd_dcf_eval_keys");
+}
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int par_depth>
+  requires(!std::is_same_v<In, uint32_t>)
+void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw_v, const int4* out_cw, const In* xs,
+                     int4* ys, int64_t nkeys, const Dcf<in_bits, Group, Prg, In, pred, par_depth>& dcf,
+                     hipStream_t stream = 0) {
+  Check(fss_amd_dcf_eval_keys(dcf.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs, detail::XBytes<In>(),
+                              nkeys, ys, stream), "fss_amd_dcf_eval_keys");
 }
 
-// :389-396 (extra -> 64-bit tr_bits)
+// include/fss/vdpf point launchers (point_eval_gpu.cuh:389-396, :514-526), 64 tr bits per key
 template <int in_bits, typename Group, typename Prg, typename In>
 void VdpfRelayoutGpu(const typename Vdpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s, uint64_t* tr_bits,
-                     const Vdpf<in_bits, Group, Prg, In>& vdpf, hipStream_t stream = 0) {
-  Check(fss_amd_vdpf_relayout(vdpf.prg.handle(), in_bits, cws, nkeys, cw_s, tr_bits, stream), "vdpf_relayout");
+                     hipStream_t stream = 0) {
+  Check(fss_amd_vdpf_relayout(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, tr_bits, stream), "fss_amd_vdpf_relayout");
 }
-// :514-526  ys[k], pi[4k..4k+3] = Vdpf::Eval(b, seeds[k], key k, cs[k], ocws[k], xs[k])
-template <int in_bits, typename Group, typename Prg, typename In>
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In>
 void VdpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* cs,
                       const int4* ocws, const In* xs, int4* ys, int4* pi, int64_t nkeys,
                       const Vdpf<in_bits, Group, Prg, In>& vdpf, hipStream_t stream = 0) {
-  Check(fss_amd_vdpf_eval_keys(vdpf.prg.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, cs, ocws, xs,
-                               detail::XBytes<In>(), nkeys, ys, pi, stream), "vdpf_eval_keys");
+  Check(fss_amd_vdpf_eval_keys(vdpf.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, cs, ocws, xs,
+                               detail::XBytes<In>(), nkeys, ys, pi, stream), "fss_amd_vdpf_eval_keys");
 }
 
-// include/fss/eval_all_gpu.cuh:478-488 (s0 and cws on the device; workspace from Dpf::EvalAllWorkspace)
-template <int in_bits, typename Group, typename Prg, typename In>
-void DpfEvalAllGpu(bool b, const int4* d_s0, const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int4* ys,
-                   void* workspace, size_t ws_bytes, const Dpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
-  dpf.EvalAll(b, d_s0, cws, ys, workspace, ws_bytes, 0, int64_t(1) << in_bits, stream);
+// eval_all_gpu.cuh:451-461: ys[x] = HalfTreeDpf::Eval(b, s0, cws, ocw, x) for every x; cws / ys device pointers,
+// s0 and ocw by value, workspace from the context's pool for `stream`
+template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+void HalfTreeDpfEvalAllGpu(bool b, int4 s0, const typename HalfTreeDpf<in_bits, Group, Prg, In, par_depth>::Cw* cws,
+                           int4 ocw, int4* ys, const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf,
+                           hipStream_t stream = 0) {
+  fss_amd_ctx* ctx = dpf.handle();
+  const size_t ws = dpf.EvalAllWorkspace();
+  const detail::Scratch sc(ctx, stream, ws);
+  const int4* d_s0 = detail::PutInt4(ctx, sc, 0, s0, stream);
+  const int4* d_ocw = detail::PutInt4(ctx, sc, 1, ocw, stream);
+  dpf.EvalAllBlock(b, d_s0, cws, d_ocw, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
 }
-// :451-461
-template <int in_bits, typename Group, typename Prg, typename In>
-void HalfTreeDpfEvalAllGpu(bool b, const int4* d_s0, const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws,
-                           const int4* d_ocw, int4* ys, void* workspace, size_t ws_bytes,
-                           const HalfTreeDpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
-  dpf.EvalAll(b, d_s0, cws, d_ocw, ys, workspace, ws_bytes, 0, int64_t(1) << in_bits, stream);
+// eval_all_gpu.cuh:478-488
+template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+void DpfEvalAllGpu(bool b, int4 s0, const typename Dpf<in_bits, Group, Prg, In, par_depth>::Cw* cws, int4* ys,
+                   const Dpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
+  fss_amd_ctx* ctx = dpf.handle();
+  const size_t ws = dpf.EvalAllWorkspace();
+  const detail::Scratch sc(ctx, stream, ws);
+  const int4* d_s0 = detail::PutInt4(ctx, sc, 0, s0, stream);
+  dpf.EvalAllBlock(b, d_s0, cws, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
 }
-
-// :511-520  ys[k * 2^in_bits + x] = Dpf::Eval(b, s0s[k], key k, x); workspace from EvalAllBatchWorkspace
-template <int in_bits, typename Group, typename Prg, typename In>
-void DpfEvalAllGpuBatch(bool b, const int4* d_s0s, const typename Dpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys,
-                        int4* ys, void* workspace, size_t ws_bytes, const Dpf<in_bits, Group, Prg, In>& dpf,
-                        hipStream_t stream = 0) {
-  Check(fss_amd_dpf_eval_all_batch(dpf.prg.handle(), in_bits, Group::kId, b, d_s0s, cws, nkeys, ys, workspace, ws_bytes,
-                                   stream), "dpf_eval_all_batch");
+// eval_all_gpu.cuh:511-520: nkeys keys, the full domain of each; ys[k * 2^in_bits + x]
+template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+void DpfEvalAllGpuBatch(bool b, const int4* s0s, const typename Dpf<in_bits, Group, Prg, In, par_depth>::Cw* cws,
+                        int nkeys, int4* ys, const Dpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
+  fss_amd_ctx* ctx = dpf.handle();
+  const size_t ws = fss_amd_eval_all_batch_workspace(FSS_AMD_DPF, in_bits, nkeys);
+  const detail::Scratch sc(ctx, stream, ws);
+  Check(fss_amd_dpf_eval_all_batch(ctx, in_bits, Group::kId, b, s0s, cws, nkeys, ys, sc.Workspace(), ws, stream),
+        "fss_amd_dpf_eval_all_batch");
 }
-// :526-535
-template <int in_bits, typename Group, typename Prg, typename In>
-void HalfTreeDpfEvalAllGpuBatch(bool b, const int4* d_s0s, const typename HalfTreeDpf<in_bits, Group, Prg, In>::Cw* cws,
-                                const int4* d_ocws, int64_t nkeys, int4* ys, void* workspace, size_t ws_bytes,
-                                const HalfTreeDpf<in_bits, Group, Prg, In>& dpf, hipStream_t stream = 0) {
-  Check(fss_amd_ht_eval_all_batch(dpf.prg.handle(), in_bits, Group::kId, b, d_s0s, cws, d_ocws, nkeys, ys, workspace,
-                                  ws_bytes, stream), "ht_eval_all_batch");
+// eval_all_gpu.cuh:526-535
+template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
+void HalfTreeDpfEvalAllGpuBatch(bool b, const int4* s0s,
+                                const typename HalfTreeDpf<in_bits, Group, Prg, In, par_depth>::Cw* cws, const int4* ocws,
+                                int nkeys, int4* ys, const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf,
+                                hipStream_t stream = 0) {
+  fss_amd_ctx* ctx = dpf.handle();
+  const size_t ws = fss_amd_eval_all_batch_workspace(FSS_AMD_HT, in_bits, nkeys);
+  const detail::Scratch sc(ctx, stream, ws);
+  Check(fss_amd_ht_eval_all_batch(ctx, in_bits, Group::kId, b, s0s, cws, ocws, nkeys, ys, sc.Workspace(), ws, stream),
+        "fss_amd_ht_eval_all_batch");
 }
-inline size_t EvalAllBatchWorkspace(int scheme, int in_bits, int64_t nkeys) {
-  return fss_amd_eval_all_batch_workspace(scheme, in_bits, nkeys);
+// DCF full domain on the device (the reference has no such launcher; same shape as DpfEvalAllGpu)
+template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int par_depth>
+void DcfEvalAllGpu(bool b, int4 s0, const typename Dcf<in_bits, Group, Prg, In, pred, par_depth>::Cw* cws, int4* ys,
+                   const Dcf<in_bits, Group, Prg, In, pred, par_depth>& dcf, hipStream_t stream = 0) {
+  fss_amd_ctx* ctx = dcf.handle();
+  const size_t ws = dcf.EvalAllWorkspace();
+  const detail::Scratch sc(ctx, stream, ws);
+  const int4* d_s0 = detail::PutInt4(ctx, sc, 0, s0, stream);
+  dcf.EvalAllBlock(b, d_s0, cws, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
 }
 
 }  // namespace gpu

@@ -5,7 +5,7 @@
 // samples/half_tree_dpf_cpu.cu (Half-Tree, here n = 64 with the ChaCha PRG and Gen straight into the
 // level-major layout) and samples/grotto_dcf_cpu.cu (Gen, Preprocess + Eval, EvalAll, reconstruct).
 //
-// build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude samples/dpf_dcf_gpu.cpp \
+// build: hipcc --offload-arch=gfx950 -O2 -std=c++20 -Iinclude samples/dpf_dcf_gpu.cpp \
 //              -Lfss_amd -lfss_amd -Wl,-rpath,$PWD/fss_amd -o samples/dpf_dcf_gpu
 #include <cstdio>
 #include <cstdlib>
@@ -75,8 +75,8 @@ int main() {
       DpfT dpf{DpfPrg(keys2)};
       DpfT::Cw* d_cws;
       HIP_OK(hipMalloc(&d_cws, (size_t)kN * DpfT::kSlots * sizeof(DpfT::Cw)));
-      dpf.Gen(d_cws, d_s0s, d_alphas, d_betas, kN);
-      fss::gpu::DpfRelayoutGpu(d_cws, kN, d_cw_s, d_tr, d_out_cw, dpf);
+      dpf.GenBatch(d_cws, d_s0s, d_alphas, d_betas, kN);
+      fss::gpu::DpfRelayoutGpu<kInBits, Group, DpfPrg, In>(d_cws, kN, d_cw_s, d_tr, d_out_cw);
       fss::gpu::DpfEvalPointGpu(false, d_seeds0, d_cw_s, d_tr, d_out_cw, d_xs, d_y0, kN, dpf);
       fss::gpu::DpfEvalPointGpu(true, d_seeds1, d_cw_s, d_tr, d_out_cw, d_xs, d_y1, kN, dpf);
       HIP_OK(hipMemcpy(y0.data(), d_y0, kN * sizeof(int4), hipMemcpyDeviceToHost));
@@ -98,8 +98,8 @@ int main() {
       DcfT dcf{DcfPrg(keys4)};
       DcfT::Cw* d_cws;
       HIP_OK(hipMalloc(&d_cws, (size_t)kN * DcfT::kSlots * sizeof(DcfT::Cw)));
-      dcf.Gen(d_cws, d_s0s, d_alphas, d_betas, kN);
-      fss::gpu::DcfRelayoutGpu(d_cws, kN, d_cw_s, d_cw_v, d_out_cw, dcf);
+      dcf.GenBatch(d_cws, d_s0s, d_alphas, d_betas, kN);
+      fss::gpu::DcfRelayoutGpu<kInBits, Group, DcfPrg, In>(d_cws, kN, d_cw_s, d_cw_v, d_out_cw);
       fss::gpu::DcfEvalPointGpu(false, d_seeds0, d_cw_s, d_cw_v, d_out_cw, d_xs, d_y0, kN, dcf);
       fss::gpu::DcfEvalPointGpu(true, d_seeds1, d_cw_s, d_cw_v, d_out_cw, d_xs, d_y1, kN, dcf);
       HIP_OK(hipMemcpy(y0.data(), d_y0, kN * sizeof(int4), hipMemcpyDeviceToHost));
@@ -115,9 +115,9 @@ int main() {
       int before = errors;
       using HtPrg = fss::prg::ChaCha<1>;
       using HtT = fss::HalfTreeDpf<64, Group, HtPrg, uint64_t>;
-      const int32_t nonce[2] = {0x12345678, (int32_t)0x9abcdef0};
-      const int32_t hash_key[4] = {0x12345678, (int32_t)0x9abcdef0, 0x13572468, 0x2468ace0};
-      HtT ht{HtPrg(nonce, 0, hash_key)};
+      const int nonce[2] = {0x12345678, (int)0x9abcdef0};
+      const int4 hash_key = {0x12345678, (int)0x9abcdef0, 0x13572468, 0x2468ace0};
+      HtT ht{HtPrg(nonce), hash_key};
       std::vector<uint64_t> a64(kN), x64(kN);
       for (int i = 0; i < kN; ++i) {
         a64[i] = ((uint64_t)std::rand() << 40) ^ ((uint64_t)std::rand() << 20) ^ (uint64_t)std::rand();
@@ -157,15 +157,15 @@ int main() {
       const size_t ws_bytes = GrT::PreprocessWorkspace();
       HIP_OK(hipMalloc(&d_cws, GrT::kSlots * sizeof(GrT::Cw)));
       HIP_OK(hipMalloc(&d_ws, ws_bytes));
-      gr.Gen(d_cws, d_s0s, d_ga, 1);
+      gr.GenBatch(d_cws, d_s0s, d_ga, 1);
       std::vector<uint8_t> b[2], all[2];
       for (int p = 0; p < 2; ++p) {
         HIP_OK(hipMalloc(&d_pt[p], GrT::ParityTreeBytes()));
         HIP_OK(hipMalloc(&d_b[p], kN));
         HIP_OK(hipMalloc(&d_all[p], size_t(1) << kG));
-        gr.Preprocess(p, d_pt[p], d_s0s + p, d_cws, d_ws, ws_bytes);
-        gr.Eval(d_pt[p], d_gx, d_b[p], kN);
-        gr.EvalAll(p, d_s0s + p, d_cws, d_all[p], d_ws, ws_bytes);
+        gr.PreprocessDevice(p, d_pt[p], d_s0s + p, d_cws, d_ws, ws_bytes);
+        gr.EvalPoints(d_pt[p], d_gx, d_b[p], kN);
+        gr.EvalAllBlock(p, d_s0s + p, d_cws, d_all[p], d_ws, ws_bytes);
         b[p].resize(kN); all[p].resize(size_t(1) << kG);
         HIP_OK(hipMemcpy(b[p].data(), d_b[p], kN, hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(all[p].data(), d_all[p], size_t(1) << kG, hipMemcpyDeviceToHost));
@@ -184,7 +184,7 @@ int main() {
       int before = errors;
       using VPrg = fss::prg::ChaCha<2>;
       using VT = fss::Vdpf<kInBits, Group, VPrg, In>;
-      const int32_t nonce[2] = {0x12345678, (int32_t)0x9abcdef0};
+      const int nonce[2] = {0x12345678, (int)0x9abcdef0};
       const int4 iv[2] = {{0x11223344, 0x55667788, (int)0x99aabbccu, (int)0xddeeff00u},
                           {0x00112233, 0x44556677, (int)0x8899aabbu, (int)0xccddeeffu}};
       VT vdpf{VPrg(nonce), fss::hash::Blake3(iv)};

@@ -72,3 +72,10 @@ def test_cxx_layer_compiles():
     """include/fss_amd.hpp (the fss::Dpf / fss::gpu::* mirror) and the sample build with hipcc."""
     from fss_amd import _build
     assert os.path.exists(_build.build_sample())
+
+
+def test_cxx_dropin_test_compiles():
+    """Caller code in the reference's call syntax (tests/cxx/dropin_test.cpp) compiles against include/fss_amd.hpp
+    unchanged; it runs under -m gpu (tests/test_gpu_parity.py::test_cxx_dropin_boundary)."""
+    from fss_amd import _build
+    assert os.path.exists(_build.build_dropin_test())

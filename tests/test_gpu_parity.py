@@ -717,3 +717,15 @@ def test_eval_all_batch_vs_oracle(engine, O, scheme, n, nkeys, g):
     one = engine.eval_all(scheme, n, g, 1, T(s0s[nkeys - 1, 1].copy()), T(cws[nkeys - 1]),
                           ocw=None if ocws is None else T(ocws[nkeys - 1])).cpu().numpy()
     assert (got[nkeys - 1] == one).all()
+
+
+def test_cxx_dropin_boundary():
+    """tests/cxx/dropin_test.cpp: caller code in the reference's own call syntax (samples/dpf_dcf_cpu.cu flow with
+    CreateCtxs / Gen / Eval / EvalAll on host arrays; samples/dpf_dcf_gpu.cu:58; src/bench_gpu.cu:578,618,625) compiled
+    against include/fss_amd.hpp, checked against the reference's known answers and by reconstruction."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_dropin_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
