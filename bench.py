@@ -10,7 +10,13 @@ evaluates its own 2^24-point batch of the same key (the points x keys batch shar
 with no collective on the data path; weak scaling), the timed region is bracketed by
 barrier + synchronize and the slowest rank's time is used.
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  `roofline` is
+`python bench.py --gpus N` with no launcher around it starts its own N ranks (one process per GPU, spawned before
+anything touches the GPU; a failed or hung rank ends the run with a non-zero exit code); under
+`python -m torch.distributed.run` (RANK / WORLD_SIZE set) it is one of the ranks.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the headline (`value`: DPF, one
+key) the line carries the rest of the metric as sub-records timed the same way: `dcf_points` (DCF n=32, one key,
+2^24 points), `dpf_keys` (2^24 independent level-major keys, one point each), `dpf_n16` / `dpf_n64`.  `roofline` is
 the binding roof of the kernel -- LDS table-lookup bandwidth (the path is
 neither HBM- nor MFMA-bound) -- and `roofline_hbm` the HBM figure next to it.
 `cpu_baseline` times the oracle's restatement of the reference CPU path (OpenSSL EVP
@@ -56,27 +62,31 @@ def hbm_bytes_per_eval(scheme, n, shared):
 
 
 def _headline_pmc(log2_batch):
-    """Counters of the headline kernel (plain DPF walk, shared key) from the committed rocprofv3 PMC passes
-    (profiles/<round>/pmc_summary.json, newest round first).  Only valid for the batch profiled (2^24)."""
+    """Counters of the headline kernel (plain DPF walk, shared key) REPLAYED from the committed rocprofv3 PMC passes
+    (profiles/r<N>/pmc_summary.json, highest N first): bench.py cannot read PMCs itself.  Only valid for the batch
+    profiled (2^24).  Returns (values, path relative to the repo) or (None, None)."""
     import glob
+    import re
     if log2_batch != 24:
-        return None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
+        return None, None
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json"))
+    rnd = lambda f: int(re.search(r"profiles[/\\]r(\d+)", f).group(1))
+    for f in sorted(files, key=rnd, reverse=True):
         try:
             d = json.load(open(f))
             for k, v in d.items():
                 name = k.replace("fssamd::Lds, ", "")
                 if "eval_points_kernel<0, true" in name and name.rstrip().endswith("false>") and "FETCH_SIZE" in v:
-                    return v
+                    return v, os.path.relpath(f, ROOT)
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def measured_hbm_traffic(log2_batch):
     """HBM bytes per launch: FETCH_SIZE and WRITE_SIZE in KiB, collected in separate passes; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950."""
-    v = _headline_pmc(log2_batch)
+    doubled as MI355X_MICROARCH.md prescribes for gfx950.  Replayed from profiles/ (see `traffic_replayed_from`)."""
+    v, _ = _headline_pmc(log2_batch)
     if not v or "WRITE_SIZE" not in v:
         return None
     return (2 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
@@ -85,18 +95,16 @@ def measured_hbm_traffic(log2_batch):
 def measured_pipe_busy(log2_batch):
     """LDS- and VALU-busy fractions of the profiled launch (north_star: "VALU-busy against the chip's peak"):
     SQ_LDS_IDX_ACTIVE per CU, and SQ_ACTIVE_INST_VALU (counted in 4-cycle issue slots) per SIMD, over the
-    kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs)."""
-    v = _headline_pmc(log2_batch)
+    kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).  Ratios of counters of one profiled launch -- not of this run."""
+    v, src = _headline_pmc(log2_batch)
     need = ("GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU")
     if not v or any(k not in v for k in need):
         return None
     cyc = v["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
-    out = {"lds_busy": v["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / cyc,
-           "valu_busy": v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / cyc,
-           "valu_wave_instructions_per_launch": v["SQ_INSTS_VALU"]["mean_per_launch"],
-           "clock_ghz_in_pmc_run": cyc / (v["AverageNs"] * 1e-9) / 1e9 if "AverageNs" in v else None,
-           "source": "profiles/ rocprofv3 --pmc passes of the same command"}
-    return out
+    return {"lds_busy": v["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / cyc,
+            "valu_busy": v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / cyc,
+            "valu_wave_instructions_per_launch": v["SQ_INSTS_VALU"]["mean_per_launch"],
+            "replayed_from": src}
 
 
 def time_steps(fn, steps, warmup, dist):
@@ -147,7 +155,7 @@ def make_key(eng, scheme, n, group_id, seed_val):
     beta = torch.randint(-2**31, 2**31, (1, 4), dtype=torch.int32, generator=g)
     beta[..., 3] &= ~1
     if n <= 32:
-        alpha = torch.randint(0, 2**31, (1,), dtype=torch.int32, generator=g)
+        alpha = torch.randint(0, 2**31, (1,), dtype=torch.int32, generator=g) & ((1 << min(n, 31)) - 1)
     else:
         alpha = torch.randint(0, 2**62, (1,), dtype=torch.int64, generator=g)
     sid = {"dpf": fss_amd.DPF, "dcf": fss_amd.DCF, "ht": fss_amd.HT}[scheme]
@@ -214,19 +222,39 @@ def cpu_baseline(scheme, n, s0s, cws, ocw, xs_sample, gpu_sample, threads):
     return out
 
 
+def _rand_xs(n, batch, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    if n <= 32:
+        xs = torch.randint(-2**31, 2**31, (batch,), dtype=torch.int32, device="cuda", generator=gen)
+        return xs & ((1 << n) - 1) if n < 32 else xs
+    return torch.randint(-2**63, 2**63 - 1, (batch,), dtype=torch.int64, device="cuda", generator=gen)
+
+
+def _sub_record(desc, scheme, n, shared, units, wall, kernel_ms, world, steps, kname):
+    """One more workload of the metric, timed like the headline (same barrier / max-over-ranks protocol)."""
+    rate = units / (kernel_ms * 1e-3)
+    aes = aes_blocks_per_eval(scheme, n)
+    lds = rate * aes * LOOKUP_BYTES_PER_AES / 1e9
+    hbm = rate * hbm_bytes_per_eval(scheme, n, shared) / 1e9
+    return {"workload": desc, "value": units * world * steps / wall, "unit": "evals/s", "ms_per_step": wall / steps * 1e3,
+            "kernel_ms": kernel_ms, "per_gpu_evals_per_s": rate, "aes_blocks_per_eval": aes,
+            "roofline": {"bound": "lds", "achieved": lds, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds / LDS_PEAK_GBS},
+            "hbm_gbs_algorithmic": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "kernel": kname}
+
+
 def run_headline(args, rank, world, dist):
     import fss_amd
     eng = fss_amd.default_engine(torch.cuda.current_device())
     n, scheme = 32, "dpf"
     batch = 1 << args.log2_batch
-    sid, s0s, cws, ocw, _, _ = make_key(eng, scheme, n, fss_amd.U64, 0x5EED0002)
-    g = torch.Generator(device="cuda").manual_seed(0x5EED0002 + rank)
-    xs = torch.randint(-2**31, 2**31, (batch,), dtype=torch.int32, device="cuda", generator=g)
+    G = fss_amd.U64
+    sid, s0s, cws, ocw, _, _ = make_key(eng, scheme, n, G, 0x5EED0002)
+    xs = _rand_xs(n, batch, 0x5EED0002 + rank)
     seed_d, cws_d = s0s[0].cuda(), cws.cuda()
     ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
 
     def step():
-        eng.eval_points(sid, n, fss_amd.U64, 0, seed_d, cws_d, xs, out=ys)
+        eng.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys)
 
     wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
     kname, grid, block = eng.last_kernel()
@@ -237,10 +265,50 @@ def run_headline(args, rank, world, dist):
     ys2 = torch.empty_like(ys)
 
     def step_shared():
-        eng.eval_points_shared(sid, n, fss_amd.U64, 0, seed_d, cws_d, xs, out=ys2)
+        eng.eval_points_shared(sid, n, G, 0, seed_d, cws_d, xs, out=ys2)
 
     wall_sp, kernel_ms_sp = time_steps(step_shared, args.steps, args.warmup, dist)
     same = bool((ys == ys2).all())
+    del ys2
+
+    # ---- the rest of the metric: DCF, independent keys, kInBits 16 / 64 (north_star), same protocol
+    subs, checks = {}, {}
+    m = min(batch, 4096)  # evaluations per sub-record handed to the CPU check (a strided sample)
+    pick = torch.arange(0, batch, max(1, batch // m), device="cuda")[:m]
+    for key, sch, nn in (("dcf_points", "dcf", 32), ("dpf_n16", "dpf", 16), ("dpf_n64", "dpf", 64)):
+        sid2, s0s2, cws2, ocw2, _, _ = make_key(eng, sch, nn, G, 0x5EED0100 + nn + (7 if sch == "dcf" else 0))
+        xs2 = _rand_xs(nn, batch, 0x5EED0200 + nn + rank)
+        sd2, cd2 = s0s2[0].cuda(), cws2.cuda()
+        step2 = lambda: eng.eval_points(sid2, nn, G, 0, sd2, cd2, xs2, out=ys)
+        w2, k2 = time_steps(step2, args.steps, args.warmup, dist)
+        subs[key] = _sub_record(f"{'DCF (Boyle 21, kLt)' if sch == 'dcf' else 'DPF'} kInBits={nn}, 1 key, 2^{args.log2_batch} random "
+                                f"points per GPU per step, party 0, Uint<uint64_t>", sch, nn, True, batch, w2, k2, world,
+                                args.steps, eng.last_kernel()[0])
+        checks[key] = (sch, nn, s0s2, cws2, None, xs2[pick].cpu().numpy(), ys[pick].cpu().numpy())
+        del xs2
+    # M(ii): 2^batch independent keys x 1 point, keys generated on the device straight into the level-major layout
+    # (outside the timed region, as the reference excludes Gen and relayout: src/bench_gpu.cu:616-627)
+    gen = torch.Generator(device="cuda").manual_seed(0x5EED0300 + rank)
+    ks0s = torch.randint(-2**31, 2**31, (batch, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
+    kbetas = torch.randint(-2**31, 2**31, (batch, 4), dtype=torch.int32, device="cuda", generator=gen)
+    kalphas = torch.randint(-2**31, 2**31, (batch,), dtype=torch.int32, device="cuda", generator=gen)
+    kxs = _rand_xs(32, batch, 0x5EED0400 + rank)
+    kxs[::2] = kalphas[::2]  # half of the points hit their key's alpha
+    keys, _ = eng.gen_level_major(fss_amd.DPF, 32, G, ks0s, kalphas, kbetas)
+    kseeds = ks0s[:, 0].contiguous()
+    step_k = lambda: eng.eval_keys(keys, G, 0, kseeds, kxs, out=ys)
+    w3, k3 = time_steps(step_k, args.steps, args.warmup, dist)
+    subs["dpf_keys"] = _sub_record(f"DPF kInBits=32, 2^{args.log2_batch} independent level-major keys x 1 point each per GPU per "
+                                   f"step (SURVEY 8d M(ii)), party 0, Uint<uint64_t>", "dpf", 32, False, batch, w3, k3, world,
+                                   args.steps, eng.last_kernel()[0])
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from fss_amd.engine import LevelMajorKeys
+        sub = LevelMajorKeys(fss_amd.DPF, 32, int(pick.numel()), keys.cw_s[:, pick].contiguous(),
+                             tr_bits=keys.tr_bits[pick].contiguous(), out_cw=keys.out_cw[pick].contiguous())
+        checks["dpf_keys"] = ("dpf_keys", 32, kseeds[pick].cpu().numpy(), eng.key_major(sub).cpu().numpy(), None,
+                              kxs[pick].cpu().numpy(), ys[pick].cpu().numpy())
+    del keys, ks0s, kbetas, kalphas, kseeds
+    eng.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys)  # the headline outputs again, for the CPU comparison below
     if rank != 0:
         return
     evals = batch * world * args.steps
@@ -251,6 +319,8 @@ def run_headline(args, rank, world, dist):
     lds_gbs = lds_bytes / (kernel_ms * 1e-3) / 1e9
     hbm_bytes = batch * hbm_bytes_per_eval(scheme, n, True)
     hbm_gbs = hbm_bytes / (kernel_ms * 1e-3) / 1e9
+    pipes = measured_pipe_busy(args.log2_batch)
+    replay_src = _headline_pmc(args.log2_batch)[1]
     out = {
         "metric": "DPF/DCF evals/sec at kInBits=32, batch=2^24", "value": value, "unit": "evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -260,36 +330,58 @@ def run_headline(args, rank, world, dist):
                    "kernel": kname, "grid": grid, "block": block, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                      "frac": lds_gbs / LDS_PEAK_GBS, "traffic": measured_hbm_traffic(args.log2_batch),
+                     "traffic_replayed_from": replay_src,
                      "kernel_ms": kernel_ms, "per_gpu_evals_per_s": per_gpu_kernel_rate,
                      "algorithmic": f"{aes} AES blocks/eval x 160 LDS lookups x 4 B; peak = 128 B/clk/CU x 256 CU x 2.4 GHz",
-                     "aes_blocks_per_s": per_gpu_kernel_rate * aes, "pipes": measured_pipe_busy(args.log2_batch)},
+                     "aes_blocks_per_s": per_gpu_kernel_rate * aes, "pipes": pipes},
         "roofline_hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": measured_hbm_traffic(args.log2_batch),
+                         "traffic_replayed_from": replay_src,
                          "algorithmic_bytes_per_launch": hbm_bytes,
                          "algorithmic": "4 B x + 16 B y per eval (key resident on chip); traffic = PMC bytes per "
-                                        "launch from profiles/ (FETCH_SIZE x2 + WRITE_SIZE)"},
+                                        "launch of the committed profile named in traffic_replayed_from "
+                                        "(FETCH_SIZE x2 + WRITE_SIZE), not of this run"},
     }
-    pipes = measured_pipe_busy(args.log2_batch)
     if pipes:
         # third roof SURVEY 8(d) asks for: VALU issue.  Peak = 256 CU x 4 SIMD x one wave64 instruction per 2 clk x
         # 2.4 GHz (the fast-class rate); this kernel's instruction mix issues at ~4 clk, so the
-        # pipe is ~0.9 busy at less than half of that peak.
+        # pipe is ~0.9 busy at less than half of that peak.  Instruction count replayed from the profile, time live.
         valu_rate = pipes["valu_wave_instructions_per_launch"] / (kernel_ms * 1e-3)
         out["roofline_valu"] = {"bound": "valu", "achieved": valu_rate / 1e12, "peak": 1.2288, "unit": "T wave64-instr/s",
                                 "frac": valu_rate / 1.2288e12, "busy_frac_pmc": pipes["valu_busy"],
-                                "instructions_per_launch": pipes["valu_wave_instructions_per_launch"]}
+                                "instructions_per_launch": pipes["valu_wave_instructions_per_launch"],
+                                "replayed_from": pipes["replayed_from"]}
     out["shared_prefix"] = {
         "value": batch * world * args.steps / wall_sp, "unit": "evals/s", "ms_per_step": wall_sp / args.steps * 1e3,
         "kernel_ms": kernel_ms_sp, "identical_to_plain_walk": same,
         "note": "fss_amd_dpf_eval_points_shared: top log2(batch) tree levels expanded once per step (EvalAll-style), "
                 "then (in_bits - log2(batch)) levels per point; ~10 AES blocks executed per eval instead of 32",
     }
+    out.update(subs)
     if world == 1 and not args.no_cpu:
         threads = usable_cores()
-        m = min(batch, args.cpu_sample)
-        out["cpu_baseline"] = cpu_baseline(scheme, n, s0s, cws, ocw, xs[:m].cpu().numpy().view(np.uint32),
-                                           ys[:m].cpu().numpy(), threads)
+        mm = min(batch, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(scheme, n, s0s, cws, ocw, xs[:mm].cpu().numpy().view(np.uint32),
+                                           ys[:mm].cpu().numpy(), threads)
+        for key, ok in cpu_check_subrecords(checks).items():  # part of the cpu_baseline leg: the oracle as checker
+            out[key]["gpu_matches_oracle_on_sample"] = ok
     print(json.dumps(out), flush=True)
+
+
+def cpu_check_subrecords(checks):
+    """The sub-records' parity gates, run with the cpu_baseline leg: a strided sample of every sub-workload's GPU
+    outputs against the oracle (party 0, Uint<uint64_t>)."""
+    from oracle import oracle as O
+    res = {}
+    for key, (sch, n, s0s, cws, ocw, xs, got) in checks.items():
+        xs64 = (xs.view(np.uint32) if xs.dtype == np.int32 else xs.view(np.uint64)).astype(np.uint64)
+        if sch == "dpf_keys":
+            want = O.eval_keys(O.Prg(2), O.DPF, n, O.U64, 0, s0s, cws, xs64, nthreads=4)
+        else:
+            sid = {"dpf": O.DPF, "dcf": O.DCF}[sch]
+            want = O.eval_points(O.Prg(2 if sch == "dpf" else 4), sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64, nthreads=4)
+        res[key] = bool((want == got).all())
+    return res
 
 
 def run_sharded(args, rank, world, dist):
@@ -561,6 +653,95 @@ def run_suite(args):
         json.dump(res, f, indent=1)
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes, spawned before
+    this one has touched the GPU -- nothing here calls into HIP), one per GPU, rendezvous on 127.0.0.1.  Rank 0's
+    stdout (the one JSON line) passes through.  If a rank exits non-zero, or the run outlives --launch-timeout, the
+    remaining ranks are killed and the exit code is non-zero: a failed rank can never leave the others in a barrier."""
+    import socket
+    import subprocess
+    n = args.gpus
+    share = os.environ.get("FSS_AMD_BENCH_SHARE_GPU") == "1"
+    dry = os.environ.get("FSS_AMD_BENCH_DRY_RUN") == "1"
+    if not (share or dry):
+        have = torch.cuda.device_count()  # counts devices without initialising the HIP runtime in this process
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    deadline = time.monotonic() + args.launch_timeout
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            for pr in list(live):
+                code = pr.poll()
+                if code is None:
+                    continue
+                live.remove(pr)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {procs.index(pr)} exited with code {code}; stopping the other ranks", file=sys.stderr)
+            if live and rc == 0:
+                if time.monotonic() > deadline:
+                    rc = 124
+                    print(f"bench.py: ranks still running after {args.launch_timeout} s; stopping them", file=sys.stderr)
+                else:
+                    time.sleep(0.05)
+    finally:
+        for pr in procs:  # exactly the process groups started above
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, 15)
+                except ProcessLookupError:
+                    pass
+        t_end = time.monotonic() + 5
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, 9)
+                except ProcessLookupError:
+                    pass
+    return rc
+
+
+def run_dry(args, rank, world, dist):
+    """FSS_AMD_BENCH_DRY_RUN=1: the launch / rendezvous / barrier / max-over-ranks / one-JSON-line control flow with an
+    empty step and no GPU -- a test hook for boxes without one (tests/test_bench_launch.py).  Its line says
+    "dry_run": true and measures nothing."""
+    fail = os.environ.get("FSS_AMD_BENCH_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        raise SystemExit(f"rank {rank}: failure injected by FSS_AMD_BENCH_FAIL_RANK")
+    hang = os.environ.get("FSS_AMD_BENCH_HANG_RANK")
+    if hang is not None and int(hang) == rank:
+        time.sleep(3600)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "DPF/DCF evals/sec at kInBits=32, batch=2^24", "value": 0.0, "unit": "evals/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3,
+                          "dry_run": True, "config": {"workload": "none (control-flow test hook, no GPU work)"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -572,36 +753,60 @@ def main():
     ap.add_argument("--suite", action="store_true")
     ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "evalall_c4", "ht_c5", "grotto_c5"],
                     help="dpf_points = the headline (BASELINE metric); the others are configs[3] / configs[4], sharded")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launched multi-GPU runs: seconds before the ranks are stopped and the run fails")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    # Not under a launcher but asked for several GPUs: become the launcher.  This must stay ahead of anything that
+    # initialises the GPU (torch.cuda.is_available() does): the ranks are fresh child processes.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = os.environ.get("FSS_AMD_BENCH_DRY_RUN") == "1"
     # Test hook for boxes with fewer GPUs than ranks (exercises the N > 1 control flow only, not a
     # measurement): ranks share the visible GPUs and rendezvous over gloo, since RCCL refuses two ranks on one device.
     share = os.environ.get("FSS_AMD_BENCH_SHARE_GPU") == "1"
-    if share:
-        local %= torch.cuda.device_count()
-    torch.cuda.set_device(local)
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        if share:
+            local %= torch.cuda.device_count()
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist_mod
-        if share:
-            dist_mod.init_process_group("gloo")
+        # a rank that dies before the first barrier must not leave the others waiting for ever (under
+        # torch.distributed.run the launcher ends them; under bench.py's own launcher launch_ranks does; this
+        # bounds the remaining cases)
+        tmo = datetime.timedelta(seconds=min(args.launch_timeout, 600.0))
+        if share or dry:
+            # gloo announces its connections on stdout; keep stdout for the one JSON line
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist_mod.init_process_group("gloo", timeout=tmo)
+            finally:
+                os.dup2(saved, 1)
+                os.close(saved)
         else:
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         dist = dist_mod
-    if args.gpus != world and rank == 0 and world > 1:
+    if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    if args.workload == "dpf_points":
+    if dry:
+        run_dry(args, rank, world, dist)
+    elif args.workload == "dpf_points":
         run_headline(args, rank, world, dist)
     else:
         run_sharded(args, rank, world, dist)
-    if args.suite and world == 1:
+    if args.suite and world == 1 and not dry:
         run_suite(args)
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,89 @@
+"""bench.py --gpus N started bare (no torch.distributed.run around it): the launcher spawns the ranks before
+anything touches the GPU, passes rank 0's single JSON line through, and ends the run with a non-zero exit code when
+a rank fails or hangs.  The CPU tests use the FSS_AMD_BENCH_DRY_RUN hook (empty step, gloo rendezvous): control
+flow only, nothing is measured.  The GPU test runs the real kernels with two ranks sharing the one GPU of the box
+(FSS_AMD_BENCH_SHARE_GPU: gloo instead of RCCL, which refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env, timeout=240):
+    e = dict(os.environ, **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, BENCH] + args, env=e, capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+def json_lines(stdout):
+    return [json.loads(ln) for ln in stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bare_gpus_2_prints_one_rank0_line():
+    r, _ = run(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"FSS_AMD_BENCH_DRY_RUN": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dry_run"] is True
+
+
+def test_under_a_launcher_env_it_is_a_rank_not_a_launcher():
+    """With RANK / WORLD_SIZE set (torch.distributed.run's contract) bench.py must not spawn anything."""
+    r, _ = run(["--gpus", "1", "--steps", "2"], {"FSS_AMD_BENCH_DRY_RUN": "1"})
+    assert r.returncode == 0 and json_lines(r.stdout)[0]["n_gpus"] == 1
+
+
+def test_a_failing_rank_ends_the_run_nonzero_and_fast():
+    r, dt = run(["--gpus", "3", "--steps", "2"], {"FSS_AMD_BENCH_DRY_RUN": "1", "FSS_AMD_BENCH_FAIL_RANK": "2"})
+    assert r.returncode != 0
+    assert "rank 2 exited" in r.stderr
+    assert not json_lines(r.stdout)
+    assert dt < 120
+
+
+def test_a_hung_rank_is_stopped_by_the_launch_timeout():
+    r, dt = run(["--gpus", "2", "--steps", "2", "--launch-timeout", "8"],
+                {"FSS_AMD_BENCH_DRY_RUN": "1", "FSS_AMD_BENCH_HANG_RANK": "1"}, timeout=200)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert dt < 90
+
+
+@pytest.mark.gpu
+def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
+    r, _ = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "20", "--no-cpu"],
+               {"FSS_AMD_BENCH_SHARE_GPU": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    for key in ("dcf_points", "dpf_keys", "dpf_n16", "dpf_n64"):
+        assert d[key]["value"] > 0 and 0 < d[key]["roofline"]["frac"] < 1.2
+
+
+@pytest.mark.gpu
+def test_default_line_carries_the_whole_metric():
+    """The driver's command at a small batch: headline + DCF / independent keys / kInBits 16, 64, each with its own
+    kernel time and LDS fraction, each checked against the oracle on a sample inside the cpu_baseline leg."""
+    r, _ = run(["--steps", "3", "--warmup", "1", "--log2-batch", "18", "--cpu-sample", "65536"], {}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json_lines(r.stdout)[0]
+    assert d["n_gpus"] == 1 and d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    for key in ("dcf_points", "dpf_keys", "dpf_n16", "dpf_n64"):
+        rec = d[key]
+        assert rec["gpu_matches_oracle_on_sample"] is True, key
+        assert rec["kernel_ms"] > 0 and rec["roofline"]["bound"] == "lds"
+    assert d["dcf_points"]["aes_blocks_per_eval"] == 64 and d["dpf_n16"]["aes_blocks_per_eval"] == 16
+    assert d["shared_prefix"]["identical_to_plain_walk"] is True
+    assert "clock_ghz_in_pmc_run" not in json.dumps(d)
