@@ -19,16 +19,23 @@ def _stale():
     return not os.path.exists(SO) or os.path.getmtime(SO) < _deps_mtime()
 
 
-def build(force=False, verbose=False):
+def build_variant(tag, defines, verbose=False):
+    """A tuning / diagnostic build of the same sources with extra -D flags -> fss_amd/libfss_amd_<tag>.so
+    (used through FSS_AMD_LIB=...; never the product library)."""
+    return build(force=True, verbose=verbose, so=os.path.join(_HERE, f"libfss_amd_{tag}.so"), defines=defines, tag=tag)
+
+
+def build(force=False, verbose=False, so=None, defines=(), tag=""):
     """Compile fss_amd/csrc/*.hip for gfx950 (one hipcc per unit, in parallel) and link fss_amd/libfss_amd.so."""
-    if not force and not _stale():
+    so = so or SO
+    if so == SO and not force and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJDIR, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines]
     procs = []
     for u in UNITS:
-        obj = os.path.join(OBJDIR, u.replace(".hip", ".o"))
+        obj = os.path.join(OBJDIR, u.replace(".hip", (f".{tag}" if tag else "") + ".o"))
         cmd = [hipcc, *flags, "-c", os.path.join(CSRC, u), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -38,11 +45,11 @@ def build(force=False, verbose=False):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
         objs.append(obj)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, *objs]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
-    return SO
+    return so
 
 
 SAMPLE_SRC = os.path.join(_HERE, "..", "samples", "dpf_dcf_gpu.cpp")

@@ -32,6 +32,7 @@ struct fss_amd_ctx {
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   std::mutex scratch_mu;
   std::unordered_map<void*, Scratch> scratch;
+  uint64_t* diag_stamps = nullptr;  // FSS_DIAG_STAMPS builds: 4 x uint64 per workgroup of the last point-walk launch
 };
 
 inline thread_local int g_last_hip = 0;  // one instance across the translation units
@@ -194,6 +195,9 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   if (rc != FSS_AMD_OK) return rc;
   a.dyn = use_dyn(a.n, 64 * ilp, grid, bs);
   a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : !a.dyn;
+#if FSS_DIAG_STAMPS
+  a.stamps = ctx->diag_stamps;
+#endif
   return launch_grid(ctx, kernel, name, grid, bs, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a);
 }
 

@@ -55,7 +55,15 @@ struct EvalArgs {
   int dyn;                  // waves take chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
   int rot_prio;             // statically distributed launches: rotate the wave priority every level (rotate_prio)
   int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
+  uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
 };
+
+// Diagnostic build (-DFSS_DIAG_STAMPS=1, a separate library: in the product no stamp executes): lane 0 of every
+// workgroup records s_memtime (shader clock) and s_memrealtime (100 MHz) around the walk loop, so that
+// in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
+#ifndef FSS_DIAG_STAMPS
+#define FSS_DIAG_STAMPS 0
+#endif
 
 // tr bits of key i: uint64_t per key, or the reference's 32-bit packing (wave-uniform choice)
 __device__ __forceinline__ uint64_t load_tr(const uint64_t* tr_bits, int tr32, int64_t i) {
@@ -290,6 +298,9 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
 
   constexpr int64_t SJ = 64;  // a lane's ILP evaluations are 64 apart: a chunk is 64 * ILP consecutive evaluations
+#if FSS_DIAG_STAMPS
+  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   WaveQ q(a.dyn, &waveq_ctr_, n, ILP);
   for (int64_t base; q.next(base);) {
     int64_t idx[ILP];
@@ -437,6 +448,12 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
     }
   }
+#if FSS_DIAG_STAMPS
+  if (threadIdx.x == 0 && a.stamps) {
+    uint64_t* o = a.stamps + 4 * (int64_t)blockIdx.x;
+    o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- Grotto DCF, path walk

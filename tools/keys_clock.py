@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""In-kernel clock of the point walks (MI355X_MICROARCH.md, DVFS give-back item 6): needs the diagnostic library
+(fss_amd/libfss_amd_diag.so, built with -DFSS_DIAG_STAMPS=1 by fss_amd._build.build_variant) through FSS_AMD_LIB.
+Runs >= 2 s of back-to-back launches of one workload, then reads the per-workgroup stamps of the last launch:
+clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, median over workgroups.  Launch variants come from the library's
+tunables in the environment (FSS_AMD_ILP, FSS_AMD_BS, FSS_AMD_DYN)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import fss_amd
+from bench import LDS_PEAK_GBS, LOOKUP_BYTES_PER_AES, aes_blocks_per_eval, hbm_bytes_per_eval, make_key, time_steps
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--mode", default="keys", choices=["points", "keys"])
+ap.add_argument("--scheme", default="dpf")
+ap.add_argument("--n", type=int, default=32)
+ap.add_argument("--log2", type=int, default=24)
+ap.add_argument("--seconds", type=float, default=2.0)
+a = ap.parse_args()
+eng = fss_amd.default_engine(0)
+L = eng._L
+n, N = a.n, 1 << a.log2
+G = fss_amd.U64
+sid = {"dpf": fss_amd.DPF, "dcf": fss_amd.DCF, "ht": fss_amd.HT}[a.scheme]
+gen = torch.Generator(device="cuda").manual_seed(1000 + n)
+dt = torch.int32 if n <= 32 else torch.int64
+lo, hi = (-2**31, 2**31) if n <= 32 else (-2**63, 2**63 - 1)
+xs = torch.randint(lo, hi, (N,), dtype=dt, device="cuda", generator=gen)
+if n < 32:
+    xs &= (1 << n) - 1
+ys = torch.empty((N, 4), dtype=torch.int32, device="cuda")
+if a.mode == "points":
+    _, s0s, cws, ocw, _, _ = make_key(eng, a.scheme, n, G, 1 + n)
+    sd, cd = s0s[0].cuda(), cws.cuda()
+    od = None if ocw is None else ocw.cuda()
+    fn = lambda: eng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys)
+    shared = True
+else:
+    s0s = torch.randint(-2**31, 2**31, (N, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
+    betas = torch.randint(-2**31, 2**31, (N, 4), dtype=torch.int32, device="cuda", generator=gen)
+    alphas = torch.randint(lo, hi, (N,), dtype=dt, device="cuda", generator=gen)
+    keys, ocws = eng.gen_level_major(sid, n, G, s0s, alphas, betas)
+    seeds0 = s0s[:, 0].contiguous()
+    del s0s, betas, alphas
+    fn = lambda: eng.eval_keys(keys, G, 0, seeds0, xs, ocws=ocws, out=ys)
+    shared = False
+
+_, est = time_steps(fn, 3, 2, None)
+steps = max(10, int(a.seconds * 1e3 / est))
+_, kms = time_steps(fn, steps, 5, None)
+kname, grid, block = eng.last_kernel()
+line = {"workload": f"{a.scheme} n={n} {'1 key x' if shared else ''} 2^{a.log2} {'points' if shared else 'independent keys'}",
+        "ilp": os.environ.get("FSS_AMD_ILP", "default"), "bs": os.environ.get("FSS_AMD_BS", "default"),
+        "launches": steps, "kernel_ms": round(kms, 4), "G_evals_per_s": round(N / kms / 1e6, 4), "grid": grid, "block": block}
+aes = aes_blocks_per_eval(a.scheme, n)
+line["lds_frac_at_2.4GHz"] = round(N / (kms * 1e-3) * aes * LOOKUP_BYTES_PER_AES / 1e9 / LDS_PEAK_GBS, 4)
+line["hbm_GBs_algorithmic"] = round(N / (kms * 1e-3) * hbm_bytes_per_eval(a.scheme, n, shared) / 1e9, 1)
+if hasattr(L, "fss_amd_diag_read_stamps"):
+    buf = np.zeros((grid, 4), dtype=np.uint64)
+    L.fss_amd_diag_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rc = L.fss_amd_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), grid)
+    assert rc == 0, rc
+    dcyc = (buf[:, 2] - buf[:, 0]).astype(np.float64)
+    dreal = (buf[:, 3] - buf[:, 1]).astype(np.float64)
+    ok = dreal > 0
+    clk = dcyc[ok] / dreal[ok] * 0.1  # GHz: realtime ticks at 100 MHz
+    line["in_kernel_clock_GHz_median"] = round(float(np.median(clk)), 4)
+    line["in_kernel_clock_GHz_min_max"] = [round(float(clk.min()), 4), round(float(clk.max()), 4)]
+    line["shader_cycles_per_launch_median"] = int(np.median(dcyc[ok]))
+    # LDS-lookup floor in shader cycles: evals x AES x 160 lookups / (32 lookups/clk/CU x 256 CU)
+    floor = N * aes * 160 / (32 * 256)
+    line["lds_floor_cycles"] = int(floor)
+    line["lds_floor_over_cycles"] = round(floor / float(np.median(dcyc[ok])), 4)
+    line["lds_frac_at_measured_clock"] = round(line["lds_frac_at_2.4GHz"] * 2.4 / line["in_kernel_clock_GHz_median"], 4)
+else:
+    line["note"] = "product library: no stamps (set FSS_AMD_LIB to the FSS_DIAG_STAMPS build)"
+import json
+print(json.dumps(line), flush=True)
