@@ -60,7 +60,7 @@ inline int leaf_extra(int scheme, int log2_leaves) {
   static int v = [] {
     const char* e = getenv("FSS_AMD_LEAF_E");
     int t = e ? atoi(e) : -1;
-    return (t < 0 || t > 2) ? -1 : t;
+    return (t < 0 || t > 3) ? -1 : t;
   }();
   if (v >= 0) return v;
   int e = scheme == S_HT ? 0 : 2;
@@ -141,8 +141,20 @@ int launch_expand(fss_amd_ctx* ctx, const SharedKey& k, const ExpandArgs& a_in, 
   int grid = (int)(want < cap ? want : cap);
   ExpandArgs a = a_in;
   a.dyn = use_dyn(a.n_in, 64, grid, BS);
-  FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((expand_kernel<LT, SCHEME, D, LEAF, BS, E, BATCH>), dim3(grid), dim3(BS), 0, st,
-                                      ctx->host, ctx->te0, k.cws, k.ocw, a));
+  // narrow output groups: the leaf-level blocks skip the lookups of the seed words the group never reads
+  constexpr bool kCanNarrow = LEAF && D >= 1 && (SCHEME == S_DPF || SCHEME == S_HT) && FSS_T4;
+  static const bool narrow_on = [] { const char* e = getenv("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
+  bool done = false;
+  if constexpr (kCanNarrow) {
+    if (narrow_on && ctx->prg != FSS_AMD_PRG_CHACHA && a.group >= G_U8 && a.group <= G_U64) {
+      hipLaunchKernelGGL((expand_kernel<Lds, SCHEME, D, LEAF, BS, E, BATCH, 2>), dim3(grid), dim3(BS), 0, st, ctx->host,
+                         ctx->te0, k.cws, k.ocw, a);
+      done = true;
+    }
+  }
+  if (!done)
+    FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((expand_kernel<LT, SCHEME, D, LEAF, BS, E, BATCH>), dim3(grid), dim3(BS), 0, st,
+                                        ctx->host, ctx->te0, k.cws, k.ocw, a));
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = LEAF ? "expand_leaf" : "expand";
   ctx->last_grid = grid;
@@ -163,6 +175,9 @@ int launch_stage(fss_amd_ctx* ctx, int T, bool leaf, const SharedKey& k, const E
     if constexpr (DM == 2) { if (T == 2) return launch_expand<SCHEME, 2, true, 0, BATCH>(ctx, k, a, st); }
     if (T == DM + 1) return launch_expand<SCHEME, DM, true, 1, BATCH>(ctx, k, a, st);
     if (T == DM + 2) return launch_expand<SCHEME, DM, true, 2, BATCH>(ctx, k, a, st);
+#if defined(FSS_EXP_LEAF_E3)
+    if constexpr (!BATCH && SCHEME == S_DPF) { if (T == DM + 3) return launch_expand<SCHEME, DM, true, 3, BATCH>(ctx, k, a, st); }
+#endif
   } else {
     if (T == 1) return launch_expand<SCHEME, 1, false, 0, BATCH>(ctx, k, a, st);
     if constexpr (DM == 2) { if (T == 2) return launch_expand<SCHEME, 2, false, 0, BATCH>(ctx, k, a, st); }

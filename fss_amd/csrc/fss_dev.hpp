@@ -409,7 +409,11 @@ __device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k,
   }
 }
 
-template <bool SEL, bool LSB3 = false>
+// OW (output words wanted, FSS_T4 only): 4 = all of out[0..3]; 2 / 1 = out[0..OW-1] whole plus bit 0 of out[3]
+// (the control bit) -- what a leaf needs when the output group reads only the low 8 / 4 bytes of the seed
+// (Uint<uint64_t> and narrower, uint.cuh:49-68).  The other outputs are unspecified and their last-round
+// lookups (7 resp. 11 of the 16) disappear as dead code.
+template <bool SEL, bool LSB3 = false, int OW = 4>
 __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], const uint32_t* k, const uint32_t* kd,
                                         uint32_t mask, const uint32_t in[4], uint32_t out[4]) {
   if constexpr (LSB3 && FSS_T4) {  // see aes_mmo: v[3] = the last-round lookup of byte 0 of s3
@@ -419,6 +423,13 @@ __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], cons
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
+    if constexpr (OW < 4 && FSS_T4) {
+      static_assert(!SEL || OW == 4, "narrow outputs are for uniform-key blocks");
+      if (j >= OW) {
+        out[j] = j == 3 ? xor3(v[3], in[3], k[3]) : 0u;  // byte 0 of word 3 only (as LSB3)
+        continue;
+      }
+    }
 #if FSS_T4
     uint32_t p = __builtin_amdgcn_bitop3_b32(L.m_ffff, __builtin_amdgcn_bitop3_b32(L.m_00ff, v[j], v[4 + j], kSelect),
                                              __builtin_amdgcn_bitop3_b32(L.m_ff0000, v[8 + j], v[12 + j], kSelect),
@@ -442,7 +453,7 @@ __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], cons
 // maskA / maskB as for aes_mmo<SEL>; they may be the same or different key schedules.
 // RESD (two-key schedules only, keyA == keyB): the 44 (rkA ^ rkB) words come from `kdv`, registers
 // loaded once per kernel, so half of the key operands are VGPRs (2-cycle issue instead of 4).
-template <bool SEL, bool RESD = false, bool LSB3 = false>
+template <bool SEL, bool RESD = false, bool LSB3 = false, int OW = 4>
 __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restrict__ keyA,
                                          const uint32_t* __restrict__ keyB, uint32_t maskA, uint32_t maskB,
                                          const uint32_t inA[4], const uint32_t inB[4], uint32_t outA[4],
@@ -505,8 +516,8 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
     for (int j = 0; j < RS; ++j) { kLB[j] = kn[j]; kLA[j] = kna[j]; }
   }
   FSS_DRAIN_LGKM();
-  aes_fin<SEL, LSB3>(L, vA, kLA, kLA + 4, maskA, inA, outA);
-  aes_fin<SEL, LSB3>(L, vB, kLB, kLB + 4, maskB, inB, outB);
+  aes_fin<SEL, LSB3, OW>(L, vA, kLA, kLA + 4, maskA, inA, outA);
+  aes_fin<SEL, LSB3, OW>(L, vB, kLB, kLB + 4, maskB, inB, outB);
 }
 
 // The DevCtx a kernel received by value as its FIRST argument, addressed in the kernarg segment
@@ -794,6 +805,17 @@ __device__ __forceinline__ void prg_hash2(const Lds& L, const DevCtx* __restrict
                                           const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
   aes_mmo2<false>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
 }
+// Leaf-level blocks whose outputs feed a narrow output group: words [0, OW) and the control bit only (aes_fin).
+template <int OW>
+__device__ __forceinline__ void prg_gen2_narrow(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t l[4],
+                                                uint32_t r[4]) {
+  aes_mmo2<false, false, false, OW>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
+}
+template <int OW>
+__device__ __forceinline__ void prg_hash2_narrow(const Lds& L, const DevCtx* __restrict__ c, const uint32_t ia[4],
+                                                 const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
+  aes_mmo2<false, false, false, OW>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
+}
 // Control bits only (Grotto: leaves of the tree, left siblings of the path walk): bit 0 of the results is
 // bit 0 of word 3 of Gen(s)[0] / Gen(s)[1]; the other bits are unspecified.
 __device__ __forceinline__ uint32_t prg_tbit_left(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4]) {
@@ -854,6 +876,16 @@ __device__ __forceinline__ void prg_hash2(const ChaChaL& L, const DevCtx* __rest
                                           const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
   prg_hash(L, c, ia, ha);
   prg_hash(L, c, ib, hb);
+}
+template <int OW>
+__device__ __forceinline__ void prg_gen2_narrow(const ChaChaL& L, const DevCtx* __restrict__ c, const uint32_t s[4],
+                                                uint32_t l[4], uint32_t r[4]) {
+  prg_gen2(L, c, s, l, r);  // one permutation yields every word anyway
+}
+template <int OW>
+__device__ __forceinline__ void prg_hash2_narrow(const ChaChaL& L, const DevCtx* __restrict__ c, const uint32_t ia[4],
+                                                 const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
+  prg_hash2(L, c, ia, ib, ha, hb);
 }
 __device__ __forceinline__ void prg_tbits2(const ChaChaL& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t& tl,
                                            uint32_t& tr) {

@@ -21,6 +21,12 @@
 #include "fss_point.hpp"
 #include "fss_quad.hpp"
 
+// FSS_HT_PAIR = 1: the Half-Tree stages hash two nodes (or the two leaves of one parent) per call as two interleaved
+// AES streams; 0: one hash at a time (A/B).
+#ifndef FSS_HT_PAIR
+#define FSS_HT_PAIR 1
+#endif
+
 namespace fssamd {
 
 struct ExpandArgs {
@@ -46,12 +52,15 @@ struct ExpandArgs {
 
 // -- one-node expansions ------------------------------------------------------
 // DPF / Grotto node -> both children, control bits packed (dpf.cuh:266-289).
-template <class LT>
+// OW < 4 (leaf level only): the children feed a narrow output group -- words [0, OW) and the control bit are
+// computed, the rest of left / right is unspecified (aes_fin).
+template <class LT, int OW = 4>
 __device__ __forceinline__ void dpf_expand(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
                                            const uint32_t st[4], uint32_t left[4], uint32_t right[4]) {
   uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
   uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
-  prg_gen2(L, c, in, left, right);  // both children (AES: two interleaved blocks)
+  if constexpr (OW < 4) prg_gen2_narrow<OW>(L, c, in, left, right);
+  else prg_gen2(L, c, in, left, right);  // both children (AES: two interleaved blocks)
   uint32_t wl = cw[3], wr = (cw[3] & ~1u) | (cw[4] & 1u);
   left[0] = and_xor(tm, cw[0], left[0]);   right[0] = and_xor(tm, cw[0], right[0]);
   left[1] = and_xor(tm, cw[1], left[1]);   right[1] = and_xor(tm, cw[1], right[1]);
@@ -104,6 +113,51 @@ __device__ __forceinline__ void ht_expand(const LT& L, const DevCtx* __restrict_
   for (int j = 0; j < 4; ++j) {
     left[j] = and_xor(tm, cw[j], h[j]);
     right[j] = left[j] ^ node[j];
+  }
+}
+
+// Two Half-Tree inner nodes at once: their hashes run as two interleaved AES streams (prg_hash2), so one
+// stream's table lookups fly under the other's VALU work (fss_dev.hpp, aes_mmo2).
+template <class LT>
+__device__ __forceinline__ void ht_expand2(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
+                                           const uint32_t na[4], const uint32_t nb[4], uint32_t la[4], uint32_t ra[4],
+                                           uint32_t lb[4], uint32_t rb[4]) {
+  const uint32_t tma = (uint32_t)__builtin_amdgcn_sbfe(na[3], 0, 1), tmb = (uint32_t)__builtin_amdgcn_sbfe(nb[3], 0, 1);
+  uint32_t ia[4], ib[4], ha[4], hb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ia[j] = na[j] ^ c->hash_key[j]; ib[j] = nb[j] ^ c->hash_key[j]; }
+  prg_hash2(L, c, ia, ib, ha, hb);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    la[j] = and_xor(tma, cw[j], ha[j]); ra[j] = la[j] ^ na[j];
+    lb[j] = and_xor(tmb, cw[j], hb[j]); rb[j] = lb[j] ^ nb[j];
+  }
+}
+
+// Half-Tree last level, both leaves of one parent (sigma = 0, 1; half_tree_dpf.cuh:325-354), the two hashes interleaved.
+template <class LT, int OW = 4>
+__device__ __forceinline__ void ht_convert2(const LT& L, const DevCtx* __restrict__ c, const Grp& g, int party,
+                                            const uint32_t* __restrict__ cw, const uint32_t* __restrict__ ocw,
+                                            const uint32_t parent[4], uint4& y0, uint4& y1) {
+  const uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(parent[3], 0, 1);
+  uint32_t in0[4] = {parent[0] ^ c->hash_key[0], parent[1] ^ c->hash_key[1], parent[2] ^ c->hash_key[2],
+                     (parent[3] & ~1u) ^ c->hash_key[3]};
+  uint32_t in1[4] = {in0[0], in0[1], in0[2], in0[3] ^ 1u};
+  uint32_t h0[4], h1[4];
+  if constexpr (OW < 4) prg_hash2_narrow<OW>(L, c, in0, in1, h0, h1);
+  else prg_hash2(L, c, in0, in1, h0, h1);
+  const uint32_t oc[4] = {ocw[0], ocw[1], ocw[2], ocw[3]};
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const uint32_t* h = s ? h1 : h0;
+    const uint32_t lcw = s ? (cw[4] & 1u) : (cw[3] & 1u);
+    const uint32_t low = (h[3] ^ (tm & lcw)) & 1u;
+    uint32_t high[4] = {and_xor(tm, cw[0], h[0]), and_xor(tm, cw[1], h[1]), and_xor(tm, cw[2], h[2]),
+                        and_xor(tm, cw[3], h[3]) & ~1u};
+    Acc y;
+    y.add(g, high);
+    y.add_if(g, 0u - low, oc);
+    (s ? y1 : y0) = y.finish(g, party != 0);
   }
 }
 
@@ -286,7 +340,10 @@ struct OuterLevels {
   }
 };
 
-template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0, bool BATCH = false>
+// OW (leaf stages of DPF / Half-Tree with the AES tables): 4 = any output group; 2 = the group reads only the low
+// 8 bytes of a leaf seed (Uint<uint8_t .. uint64_t>, uint.cuh:49-68), so the leaf-level blocks compute words 0, 1 and
+// the control bit only -- 7 of their last round's 16 lookups vanish (aes_fin), about 2 % of a DPF tree's lookups.
+template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0, bool BATCH = false, int OW = 4>
 __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                     const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
                                                     const uint32_t* __restrict__ k_ocw,  // Half-Tree
@@ -313,6 +370,20 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
 #pragma unroll
       for (int k = (1 << lev) - 1; k >= 0; --k) {
         uint32_t l[4], r[4];
+        if constexpr (SCHEME == S_HT && FSS_HT_PAIR) {
+          if (lev > 0) {  // nodes k and k - 1 of this level together (k odd first: their outputs land above k - 1's)
+            if (k & 1) {
+              uint32_t l2[4], r2[4];
+              ht_expand2(L, c, cw, nodes[k], nodes[k - 1], l, r, l2, r2);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                nodes[2 * k][q] = l[q]; nodes[2 * k + 1][q] = r[q];
+                nodes[2 * k - 2][q] = l2[q]; nodes[2 * k - 1][q] = r2[q];
+              }
+            }
+            continue;
+          }
+        }
         if constexpr (SCHEME == S_DCF) {
           Acc vl, vr;
           dcf_expand(L, c, g, cw, nodes[k], vs[k], l, vl, r, vr);
@@ -327,7 +398,8 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
             dpf_expand(L, c, cw, nodes[k], l, r);
           }
         } else {
-          dpf_expand(L, c, cw, nodes[k], l, r);
+          if (LEAF && SCHEME == S_DPF && lev == DE - 1) dpf_expand<LT, OW>(L, c, cw, nodes[k], l, r);
+          else dpf_expand(L, c, cw, nodes[k], l, r);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { nodes[2 * k][q] = l[q]; nodes[2 * k + 1][q] = r[q]; }
@@ -344,8 +416,15 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
       uint4* ys = reinterpret_cast<uint4*>(a.ys);
 #pragma unroll
       for (int k = 0; k < (1 << DE); ++k) {
+#if FSS_HT_PAIR
+        uint4 y0, y1;
+        ht_convert2<LT, OW>(L, c, g, party, cw, koc, nodes[k], y0, y1);
+        ys[ob + 2 * k] = y0;
+        ys[ob + 2 * k + 1] = y1;
+#else
         ys[ob + 2 * k] = ht_convert(L, c, g, party, cw, koc, nodes[k], 0u);
         ys[ob + 2 * k + 1] = ht_convert(L, c, g, party, cw, koc, nodes[k], 1u);
+#endif
       }
     } else if constexpr (SCHEME == S_GROTTO) {
       uint8_t* ys = reinterpret_cast<uint8_t*>(a.ys);
