@@ -66,18 +66,24 @@ inline int leaf_extra(int scheme, int log2_leaves) {
   int e = scheme == S_HT ? 0 : 2;
   const int room = log2_leaves - dmax_for(scheme) - 18;
   if (e > room) e = room < 0 ? 0 : room;
+  // DPF below 2^25 leaves: one rolled level (2^24: 0.343 ms against 0.355 with two; equal at 2^25, two ahead by
+  // 0.6 % at 2^26 -- gpurun_out/ab_evalall_3.txt, round 2)
+  if (scheme == S_DPF && log2_leaves < 25 && e > 1) e = 1;
   return e;
 }
 
 // Extra rolled levels of the stages between the frontier and the leaf stage (FSS_AMD_MID_E = 0 .. 2): fewer,
 // deeper launches above the leaf stage.
-inline int mid_extra() {
+inline int mid_extra(int scheme) {
   static int v = [] {
     const char* e = getenv("FSS_AMD_MID_E");
-    int t = e ? atoi(e) : 0;
-    return (t < 0 || t > 2) ? 0 : t;
+    int t = e ? atoi(e) : -1;
+    return (t < 0 || t > 2) ? -1 : t;
   }();
-  return v;
+  if (v >= 0) return v;
+  // DPF / Grotto: one rolled level per intermediate stage -- the 2^25-leaf block goes 2^18 -> 2^21 in one launch
+  // instead of two (0.647 -> 0.639 ms); Half-Tree and DCF measured flat
+  return (scheme == S_DPF || scheme == S_GROTTO) ? 1 : 0;
 }
 
 bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl) {
@@ -106,7 +112,7 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
     const int le = leaf_extra(scheme, r);
     const int leaf = rem < dm + le ? rem : dm + le;
     rem -= leaf;
-    const int mid = dm + mid_extra();  // shallowest stage first: it runs on the fewest nodes
+    const int mid = dm + mid_extra(scheme);  // shallowest stage first: it runs on the fewest nodes
     if (rem % mid) pl->D[pl->nstages++] = rem % mid;
     for (int i = 0; i < rem / mid; ++i) pl->D[pl->nstages++] = mid;
     pl->D[pl->nstages++] = leaf;
