@@ -275,7 +275,7 @@ def run_headline(args, rank, world, dist):
     subs, checks = {}, {}
     m = min(batch, 4096)  # evaluations per sub-record handed to the CPU check (a strided sample)
     pick = torch.arange(0, batch, max(1, batch // m), device="cuda")[:m]
-    for key, sch, nn in (("dcf_points", "dcf", 32), ("dpf_n16", "dpf", 16), ("dpf_n64", "dpf", 64)):
+    for key, sch, nn in (() if args.only_headline else (("dcf_points", "dcf", 32), ("dpf_n16", "dpf", 16), ("dpf_n64", "dpf", 64))):
         sid2, s0s2, cws2, ocw2, _, _ = make_key(eng, sch, nn, G, 0x5EED0100 + nn + (7 if sch == "dcf" else 0))
         xs2 = _rand_xs(nn, batch, 0x5EED0200 + nn + rank)
         sd2, cd2 = s0s2[0].cuda(), cws2.cuda()
@@ -286,6 +286,17 @@ def run_headline(args, rank, world, dist):
                                 args.steps, eng.last_kernel()[0])
         checks[key] = (sch, nn, s0s2, cws2, None, xs2[pick].cpu().numpy(), ys[pick].cpu().numpy())
         del xs2
+    if not args.only_headline:
+        _keys_subrecord(args, rank, world, dist, eng, G, batch, ys, pick, subs, checks)
+    eng.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys)  # the headline outputs again, for the CPU comparison below
+    if rank != 0:
+        return
+    _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, kernel_ms, wall_sp, kernel_ms_sp, same,
+                    kname, grid, block, subs, checks)
+
+
+def _keys_subrecord(args, rank, world, dist, eng, G, batch, ys, pick, subs, checks):
+    import fss_amd
     # M(ii): 2^batch independent keys x 1 point, keys generated on the device straight into the level-major layout
     # (outside the timed region, as the reference excludes Gen and relayout: src/bench_gpu.cu:616-627)
     gen = torch.Generator(device="cuda").manual_seed(0x5EED0300 + rank)
@@ -308,9 +319,10 @@ def run_headline(args, rank, world, dist):
         checks["dpf_keys"] = ("dpf_keys", 32, kseeds[pick].cpu().numpy(), eng.key_major(sub).cpu().numpy(), None,
                               kxs[pick].cpu().numpy(), ys[pick].cpu().numpy())
     del keys, ks0s, kbetas, kalphas, kseeds
-    eng.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys)  # the headline outputs again, for the CPU comparison below
-    if rank != 0:
-        return
+
+
+def _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, kernel_ms, wall_sp, kernel_ms_sp, same,
+                    kname, grid, block, subs, checks):
     evals = batch * world * args.steps
     value = evals / wall
     per_gpu_kernel_rate = batch / (kernel_ms * 1e-3)
@@ -753,6 +765,9 @@ def main():
     ap.add_argument("--suite", action="store_true")
     ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "evalall_c4", "ht_c5", "grotto_c5"],
                     help="dpf_points = the headline (BASELINE metric); the others are configs[3] / configs[4], sharded")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="skip the sub-records (DCF, independent keys, kInBits 16 / 64): the PMC passes of tools/profile.sh "
+                         "use this so that one kernel template means one workload")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="self-launched multi-GPU runs: seconds before the ranks are stopped and the run fails")
     args = ap.parse_args()

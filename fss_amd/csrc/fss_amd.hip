@@ -182,6 +182,13 @@ int fss_amd_upload(fss_amd_ctx* ctx, void* dst, const void* src_host, size_t byt
 
 int fss_amd_ctx_device(const fss_amd_ctx* ctx) { return ctx ? ctx->device : -1; }
 
+int fss_amd_ctx_read_te0(fss_amd_ctx* ctx, uint32_t out_host[256]) {
+  if (!ctx || !out_host) return FSS_AMD_EINVAL;
+  FSS_ON_DEVICE(ctx);
+  HIP_TRY(hipMemcpy(out_host, ctx->te0, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return FSS_AMD_OK;
+}
+
 int fss_amd_ctx_set_prg(fss_amd_ctx* ctx, int prg, const int32_t nonce[2], int rounds) {
   if (!ctx) return FSS_AMD_EINVAL;
   if (prg == FSS_AMD_PRG_AES128_MMO) {

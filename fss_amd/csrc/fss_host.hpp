@@ -210,6 +210,10 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   // (2^18 points: 0.10 ms with one per lane, 0.17 ms with two and half of the waves idle)
   const int64_t resident_waves = (int64_t)ctx->num_cu * (ctx->prg == FSS_AMD_PRG_CHACHA ? 2 : 1) * (bs / 64);
   if (!tune().ilp_set && a.n < 128 * resident_waves) ilp = 1;
+  // a DCF evaluation already runs two interleaved AES streams (seed and value block of the taken child): a second
+  // evaluation per lane only adds registers -- one per lane is ahead at every batch size (2^20 points: 0.616 ms
+  // against 0.663, 2^22: 2.43 against 2.48, 2^24 even; profiles/r2/points_ab.txt)
+  if (!tune().ilp_set && SCHEME == S_DCF) ilp = 1;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
   return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st)))

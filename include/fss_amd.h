@@ -323,6 +323,10 @@ int fss_amd_upload(fss_amd_ctx *ctx, void *dst, const void *src_host, size_t byt
 /* Name and launch geometry of the kernel the last eval call on this ctx launched
  * (for bench.py / profiles). */
 const char *fss_amd_last_kernel(const fss_amd_ctx *ctx, int *grid, int *block);
+/* The 256-entry round table the AES kernels fill their LDS copies from, read back from the device: entry x holds
+ * the bytes (2 S(x), S(x), S(x), 3 S(x)) in memory order, i.e. the reference's Te0 (ComputeTe0,
+ * include/fss/prg/aes128_mmo_soft.cuh:55-60) stored little-endian.  For known-answer tests.  Synchronous. */
+int fss_amd_ctx_read_te0(fss_amd_ctx *ctx, uint32_t out_host[256]);
 
 #ifdef __cplusplus
 }

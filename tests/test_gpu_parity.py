@@ -64,6 +64,23 @@ def test_prg_matches_oracle(engine, O, mul):
 
 
 # ---------------------------------------------------------------- reference KATs on the GPU
+def test_reference_te0_on_gpu(engine):
+    """The round table the kernels fill LDS from is the reference's Te0 (te0[0] = c66363a5, te0[1] =
+    f87c7c84 as the reference stores them, big-endian words; here little-endian, so byte-swapped)."""
+    import ctypes as C
+    K = load()
+    buf = (C.c_uint32 * 256)()
+    from fss_amd import _lib
+    _lib.check(engine._L.fss_amd_ctx_read_te0(engine._h, buf), "fss_amd_ctx_read_te0")
+    for i, want in enumerate(K["te0_be"]):
+        assert int.from_bytes(int(buf[i]).to_bytes(4, "little"), "big") == int(want, 16)
+    # every entry has the (2S, S, S, 3S) shape over GF(2^8)
+    for x in range(256):
+        b = int(buf[x]).to_bytes(4, "little")
+        s = b[1]
+        assert b[2] == s and b[0] == ((s << 1) ^ (0x1B if s & 0x80 else 0)) & 0xFF and b[3] == b[0] ^ s
+
+
 def test_reference_kats_on_gpu(engine):
     import fss_amd
     K = load()
@@ -84,6 +101,7 @@ def test_reference_kats_on_gpu(engine):
     k = K["dcf8_bytes_lt"]
     d = fss_amd.Dcf(8, "bytes", pred="lt")
     cws = d.gen(s0s, k["alpha"], beta)
+    assert (cws[0, :4].numpy() == words(k["cw0_s"])).all() and (cws[0, 4:].numpy() == words(k["cw0_v"])).all()
     assert hashlib.sha256(cws.numpy().tobytes()).hexdigest() == k["cws_sha256"]
     assert (d.eval(0, s0, cws, 10).numpy() == words(k["y0_10"])).all()
     assert (d.eval(1, s1, cws, 10).numpy() == words(k["y1_10"])).all()

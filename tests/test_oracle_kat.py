@@ -11,6 +11,14 @@ K = load()
 S0, S1, BETA = words(K["s0"]), words(K["s1"]), words(K["beta"])
 
 
+def test_te0_known_answer_is_the_fips197_sbox_shape():
+    """SURVEY 8c recorded te0[0] = c66363a5, te0[1] = f87c7c84: (2S, S, S, 3S) of S(0) = 0x63, S(1) = 0x7c (FIPS-197 fig. 7)."""
+    K = load()
+    for x, s in ((0, 0x63), (1, 0x7C)):
+        s2 = ((s << 1) ^ (0x1B if s & 0x80 else 0)) & 0xFF
+        assert int(K["te0_be"][x], 16) == (s2 << 24) | (s << 16) | (s << 8) | (s2 ^ s)
+
+
 def test_fips197_appendix_c1(O):
     key = bytes(range(16))
     pt = bytes.fromhex("00112233445566778899aabbccddeeff")

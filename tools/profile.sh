@@ -2,12 +2,16 @@
 # rocprofv3 passes for the headline kernel: kernel-trace stats, then PMC passes (each on its own).
 # usage: tools/profile.sh <tag>   -> gpurun_out/prof_<tag>/
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-TAG="${1:-r1}"
+TAG="${1:-r2}"
 OUT="$R/gpurun_out/prof_$TAG"
 rm -rf "$OUT"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu --steps 5 --warmup 1"
+# (1) the DEFAULT bench command under --kernel-trace --stats; tools/trace_phases.py splits it by workload
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python3 $R/bench.py > "$OUT/bench_line_under_rocprof.json" 2> "$OUT/trace_default.log"
+python3 $R/tools/trace_phases.py "$OUT/trace_default" > "$OUT/kernel_stats_by_workload.txt"
+# (2) PMC passes on the headline alone (--only-headline: one kernel template = one workload), few launches each
+BENCH="python3 $R/bench.py --no-cpu --only-headline --steps 5 --warmup 1"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
 i=0
 for PMC in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-workload kernel statistics from a rocprofv3 --kernel-trace of `python3 bench.py` (default command).
+
+The default run times several workloads one after the other and three of them (DPF kInBits 32 / 16 / 64) launch the
+SAME kernel template, so rocprofv3's own per-name --stats average mixes them.  This splits the dispatches, in time
+order, into phases -- a phase starts at every key-generation launch (gen_kernel / ht_gen_kernel: bench.py makes a key
+before each workload) -- and prints calls / average / min / max per kernel name and phase.
+usage: tools/trace_phases.py <dir with *_kernel_trace.csv>"""
+import csv
+import glob
+import sys
+
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
+rows.sort()
+phase, stats, order = 0, {}, []
+for st, en, name in rows:
+    if "fssamd" not in name:
+        continue
+    if "gen_kernel" in name and "prg_gen" not in name:
+        phase += 1
+    key = (phase, name.replace("void fssamd::", "").replace("fssamd::", ""))
+    if key not in stats:
+        stats[key] = []
+        order.append(key)
+    stats[key].append((en - st) / 1e3)
+for key in order:
+    v = stats[key]
+    print("phase %2d  %-66s calls %4d  avg_us %9.2f  min_us %9.2f  max_us %9.2f" % (key[0], key[1][:66], len(v), sum(v) / len(v), min(v), max(v)))
