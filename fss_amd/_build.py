@@ -10,13 +10,26 @@ HEADERS = ["fss_dev.hpp", "fss_point.hpp", "fss_quad.hpp", "fss_evalall.hpp", "f
 OBJDIR = os.path.join(_HERE, "csrc", "build")
 
 
-def _deps_mtime():
-    deps = [os.path.join(CSRC, s) for s in UNITS + HEADERS] + [os.path.join(_HERE, "..", "include", "fss_amd.h")]
-    return max(os.path.getmtime(d) for d in deps)
+STAMP = os.path.join(_HERE, "libfss_amd.so.sources.sha256")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _sources_digest():
+    """SHA-256 over the library's sources and compile flags: what the built .so is stamped with."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in [os.path.join(CSRC, s) for s in UNITS + HEADERS] + [os.path.join(_HERE, "..", "include", "fss_amd.h")]:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
 
 
 def _stale():
-    return not os.path.exists(SO) or os.path.getmtime(SO) < _deps_mtime()
+    """The .so is rebuilt unless its stamp equals the digest of the sources it would be built from (file times are
+    not trusted: a checkout or a copied snapshot resets them)."""
+    if not os.path.exists(SO) or not os.path.exists(STAMP):
+        return True
+    return open(STAMP).read().strip() != _sources_digest()
 
 
 def build_variant(tag, defines, verbose=False):
@@ -32,7 +45,7 @@ def build(force=False, verbose=False, so=None, defines=(), tag=""):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJDIR, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines]
+    flags = FLAGS + [f"-D{d}" for d in defines]
     procs = []
     for u in UNITS:
         obj = os.path.join(OBJDIR, u.replace(".hip", (f".{tag}" if tag else "") + ".o"))
@@ -49,6 +62,9 @@ def build(force=False, verbose=False, so=None, defines=(), tag=""):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    if so == SO:
+        with open(STAMP, "w") as f:
+            f.write(_sources_digest() + "\n")
     return so
 
 

@@ -365,7 +365,17 @@ static int key_major_common(fss_amd_ctx* ctx, int in_bits, const void* cw_s, con
     return FSS_AMD_EINVAL;
   if (!aligned16(cw_s, cw_v, out_cw, cws) || !aligned_to(tr_bits, 8) || !aligned_to(extra, 4)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
+  const int slots = SCHEME == S_HT ? in_bits : in_bits + 1;
   int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 8;
+  if (relayout_mode(slots) >= 2) {  // whole lines on both sides (relayout_flat_kernel's mirror image)
+    const int bs = flat_block(slots), nw = bs / 64;
+    want = ((nkeys + kFlatKeys - 1) / kFlatKeys + nw - 1) / nw;
+    hipLaunchKernelGGL(key_major_flat_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(bs),
+                       flat_lds_bytes(slots, nw), S(stream), in_bits, slots, reinterpret_cast<const uint4*>(cw_s),
+                       reinterpret_cast<const uint4*>(cw_v), reinterpret_cast<const uint64_t*>(tr_bits),
+                       reinterpret_cast<const uint4*>(out_cw), reinterpret_cast<const uint32_t*>(extra), nkeys,
+                       reinterpret_cast<uint4*>(cws));
+  } else
   hipLaunchKernelGGL(key_major_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, S(stream), in_bits,
                      reinterpret_cast<const uint4*>(cw_s), reinterpret_cast<const uint4*>(cw_v),
                      reinterpret_cast<const uint64_t*>(tr_bits), reinterpret_cast<const uint4*>(out_cw),

@@ -123,12 +123,151 @@ __global__ __launch_bounds__(256) void relayout_tiled_kernel(int in_bits, int st
   }
 }
 
-// Host side: the tiled kernel by default, FSS_AMD_RELAYOUT=0 selects the one-key-per-lane kernel (A/B).
+
+// ---- the same two transpositions with whole lines on BOTH sides ("flat") ---------------------------------------
+// A wave owns 8 keys at a time.  Eight keys are one 128-byte line per level on the level-major side (8 x 16 B), and
+// on the key-major side their slots are one contiguous region of 8 x slots x 32 B that starts on a line boundary
+// (8 x 32 x slots is a multiple of 128) -- so the wave moves that region as a flat run of 16-byte pieces, 1 KiB per
+// instruction, every line whole and touched by this wave only, whatever the slot count (33-slot DPF / DCF keys
+// start 32 bytes off a line, which cost the 4-level-tiled kernels above half of their bandwidth).  The tile lives in
+// LDS as [slot * 2 + half][key], rows padded to 9 entries so that both access patterns are conflict-free within the
+// 8-lane groups a 16-byte LDS access is served in.
+constexpr int kFlatKeys = 8;
+constexpr int kFlatRow = 9;  // padded keys per LDS row
+inline size_t flat_lds_bytes(int slots, int waves) { return (size_t)waves * slots * 2 * kFlatRow * sizeof(uint4); }
+inline int flat_block(int slots) { return slots <= 34 ? 256 : (slots <= 66 ? 128 : 64); }  // <= ~40 KiB of LDS per workgroup
+
+__device__ __forceinline__ void flat_next(int& key, int& r, int step, int per_key) {
+  r += step;
+  while (r >= per_key) { r -= per_key; ++key; }
+}
+
+template <int SCHEME>
+__global__ void relayout_flat_kernel(int in_bits, int slots, const uint4* __restrict__ cws, int64_t nkeys,
+                                     uint4* __restrict__ cw_s, uint4* __restrict__ cw_v, uint64_t* __restrict__ tr_bits,
+                                     uint4* __restrict__ out_cw, uint32_t* __restrict__ extra, int tr32) {
+  extern __shared__ uint4 flat_lds[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  uint4* tile = flat_lds + (size_t)wv * slots * 2 * kFlatRow;
+  const int key = lane & 7, l8 = lane >> 3, per_key = 2 * slots;
+  const int64_t ntiles = (nkeys + kFlatKeys - 1) / kFlatKeys;
+  for (int64_t t = (int64_t)blockIdx.x * nw + wv; t < ntiles; t += (int64_t)gridDim.x * nw) {
+    const int64_t k0 = t * kFlatKeys, k = k0 + key;
+    const int nk = nkeys - k0 < kFlatKeys ? (int)(nkeys - k0) : kFlatKeys;
+    const int npieces = nk * per_key;
+    const uint4* src = cws + k0 * per_key;
+    {  // flat read of the key-major region
+      int kf = 0, r = 0;
+      flat_next(kf, r, lane, per_key);
+      for (int f = lane; f < npieces; f += 64) {
+        tile[r * kFlatRow + kf] = src[f];
+        flat_next(kf, r, 64, per_key);
+      }
+    }
+    wave_lds_sync();
+    unsigned long long lo = 0ull, hi = 0ull;
+    for (int s0 = 0; s0 < slots; s0 += 8) {
+      const int slot = s0 + l8;
+      if (slot >= slots || key >= nk) continue;
+      const uint4 s4 = tile[(2 * slot) * kFlatRow + key], v4 = tile[(2 * slot + 1) * kFlatRow + key];
+      if (slot < in_bits) {
+        cw_s[(int64_t)slot * nkeys + k] = s4;
+        if (SCHEME == S_DCF) cw_v[(int64_t)slot * nkeys + k] = v4;
+        if (SCHEME == S_DPF) {
+          if (slot < 64) lo |= (unsigned long long)(v4.x & 1u) << slot;
+          else hi |= (unsigned long long)(v4.x & 1u) << (slot - 64);
+        }
+        if (SCHEME == S_HT && slot == in_bits - 1) extra[k] = v4.x & 1u;
+      } else {  // slot in_bits of a DPF / DCF key
+        if (SCHEME == S_DPF && out_cw) out_cw[k] = s4;
+        if (SCHEME == S_DCF) out_cw[k] = v4;
+      }
+    }
+    if (SCHEME == S_DPF) {  // the eight lanes of a key (l8 = 0..7) each saw every eighth level
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) {
+        lo |= __shfl_xor(lo, m);
+        hi |= __shfl_xor(hi, m);
+      }
+      if (l8 == 0 && key < nk) {
+        if (tr32) reinterpret_cast<uint32_t*>(tr_bits)[k] = (uint32_t)lo;
+        else tr_bits[k] = lo;
+        if (in_bits > 64) tr_bits[nkeys + k] = hi;
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+template <int SCHEME>
+__global__ void key_major_flat_kernel(int in_bits, int slots, const uint4* __restrict__ cw_s, const uint4* __restrict__ cw_v,
+                                      const uint64_t* __restrict__ tr_bits, const uint4* __restrict__ out_cw,
+                                      const uint32_t* __restrict__ extra, int64_t nkeys, uint4* __restrict__ cws) {
+  extern __shared__ uint4 flat_lds[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  uint4* tile = flat_lds + (size_t)wv * slots * 2 * kFlatRow;
+  const int key = lane & 7, l8 = lane >> 3, per_key = 2 * slots;
+  const int64_t ntiles = (nkeys + kFlatKeys - 1) / kFlatKeys;
+  for (int64_t t = (int64_t)blockIdx.x * nw + wv; t < ntiles; t += (int64_t)gridDim.x * nw) {
+    const int64_t k0 = t * kFlatKeys, k = k0 + key;
+    const int nk = nkeys - k0 < kFlatKeys ? (int)(nkeys - k0) : kFlatKeys;
+    const bool mine = key < nk;
+    unsigned long long lo = 0ull, hi = 0ull;
+    uint32_t ex = 0;
+    if (mine) {
+      if (SCHEME == S_DPF) { lo = tr_bits[k]; hi = in_bits > 64 ? tr_bits[nkeys + k] : 0ull; }
+      if (SCHEME == S_HT) ex = extra[k] & 1u;
+    }
+    for (int s0 = 0; s0 < slots; s0 += 8) {
+      const int slot = s0 + l8;
+      if (slot >= slots) continue;
+      uint4 s4 = make_uint4(0, 0, 0, 0), v4 = make_uint4(0, 0, 0, 0);
+      if (mine && slot < in_bits) {
+        s4 = cw_s[(int64_t)slot * nkeys + k];
+        if (SCHEME == S_DCF) v4 = cw_v[(int64_t)slot * nkeys + k];
+        else if (SCHEME == S_DPF) v4.x = (uint32_t)(((slot < 64 ? lo : hi) >> (slot & 63)) & 1ull);
+        else if (slot == in_bits - 1) v4.x = ex;
+      } else if (mine && slot == in_bits) {  // cws[in_bits]: DPF {out_cw, 0}, DCF {0, out_cw}
+        if (SCHEME == S_DCF) v4 = out_cw[k];
+        else s4 = out_cw[k];
+      }
+      tile[(2 * slot) * kFlatRow + key] = s4;
+      tile[(2 * slot + 1) * kFlatRow + key] = v4;
+    }
+    wave_lds_sync();
+    {  // flat write of the key-major region
+      const int npieces = nk * per_key;
+      uint4* dst = cws + k0 * per_key;
+      int kf = 0, r = 0;
+      flat_next(kf, r, lane, per_key);
+      for (int f = lane; f < npieces; f += 64) {
+        dst[f] = tile[r * kFlatRow + kf];
+        flat_next(kf, r, 64, per_key);
+      }
+    }
+    wave_lds_sync();
+  }
+}
+
+// Host side.  Keys whose slots fill whole lines (slots % 4 == 0: Half-Tree n = 64, 2 KiB per key) take the
+// 4-level-tiled kernel (5.1 TB/s there against 4.3 for the flat one, which runs fewer waves per CU on long keys);
+// every other shape -- the 33-slot DPF / DCF keys first of all -- takes the flat kernel (DPF n = 32: relayout 4.4 ->
+// 5.4 TB/s, key_major 2.9 -> 5.4 TB/s).  FSS_AMD_RELAYOUT = 2 / 1 / 0 forces flat / tiled / one key per lane (A/B).
+inline int relayout_mode(int slots) {
+  static const int forced = [] { const char* e = getenv("FSS_AMD_RELAYOUT"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced;
+  return slots % 4 == 0 ? 1 : 2;
+}
 template <int SCHEME, class Ctx>
 void launch_relayout(Ctx* ctx, hipStream_t st, int in_bits, int stride, const uint4* cws, int64_t nkeys, uint4* cw_s,
                      uint4* cw_v, uint64_t* tr_bits, uint4* out_cw, uint32_t* extra, int tr32 = 0) {
-  static const bool tiled = [] { const char* e = getenv("FSS_AMD_RELAYOUT"); return !(e && atoi(e) == 0); }();
-  if (tiled) {
+  const int mode = relayout_mode(stride);
+  if (mode >= 2) {
+    const int bs = flat_block(stride), nw = bs / 64;
+    const int64_t want = ((nkeys + kFlatKeys - 1) / kFlatKeys + nw - 1) / nw, cap = (int64_t)ctx->num_cu * 8;
+    hipLaunchKernelGGL(relayout_flat_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(bs),
+                       flat_lds_bytes(stride, nw), st, in_bits, stride, cws, nkeys, cw_s, cw_v, tr_bits, out_cw, extra, tr32);
+  } else if (mode == 1) {
     const int64_t want = (nkeys + 255) / 256, cap = (int64_t)ctx->num_cu * 4;
     hipLaunchKernelGGL(relayout_tiled_kernel<SCHEME>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st, in_bits,
                        stride, cws, nkeys, cw_s, cw_v, tr_bits, out_cw, extra, tr32);
