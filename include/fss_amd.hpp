@@ -263,7 +263,7 @@ inline bool OnDevice(const void* p) {
 // stream.  Blocking copies on the null stream keep the reference's synchronous semantics.
 class Stage {
  public:
-  Stage(fss_amd_ctx* ctx, size_t bytes) : lock_(Reg().stage_mu) {
+  Stage(fss_amd_ctx* ctx, size_t bytes) : lock_(Reg().stage_mu), ctx_(ctx) {
     Check(fss_amd_ctx_scratch(ctx, nullptr, bytes + 256, &base_), "fss_amd_ctx_scratch");  // + alignment slack
   }
   // the next `bytes` of the area (32-byte aligned)
@@ -277,13 +277,13 @@ class Stage {
   const T* Load(const T* src, size_t count) {
     if (OnDevice(src)) return src;
     void* d = Take(count * sizeof(T));
-    CheckHip(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy (stage in)");
+    Put(d, src, count * sizeof(T));
     return static_cast<const T*>(d);
   }
   template <typename T>
   const T* Value(const T& v) {
     void* d = Take(sizeof(T));
-    CheckHip(hipMemcpy(d, &v, sizeof(T), hipMemcpyHostToDevice), "hipMemcpy (stage in)");
+    Put(d, &v, sizeof(T));
     return static_cast<const T*>(d);
   }
   // device buffer for an output: the destination itself when it is device memory
@@ -302,7 +302,13 @@ class Stage {
   }
 
  private:
+  // seeds, points and single keys (at most a few KiB) go up as kernel arguments: stream-ordered, no blocking copy
+  void Put(void* d, const void* src, size_t bytes) {
+    if (bytes <= (size_t(1) << 16)) Check(fss_amd_upload(ctx_, d, src, bytes, nullptr), "fss_amd_upload");
+    else CheckHip(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice), "hipMemcpy (stage in)");
+  }
   std::lock_guard<std::mutex> lock_;
+  fss_amd_ctx* ctx_;
   void* base_ = nullptr;
   size_t off_ = 0;
 };

@@ -100,6 +100,19 @@ static void HostSignatureDpf() {
   auto out = prg.Gen(kSeeds[0]);
   EXPECT(Same(out[0], I4(0x1423e6d2, 0x60533602, 0x813b3fbc, 0x412b31dc)));
   EXPECT(Same(out[1], I4(0x2d18cbe7, 0xa5eddcc9, 0xc691e4f6, 0x97831704)));
+  {  // what one host-signature call costs (a batch of one on the GPU; the batched forms are the fast path)
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0));
+    int4 acc = kZero;
+    for (int i = 0; i < 200; ++i) acc = fss::util::Xor(acc, dpf.Eval(false, seeds[0], cws, (In)i));
+    HIP_OK(hipEventRecord(e1));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("     (host-signature Eval: %.1f us per call, checksum %08x)\n", ms * 1000.0f / 200, (unsigned)acc.x);
+  }
   DpfPrg::FreeCtxs(ctxs);
   std::printf("DPF  n=8  Bytes      host-signature Gen/Eval/EvalAll + PRG KAT: %s\n", g_fail ? "FAILED" : "ok");
 }
