@@ -147,6 +147,8 @@ int launch_expand(fss_amd_ctx* ctx, const SharedKey& k, const ExpandArgs& a_in, 
   int grid = (int)(want < cap ? want : cap);
   ExpandArgs a = a_in;
   a.dyn = use_dyn(a.n_in, 64, grid, BS);
+  // no launch-wide tail here: a stage's chunks last microseconds, and thousands of requests to one device-memory
+  // word in that time serialise (Half-Tree 2^25 leaves: 0.53 -> 0.82 ms with it; the walks' chunks last 70 - 150 us)
   // narrow output groups: the leaf-level blocks skip the lookups of the seed words the group never reads
   constexpr bool kCanNarrow = LEAF && D >= 1 && (SCHEME == S_DPF || SCHEME == S_HT) && FSS_T4;
   static const bool narrow_on = [] { const char* e = getenv("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
@@ -643,6 +645,7 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
       int rc = persistent_grid(ctx, kernel, bs, nkeys, &grid);
       if (rc != FSS_AMD_OK) return rc;
       a.dyn = use_dyn(nkeys, 64, grid, bs);
+      if (in_bits >= 16) set_tail(ctx, S(stream), a.dyn, nkeys, 64, grid, &a.gq, &a.static_chunks);  // long chunks only
       return launch_grid(ctx, kernel, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
     };
     // AES: taken child per level, siblings deferred to dense batches (FSS_AMD_GROTTO_DEFER=0: both children per level)
@@ -653,6 +656,7 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
         int rc = persistent_grid(ctx, grotto_walk_defer_kernel<1024>, bs, (nkeys + 1) / 2, &grid);
         if (rc != FSS_AMD_OK) return rc;
         a.dyn = use_dyn(nkeys, 128, grid, bs);
+        if (in_bits >= 16) set_tail(ctx, S(stream), a.dyn, nkeys, 128, grid, &a.gq, &a.static_chunks);
         return launch_grid(ctx, grotto_walk_defer_kernel<1024>, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
       }
     }

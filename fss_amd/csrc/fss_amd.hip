@@ -97,6 +97,8 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
     c->host.self_dev = c->te0 + 256;
     e = hipMemcpy(c->te0 + 256, &c->host, sizeof(DevCtx), hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess) e = hipMalloc(&c->tail_pairs, fss_amd_ctx::kTailPairs * 2 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(c->tail_pairs, 0, fss_amd_ctx::kTailPairs * 2 * sizeof(uint32_t));
 #if FSS_DIAG_STAMPS
   if (e == hipSuccess) e = hipMalloc(&c->diag_stamps, 4096 * 4 * sizeof(uint64_t));
   if (e == hipSuccess) e = hipMemset(c->diag_stamps, 0, 4096 * 4 * sizeof(uint64_t));
@@ -115,7 +117,7 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
 // diagnostic library only (not declared in fss_amd.h): the stamps of the last point-walk launch, 4 x uint64 per
 // workgroup {memtime0, realtime0, memtime1, realtime1}; synchronises the device
 int fss_amd_diag_read_stamps(fss_amd_ctx* ctx, uint64_t* out_host, int workgroups) {
-  if (!ctx || !out_host || workgroups < 1 || workgroups > 4096) return FSS_AMD_EINVAL;
+  if (!ctx || !out_host || workgroups < 1 || workgroups > 4096) return FSS_AMD_EINVAL;  // `workgroups` = records (waves)
   FSS_ON_DEVICE(ctx);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out_host, ctx->diag_stamps, (size_t)workgroups * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
@@ -127,6 +129,7 @@ void fss_amd_ctx_destroy(fss_amd_ctx* ctx) {
   if (!ctx) return;
   if (ctx->te0) (void)hipFree(ctx->te0);
   if (ctx->diag_stamps) (void)hipFree(ctx->diag_stamps);
+  if (ctx->tail_pairs) (void)hipFree(ctx->tail_pairs);
   for (auto& kv : ctx->scratch)
     if (kv.second.p) (void)hipFree(kv.second.p);
   delete ctx;

@@ -595,22 +595,58 @@ __device__ __forceinline__ int64_t waveq_fetch(uint32_t* lds_ctr) {
 // unit of this lane in the current chunk.  Usage:
 //   FSS_WAVEQ_PROLOGUE();  WaveQ q(dyn, &waveq_ctr_, total_units, units_per_lane);
 //   for (int64_t u; q.next(u);) { ... lane handles units u + j * q.stride(), j < units_per_lane ... }
+//
+// Launch-wide tail (gq != nullptr).  Equal shares per CU still finish ragged ACROSS CUs: the XCDs do not hold the
+// same clock under load (in-kernel clocks 1.90 - 2.13 GHz across the workgroups of one independent-keys launch,
+// 2.32 - 2.39 for a shared key), so the slowest CU's workgroup ends 3 % (shared key) to 11 % (independent keys)
+// after the fastest (per-wave stamps, tools/keys_clock.py).  So only the first `static_chunks` chunks are dealt out
+// per workgroup; a workgroup that has used up its share takes the remaining chunks one at a time from a counter in
+// device memory (gq[0]) that all workgroups share -- a few thousand device-scope atomics per launch, each requested a
+// whole chunk ahead of its use.  Requests to one word serialise at a few tens of millions per second, so the host
+// only enables the tail where a chunk lasts tens of microseconds (the point walks from ~24 AES blocks per lane and
+// chunk on, the Grotto walk; not the EvalAll stages).  gq[1] counts the workgroups that have left the loop; the last
+// one zeroes both words, so the pair is ready for the next launch on the same stream (the host hands every stream
+// its own pair).
 struct WaveQ {
   uint32_t* ctr;
   int64_t nchunks, cur, per_chunk;
   bool dyn;
-  __device__ __forceinline__ WaveQ(int dyn_, uint32_t* lds_ctr, int64_t total_units, int units_per_lane)
-      : ctr(lds_ctr), per_chunk(64 * (int64_t)units_per_lane), dyn(dyn_ != 0) {
+  uint32_t* gq;
+  int64_t static_chunks;
+  __device__ __forceinline__ int64_t fetch() {
+    int64_t c = waveq_fetch(ctr);
+    if (gq != nullptr && c >= static_chunks) {
+      uint32_t g = 0;
+      if ((threadIdx.x & 63) == 0) g = atomicAdd(gq, 1u);
+      c = static_chunks + (int64_t)__builtin_amdgcn_readfirstlane(g);
+    }
+    return c;
+  }
+  __device__ __forceinline__ WaveQ(int dyn_, uint32_t* lds_ctr, int64_t total_units, int units_per_lane,
+                                   uint32_t* gq_ = nullptr, int64_t static_chunks_ = 0)
+      : ctr(lds_ctr), per_chunk(64 * (int64_t)units_per_lane), dyn(dyn_ != 0), gq(dyn_ != 0 ? gq_ : nullptr),
+        static_chunks(static_chunks_) {
     nchunks = (total_units + per_chunk - 1) / per_chunk;
     // static: the wave's own chunks, spaced by the number of waves in the grid
-    cur = dyn ? waveq_fetch(ctr) : ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    cur = dyn ? fetch() : ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
   }
   // first unit of this lane in the next chunk of this wave; false when the wave is done
   __device__ __forceinline__ bool next(int64_t& unit0) {
     if (cur >= nchunks) return false;
     unit0 = cur * per_chunk + (threadIdx.x & 63);
-    cur = dyn ? waveq_fetch(ctr) : cur + (int64_t)gridDim.x * (blockDim.x >> 6);
+    cur = dyn ? fetch() : cur + (int64_t)gridDim.x * (blockDim.x >> 6);
     return true;
+  }
+  // After the loop, every wave of the launch (a workgroup barrier inside): hand the launch-wide counter back zeroed.
+  // One count per workgroup, not per wave: 4096 requests to one word at the end of a launch would take tens of
+  // microseconds by themselves.
+  __device__ __forceinline__ void done() {
+    if (gq == nullptr) return;  // wave-uniform, launch-uniform
+    __syncthreads();            // every wave of this workgroup has made its last request
+    if (threadIdx.x == 0 && atomicAdd(gq + 1, 1u) == gridDim.x - 1) {  // ... and so has every other workgroup
+      gq[0] = 0u;
+      gq[1] = 0u;
+    }
   }
 };
 

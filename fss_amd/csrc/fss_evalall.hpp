@@ -43,6 +43,8 @@ struct ExpandArgs {
   uint4* out_v;
   void* ys;             // leaf stage: uint4 per leaf (Grotto: uint8 control bit per leaf)
   int dyn;              // expand_kernel: waves take 64-node chunks from the workgroup's LDS counter (WaveQ)
+  uint32_t* gq;         // WaveQ's launch-wide tail: this stream's {counter, waves done}, or nullptr
+  int64_t static_chunks;
   // BATCH kernels (fss::gpu::*EvalAllGpuBatch, eval_all_gpu.cuh:511-535): nkeys trees side by side.  Node f of a
   // stage whose inputs are at level l belongs to key f >> l; keys are key-major raw slots, `key_slots` per key.
   int64_t nkeys;
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
     }
   };
 
-  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1);
+  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1, a.gq, a.static_chunks);
   for (int64_t j; q.next(j);) {
     if (j >= a.n_in) continue;  // ragged last chunk
     uint32_t n0[4];
@@ -481,6 +483,7 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
     const uint32_t* koc = (BATCH && k_ocw) ? k_ocw + 4 * key : k_ocw;
     OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
   }
+  q.done();
 }
 
 // Grotto EvalAll phase 2 (grotto_dcf.cuh:158-162): in-place running XOR over the

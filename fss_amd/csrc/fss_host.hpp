@@ -33,6 +33,22 @@ struct fss_amd_ctx {
   std::mutex scratch_mu;
   std::unordered_map<void*, Scratch> scratch;
   uint64_t* diag_stamps = nullptr;  // FSS_DIAG_STAMPS builds: 4 x uint64 per workgroup of the last point-walk launch
+  // WaveQ's launch-wide tail counters: one {counter, waves done} pair per stream that launched a dynamic walk
+  // (launches on one stream run one after the other, and the kernel hands its pair back zeroed); nothing is
+  // allocated after creation, so a first launch may sit inside a stream capture
+  static constexpr int kTailPairs = 1024;
+  uint32_t* tail_pairs = nullptr;   // device: kTailPairs x 2 words, zero
+  std::mutex tail_mu;
+  std::unordered_map<void*, int> tail_slot;
+  uint32_t* tail_pair(void* stream) {
+    std::lock_guard<std::mutex> lk(tail_mu);
+    auto it = tail_slot.find(stream);
+    if (it == tail_slot.end()) {
+      if ((int)tail_slot.size() >= kTailPairs) return nullptr;  // more streams than pairs: those launch without a tail
+      it = tail_slot.emplace(stream, (int)tail_slot.size()).first;
+    }
+    return tail_pairs + 2 * it->second;
+  }
 };
 
 inline thread_local int g_last_hip = 0;  // one instance across the translation units
@@ -97,7 +113,9 @@ struct Tune {
   bool ilp_set = false;  // FSS_AMD_ILP given: do not second-guess it for small batches
   int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
   int rot_prio = -1;  // FSS_AMD_ROTPRIO: 1 / 0 force; default: on for static launches
+  int tail_pct = 8;  // FSS_AMD_TAIL_PCT: share of a dynamic walk's chunks in the launch-wide tail queue (0: none)
   Tune() {
+    if (const char* e = getenv("FSS_AMD_TAIL_PCT")) { tail_pct = atoi(e); if (tail_pct < 0 || tail_pct > 100) tail_pct = 8; }
     if (const char* e = getenv("FSS_AMD_ROTPRIO")) rot_prio = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
@@ -147,6 +165,19 @@ int use_dyn(int64_t units, int per_chunk, int grid, int bs) {
   return nchunks >= 4 * waves ? 1 : 0;
 }
 
+// WaveQ's launch-wide tail for a dynamic launch of `units` units in chunks of `per_chunk` over `grid` workgroups:
+// the stream's counter pair and the number of chunks dealt out per workgroup before it takes over.
+inline void set_tail(fss_amd_ctx* ctx, hipStream_t st, int dyn, int64_t units, int64_t per_chunk, int grid, uint32_t** gq,
+                     int64_t* static_chunks) {
+  *gq = nullptr;
+  *static_chunks = 0;
+  if (!dyn || tune().tail_pct <= 0 || !ctx->tail_pairs) return;
+  const int64_t nchunks = (units + per_chunk - 1) / per_chunk;
+  int64_t stat = nchunks - nchunks * tune().tail_pct / 100;
+  stat -= stat % grid;
+  if (stat < nchunks && (*gq = ctx->tail_pair((void*)st)) != nullptr) *static_chunks = stat;
+}
+
 template <typename K, typename... Args>
 int launch_grid(fss_amd_ctx* ctx, K kernel, const char* name, int grid, int bs, hipStream_t st, Args... args) {
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(bs), 0, st, args...);
@@ -189,12 +220,22 @@ struct SharedKey {
 
 template <typename K>
 int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int bs, const SharedKey& k, EvalArgs a,
-                    hipStream_t st) {
+                    hipStream_t st, bool tail_ok) {
   int grid = 0;
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
-  a.dyn = use_dyn(a.n, 64 * ilp, grid, bs);
+  // dynamic distribution from 512 evaluations per resident wave on (2^21 on the whole chip: 8 chunks per wave with one
+  // evaluation per lane, 4 with two); below that the chunks are too few to even out and fixed shares with rotating
+  // priorities win (2^20 points: 0.320 ms static against 0.356 dynamic; 2^21: 0.629 against 0.616; profiles/r2/points_ab.txt)
+  a.dyn = tune().dyn >= 0 ? tune().dyn : (a.n >= (int64_t)512 * grid * (bs / 64) ? 1 : 0);
   a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : !a.dyn;
+  // the last tail_pct % of the chunks go to whichever workgroup asks first (WaveQ); shares stay whole rounds of the grid.
+  // Only where a chunk is long enough: in the tail every chunk costs a request to one device-memory word, and those
+  // serialise at a few tens of millions per second -- DPF n = 8, one evaluation per lane: 1.20 -> 1.39 ms WITH the tail;
+  // from about 24 AES blocks per lane and chunk on it pays (n = 24: 3.53 -> 3.49 ms, n = 32: 4.66 -> 4.62).
+  a.gq = nullptr;
+  a.static_chunks = 0;
+  if (tail_ok) set_tail(ctx, st, a.dyn, a.n, 64 * (int64_t)ilp, grid, &a.gq, &a.static_chunks);
 #if FSS_DIAG_STAMPS
   a.stamps = ctx->diag_stamps;
 #endif
@@ -214,9 +255,15 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   // evaluation per lane only adds registers -- one per lane is ahead at every batch size (2^20 points: 0.616 ms
   // against 0.663, 2^22: 2.43 against 2.48, 2^24 even; profiles/r2/points_ab.txt)
   if (!tune().ilp_set && SCHEME == S_DCF) ilp = 1;
+  // one shared DPF key: with the launch-wide tail queue the finer chunks of one evaluation per lane are worth more
+  // than the second interleaved stream (2^24 points: 4.62 against 4.69 ms, 2^22: 1.186 against 1.237; equal at
+  // 2^19 .. 2^21).  Independent keys and Half-Tree keep two (5.28 against 5.32 ms, 10.13 against 10.20).
+  // Short walks (n < 24) keep two, so that a chunk stays long enough for the tail queue (launch_points_k).
+  if (!tune().ilp_set && SCHEME == S_DPF && SHARED && !PREFIX && a.in_bits >= 24) ilp = 1;
+  const bool tail_ok = (a.in_bits - (PREFIX ? a.start_level : 0)) * ilp * (SCHEME == S_DCF ? 2 : 1) >= 24;  // levels actually walked
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
-  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st)))
+  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;

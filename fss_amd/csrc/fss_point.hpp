@@ -56,6 +56,8 @@ struct EvalArgs {
   int rot_prio;             // statically distributed launches: rotate the wave priority every level (rotate_prio)
   int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
   uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
+  uint32_t* gq;             // WaveQ's launch-wide tail: {counter, waves done} of this stream, or nullptr
+  int64_t static_chunks;    // chunks dealt out per workgroup before the launch-wide tail starts
 };
 
 // Diagnostic build (-DFSS_DIAG_STAMPS=1, a separate library: in the product no stamp executes): lane 0 of every
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #if FSS_DIAG_STAMPS
   const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  WaveQ q(a.dyn, &waveq_ctr_, n, ILP);
+  WaveQ q(a.dyn, &waveq_ctr_, n, ILP, a.gq, a.static_chunks);
   for (int64_t base; q.next(base);) {
     int64_t idx[ILP];
 #pragma unroll
@@ -448,9 +450,10 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
     }
   }
+  q.done();
 #if FSS_DIAG_STAMPS
-  if (threadIdx.x == 0 && a.stamps) {
-    uint64_t* o = a.stamps + 4 * (int64_t)blockIdx.x;
+  if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave
+    uint64_t* o = a.stamps + 4 * ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
     o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits;
   uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
-  WaveQ q(a.dyn, &waveq_ctr_, a.n, 1);
+  WaveQ q(a.dyn, &waveq_ctr_, a.n, 1, a.gq, a.static_chunks);
   for (int64_t k; q.next(k);) {
     if (k >= a.n) continue;
     const uint64_t x = load_x(a.xs, a.x_bytes, k).lo;
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
     }
     ys[k] = (uint8_t)(whole ? (uint32_t)a.party : pi);
   }
+  q.done();
 }
 
 // The same walk with the siblings deferred (AES tables only).  A level needs the taken child of every lane
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
     }
     wave_lds_sync();
   };
-  WaveQ q(a.dyn, &waveq_ctr_, a.n, 2);
+  WaveQ q(a.dyn, &waveq_ctr_, a.n, 2, a.gq, a.static_chunks);
   for (int64_t base; q.next(base);) {
     int64_t k[2];
     bool valid[2], whole[2];
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
     }
     wave_lds_sync();
   }
+  q.done();
 }
 
 }  // namespace fssamd

@@ -61,12 +61,23 @@ aes = aes_blocks_per_eval(a.scheme, n)
 line["lds_frac_at_2.4GHz"] = round(N / (kms * 1e-3) * aes * LOOKUP_BYTES_PER_AES / 1e9 / LDS_PEAK_GBS, 4)
 line["hbm_GBs_algorithmic"] = round(N / (kms * 1e-3) * hbm_bytes_per_eval(a.scheme, n, shared) / 1e9, 1)
 if hasattr(L, "fss_amd_diag_read_stamps"):
-    buf = np.zeros((grid, 4), dtype=np.uint64)
+    nrec = grid * (block // 64)  # one record per wave
+    buf = np.zeros((nrec, 4), dtype=np.uint64)
     L.fss_amd_diag_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    rc = L.fss_amd_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), grid)
+    rc = L.fss_amd_diag_read_stamps(eng._h, buf.ctypes.data_as(C.c_void_p), nrec)
     assert rc == 0, rc
     dcyc = (buf[:, 2] - buf[:, 0]).astype(np.float64)
     dreal = (buf[:, 3] - buf[:, 1]).astype(np.float64)
+    # the launch on the 100 MHz clock all XCDs share: how full the chip is kept to the end
+    r0, r1 = buf[:, 1].astype(np.float64), buf[:, 3].astype(np.float64)
+    span = r1.max() - r0.min()
+    line["walk_span_us"] = round(span / 100.0, 1)
+    line["mean_wave_busy_frac_of_span"] = round(float((r1 - r0).mean() / span), 4)
+    ends = np.sort(r1.max() - r1) / 100.0  # us before the last wave's end at which each wave left its loop
+    line["waves_done_before_end_us_p50_p90_max"] = [round(float(np.percentile(ends, q)), 1) for q in (50, 90, 100)]
+    per_wg_end = r1.reshape(grid, -1).max(axis=1)
+    line["workgroup_end_spread_us"] = round(float(per_wg_end.max() - per_wg_end.min()) / 100.0, 1)
+    line["starts_spread_us"] = round(float(r0.max() - r0.min()) / 100.0, 1)
     ok = dreal > 0
     clk = dcyc[ok] / dreal[ok] * 0.1  # GHz: realtime ticks at 100 MHz
     line["in_kernel_clock_GHz_median"] = round(float(np.median(clk)), 4)
