@@ -220,14 +220,15 @@ struct SharedKey {
 
 template <typename K>
 int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int bs, const SharedKey& k, EvalArgs a,
-                    hipStream_t st, bool tail_ok) {
+                    hipStream_t st, bool tail_ok, int blocks_per_eval) {
   int grid = 0;
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
-  // dynamic distribution from 512 evaluations per resident wave on (2^21 on the whole chip: 8 chunks per wave with one
-  // evaluation per lane, 4 with two); below that the chunks are too few to even out and fixed shares with rotating
-  // priorities win (2^20 points: 0.320 ms static against 0.356 dynamic; 2^21: 0.629 against 0.616; profiles/r2/points_ab.txt)
-  a.dyn = tune().dyn >= 0 ? tune().dyn : (a.n >= (int64_t)512 * grid * (bs / 64) ? 1 : 0);
+  // dynamic distribution from 16 384 AES blocks per resident wave on (DPF n = 32: 2^21 points on the whole chip; DCF
+  // n = 32 and Half-Tree n = 64: 2^20); below that the chunks are too few or too short to even out and fixed shares
+  // with rotating priorities win (DPF 2^20 points: 0.320 ms static against 0.356 dynamic, 2^21: 0.629 against 0.616;
+  // DCF 2^20: 0.660 static against 0.616 dynamic; profiles/r2/points_ab.txt)
+  a.dyn = tune().dyn >= 0 ? tune().dyn : (a.n * blocks_per_eval >= (int64_t)16384 * grid * (bs / 64) ? 1 : 0);
   a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : !a.dyn;
   // the last tail_pct % of the chunks go to whichever workgroup asks first (WaveQ); shares stay whole rounds of the grid.
   // Only where a chunk is long enough: in the tail every chunk costs a request to one device-memory word, and those
@@ -255,15 +256,18 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   // evaluation per lane only adds registers -- one per lane is ahead at every batch size (2^20 points: 0.616 ms
   // against 0.663, 2^22: 2.43 against 2.48, 2^24 even; profiles/r2/points_ab.txt)
   if (!tune().ilp_set && SCHEME == S_DCF) ilp = 1;
-  // one shared DPF key: with the launch-wide tail queue the finer chunks of one evaluation per lane are worth more
-  // than the second interleaved stream (2^24 points: 4.62 against 4.69 ms, 2^22: 1.186 against 1.237; equal at
-  // 2^19 .. 2^21).  Independent keys and Half-Tree keep two (5.28 against 5.32 ms, 10.13 against 10.20).
-  // Short walks (n < 24) keep two, so that a chunk stays long enough for the tail queue (launch_points_k).
-  if (!tune().ilp_set && SCHEME == S_DPF && SHARED && !PREFIX && a.in_bits >= 24) ilp = 1;
-  const bool tail_ok = (a.in_bits - (PREFIX ? a.start_level : 0)) * ilp * (SCHEME == S_DCF ? 2 : 1) >= 24;  // levels actually walked
+  // DPF and Half-Tree: with the launch-wide tail queue the finer chunks of one evaluation per lane are worth more than
+  // the second interleaved stream wherever a one-evaluation chunk is still long enough for that queue (>= 24 levels
+  // walked): one shared DPF key 2^24 points 4.62 against 4.69 ms, 2^22 1.186 against 1.237, equal at 2^19 .. 2^21;
+  // independent DPF keys 5.28 against 5.34 ms, Half-Tree keys 10.155 against 10.176 (profiles/r2/keys_clock.txt,
+  // tail_queue_ab.txt).  Short walks (n < 24, the shared-prefix walks) keep two.
+  const int walked = a.in_bits - (PREFIX ? a.start_level : 0);
+  if (!tune().ilp_set && walked >= 24) ilp = 1;
+  const int blocks_per_eval = walked * (SCHEME == S_DCF ? 2 : 1);
+  const bool tail_ok = blocks_per_eval * ilp >= 24;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
-  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok)))
+  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, blocks_per_eval)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;

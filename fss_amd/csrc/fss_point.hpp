@@ -450,13 +450,13 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
     }
   }
-  q.done();
 #if FSS_DIAG_STAMPS
-  if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave
+  if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave, taken as the wave leaves its loop (before done()'s barrier)
     uint64_t* o = a.stamps + 4 * ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
     o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+  q.done();
 }
 
 // ---------------------------------------------------------------- Grotto DCF, path walk
