@@ -147,6 +147,9 @@ int launch_expand(fss_amd_ctx* ctx, const SharedKey& k, const ExpandArgs& a_in, 
   int grid = (int)(want < cap ? want : cap);
   ExpandArgs a = a_in;
   a.dyn = use_dyn(a.n_in, 64, grid, BS);
+#if FSS_DIAG_STAMPS
+  a.stamps = ctx->diag_stamps;
+#endif
   // no launch-wide tail here: a stage's chunks last microseconds, and thousands of requests to one device-memory
   // word in that time serialise (Half-Tree 2^25 leaves: 0.53 -> 0.82 ms with it; the walks' chunks last 70 - 150 us)
   // narrow output groups: the leaf-level blocks skip the lookups of the seed words the group never reads

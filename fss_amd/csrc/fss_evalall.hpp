@@ -45,6 +45,7 @@ struct ExpandArgs {
   int dyn;              // expand_kernel: waves take 64-node chunks from the workgroup's LDS counter (WaveQ)
   uint32_t* gq;         // WaveQ's launch-wide tail: this stream's {counter, waves done}, or nullptr
   int64_t static_chunks;
+  uint64_t* stamps;     // FSS_DIAG_STAMPS builds: per-wave {memtime, realtime} x {start, end} of the leaf stage
   // BATCH kernels (fss::gpu::*EvalAllGpuBatch, eval_all_gpu.cuh:511-535): nkeys trees side by side.  Node f of a
   // stage whose inputs are at level l belongs to key f >> l; keys are key-major raw slots, `key_slots` per key.
   int64_t nkeys;
@@ -464,6 +465,9 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
     }
   };
 
+#if FSS_DIAG_STAMPS
+  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1, a.gq, a.static_chunks);
   for (int64_t j; q.next(j);) {
     if (j >= a.n_in) continue;  // ragged last chunk
@@ -483,6 +487,12 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
     const uint32_t* koc = (BATCH && k_ocw) ? k_ocw + 4 * key : k_ocw;
     OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
   }
+#if FSS_DIAG_STAMPS
+  if (LEAF && (threadIdx.x & 63) == 0 && a.stamps) {
+    uint64_t* o = a.stamps + 4 * ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
+    o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   q.done();
 }
 
