@@ -172,6 +172,11 @@ inline void set_tail(fss_amd_ctx* ctx, hipStream_t st, int dyn, int64_t units, i
   *gq = nullptr;
   *static_chunks = 0;
   if (!dyn || tune().tail_pct <= 0 || !ctx->tail_pairs) return;
+  // A launch recorded into a graph may be replayed later on any stream, next to other work of the stream it was
+  // captured on: its counter pair would no longer be its own.  Captured launches go without the tail.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (cap != hipStreamCaptureStatusNone) return;
   const int64_t nchunks = (units + per_chunk - 1) / per_chunk;
   int64_t stat = nchunks - nchunks * tune().tail_pct / 100;
   stat -= stat % grid;

@@ -422,6 +422,47 @@ def test_eval_points_graph_capture(engine, O):
     assert bool((ys == eager).all())
 
 
+def test_large_batch_graph_capture_and_streams(engine, O):
+    """Large walks use the launch-wide tail queue (a counter pair per stream).  A captured launch must not depend on a
+    stream's pair (it may be replayed anywhere), a first launch may sit inside a capture (nothing is allocated), and
+    launches on several streams at once stay independent: all of them bit-identical with the eager result."""
+    n, g, N = 32, G.U64, 1 << 22
+    rng = SplitMix64(77)
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    cws = O.dpf_gen(p, n, g, s, 0x0BADF00D, beta_for(rng))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    xs = torch.randint(-2**31, 2**31, (N,), dtype=torch.int32, device="cuda", generator=gen)
+    seed, cw = T(s[0]).cuda(), T(cws).cuda()
+    eager = engine.eval_points(DPF, n, g, 0, seed, cw, xs).clone()
+    idx = np.arange(0, N, 8191)
+    want = O.eval_points(p, DPF, n, g, 0, s[0], cws, xs.cpu().numpy().view(np.uint32)[idx].astype(np.uint64), nthreads=4)
+    assert (eager.cpu().numpy()[idx] == want).all()
+    # capture on a fresh stream with no warm-up launch on it, replay twice
+    ys = torch.zeros((N, 4), dtype=torch.int32, device="cuda")
+    st = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(graph, stream=st):
+            engine.eval_points(DPF, n, g, 0, seed, cw, xs, out=ys)
+    for _ in range(2):
+        ys.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ys, eager)
+    # four streams at once, several launches each
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [torch.zeros((N, 4), dtype=torch.int32, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for st_i, o in zip(streams, outs):
+            with torch.cuda.stream(st_i):
+                engine.eval_points(DPF, n, g, 0, seed, cw, xs, out=o)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, eager)
+
+
 def test_grotto_eval_all_sharded_with_carry(engine, O):
     """Domain-sharded Grotto EvalAll: per-block running XOR plus the parity carry of fss_amd.shard."""
     from fss_amd import shard
