@@ -604,9 +604,13 @@ __device__ __forceinline__ int64_t waveq_fetch(uint32_t* lds_ctr) {
 // device memory (gq[0]) that all workgroups share -- a few thousand device-scope atomics per launch, each requested a
 // whole chunk ahead of its use.  Requests to one word serialise at a few tens of millions per second, so the host
 // only enables the tail where a chunk lasts tens of microseconds (the point walks from ~24 AES blocks per lane and
-// chunk on, the Grotto walk; not the EvalAll stages).  gq[1] counts the workgroups that have left the loop; the last
-// one zeroes both words, so the pair is ready for the next launch on the same stream (the host hands every stream
-// its own pair).
+// chunk on, the Grotto walk; not the EvalAll stages: Half-Tree 2^25 leaves 0.53 -> 0.82 ms with it).  Claiming a
+// block of chunks (one per wave) per request -- first ticket of a block makes the request, the others pick the base
+// up from LDS -- removes that limit but balances a whole round of a workgroup at a time: measured on one box, it gave
+// a third of the per-chunk tail's gain on the long walks and nothing on short walks or stages, so it is not kept
+// (profiles/r2/tail_queue_blocked_ab.txt).  gq[1] counts the workgroups that have left the loop; the last one
+// zeroes both words, so the pair is ready for the next launch on the same stream (the host hands every stream its
+// own pair).
 struct WaveQ {
   uint32_t* ctr;
   int64_t nchunks, cur, per_chunk;

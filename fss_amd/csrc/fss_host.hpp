@@ -269,7 +269,8 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   const int walked = a.in_bits - (PREFIX ? a.start_level : 0);
   if (!tune().ilp_set && walked >= 24) ilp = 1;
   const int blocks_per_eval = walked * (SCHEME == S_DCF ? 2 : 1);
-  const bool tail_ok = blocks_per_eval * ilp >= 24;
+  static const int tail_minwork = [] { const char* e = getenv("FSS_AMD_TAIL_MINWORK"); return e ? atoi(e) : 24; }();
+  const bool tail_ok = blocks_per_eval * ilp >= tail_minwork;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
   return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, blocks_per_eval)))
