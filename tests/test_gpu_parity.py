@@ -788,3 +788,64 @@ def test_cxx_dropin_boundary():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
+
+
+@pytest.mark.parametrize("n,nkeys", [(1, 70), (20, 1000), (32, 5000), (31, 129)])
+def test_u32_extra_entry_points_vs_u64(engine, O, n, nkeys):
+    """fss_amd_dpf_relayout_u32 / fss_amd_dpf_eval_keys_u32: the reference's uint32_t `extra` packing of the tr bits
+    (point_eval_gpu.cuh:57-62) gives the same level-major words, the low 32 tr bits, and the same shares as the
+    64-bit layout; in_bits > 32 is refused."""
+    import ctypes as C
+    from fss_amd import _lib
+    L, h = engine._L, engine._h
+    rng = SplitMix64(4400 + n)
+    p = O.Prg(2)
+    s0s = np.stack([np.stack([rng.i4(), rng.i4()]) for _ in range(nkeys)])
+    alphas = np.array([rng.below(n) for _ in range(nkeys)], dtype=np.uint64)
+    betas = np.stack([rng.i4() for _ in range(nkeys)])
+    cws, _ = O.gen_keys(p, DPF, n, G.U64, s0s, alphas, betas, nthreads=4)
+    xs = np.array([alphas[i] if i % 2 else rng.below(n) for i in range(nkeys)], dtype=np.uint64)
+    cd = T(cws).cuda()
+    keys = engine.relayout(DPF, n, cd)
+    cw_s = torch.empty((n, nkeys, 4), dtype=torch.int32, device="cuda")
+    extra = torch.empty((nkeys,), dtype=torch.int32, device="cuda")
+    out_cw = torch.empty((nkeys, 4), dtype=torch.int32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(L.fss_amd_dpf_relayout_u32(h, n, P(cd), nkeys, P(cw_s), P(extra), P(out_cw), None), "relayout_u32")
+    assert torch.equal(cw_s, keys.cw_s) and torch.equal(out_cw, keys.out_cw)
+    assert torch.equal(extra.to(torch.int64) & 0xFFFFFFFF, keys.tr_bits & 0xFFFFFFFF)
+    xt = xs_tensor(xs, n).cuda()
+    for b in (0, 1):
+        seeds = T(np.ascontiguousarray(s0s[:, b])).cuda()
+        ys = torch.empty((nkeys, 4), dtype=torch.int32, device="cuda")
+        _lib.check(L.fss_amd_dpf_eval_keys_u32(h, n, G.U64, b, P(seeds), P(cw_s), P(extra), P(out_cw), P(xt), 4, nkeys, P(ys),
+                                               None), "eval_keys_u32")
+        want = O.eval_keys(p, DPF, n, G.U64, b, s0s[:, b], cws, xs, nthreads=4)
+        assert (ys.cpu().numpy() == want).all()
+    assert L.fss_amd_dpf_relayout_u32(h, 33, P(cd), 1, P(cw_s), P(extra), P(out_cw), None) == -1
+    assert L.fss_amd_dpf_eval_keys_u32(h, 33, G.U64, 0, P(cw_s), P(cw_s), P(extra), P(out_cw), P(xt), 8, 1, P(out_cw), None) == -1
+
+
+def test_ctx_scratch_and_upload(engine):
+    """fss_amd_ctx_scratch: grow-only per-stream device scratch; fss_amd_upload: host bytes to device memory through
+    kernel arguments, stream-ordered, any size up to 1 MiB and any alignment."""
+    import ctypes as C
+    from fss_amd import _lib
+    L, h = engine._L, engine._h
+    p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(L.fss_amd_ctx_scratch(h, None, 1000, C.byref(p1)), "scratch")
+    _lib.check(L.fss_amd_ctx_scratch(h, None, 500, C.byref(p2)), "scratch")
+    assert p1.value == p2.value and p1.value % 256 == 0           # no shrink, no realloc for a smaller request
+    st = torch.cuda.Stream()
+    _lib.check(L.fss_amd_ctx_scratch(h, C.c_void_p(st.cuda_stream), 1 << 20, C.byref(p3)), "scratch")
+    assert p3.value != p1.value                                    # another stream, another buffer
+    assert L.fss_amd_ctx_scratch(h, None, 16, None) == -1
+    dst = torch.zeros(5003, dtype=torch.uint8, device="cuda")
+    src = np.random.RandomState(3).randint(0, 256, size=5000, dtype=np.uint8)
+    for off, nbytes in ((0, 5000), (1, 4999), (3, 17), (2, 2049), (0, 1)):
+        dst.zero_()
+        _lib.check(L.fss_amd_upload(h, C.c_void_p(dst.data_ptr() + off), src.ctypes.data_as(C.c_void_p), nbytes, None), "upload")
+        got = dst.cpu().numpy()
+        assert (got[off:off + nbytes] == src[:nbytes]).all() and not got[:off].any() and not got[off + nbytes:].any()
+    assert L.fss_amd_upload(h, C.c_void_p(dst.data_ptr()), src.ctypes.data_as(C.c_void_p), (1 << 20) + 1, None) == -1
+    assert L.fss_amd_upload(h, None, src.ctypes.data_as(C.c_void_p), 16, None) == -1
