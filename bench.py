@@ -77,6 +77,7 @@ def _headline_pmc(log2_batch):
             for k, v in d.items():
                 name = k.replace("fssamd::Lds, ", "")
                 if "eval_points_kernel<0, true" in name and name.rstrip().endswith("false>") and "FETCH_SIZE" in v:
+                    v = dict(v, _captured_for=d.get("_captured_for", {}).get("headline_sources_sha256"))
                     return v, os.path.relpath(f, ROOT)
         except Exception:
             pass
@@ -332,7 +333,10 @@ def _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, 
     hbm_bytes = batch * hbm_bytes_per_eval(scheme, n, True)
     hbm_gbs = hbm_bytes / (kernel_ms * 1e-3) / 1e9
     pipes = measured_pipe_busy(args.log2_batch)
-    replay_src = _headline_pmc(args.log2_batch)[1]
+    replay_v, replay_src = _headline_pmc(args.log2_batch)
+    from fss_amd import _build
+    # True only when the profile was captured for exactly the sources this library's point walk is compiled from
+    replay_ok = bool(replay_v) and replay_v.get("_captured_for") == _build.headline_digest()
     out = {
         "metric": "DPF/DCF evals/sec at kInBits=32, batch=2^24", "value": value, "unit": "evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -342,7 +346,7 @@ def _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, 
                    "kernel": kname, "grid": grid, "block": block, "parallelism": f"batch-sharded x{world}, no collective"},
         "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                      "frac": lds_gbs / LDS_PEAK_GBS, "traffic": measured_hbm_traffic(args.log2_batch),
-                     "traffic_replayed_from": replay_src,
+                     "traffic_replayed_from": replay_src, "replay_matches_kernel_sources": replay_ok,
                      "kernel_ms": kernel_ms, "per_gpu_evals_per_s": per_gpu_kernel_rate,
                      "algorithmic": f"{aes} AES blocks/eval x 160 LDS lookups x 4 B; peak = 128 B/clk/CU x 256 CU x 2.4 GHz",
                      "aes_blocks_per_s": per_gpu_kernel_rate * aes, "pipes": pipes},

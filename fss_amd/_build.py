@@ -24,6 +24,21 @@ def _sources_digest():
     return h.hexdigest()
 
 
+HEADLINE_SOURCES = ("fss_dev.hpp", "fss_point.hpp", "fss_host.hpp", "fss_amd.hip")
+
+
+def headline_digest():
+    """SHA-256 over the sources (and flags) the point-walk kernels and their launch plan are compiled from: the
+    rocprofv3 PMC summaries under profiles/ carry it, and bench.py says whether the counters it replays were
+    captured for these sources."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in HEADLINE_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def _stale():
     """The .so is rebuilt unless its stamp equals the digest of the sources it would be built from (file times are
     not trusted: a checkout or a copied snapshot resets them)."""

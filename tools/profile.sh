@@ -20,10 +20,13 @@ for PMC in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_L
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT/pmc$i" -- $BENCH > "$OUT/pmc$i.log" 2>&1
 done
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$R" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
+sys.path.insert(0, sys.argv[2])
+from fss_amd import _build
 res = collections.OrderedDict()
+res["_captured_for"] = {"headline_sources_sha256": _build.headline_digest(), "sources": list(_build.HEADLINE_SOURCES)}
 for f in sorted(glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
