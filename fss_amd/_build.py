@@ -90,7 +90,7 @@ SAMPLE_BIN = os.path.join(_HERE, "..", "samples", "dpf_dcf_gpu")
 def build_sample(force=False):
     """Compile the C++ sample (include/fss_amd.hpp over the C ABI) against libfss_amd.so."""
     build()
-    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("fss_amd.h", "fss_amd.hpp")]
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("fss_amd.h", "fss_amd.hpp", "fss_amd_thread.hpp")]
     if (not force and os.path.exists(SAMPLE_BIN)
             and os.path.getmtime(SAMPLE_BIN) >= max(os.path.getmtime(f) for f in [SAMPLE_SRC, SO] + hdrs)):
         return SAMPLE_BIN
@@ -100,17 +100,32 @@ def build_sample(force=False):
     return SAMPLE_BIN
 
 
-DROPIN_SRC = os.path.join(_HERE, "..", "tests", "cxx", "dropin_test.cpp")
-DROPIN_BIN = os.path.join(_HERE, "..", "tests", "cxx", "dropin_test")
+CXX_TESTS = os.path.join(_HERE, "..", "tests", "cxx")
+DROPIN_SRC = os.path.join(CXX_TESTS, "dropin_test.cpp")
+DROPIN_BIN = os.path.join(CXX_TESTS, "dropin_test")
+PUBLIC_HEADERS = ("fss_amd.h", "fss_amd.hpp", "fss_amd_thread.hpp")
+
+
+def _build_cxx_test(name, force=False):
+    build()
+    src, exe = os.path.join(CXX_TESTS, name + ".cpp"), os.path.join(CXX_TESTS, name)
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in PUBLIC_HEADERS]
+    if not force and os.path.exists(exe) and os.path.getmtime(exe) >= max(os.path.getmtime(f) for f in [src, SO] + hdrs):
+        return exe
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20", "-I" + os.path.join(_HERE, "..", "include"),
+                           src, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../../fss_amd", "-o", exe])
+    return exe
 
 
 def build_dropin_test(force=False):
     """Compile tests/cxx/dropin_test.cpp: caller code in the reference's own call syntax against include/fss_amd.hpp."""
-    build()
-    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("fss_amd.h", "fss_amd.hpp")]
-    if (not force and os.path.exists(DROPIN_BIN)
-            and os.path.getmtime(DROPIN_BIN) >= max(os.path.getmtime(f) for f in [DROPIN_SRC, SO] + hdrs)):
-        return DROPIN_BIN
+    return _build_cxx_test("dropin_test", force)
+
+
+def build_dropin_device_test(force=False):
+    """Compile tests/cxx/dropin_device_test.cpp: Gen / Eval called per thread inside the caller's own kernels."""
+    return _build_cxx_test("dropin_device_test", force)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20", "-I" + os.path.join(_HERE, "..", "include"),
                            DROPIN_SRC, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../../fss_amd", "-o", DROPIN_BIN])

@@ -15,11 +15,15 @@
 //                                             grotto_dcf.cuh:45-238: same template parameters (incl. par_depth, accepted
 //                                             and unused: the GPU expands the whole tree in parallel), public `prg`
 //                                             (and `hash_key`) members, aggregate initialisation, 32-byte `Cw`, and the
-//                                             reference's Gen / Eval / EvalAll signatures.  They are HOST functions:
-//                                             every one is computed by the engine's kernels (buffers staged through a
-//                                             context-owned pool; a device pointer is used in place).  Next to them
-//                                             are the batched device forms the engine is built for (GenBatch,
-//                                             GenLevelMajor, EvalPoints, EvalAllBlock).
+//                                             reference's Gen / Eval / EvalAll signatures.  Gen and Eval are callable
+//                                             from host and from device code like the reference's (here a __host__
+//                                             and a __device__ overload of each).  Called on the HOST they are
+//                                             computed by the engine's kernels (buffers staged through a context-owned
+//                                             pool; a device pointer is used in place).  Called from a DEVICE function
+//                                             -- one key per thread inside the caller's own kernel, the way
+//                                             samples/dpf_dcf_gpu.cu:39-80 uses them -- they run the per-thread walk of
+//                                             fss_amd_thread.hpp.  Next to them are the batched device forms the
+//                                             engine is built for (GenBatch, GenLevelMajor, EvalPoints, EvalAllBlock).
 //   fss::gpu::*RelayoutGpu / *EvalPointGpu / *EvalAllGpu[Batch]
 //                                          <- include/fss/point_eval_gpu.cuh:324-491, include/fss/eval_all_gpu.cuh:451-535:
 //                                             the reference's template-parameter order (leading `unroll`, `z, b1, bs`;
@@ -27,10 +31,12 @@
 //                                             and uint32_t `xs` for in_bits <= 32, the seed by value and no workspace
 //                                             argument; plus overloads with uint64_t tr bits and `In` points for
 //                                             in_bits > 32, where the reference's launchers stop.
-// What does not carry over: calling Gen / Eval per thread inside a user's own kernel (the reference's members are
-// __host__ __device__; src/bench_gpu.cu:85-95) -- that per-thread walk is what this engine replaces, see the batched
-// forms -- and user-defined Groupable / Prgable types, which the prebuilt kernels cannot execute: Group must be
-// Bytes or Uint, Prg must be Aes128Mmo or ChaCha (static_assert).  Errors throw fss::Error (the reference asserts).
+// User-defined Groupable / Prgable types (members __host__ __device__ and trivially copyable, as the reference
+// requires of anything passed to a kernel): the prebuilt kernels cannot execute them, so Gen / Eval / EvalAll /
+// GenBatch / EvalPoints instantiate the per-thread walk in generic kernels of this header, compiled with the caller's
+// types -- still on the GPU, one thread per key or point, not the tuned path.  The level-major forms, EvalAllBlock and
+// the fss::gpu launchers need the built-in types (static_assert).  Nothing in this header computes on the CPU.
+// Errors throw fss::Error (the reference asserts).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -47,6 +53,7 @@
 #include <utility>
 
 #include "fss_amd.h"
+#include "fss_amd_thread.hpp"
 
 // include/fss/prg.cuh:20-23
 template <typename Prg, int mul>
@@ -350,15 +357,21 @@ template <int mul>
 class Aes128Mmo {
   static_assert(mul == 1 || mul == 2 || mul == 4);
   unsigned char keys_[mul][16];
+  uint32_t rk_[mul][44];  // the expanded keys, for Gen called on the device (the engine expands its own)
+
+  __host__ __device__ void SetKey(int i, const unsigned char* key) {
+    for (int j = 0; j < 16; ++j) keys_[i][j] = key[j];
+    thread::AesExpandKey(keys_[i], rk_[i]);
+  }
 
  public:
   // ctxs: from CreateCtxs(); only read here, the caller frees them with FreeCtxs()  (aes128_mmo.cuh:40-42)
   Aes128Mmo(std::span<AesKeyCtx*, mul> ctxs) {
-    for (int i = 0; i < mul; ++i) std::memcpy(keys_[i], ctxs[i]->key, 16);
+    for (int i = 0; i < mul; ++i) SetKey(i, ctxs[i]->key);
   }
-  // the key bytes directly (no context objects to manage)
-  explicit Aes128Mmo(const unsigned char* const keys[mul]) {
-    for (int i = 0; i < mul; ++i) std::memcpy(keys_[i], keys[i], 16);
+  // the key bytes directly (no context objects to manage); also constructible inside a kernel
+  __host__ __device__ explicit Aes128Mmo(const unsigned char* const keys[mul]) {
+    for (int i = 0; i < mul; ++i) SetKey(i, keys[i]);
   }
   static std::array<AesKeyCtx*, mul> CreateCtxs(const unsigned char* keys[mul]) {
     std::array<AesKeyCtx*, mul> ctxs;
@@ -371,8 +384,16 @@ class Aes128Mmo {
   static void FreeCtxs(std::span<AesKeyCtx*, mul> ctxs) {
     for (AesKeyCtx* c : ctxs) delete c;
   }
-  // One seed through the engine (a batch of one on the GPU; fss_amd_prg_gen is the batched form).
-  std::array<int4, mul> Gen(int4 seed) const { return detail::GenOne(*this, seed); }
+  // Host: one seed through the engine (a batch of one on the GPU; fss_amd_prg_gen is the batched form).
+  // Device: computed by the calling thread (the reference's OpenSSL-backed Gen traps there, aes128_mmo.cuh:75-77).
+  __device__ std::array<int4, mul> Gen(int4 seed) const {
+    std::array<int4, mul> out;
+    for (int i = 0; i < mul; ++i) out[i] = thread::AesMmo(rk_[i], seed);
+    return out;
+  }
+  __host__ std::array<int4, mul> Gen(int4 seed) const {
+    return detail::GenOne(*this, seed);
+  }
 
   static constexpr int kMul = mul;
   void Describe(detail::Spec& s) const {
@@ -388,9 +409,15 @@ class ChaCha {
   int nonce_[2];
 
  public:
-  // nonce: two ints, read here (the reference keeps the pointer, chacha.cuh:93; a host-readable pointer is needed)
-  ChaCha(const int* nonce) : nonce_{nonce[0], nonce[1]} {}
-  std::array<int4, mul> Gen(int4 seed) const { return detail::GenOne(*this, seed); }
+  // nonce: two ints, read here (the reference keeps the pointer, chacha.cuh:93): a pointer readable on the side
+  // that constructs the object -- __constant__ / device memory inside a kernel, host memory on the host
+  __host__ __device__ ChaCha(const int* nonce) : nonce_{nonce[0], nonce[1]} {}
+  __device__ std::array<int4, mul> Gen(int4 seed) const {
+    return thread::ChaChaGen<mul, rounds>(nonce_[0], nonce_[1], seed);
+  }
+  __host__ std::array<int4, mul> Gen(int4 seed) const {
+    return detail::GenOne(*this, seed);
+  }
 
   static constexpr int kMul = mul;
   void Describe(detail::Spec& s) const {
@@ -447,12 +474,52 @@ static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Ae
 static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
 }  // namespace prg
 
+// ---------------------------------------------------------------- generic kernels for caller-defined PRG / group types
+// One thread per key (Gen) or per point (Eval) running the scheme's own device-side member; instantiated in the
+// caller's translation unit with the caller's types.  The built-in types never come here: they go to the engine.
+namespace detail {
+// scratch and uploads need no key material: any context of the current device will do
+inline fss_amd_ctx* AnyCtx() { return Engine(Spec{}); }
+
+template <typename S, typename In>
+__global__ void ThreadGenKernel(S sch, typename S::Cw* cws, const int4* s0s, const In* alphas, const int4* betas,
+                                int64_t nkeys) {
+  const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (k < nkeys) sch.Gen(cws + k * S::kSlots, s0s + 2 * k, alphas[k], betas ? betas[k] : int4{0, 0, 0, 0});
+}
+template <typename S, typename In>
+__global__ void ThreadGenOcwKernel(S sch, typename S::Cw* cws, int4* ocws, const int4* s0s, const In* alphas,
+                                   const int4* betas, int64_t nkeys) {
+  const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (k < nkeys) sch.Gen(cws + k * S::kSlots, ocws[k], s0s + 2 * k, alphas[k], betas[k]);
+}
+// xs == nullptr: the whole domain, point i = i
+template <typename S, typename In>
+__global__ void ThreadEvalKernel(S sch, bool b, const int4* s0, const typename S::Cw* cws, const In* xs, int4* ys,
+                                 int64_t n) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i < n) ys[i] = sch.Eval(b, *s0, cws, xs ? xs[i] : static_cast<In>(i));
+}
+template <typename S, typename In>
+__global__ void ThreadEvalOcwKernel(S sch, bool b, const int4* s0, const typename S::Cw* cws, const int4* ocw,
+                                    const In* xs, int4* ys, int64_t n) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i < n) ys[i] = sch.Eval(b, *s0, cws, *ocw, xs ? xs[i] : static_cast<In>(i));
+}
+template <typename K, typename... Args>
+void LaunchThreads(K kernel, int64_t n, hipStream_t stream, Args... args) {
+  if (n <= 0) return;
+  static_assert((std::is_trivially_copyable_v<Args> && ...), "scheme, PRG and group objects are passed to kernels by "
+                                                              "value: they must be trivially copyable");
+  hipLaunchKernelGGL(kernel, dim3(static_cast<unsigned>((n + 127) / 128)), dim3(128), 0, stream, args...);
+  CheckHip(hipGetLastError(), "generic per-thread kernel");
+}
+}  // namespace detail
+
 // ---------------------------------------------------------------- DPF (include/fss/dpf.cuh:61-303)
 template <int in_bits, typename Group, typename Prg, typename In = uint32_t, int par_depth = -1>
   requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 2>)
 class Dpf {
-  static_assert(detail::EngineGroup<Group>, "Group must be fss::group::Bytes or fss::group::Uint<T, mod>");
-
  public:
   Prg prg;
   struct alignas(32) Cw {  // dpf.cuh:76-81
@@ -461,13 +528,25 @@ class Dpf {
   };
   static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits + 1;
-  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod); }
+  // built-in PRG and group: the engine's kernels; anything else: the generic per-thread kernels of this header
+  static constexpr bool kEngine = detail::EnginePrg<Prg> && detail::EngineGroup<Group>;
+  fss_amd_ctx* handle() const {
+    static_assert(kEngine, "this form needs fss::prg::Aes128Mmo / ChaCha and fss::group::Bytes / Uint<T, mod>");
+    return detail::CtxOf(prg, Group::kMod);
+  }
+  fss_amd_ctx* StageCtx() const {
+    if constexpr (kEngine) return handle();
+    else return detail::AnyCtx();
+  }
 
-  // ---- the reference's signatures; buffers on the host (or the device), computed on the GPU, synchronous
+  // ---- the reference's signatures.  Host: buffers on the host (or the device), computed on the GPU, synchronous.
+  // Device: the calling thread walks the key itself (fss_amd_thread.hpp).
   // dpf.cuh:93: cws[in_bits + 1] out; s0s: the two party seeds; a: alpha; b_buf: beta (clamped)
-  void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {
-    fss_amd_ctx* ctx = handle();
-    detail::Stage st(ctx, 32 + 32 + 32 + sizeof(Cw) * kSlots);
+  __device__ void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {
+    thread::DpfGen<in_bits, Group, In>(prg, reinterpret_cast<int4*>(cws), s0s, a, b_buf);
+  }
+  __host__ void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {
+    detail::Stage st(StageCtx(), 32 + 32 + 32 + sizeof(Cw) * kSlots);
     const int4* d_s0s = st.Load(s0s, 2);
     const In* d_a = st.Value(a);
     const int4* d_b = st.Value(b_buf);
@@ -476,9 +555,11 @@ class Dpf {
     st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
   }
   // dpf.cuh:170: party b's share of f(x)
-  int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {
-    fss_amd_ctx* ctx = handle();
-    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + 32);
+  __device__ int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {
+    return thread::DpfEval<in_bits, Group, In>(prg, b, s0, reinterpret_cast<const int4*>(cws), x);
+  }
+  __host__ int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 32 + 32);
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     const In* d_x = st.Value(x);
@@ -491,15 +572,17 @@ class Dpf {
   // dpf.cuh:232: ys[x] = Eval(b, s0, cws, x) for every x of the domain, in index order
   void EvalAll(bool b, int4 s0, const Cw cws[], int4 ys[]) const {
     static_assert(in_bits <= 40, "a full-domain output of 2^in_bits int4s");
-    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
-    fss_amd_ctx* ctx = handle();
+    const size_t n = size_t(1) << in_bits;
+    size_t ws = 0;
+    if constexpr (kEngine) ws = EvalAllWorkspace();
     const bool direct = detail::OnDevice(ys);
-    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     void* d_ws = st.Take(ws);
     int4* d_ys = st.Out(ys, n);
-    EvalAllBlock(b, d_s0, d_cws, d_ys, d_ws, ws);
+    if constexpr (kEngine) EvalAllBlock(b, d_s0, d_cws, d_ys, d_ws, ws);
+    else EvalPoints(b, d_s0, d_cws, nullptr, d_ys, static_cast<int64_t>(n));  // one thread per leaf
     st.Back(ys, static_cast<const int4*>(d_ys), n);
   }
 
@@ -507,8 +590,12 @@ class Dpf {
   // nkeys keys at once, one per GPU lane: s0s[2k], s0s[2k+1] the party seeds of key k; cws key-major, kSlots per key.
   void GenBatch(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
                 hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
-                          stream), "fss_amd_dpf_gen");
+    if constexpr (kEngine)
+      Check(fss_amd_dpf_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
+                            stream), "fss_amd_dpf_gen");
+    else
+      detail::LaunchThreads(detail::ThreadGenKernel<Dpf, In>, nkeys, stream, *this, d_cws, d_s0s, d_alphas, d_betas,
+                            nkeys);
   }
   // The same keys written level-major (what gpu::DpfRelayoutGpu would make of d_cws), no intermediate.
   void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* out_cw, const int4* d_s0s, const In* d_alphas,
@@ -519,8 +606,11 @@ class Dpf {
   // ys[i] = Eval(b, *d_s0, d_cws, xs[i]): one key, a whole batch of points
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
-    Check(fss_amd_dpf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n, d_ys,
-                                  stream), "fss_amd_dpf_eval_points");
+    if constexpr (kEngine)
+      Check(fss_amd_dpf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n, d_ys,
+                                    stream), "fss_amd_dpf_eval_points");
+    else
+      detail::LaunchThreads(detail::ThreadEvalKernel<Dpf, In>, n, stream, *this, b, d_s0, d_cws, d_xs, d_ys, n);
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_DPF, in_bits, nleaves);
@@ -538,8 +628,6 @@ template <int in_bits, typename Group, typename Prg, typename In = uint32_t, Dcf
           int par_depth = -1>
   requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 4>)
 class Dcf {
-  static_assert(detail::EngineGroup<Group>, "Group must be fss::group::Bytes or fss::group::Uint<T, mod>");
-
  public:
   Prg prg;
   struct alignas(32) Cw {  // dcf.cuh:91-96
@@ -548,11 +636,21 @@ class Dcf {
   };
   static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits + 1;
-  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod); }
+  static constexpr bool kEngine = detail::EnginePrg<Prg> && detail::EngineGroup<Group>;
+  fss_amd_ctx* handle() const {
+    static_assert(kEngine, "this form needs fss::prg::Aes128Mmo / ChaCha and fss::group::Bytes / Uint<T, mod>");
+    return detail::CtxOf(prg, Group::kMod);
+  }
+  fss_amd_ctx* StageCtx() const {
+    if constexpr (kEngine) return handle();
+    else return detail::AnyCtx();
+  }
 
-  void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {  // dcf.cuh:108
-    fss_amd_ctx* ctx = handle();
-    detail::Stage st(ctx, 32 + 32 + 32 + sizeof(Cw) * kSlots);
+  __device__ void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {  // dcf.cuh:108
+    thread::DcfGen<in_bits, Group, In, pred == DcfPred::kGt>(prg, reinterpret_cast<int4*>(cws), s0s, a, b_buf);
+  }
+  __host__ void Gen(Cw cws[], const int4 s0s[2], In a, int4 b_buf) const {
+    detail::Stage st(StageCtx(), 32 + 32 + 32 + sizeof(Cw) * kSlots);
     const int4* d_s0s = st.Load(s0s, 2);
     const In* d_a = st.Value(a);
     const int4* d_b = st.Value(b_buf);
@@ -560,9 +658,11 @@ class Dcf {
     GenBatch(d_cws, d_s0s, d_a, d_b, 1);
     st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
   }
-  int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {  // dcf.cuh:205
-    fss_amd_ctx* ctx = handle();
-    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + 32);
+  __device__ int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {  // dcf.cuh:205
+    return thread::DcfEval<in_bits, Group, In>(prg, b, s0, reinterpret_cast<const int4*>(cws), x);
+  }
+  __host__ int4 Eval(bool b, int4 s0, const Cw cws[], In x) const {
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 32 + 32);
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     const In* d_x = st.Value(x);
@@ -574,22 +674,28 @@ class Dcf {
   }
   void EvalAll(bool b, int4 s0, const Cw cws[], int4 ys[]) const {  // dcf.cuh:294
     static_assert(in_bits <= 40, "a full-domain output of 2^in_bits int4s");
-    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
-    fss_amd_ctx* ctx = handle();
+    const size_t n = size_t(1) << in_bits;
+    size_t ws = 0;
+    if constexpr (kEngine) ws = EvalAllWorkspace();
     const bool direct = detail::OnDevice(ys);
-    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     void* d_ws = st.Take(ws);
     int4* d_ys = st.Out(ys, n);
-    EvalAllBlock(b, d_s0, d_cws, d_ys, d_ws, ws);
+    if constexpr (kEngine) EvalAllBlock(b, d_s0, d_cws, d_ys, d_ws, ws);
+    else EvalPoints(b, d_s0, d_cws, nullptr, d_ys, static_cast<int64_t>(n));  // one thread per leaf
     st.Back(ys, static_cast<const int4*>(d_ys), n);
   }
 
   void GenBatch(Cw* d_cws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
                 hipStream_t stream = 0) const {
-    Check(fss_amd_dcf_gen(handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys,
-                          d_cws, stream), "fss_amd_dcf_gen");
+    if constexpr (kEngine)
+      Check(fss_amd_dcf_gen(handle(), in_bits, Group::kId, (int)pred, d_s0s, d_alphas, detail::XBytes<In>(), d_betas,
+                            nkeys, d_cws, stream), "fss_amd_dcf_gen");
+    else
+      detail::LaunchThreads(detail::ThreadGenKernel<Dcf, In>, nkeys, stream, *this, d_cws, d_s0s, d_alphas, d_betas,
+                            nkeys);
   }
   void GenLevelMajor(int4* cw_s, int4* cw_v, int4* out_cw, const int4* d_s0s, const In* d_alphas, const int4* d_betas,
                      int64_t nkeys, hipStream_t stream = 0) const {
@@ -598,8 +704,11 @@ class Dcf {
   }
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
-    Check(fss_amd_dcf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n, d_ys,
-                                  stream), "fss_amd_dcf_eval_points");
+    if constexpr (kEngine)
+      Check(fss_amd_dcf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_xs, detail::XBytes<In>(), n, d_ys,
+                                    stream), "fss_amd_dcf_eval_points");
+    else
+      detail::LaunchThreads(detail::ThreadEvalKernel<Dcf, In>, n, stream, *this, b, d_s0, d_cws, d_xs, d_ys, n);
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_DCF, in_bits, nleaves);
@@ -615,8 +724,6 @@ class Dcf {
 template <int in_bits, typename Group, typename Prg, typename In = uint32_t, int par_depth = -1>
   requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 1>)
 class HalfTreeDpf {
-  static_assert(detail::EngineGroup<Group>, "Group must be fss::group::Bytes or fss::group::Uint<T, mod>");
-
  public:
   Prg prg;
   int4 hash_key;           // half_tree_dpf.cuh:45
@@ -626,11 +733,21 @@ class HalfTreeDpf {
   };
   static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits;
-  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod, &hash_key); }
+  static constexpr bool kEngine = detail::EnginePrg<Prg> && detail::EngineGroup<Group>;
+  fss_amd_ctx* handle() const {
+    static_assert(kEngine, "this form needs fss::prg::Aes128Mmo / ChaCha and fss::group::Bytes / Uint<T, mod>");
+    return detail::CtxOf(prg, Group::kMod, &hash_key);
+  }
+  fss_amd_ctx* StageCtx() const {
+    if constexpr (kEngine) return handle();
+    else return detail::AnyCtx();
+  }
 
-  void Gen(Cw cws[], int4& ocw, const int4 s0s[2], In a, int4 b_buf) const {  // half_tree_dpf.cuh:68
-    fss_amd_ctx* ctx = handle();
-    detail::Stage st(ctx, 32 + 32 + 32 + sizeof(Cw) * kSlots + 32);
+  __device__ void Gen(Cw cws[], int4& ocw, const int4 s0s[2], In a, int4 b_buf) const {  // half_tree_dpf.cuh:68
+    thread::HtGen<in_bits, Group, In>(prg, hash_key, reinterpret_cast<int4*>(cws), ocw, s0s, a, b_buf);
+  }
+  __host__ void Gen(Cw cws[], int4& ocw, const int4 s0s[2], In a, int4 b_buf) const {
+    detail::Stage st(StageCtx(), 32 + 32 + 32 + sizeof(Cw) * kSlots + 32);
     const int4* d_s0s = st.Load(s0s, 2);
     const In* d_a = st.Value(a);
     const int4* d_b = st.Value(b_buf);
@@ -640,9 +757,11 @@ class HalfTreeDpf {
     st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
     st.Back(&ocw, static_cast<const int4*>(d_ocw), 1);
   }
-  int4 Eval(bool b, int4 s0, const Cw cws[], int4 ocw, In x) const {  // half_tree_dpf.cuh:187
-    fss_amd_ctx* ctx = handle();
-    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + 32 + 32);
+  __device__ int4 Eval(bool b, int4 s0, const Cw cws[], int4 ocw, In x) const {  // half_tree_dpf.cuh:187
+    return thread::HtEval<in_bits, Group, In>(prg, hash_key, b, s0, reinterpret_cast<const int4*>(cws), ocw, x);
+  }
+  __host__ int4 Eval(bool b, int4 s0, const Cw cws[], int4 ocw, In x) const {
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 32 + 32 + 32);
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     const int4* d_ocw = st.Value(ocw);
@@ -655,23 +774,29 @@ class HalfTreeDpf {
   }
   void EvalAll(bool b, int4 s0, const Cw cws[], int4 ocw, int4 ys[]) const {  // half_tree_dpf.cuh:246
     static_assert(in_bits <= 40, "a full-domain output of 2^in_bits int4s");
-    const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
-    fss_amd_ctx* ctx = handle();
+    const size_t n = size_t(1) << in_bits;
+    size_t ws = 0;
+    if constexpr (kEngine) ws = EvalAllWorkspace();
     const bool direct = detail::OnDevice(ys);
-    detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + 32 + ws + 32 + (direct ? 0 : n * sizeof(int4)));
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 32 + ws + 32 + (direct ? 0 : n * sizeof(int4)));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     const int4* d_ocw = st.Value(ocw);
     void* d_ws = st.Take(ws);
     int4* d_ys = st.Out(ys, n);
-    EvalAllBlock(b, d_s0, d_cws, d_ocw, d_ys, d_ws, ws);
+    if constexpr (kEngine) EvalAllBlock(b, d_s0, d_cws, d_ocw, d_ys, d_ws, ws);
+    else EvalPoints(b, d_s0, d_cws, d_ocw, nullptr, d_ys, static_cast<int64_t>(n));  // one thread per leaf
     st.Back(ys, static_cast<const int4*>(d_ys), n);
   }
 
   void GenBatch(Cw* d_cws, int4* d_ocws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
                 hipStream_t stream = 0) const {
-    Check(fss_amd_ht_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
-                         d_ocws, stream), "fss_amd_ht_gen");
+    if constexpr (kEngine)
+      Check(fss_amd_ht_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
+                           d_ocws, stream), "fss_amd_ht_gen");
+    else
+      detail::LaunchThreads(detail::ThreadGenOcwKernel<HalfTreeDpf, In>, nkeys, stream, *this, d_cws, d_ocws, d_s0s,
+                            d_alphas, d_betas, nkeys);
   }
   void GenLevelMajor(int4* cw_s, uint32_t* extra, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
                      const int4* d_betas, int64_t nkeys, hipStream_t stream = 0) const {
@@ -680,8 +805,12 @@ class HalfTreeDpf {
   }
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, const In* d_xs, int4* d_ys, int64_t n,
                   hipStream_t stream = 0) const {
-    Check(fss_amd_ht_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, d_xs, detail::XBytes<In>(), n,
-                                 d_ys, stream), "fss_amd_ht_eval_points");
+    if constexpr (kEngine)
+      Check(fss_amd_ht_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_ocw, d_xs, detail::XBytes<In>(), n,
+                                   d_ys, stream), "fss_amd_ht_eval_points");
+    else
+      detail::LaunchThreads(detail::ThreadEvalOcwKernel<HalfTreeDpf, In>, n, stream, *this, b, d_s0, d_cws, d_ocw, d_xs,
+                            d_ys, n);
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_HT, in_bits, nleaves);
@@ -706,10 +835,16 @@ class GrottoDcf {
   using Cw = typename DpfType::Cw;
   Prg prg;
   static constexpr int kSlots = in_bits + 1;
-  fss_amd_ctx* handle() const { return detail::CtxOf(prg); }
+  static constexpr bool kEngine = detail::EnginePrg<Prg>;
+  fss_amd_ctx* handle() const {
+    static_assert(kEngine, "the parity table, EvalAll and the batched forms need fss::prg::Aes128Mmo / ChaCha");
+    return detail::CtxOf(prg);
+  }
 
   // grotto_dcf.cuh:63-67
-  void Gen(Cw cws[], const int4 s0s[2], In a) const { DpfType{prg}.Gen(cws, s0s, a, int4{0, 0, 0, 0}); }
+  __host__ __device__ void Gen(Cw cws[], const int4 s0s[2], In a) const {
+    DpfType{prg}.Gen(cws, s0s, a, int4{0, 0, 0, 0});
+  }
 
   // grotto_dcf.cuh:76-84: p = 2N-1 bools, level order (root p[0], leaf x at p[x + N - 1]); b = the party
   struct ParityTree {
@@ -868,8 +1003,7 @@ class Vdpf {
 // cudaPeekAtLastError.
 namespace gpu {
 namespace detail_gpu {
-// relayout needs no key material: any context of the current device will do
-inline fss_amd_ctx* AnyCtx() { return detail::Engine(detail::Spec{}); }
+using detail::AnyCtx;  // relayout needs no key material
 }  // namespace detail_gpu
 
 // point_eval_gpu.cuh:324-331

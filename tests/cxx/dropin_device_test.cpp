@@ -1,0 +1,683 @@
+// Drop-in check of the DEVICE side of include/fss_amd.hpp: Gen / Eval called per thread from inside the caller's own
+// kernels, the way myl7/fss's GPU sample and benches call them (samples/dpf_dcf_gpu.cu:39-80: `DpfPrg prg(kNonce);
+// Dpf dpf{prg}; dpf.Gen(cws + tid * (kInBits + 1), s, alphas[tid], betas[tid]);` and `ys[tid] = dpf.Eval(party,
+// seeds[tid], cws + tid * (kInBits + 1), xs[tid]);`; src/bench_gpu.cu:85-95).
+//   part 1  ChaCha, the sample's flow: 1024 keys generated and evaluated one per thread; reconstructed, and compared
+//           bit for bit with the engine's batched forms on the same inputs (GenBatch, RelayoutGpu + EvalPointGpu);
+//   part 2  AES-128-MMO on the device (the reference's OpenSSL PRG traps there): scheme objects passed to kernels by
+//           value and a PRG constructed inside the kernel from key bytes in __constant__ memory, against the
+//           reference's known answers (DPF n=8 Bytes, DCF n=8, DPF n=32 Uint<u64>, Half-Tree n=64) and
+//           against the engine on random DCF (kGt) and Half-Tree n=64 batches;
+//   part 3  a caller-defined Prgable and Groupable: per thread in a kernel, and through the host signatures
+//           (Gen / Eval / EvalAll / GenBatch / EvalPoints -> the generic per-thread kernels), reconstructed.
+// Exit code 0 and a final "OK" line on success.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "fss_amd.hpp"
+
+#define HIP_OK(e)                                                                                        \
+  do {                                                                                                   \
+    hipError_t r_ = (e);                                                                                 \
+    if (r_ != hipSuccess) {                                                                              \
+      std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(r_), __FILE__, __LINE__);        \
+      std::exit(2);                                                                                      \
+    }                                                                                                    \
+  } while (0)
+
+static int g_fail = 0;
+#define EXPECT(cond)                                                          \
+  do {                                                                        \
+    if (!(cond)) {                                                            \
+      ++g_fail;                                                               \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);  \
+    }                                                                         \
+  } while (0)
+
+static bool Same(int4 a, int4 b) { return std::memcmp(&a, &b, sizeof a) == 0; }
+static int4 I4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return int4{(int)x, (int)y, (int)z, (int)w}; }
+template <typename G>
+static int4 Recon(int4 y0, int4 y1) {
+  return (G::From(y0) + G::From(y1)).Into();
+}
+static const int4 kZero = {0, 0, 0, 0};
+
+template <typename T>
+static T* ToDevice(const T* host, size_t n) {
+  T* dev;
+  HIP_OK(hipMalloc(&dev, sizeof(T) * n));
+  HIP_OK(hipMemcpy(dev, host, sizeof(T) * n, hipMemcpyHostToDevice));
+  return dev;
+}
+template <typename T>
+static T* DeviceBuf(size_t n) {
+  T* dev;
+  HIP_OK(hipMalloc(&dev, sizeof(T) * n));
+  HIP_OK(hipMemset(dev, 0, sizeof(T) * n));
+  return dev;
+}
+template <typename T>
+static std::vector<T> ToHost(const T* dev, size_t n) {
+  std::vector<T> h(n);
+  HIP_OK(hipMemcpy(h.data(), dev, sizeof(T) * n, hipMemcpyDeviceToHost));
+  return h;
+}
+static uint64_t g_rng = 0x5EED0000u + 77;
+static uint64_t Next() {  // SplitMix64
+  uint64_t z = (g_rng += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+static int4 RandSeed() { return int4{(int)Next(), (int)Next(), (int)Next(), (int)(Next() & ~1ull)}; }
+
+// ---------------------------------------------------------------------------------------------- part 1: ChaCha
+namespace p1 {
+constexpr int kN = 1024;
+constexpr int kInBits = 8;
+constexpr int kThreadsPerBlock = 256;
+using In = uint8_t;
+using Group = fss::group::Bytes;
+using DpfPrg = fss::prg::ChaCha<2>;
+using DcfPrg = fss::prg::ChaCha<4>;
+using Dpf = fss::Dpf<kInBits, Group, DpfPrg, In>;
+using Dcf = fss::Dcf<kInBits, Group, DcfPrg, In>;
+
+__constant__ int kNonce[2] = {0x12345678, static_cast<int>(0x9abcdef0u)};
+static const int kHostNonce[2] = {0x12345678, static_cast<int>(0x9abcdef0u)};
+
+__global__ void DpfGenKernel(Dpf::Cw* cws, const int4* seeds, const In* alphas, const int4* betas) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= kN) return;
+  DpfPrg prg(kNonce);
+  Dpf dpf{prg};
+  int4 s[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  dpf.Gen(cws + tid * (kInBits + 1), s, alphas[tid], betas[tid]);
+}
+__global__ void DpfEvalKernel(int4* ys, bool party, const int4* seeds, const Dpf::Cw* cws, const In* xs) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= kN) return;
+  DpfPrg prg(kNonce);
+  Dpf dpf{prg};
+  ys[tid] = dpf.Eval(party, seeds[tid], cws + tid * (kInBits + 1), xs[tid]);
+}
+__global__ void DcfGenKernel(Dcf::Cw* cws, const int4* seeds, const In* alphas, const int4* betas) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= kN) return;
+  DcfPrg prg(kNonce);
+  Dcf dcf{prg};
+  int4 s[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  dcf.Gen(cws + tid * (kInBits + 1), s, alphas[tid], betas[tid]);
+}
+__global__ void DcfEvalKernel(int4* ys, bool party, const int4* seeds, const Dcf::Cw* cws, const In* xs) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= kN) return;
+  DcfPrg prg(kNonce);
+  Dcf dcf{prg};
+  ys[tid] = dcf.Eval(party, seeds[tid], cws + tid * (kInBits + 1), xs[tid]);
+}
+
+struct Inputs {
+  std::vector<int4> seeds, seeds0, seeds1, betas;
+  std::vector<In> alphas, xs;
+  Inputs() : seeds(2 * kN), seeds0(kN), seeds1(kN), betas(kN), alphas(kN), xs(kN) {
+    for (int i = 0; i < kN; ++i) {
+      seeds0[i] = seeds[2 * i] = RandSeed();
+      seeds1[i] = seeds[2 * i + 1] = RandSeed();
+      alphas[i] = static_cast<In>(Next());
+      betas[i] = RandSeed();
+      xs[i] = i % 2 == 0 ? alphas[i] : static_cast<In>(Next());  // at alpha for even keys, random for odd ones
+    }
+  }
+};
+
+static void Run() {
+  const int before = g_fail;
+  Inputs in;
+  int4* d_seeds = ToDevice(in.seeds.data(), 2 * kN);
+  int4* d_seeds0 = ToDevice(in.seeds0.data(), kN);
+  int4* d_seeds1 = ToDevice(in.seeds1.data(), kN);
+  In* d_alphas = ToDevice(in.alphas.data(), kN);
+  int4* d_betas = ToDevice(in.betas.data(), kN);
+  In* d_xs = ToDevice(in.xs.data(), kN);
+  int4* d_ys0 = DeviceBuf<int4>(kN);
+  int4* d_ys1 = DeviceBuf<int4>(kN);
+  const int blocks = (kN + kThreadsPerBlock - 1) / kThreadsPerBlock;
+  std::vector<uint32_t> xs32(in.xs.begin(), in.xs.end());  // the launchers take uint32_t points
+  uint32_t* d_xs32 = ToDevice(xs32.data(), kN);
+  int4* d_cw_s = DeviceBuf<int4>(size_t(kInBits) * kN);
+  int4* d_cw_v = DeviceBuf<int4>(size_t(kInBits) * kN);
+  uint32_t* d_extra = DeviceBuf<uint32_t>(kN);
+  int4* d_out_cw = DeviceBuf<int4>(kN);
+  int4* d_ys_engine = DeviceBuf<int4>(kN);
+
+  {  // DPF
+    Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(size_t(kInBits + 1) * kN);
+    DpfGenKernel<<<blocks, kThreadsPerBlock>>>(d_cws, d_seeds, d_alphas, d_betas);
+    HIP_OK(hipGetLastError());
+    DpfEvalKernel<<<blocks, kThreadsPerBlock>>>(d_ys0, false, d_seeds0, d_cws, d_xs);
+    DpfEvalKernel<<<blocks, kThreadsPerBlock>>>(d_ys1, true, d_seeds1, d_cws, d_xs);
+    HIP_OK(hipDeviceSynchronize());
+    auto ys0 = ToHost(d_ys0, kN), ys1 = ToHost(d_ys1, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) {
+      int4 want = in.xs[i] == in.alphas[i] ? in.betas[i] : kZero;
+      if (!Same(Recon<Group>(ys0[i], ys1[i]), want)) ++bad;
+    }
+    EXPECT(bad == 0);
+    // the engine on the same inputs: keys, then the level-major launchers
+    DpfPrg prg(kHostNonce);
+    Dpf dpf{prg};
+    Dpf::Cw* d_cws_engine = DeviceBuf<Dpf::Cw>(size_t(kInBits + 1) * kN);
+    dpf.GenBatch(d_cws_engine, d_seeds, d_alphas, d_betas, kN);
+    auto a = ToHost(d_cws, size_t(kInBits + 1) * kN), e = ToHost(d_cws_engine, size_t(kInBits + 1) * kN);
+    bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+      const bool last = i % (kInBits + 1) == kInBits;
+      if (!Same(a[i].s, e[i].s) || (!last && a[i].tr != e[i].tr)) ++bad;
+    }
+    EXPECT(bad == 0);
+    fss::gpu::DpfRelayoutGpu<kInBits, Group, DpfPrg, In>(d_cws, kN, d_cw_s, d_extra, d_out_cw);
+    fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, d_cw_s, d_extra, d_out_cw, d_xs32, d_ys_engine, kN, dpf);
+    HIP_OK(hipDeviceSynchronize());
+    auto ye = ToHost(d_ys_engine, kN);
+    bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys0[i]);
+    EXPECT(bad == 0);
+    HIP_OK(hipFree(d_cws));
+    HIP_OK(hipFree(d_cws_engine));
+  }
+  {  // DCF
+    Dcf::Cw* d_cws = DeviceBuf<Dcf::Cw>(size_t(kInBits + 1) * kN);
+    DcfGenKernel<<<blocks, kThreadsPerBlock>>>(d_cws, d_seeds, d_alphas, d_betas);
+    HIP_OK(hipGetLastError());
+    DcfEvalKernel<<<blocks, kThreadsPerBlock>>>(d_ys0, false, d_seeds0, d_cws, d_xs);
+    DcfEvalKernel<<<blocks, kThreadsPerBlock>>>(d_ys1, true, d_seeds1, d_cws, d_xs);
+    HIP_OK(hipDeviceSynchronize());
+    auto ys0 = ToHost(d_ys0, kN), ys1 = ToHost(d_ys1, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) {
+      int4 want = in.xs[i] < in.alphas[i] ? in.betas[i] : kZero;
+      if (!Same(Recon<Group>(ys0[i], ys1[i]), want)) ++bad;
+    }
+    EXPECT(bad == 0);
+    DcfPrg prg(kHostNonce);
+    Dcf dcf{prg};
+    Dcf::Cw* d_cws_engine = DeviceBuf<Dcf::Cw>(size_t(kInBits + 1) * kN);
+    dcf.GenBatch(d_cws_engine, d_seeds, d_alphas, d_betas, kN);
+    auto a = ToHost(d_cws, size_t(kInBits + 1) * kN), e = ToHost(d_cws_engine, size_t(kInBits + 1) * kN);
+    bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) bad += !Same(a[i].s, e[i].s) || !Same(a[i].v, e[i].v);
+    EXPECT(bad == 0);
+    fss::gpu::DcfRelayoutGpu<kInBits, Group, DcfPrg, In>(d_cws, kN, d_cw_s, d_cw_v, d_out_cw);
+    fss::gpu::DcfEvalPointGpu<4>(true, d_seeds1, d_cw_s, d_cw_v, d_out_cw, d_xs32, d_ys_engine, kN, dcf);
+    HIP_OK(hipDeviceSynchronize());
+    auto ye = ToHost(d_ys_engine, kN);
+    bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys1[i]);
+    EXPECT(bad == 0);
+    HIP_OK(hipFree(d_cws));
+    HIP_OK(hipFree(d_cws_engine));
+  }
+  std::printf("ChaCha  n=8  Bytes   per-thread Gen/Eval in caller kernels (1024 keys) == engine, reconstructs: %s\n",
+              g_fail == before ? "ok" : "FAILED");
+}
+}  // namespace p1
+
+// ---------------------------------------------------------------------------------------------- part 2: AES-128-MMO
+namespace p2 {
+static unsigned char k0[16] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static unsigned char k1[16] = {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1};
+static unsigned char k2[16] = {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8};
+static unsigned char k3[16] = {8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1};
+__constant__ unsigned char kDevKeys[2][16] = {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16},
+                                              {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1}};
+static const int4 kSeeds[2] = {{0x11111111, 0x22222222, 0x33333333, 0x44444440},
+                               {0x55555555, 0x66666666, 0x77777777, static_cast<int>(0x88888880u)}};
+
+// one key, generated and evaluated by thread 0 with the scheme object handed over by value
+template <typename S, typename In>
+__global__ void GenEvalKernel(S sch, typename S::Cw* cws, const int4* s0s, In alpha, int4 beta, const In* xs, int nx,
+                              int4* ys /* [2][nx] */) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  sch.Gen(cws, s0s, alpha, beta);
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < nx; ++i) ys[b * nx + i] = sch.Eval(b, s0s[b], cws, xs[i]);
+}
+template <typename S, typename In>
+__global__ void HtGenEvalKernel(S sch, typename S::Cw* cws, int4* ocw, const int4* s0s, In alpha, int4 beta, const In* xs,
+                                int nx, int4* ys) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  sch.Gen(cws, *ocw, s0s, alpha, beta);
+  for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < nx; ++i) ys[b * nx + i] = sch.Eval(b, s0s[b], cws, *ocw, xs[i]);
+}
+// the PRG built inside the kernel from key bytes in constant memory
+using Dpf8 = fss::Dpf<8, fss::group::Bytes, fss::prg::Aes128Mmo<2>, uint8_t>;
+__global__ void InKernelPrgKernel(int4* prg_out, int4* y, const int4* s0s, const Dpf8::Cw* cws) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const unsigned char* keys[2] = {kDevKeys[0], kDevKeys[1]};
+  fss::prg::Aes128Mmo<2> prg(keys);
+  auto out = prg.Gen(s0s[0]);
+  prg_out[0] = out[0];
+  prg_out[1] = out[1];
+  Dpf8 dpf{prg};
+  *y = dpf.Eval(false, s0s[0], cws, static_cast<uint8_t>(42));
+}
+
+static void Kats() {
+  const int before = g_fail;
+  int4* d_s0s = ToDevice(kSeeds, 2);
+  {  // C1: Dpf<8, Bytes, Aes128Mmo<2>, uint8_t>, alpha 42, beta {7,0,0,0}
+    const unsigned char* keys[2] = {k0, k1};
+    auto ctxs = fss::prg::Aes128Mmo<2>::CreateCtxs(keys);
+    fss::prg::Aes128Mmo<2> prg(ctxs);
+    Dpf8 dpf{prg};
+    const uint8_t xs[2] = {42, 100};
+    uint8_t* d_xs = ToDevice(xs, 2);
+    Dpf8::Cw* d_cws = DeviceBuf<Dpf8::Cw>(9);
+    int4* d_ys = DeviceBuf<int4>(4);
+    GenEvalKernel<Dpf8, uint8_t><<<1, 64>>>(dpf, d_cws, d_s0s, uint8_t(42), int4{7, 0, 0, 0}, d_xs, 2, d_ys);
+    HIP_OK(hipDeviceSynchronize());
+    auto cws = ToHost(d_cws, 9);
+    auto ys = ToHost(d_ys, 4);
+    EXPECT(Same(cws[0].s, I4(0x84863059, 0xb57c0062, 0xc0a8015f, 0x3520c9e8)) && cws[0].tr == true);
+    EXPECT(Same(cws[8].s, I4(0x0b17cf59, 0xcd54e225, 0xef2cd79f, 0x30ad9cf8)));
+    EXPECT(Same(ys[0], I4(0xa81892ad, 0xad2e583e, 0x272d1483, 0xd2bfa094)));
+    EXPECT(Same(ys[2], I4(0xa81892aa, 0xad2e583e, 0x272d1483, 0xd2bfa094)));
+    EXPECT(Same(ys[1], I4(0x7e2be32f, 0x4508eb0c, 0x537f8e89, 0x39b1bd96)));
+    // the host-side (engine) members on the key the device thread generated, and the other way round
+    Dpf8::Cw hcws[9];
+    int4 seeds[2] = {kSeeds[0], kSeeds[1]};
+    dpf.Gen(hcws, seeds, uint8_t(42), int4{7, 0, 0, 0});
+    int bad = 0;
+    for (int i = 0; i < 9; ++i) bad += !Same(hcws[i].s, cws[i].s) || (i < 8 && hcws[i].tr != cws[i].tr);
+    EXPECT(bad == 0);
+    EXPECT(Same(dpf.Eval(false, kSeeds[0], cws.data(), uint8_t(100)), ys[1]));
+    // PRG constructed inside a kernel
+    int4* d_prg = DeviceBuf<int4>(2);
+    int4* d_y = DeviceBuf<int4>(1);
+    InKernelPrgKernel<<<1, 64>>>(d_prg, d_y, d_s0s, d_cws);
+    HIP_OK(hipDeviceSynchronize());
+    auto po = ToHost(d_prg, 2);
+    EXPECT(Same(po[0], I4(0x1423e6d2, 0x60533602, 0x813b3fbc, 0x412b31dc)));
+    EXPECT(Same(po[1], I4(0x2d18cbe7, 0xa5eddcc9, 0xc691e4f6, 0x97831704)));
+    EXPECT(Same(ToHost(d_y, 1)[0], ys[0]));
+    fss::prg::Aes128Mmo<2>::FreeCtxs(ctxs);
+  }
+  {  // Dcf<8, Bytes, Aes128Mmo<4>, uint8_t, kLt>
+    using Dcf = fss::Dcf<8, fss::group::Bytes, fss::prg::Aes128Mmo<4>, uint8_t>;
+    const unsigned char* keys[4] = {k0, k1, k2, k3};
+    fss::prg::Aes128Mmo<4> prg(keys);
+    Dcf dcf{prg};
+    const uint8_t xs[1] = {10};
+    uint8_t* d_xs = ToDevice(xs, 1);
+    Dcf::Cw* d_cws = DeviceBuf<Dcf::Cw>(9);
+    int4* d_ys = DeviceBuf<int4>(2);
+    GenEvalKernel<Dcf, uint8_t><<<1, 64>>>(dcf, d_cws, d_s0s, uint8_t(42), int4{7, 0, 0, 0}, d_xs, 1, d_ys);
+    HIP_OK(hipDeviceSynchronize());
+    auto cws = ToHost(d_cws, 9);
+    auto ys = ToHost(d_ys, 2);
+    EXPECT(Same(cws[0].s, I4(0x79f28305, 0x7b1a2718, 0xc9874166, 0xfe3afd02)));
+    EXPECT(Same(cws[0].v, I4(0x0b706acf, 0xe72e35b7, 0x1984be09, 0x3d5a09d1)));
+    EXPECT(Same(ys[0], I4(0x3a28e8cb, 0x5f11990b, 0xf2fee90f, 0xa7604478)));
+    EXPECT(Same(ys[1], I4(0x3a28e8cc, 0x5f11990b, 0xf2fee90f, 0xa7604478)));
+  }
+  {  // Dpf<32, Uint<u64>, Aes128Mmo<2>, uint32_t>, alpha 0x12345678
+    using Dpf = fss::Dpf<32, fss::group::Uint<uint64_t>, fss::prg::Aes128Mmo<2>, uint32_t>;
+    const unsigned char* keys[2] = {k0, k1};
+    fss::prg::Aes128Mmo<2> prg(keys);
+    Dpf dpf{prg};
+    const uint32_t xs[2] = {0x12345678u, 0xdeadbeefu};
+    uint32_t* d_xs = ToDevice(xs, 2);
+    Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(33);
+    int4* d_ys = DeviceBuf<int4>(4);
+    GenEvalKernel<Dpf, uint32_t><<<1, 64>>>(dpf, d_cws, d_s0s, 0x12345678u, int4{7, 0, 0, 0}, d_xs, 2, d_ys);
+    HIP_OK(hipDeviceSynchronize());
+    auto cws = ToHost(d_cws, 33);
+    auto ys = ToHost(d_ys, 4);
+    EXPECT(Same(cws[32].s, I4(0xd316e94a, 0x28e6b72d, 0, 0)));
+    EXPECT(Same(ys[0], I4(0x3ffa817c, 0xf3ec1fb3, 0, 0)));
+    EXPECT(Same(ys[2], I4(0xc0057e8b, 0x0c13e04c, 0, 0)));
+    EXPECT(Same(ys[1], I4(0xa840848f, 0x144d9ccf, 0, 0)));
+  }
+  {  // HalfTreeDpf<64, Uint<u64>, Aes128Mmo<1>, uint64_t>, alpha 0x0123456789abcdef
+    using Ht = fss::HalfTreeDpf<64, fss::group::Uint<uint64_t>, fss::prg::Aes128Mmo<1>, uint64_t>;
+    const unsigned char* keys[1] = {k0};
+    fss::prg::Aes128Mmo<1> prg(keys);
+    Ht ht{prg, int4{0x12345678, static_cast<int>(0x9abcdef0u), 0x13572468, 0x2468ace0}};
+    const uint64_t xs[2] = {0x0123456789abcdefull, 0xdeadbeefcafef00dull};
+    uint64_t* d_xs = ToDevice(xs, 2);
+    Ht::Cw* d_cws = DeviceBuf<Ht::Cw>(64);
+    int4* d_ocw = DeviceBuf<int4>(1);
+    int4* d_ys = DeviceBuf<int4>(4);
+    HtGenEvalKernel<Ht, uint64_t><<<1, 64>>>(ht, d_cws, d_ocw, d_s0s, xs[0], int4{7, 0, 0, 0}, d_xs, 2, d_ys);
+    HIP_OK(hipDeviceSynchronize());
+    auto cws = ToHost(d_cws, 64);
+    auto ys = ToHost(d_ys, 4);
+    EXPECT(Same(cws[0].s, I4(0x02fc4a65, 0xf8fecae6, 0xf249f101, 0x66111f80)));
+    EXPECT(cws[63].extra == true);
+    EXPECT(Same(ToHost(d_ocw, 1)[0], I4(0x7c3c2870, 0x598af3a9, 0, 0)));
+    EXPECT(Same(ys[0], I4(0x98317401, 0xbf535b1d, 0, 0)));
+    EXPECT(Same(ys[2], I4(0x67ce8c06, 0x40aca4e2, 0, 0)));
+    EXPECT(Same(ys[1], I4(0xe7bf5193, 0x17c707b4, 0, 0)));
+  }
+  std::printf("AES-128-MMO  per-thread Gen/Eval on the device == the reference's known answers (4 schemes): %s\n",
+              g_fail == before ? "ok" : "FAILED");
+}
+
+// random batches: one key per thread vs the engine's level-major launchers
+template <typename S, typename In>
+__global__ void GenKeysKernel(S sch, typename S::Cw* cws, const int4* seeds, const In* alphas, const int4* betas, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  int4 s[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  sch.Gen(cws + size_t(tid) * S::kSlots, s, alphas[tid], betas[tid]);
+}
+template <typename S, typename In>
+__global__ void EvalKeysKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws, const In* xs,
+                               int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
+}
+template <typename S, typename In>
+__global__ void HtGenKeysKernel(S sch, typename S::Cw* cws, int4* ocws, const int4* seeds, const In* alphas,
+                                const int4* betas, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  int4 s[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  sch.Gen(cws + size_t(tid) * S::kSlots, ocws[tid], s, alphas[tid], betas[tid]);
+}
+template <typename S, typename In>
+__global__ void HtEvalKeysKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws,
+                                 const int4* ocws, const In* xs, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, ocws[tid], xs[tid]);
+}
+
+static void Batches() {
+  const int before = g_fail;
+  constexpr int kN = 4096;
+  std::vector<int4> seeds(2 * kN), seeds0(kN), seeds1(kN), betas(kN);
+  for (int i = 0; i < kN; ++i) {
+    seeds0[i] = seeds[2 * i] = RandSeed();
+    seeds1[i] = seeds[2 * i + 1] = RandSeed();
+    betas[i] = RandSeed();
+  }
+  int4* d_seeds = ToDevice(seeds.data(), 2 * kN);
+  int4* d_seeds0 = ToDevice(seeds0.data(), kN);
+  int4* d_seeds1 = ToDevice(seeds1.data(), kN);
+  int4* d_betas = ToDevice(betas.data(), kN);
+  int4* d_ys0 = DeviceBuf<int4>(kN);
+  int4* d_ys1 = DeviceBuf<int4>(kN);
+  int4* d_ye = DeviceBuf<int4>(kN);
+  {  // DCF n=32, Uint<u64>, kGt
+    using G = fss::group::Uint<uint64_t>;
+    using Prg = fss::prg::Aes128Mmo<4>;
+    using Dcf = fss::Dcf<32, G, Prg, uint32_t, fss::DcfPred::kGt>;
+    const unsigned char* keys[4] = {k0, k1, k2, k3};
+    Prg prg(keys);
+    Dcf dcf{prg};
+    std::vector<uint32_t> alphas(kN), xs(kN);
+    for (int i = 0; i < kN; ++i) {
+      alphas[i] = static_cast<uint32_t>(Next());
+      xs[i] = i % 3 == 0 ? alphas[i] : i % 3 == 1 ? alphas[i] + 1 + static_cast<uint32_t>(Next() % 1000) : static_cast<uint32_t>(Next());
+    }
+    uint32_t* d_alphas = ToDevice(alphas.data(), kN);
+    uint32_t* d_xs = ToDevice(xs.data(), kN);
+    Dcf::Cw* d_cws = DeviceBuf<Dcf::Cw>(size_t(33) * kN);
+    GenKeysKernel<Dcf, uint32_t><<<kN / 128, 128>>>(dcf, d_cws, d_seeds, d_alphas, d_betas, kN);
+    EvalKeysKernel<Dcf, uint32_t><<<kN / 128, 128>>>(dcf, d_ys0, false, d_seeds0, d_cws, d_xs, kN);
+    EvalKeysKernel<Dcf, uint32_t><<<kN / 128, 128>>>(dcf, d_ys1, true, d_seeds1, d_cws, d_xs, kN);
+    HIP_OK(hipDeviceSynchronize());
+    auto ys0 = ToHost(d_ys0, kN), ys1 = ToHost(d_ys1, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) {
+      int4 want = xs[i] > alphas[i] ? G::From(betas[i]).Into() : kZero;
+      bad += !Same(Recon<G>(ys0[i], ys1[i]), want);
+    }
+    EXPECT(bad == 0);
+    Dcf::Cw* d_cws_e = DeviceBuf<Dcf::Cw>(size_t(33) * kN);
+    dcf.GenBatch(d_cws_e, d_seeds, d_alphas, d_betas, kN);
+    auto a = ToHost(d_cws, size_t(33) * kN), e = ToHost(d_cws_e, size_t(33) * kN);
+    bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) bad += !Same(a[i].s, e[i].s) || !Same(a[i].v, e[i].v);
+    EXPECT(bad == 0);
+    int4* cw_s = DeviceBuf<int4>(size_t(32) * kN);
+    int4* cw_v = DeviceBuf<int4>(size_t(32) * kN);
+    int4* out_cw = DeviceBuf<int4>(kN);
+    fss::gpu::DcfRelayoutGpu<32, G, Prg, uint32_t, fss::DcfPred::kGt>(d_cws, kN, cw_s, cw_v, out_cw);
+    fss::gpu::DcfEvalPointGpu<4>(false, d_seeds0, cw_s, cw_v, out_cw, d_xs, d_ye, kN, dcf);
+    HIP_OK(hipDeviceSynchronize());
+    auto ye = ToHost(d_ye, kN);
+    bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys0[i]);
+    EXPECT(bad == 0);
+  }
+  {  // Half-Tree n=64, Uint<u64>
+    using G = fss::group::Uint<uint64_t>;
+    using Prg = fss::prg::Aes128Mmo<1>;
+    using Ht = fss::HalfTreeDpf<64, G, Prg, uint64_t>;
+    const unsigned char* keys[1] = {k0};
+    Prg prg(keys);
+    Ht ht{prg, int4{0x12345678, static_cast<int>(0x9abcdef0u), 0x13572468, 0x2468ace0}};
+    std::vector<uint64_t> alphas(kN), xs(kN);
+    for (int i = 0; i < kN; ++i) {
+      alphas[i] = Next();
+      xs[i] = i % 2 == 0 ? alphas[i] : (i % 4 == 1 ? alphas[i] ^ 1 : Next());
+    }
+    uint64_t* d_alphas = ToDevice(alphas.data(), kN);
+    uint64_t* d_xs = ToDevice(xs.data(), kN);
+    Ht::Cw* d_cws = DeviceBuf<Ht::Cw>(size_t(64) * kN);
+    int4* d_ocws = DeviceBuf<int4>(kN);
+    HtGenKeysKernel<Ht, uint64_t><<<kN / 128, 128>>>(ht, d_cws, d_ocws, d_seeds, d_alphas, d_betas, kN);
+    HtEvalKeysKernel<Ht, uint64_t><<<kN / 128, 128>>>(ht, d_ys0, false, d_seeds0, d_cws, d_ocws, d_xs, kN);
+    HtEvalKeysKernel<Ht, uint64_t><<<kN / 128, 128>>>(ht, d_ys1, true, d_seeds1, d_cws, d_ocws, d_xs, kN);
+    HIP_OK(hipDeviceSynchronize());
+    auto ys0 = ToHost(d_ys0, kN), ys1 = ToHost(d_ys1, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) {
+      int4 want = xs[i] == alphas[i] ? G::From(betas[i]).Into() : kZero;
+      bad += !Same(Recon<G>(ys0[i], ys1[i]), want);
+    }
+    EXPECT(bad == 0);
+    Ht::Cw* d_cws_e = DeviceBuf<Ht::Cw>(size_t(64) * kN);
+    int4* d_ocws_e = DeviceBuf<int4>(kN);
+    ht.GenBatch(d_cws_e, d_ocws_e, d_seeds, d_alphas, d_betas, kN);
+    auto a = ToHost(d_cws, size_t(64) * kN), e = ToHost(d_cws_e, size_t(64) * kN);
+    bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) bad += !Same(a[i].s, e[i].s) || a[i].extra != e[i].extra;
+    auto oa = ToHost(d_ocws, kN), oe = ToHost(d_ocws_e, kN);
+    for (int i = 0; i < kN; ++i) bad += !Same(oa[i], oe[i]);
+    EXPECT(bad == 0);
+    int4* cw_s = DeviceBuf<int4>(size_t(64) * kN);
+    uint32_t* extra = DeviceBuf<uint32_t>(kN);
+    fss::gpu::HalfTreeDpfRelayoutGpu<64, G, Prg, uint64_t>(d_cws, kN, cw_s, extra);
+    fss::gpu::HalfTreeDpfEvalPointGpu<4>(true, d_seeds1, cw_s, extra, d_ocws, d_xs, d_ye, kN, ht);
+    HIP_OK(hipDeviceSynchronize());
+    auto ye = ToHost(d_ye, kN);
+    bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys1[i]);
+    EXPECT(bad == 0);
+  }
+  std::printf("AES-128-MMO  DCF n=32 kGt, Half-Tree n=64: 4096 keys per thread == engine (keys and shares): %s\n",
+              g_fail == before ? "ok" : "FAILED");
+}
+}  // namespace p2
+
+// ---------------------------------------------------------------------------------------------- part 3: caller's own types
+namespace p3 {
+// a toy ARX generator -- NOT a cryptographic PRG; it only has to be deterministic and well mixed for the test
+template <int mul>
+struct MixPrg {
+  uint32_t tweak;
+  __host__ __device__ static uint32_t Mix(uint32_t v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+  }
+  __host__ __device__ std::array<int4, mul> Gen(int4 seed) const {
+    std::array<int4, mul> out;
+    for (int i = 0; i < mul; ++i) {
+      uint32_t a = Mix(static_cast<uint32_t>(seed.x) + tweak + 0x9e3779b9u * (i + 1));
+      uint32_t b = Mix(static_cast<uint32_t>(seed.y) ^ a);
+      uint32_t c = Mix(static_cast<uint32_t>(seed.z) + b);
+      uint32_t d = Mix(static_cast<uint32_t>(seed.w) ^ c);
+      a = Mix(a + d);
+      out[i] = int4{static_cast<int>(a), static_cast<int>(b ^ a), static_cast<int>(c + b), static_cast<int>(d ^ c)};
+    }
+    return out;
+  }
+};
+// (Z_2^32)^3 on x, y, z; w (where the control bit lives) is not part of the group
+struct Vec3 {
+  uint32_t v[3];
+  __host__ __device__ Vec3() : v{0, 0, 0} {}
+  __host__ __device__ Vec3 operator+(Vec3 o) const {
+    Vec3 r;
+    for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i];
+    return r;
+  }
+  __host__ __device__ Vec3 operator-() const {
+    Vec3 r;
+    for (int i = 0; i < 3; ++i) r.v[i] = 0u - v[i];
+    return r;
+  }
+  __host__ __device__ static Vec3 From(int4 b) {
+    Vec3 r;
+    r.v[0] = static_cast<uint32_t>(b.x); r.v[1] = static_cast<uint32_t>(b.y); r.v[2] = static_cast<uint32_t>(b.z);
+    return r;
+  }
+  __host__ __device__ int4 Into() const { return int4{static_cast<int>(v[0]), static_cast<int>(v[1]), static_cast<int>(v[2]), 0}; }
+};
+static_assert(Prgable<MixPrg<2>, 2> && Prgable<MixPrg<4>, 4> && Groupable<Vec3>);
+
+constexpr int kInBits = 10;
+using In = uint16_t;
+using Dpf = fss::Dpf<kInBits, Vec3, MixPrg<2>, In>;
+using Dcf = fss::Dcf<kInBits, Vec3, MixPrg<4>, In>;
+using Ht = fss::HalfTreeDpf<kInBits, Vec3, MixPrg<1>, In>;
+static_assert(!Dpf::kEngine && !Dcf::kEngine && !Ht::kEngine);
+
+__global__ void UserDpfKernel(Dpf dpf, Dpf::Cw* cws, const int4* s0s, In alpha, int4 beta, int4* ys /* [2][1 << n] */) {
+  // thread 0 of block 0 deals the key, then every thread evaluates its own points of the whole domain
+  __shared__ int ready;
+  if (threadIdx.x == 0) {
+    dpf.Gen(cws, s0s, alpha, beta);
+    ready = 1;
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < (1 << kInBits); x += blockDim.x)
+    for (int b = 0; b < 2; ++b) ys[(b << kInBits) + x] = dpf.Eval(b, s0s[b], cws, static_cast<In>(x));
+  (void)ready;
+}
+
+static void Run() {
+  const int before = g_fail;
+  const int4 seeds[2] = {RandSeed(), RandSeed()};
+  const In alpha = 777;
+  const int4 beta = {11, 22, 33, 0};
+  const int n = 1 << kInBits;
+  {  // inside the caller's kernel
+    Dpf dpf{MixPrg<2>{0xabcdef01u}};
+    int4* d_s0s = ToDevice(seeds, 2);
+    Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(kInBits + 1);
+    int4* d_ys = DeviceBuf<int4>(2 * n);
+    UserDpfKernel<<<1, 256>>>(dpf, d_cws, d_s0s, alpha, beta, d_ys);
+    HIP_OK(hipDeviceSynchronize());
+    auto ys = ToHost(d_ys, 2 * n);
+    int bad = 0;
+    for (int x = 0; x < n; ++x) bad += !Same(Recon<Vec3>(ys[x], ys[n + x]), x == alpha ? beta : kZero);
+    EXPECT(bad == 0);
+    // the host signatures on the same key: generic kernels, same shares
+    Dpf::Cw cws[kInBits + 1];
+    dpf.Gen(cws, seeds, alpha, beta);
+    auto dc = ToHost(d_cws, kInBits + 1);
+    bad = 0;
+    for (int i = 0; i <= kInBits; ++i) bad += !Same(cws[i].s, dc[i].s) || cws[i].tr != dc[i].tr;
+    EXPECT(bad == 0);
+    EXPECT(Same(dpf.Eval(false, seeds[0], cws, alpha), ys[alpha]));
+    EXPECT(Same(dpf.Eval(true, seeds[1], cws, In(5)), ys[n + 5]));
+    std::vector<int4> all(n);
+    dpf.EvalAll(true, seeds[1], cws, all.data());
+    bad = 0;
+    for (int x = 0; x < n; ++x) bad += !Same(all[x], ys[n + x]);
+    EXPECT(bad == 0);
+  }
+  {  // DCF through the host signatures only
+    Dcf dcf{MixPrg<4>{0x1234u}};
+    Dcf::Cw cws[kInBits + 1];
+    dcf.Gen(cws, seeds, alpha, beta);
+    std::vector<int4> y0(n), y1(n);
+    dcf.EvalAll(false, seeds[0], cws, y0.data());
+    dcf.EvalAll(true, seeds[1], cws, y1.data());
+    int bad = 0;
+    for (int x = 0; x < n; ++x) bad += !Same(Recon<Vec3>(y0[x], y1[x]), x < alpha ? beta : kZero);
+    EXPECT(bad == 0);
+    EXPECT(Same(dcf.Eval(false, seeds[0], cws, In(3)), y0[3]));
+  }
+  {  // Half-Tree: batched device forms with the caller's types
+    Ht ht{MixPrg<1>{0x55u}, int4{1, 2, 3, 4}};
+    constexpr int kKeys = 300;
+    std::vector<int4> s(2 * kKeys), s0(kKeys), s1(kKeys), betas(kKeys);
+    std::vector<In> alphas(kKeys);
+    for (int i = 0; i < kKeys; ++i) {
+      s0[i] = s[2 * i] = RandSeed();
+      s1[i] = s[2 * i + 1] = RandSeed();
+      betas[i] = int4{(int)Next(), (int)Next(), (int)Next(), 0};
+      alphas[i] = static_cast<In>(Next() % n);
+    }
+    int4* d_s = ToDevice(s.data(), 2 * kKeys);
+    int4* d_betas = ToDevice(betas.data(), kKeys);
+    In* d_alphas = ToDevice(alphas.data(), kKeys);
+    Ht::Cw* d_cws = DeviceBuf<Ht::Cw>(size_t(kInBits) * kKeys);
+    int4* d_ocws = DeviceBuf<int4>(kKeys);
+    ht.GenBatch(d_cws, d_ocws, d_s, d_alphas, d_betas, kKeys);
+    int4* d_y0 = DeviceBuf<int4>(n);
+    int4* d_y1 = DeviceBuf<int4>(n);
+    std::vector<In> xs(n);
+    for (int x = 0; x < n; ++x) xs[x] = static_cast<In>(x);
+    In* d_xs = ToDevice(xs.data(), n);
+    int4* d_s0 = ToDevice(s0.data(), kKeys);
+    int4* d_s1 = ToDevice(s1.data(), kKeys);
+    int bad = 0;
+    for (int k : {0, 1, 150, kKeys - 1}) {
+      ht.EvalPoints(false, d_s0 + k, d_cws + size_t(k) * kInBits, d_ocws + k, d_xs, d_y0, n);
+      ht.EvalPoints(true, d_s1 + k, d_cws + size_t(k) * kInBits, d_ocws + k, d_xs, d_y1, n);
+      HIP_OK(hipDeviceSynchronize());
+      auto y0 = ToHost(d_y0, n), y1 = ToHost(d_y1, n);
+      for (int x = 0; x < n; ++x) bad += !Same(Recon<Vec3>(y0[x], y1[x]), x == alphas[k] ? betas[k] : kZero);
+    }
+    EXPECT(bad == 0);
+  }
+  std::printf("caller-defined Prgable + Groupable  in a kernel and through the host signatures, reconstructs: %s\n",
+              g_fail == before ? "ok" : "FAILED");
+}
+}  // namespace p3
+
+int main() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    std::fprintf(stderr, "no GPU\n");
+    return 3;
+  }
+  try {
+    p1::Run();
+    p2::Kats();
+    p2::Batches();
+    p3::Run();
+    fss::ReleaseEngines();
+  } catch (const fss::Error& e) {
+    std::fprintf(stderr, "fss::Error: %s\n", e.what());
+    return 2;
+  }
+  if (g_fail) {
+    std::fprintf(stderr, "%d check(s) FAILED\n", g_fail);
+    return 1;
+  }
+  std::printf("OK\n");
+  return 0;
+}

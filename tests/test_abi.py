@@ -79,3 +79,11 @@ def test_cxx_dropin_test_compiles():
     unchanged; it runs under -m gpu (tests/test_gpu_parity.py::test_cxx_dropin_boundary)."""
     from fss_amd import _build
     assert os.path.exists(_build.build_dropin_test())
+
+
+def test_cxx_dropin_device_test_compiles():
+    """Gen / Eval called per thread inside caller kernels, with the built-in PRGs and with caller-defined Prgable /
+    Groupable types (tests/cxx/dropin_device_test.cpp), compiles; it runs under -m gpu
+    (tests/test_gpu_parity.py::test_cxx_dropin_device_side)."""
+    from fss_amd import _build
+    assert os.path.exists(_build.build_dropin_device_test())

@@ -790,6 +790,19 @@ def test_cxx_dropin_boundary():
     assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
 
 
+def test_cxx_dropin_device_side():
+    """tests/cxx/dropin_device_test.cpp: Gen / Eval called per thread from inside the caller's own kernels (the flow of
+    samples/dpf_dcf_gpu.cu:39-80) with ChaCha and with AES-128-MMO, against the reference's known answers and bit for
+    bit against the engine's batched forms; caller-defined Prgable / Groupable types in a kernel and through the host
+    signatures."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_dropin_device_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
+
+
 @pytest.mark.parametrize("n,nkeys", [(1, 70), (20, 1000), (32, 5000), (31, 129)])
 def test_u32_extra_entry_points_vs_u64(engine, O, n, nkeys):
     """fss_amd_dpf_relayout_u32 / fss_amd_dpf_eval_keys_u32: the reference's uint32_t `extra` packing of the tr bits
