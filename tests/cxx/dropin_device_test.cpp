@@ -507,6 +507,62 @@ static void Batches() {
   std::printf("AES-128-MMO  DCF n=32 kGt, Half-Tree n=64: 4096 keys per thread == engine (keys and shares): %s\n",
               g_fail == before ? "ok" : "FAILED");
 }
+
+// what the compatibility form costs next to the engine: DPF n=32, 2^18 independent keys, one evaluation each
+static void Timing() {
+  constexpr int kN = 1 << 18;
+  using G = fss::group::Uint<uint64_t>;
+  using Prg = fss::prg::Aes128Mmo<2>;
+  using Dpf = fss::Dpf<32, G, Prg, uint32_t>;
+  const unsigned char* keys[2] = {k0, k1};
+  Prg prg(keys);
+  Dpf dpf{prg};
+  std::vector<int4> seeds(2 * kN), seeds0(kN), betas(kN);
+  std::vector<uint32_t> alphas(kN), xs(kN);
+  for (int i = 0; i < kN; ++i) {
+    seeds0[i] = seeds[2 * i] = RandSeed();
+    seeds[2 * i + 1] = RandSeed();
+    betas[i] = RandSeed();
+    alphas[i] = static_cast<uint32_t>(Next());
+    xs[i] = i % 2 ? alphas[i] : static_cast<uint32_t>(Next());
+  }
+  int4* d_seeds = ToDevice(seeds.data(), 2 * kN);
+  int4* d_seeds0 = ToDevice(seeds0.data(), kN);
+  int4* d_betas = ToDevice(betas.data(), kN);
+  uint32_t* d_alphas = ToDevice(alphas.data(), kN);
+  uint32_t* d_xs = ToDevice(xs.data(), kN);
+  Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(size_t(33) * kN);
+  int4* d_yt = DeviceBuf<int4>(kN);
+  int4* d_ye = DeviceBuf<int4>(kN);
+  int4* cw_s = DeviceBuf<int4>(size_t(32) * kN);
+  uint32_t* extra = DeviceBuf<uint32_t>(kN);
+  int4* out_cw = DeviceBuf<int4>(kN);
+  dpf.GenBatch(d_cws, d_seeds, d_alphas, d_betas, kN);
+  fss::gpu::DpfRelayoutGpu<32, G, Prg, uint32_t>(d_cws, kN, cw_s, extra, out_cw);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  float ms_thread = 0, ms_engine = 0;
+  for (int rep = 0; rep < 2; ++rep) {  // the second pass is the timed one
+    HIP_OK(hipEventRecord(e0));
+    EvalKeysKernel<Dpf, uint32_t><<<kN / 256, 256>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN);
+    HIP_OK(hipEventRecord(e1));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventElapsedTime(&ms_thread, e0, e1));
+    HIP_OK(hipEventRecord(e0));
+    fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, cw_s, extra, out_cw, d_xs, d_ye, kN, dpf);
+    HIP_OK(hipEventRecord(e1));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventElapsedTime(&ms_engine, e0, e1));
+  }
+  auto yt = ToHost(d_yt, kN), ye = ToHost(d_ye, kN);
+  int bad = 0;
+  for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+  EXPECT(bad == 0);
+  std::printf("     (DPF n=32, 2^18 keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+              "DpfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n",
+              ms_thread, kN / ms_thread / 1e3, ms_engine, kN / ms_engine / 1e3, bad ? "NO" : "yes");
+}
 }  // namespace p2
 
 // ---------------------------------------------------------------------------------------------- part 3: caller's own types
@@ -668,6 +724,7 @@ int main() {
     p1::Run();
     p2::Kats();
     p2::Batches();
+    p2::Timing();
     p3::Run();
     fss::ReleaseEngines();
   } catch (const fss::Error& e) {
