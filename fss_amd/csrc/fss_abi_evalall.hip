@@ -3,6 +3,9 @@
 #include "fss_host.hpp"
 #include "fss_evalall.hpp"
 
+// fss_abi_fused.hip
+int launch_fused_evalall(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* seed, const uint32_t* cws,
+                         const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st);
 
 namespace {
 
@@ -125,6 +128,42 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
     if (s % 2 == 0) { if (f > pl->cap_b) pl->cap_b = f; }
     else { if (f > pl->cap_a) pl->cap_a = f; }
   }
+  // The one-launch form (evalall_fused_kernel) gives every workgroup a private slice, ceil(walks / grid) walks wide:
+  // room for the rounding of up to 1024 workgroups (a few hundred KiB at most).
+  {
+    const int64_t slack = 1023;
+    int sh = pl->tail;
+    int64_t fa = (((int64_t)1 << (top - pl->tail)) + slack) << sh, fb = 0;
+    for (int s = 0; s + 1 < pl->nstages; ++s) {
+      sh += pl->D[s];
+      const int64_t v = (((int64_t)1 << (top - pl->tail)) + slack) << sh;
+      if (s % 2 == 0) { if (v > fb) fb = v; }
+      else { if (v > fa) fa = v; }
+    }
+    if (top - pl->tail >= 12) {  // only plans the fused form takes (fused_ok)
+      if (fa > pl->cap_a) pl->cap_a = fa;
+      if (fb > pl->cap_b) pl->cap_b = fb;
+    }
+  }
+  return true;
+}
+
+// The plan as one launch (fss_abi_fused.hip): AES tables, DPF / Grotto / Half-Tree, a capped quad frontier with at
+// least 16 walks per workgroup, stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
+// launches (A/B).
+inline bool fused_on() {
+  static const bool v = [] { const char* e = getenv("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
+  return v;
+}
+bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl) {
+  if (!fused_on() || !quad_frontier() || ctx->prg == FSS_AMD_PRG_CHACHA) return false;
+  if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT) return false;
+  if (pl.nstages < 1 || pl.nstages > 7) return false;
+  if (pl.top - pl.tail < 12 || (((int64_t)1 << (pl.top - pl.tail)) < (int64_t)16 * ctx->num_cu)) return false;
+  const int leaf = pl.D[pl.nstages - 1];
+  if (leaf < 2 || leaf > 4 || (scheme == S_HT && leaf != 2)) return false;
+  for (int s = 0; s + 1 < pl.nstages; ++s)
+    if (pl.D[s] < 1 || pl.D[s] > 3) return false;
   return true;
 }
 
@@ -253,18 +292,41 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   a.prefix = pl.r >= 63 ? 0ull : (uint64_t)(first_leaf >> pl.r);
   a.ys = ys;
 
+  bool fused = false;
+  if (fused_ok(ctx, SCHEME, pl)) {
+    FusedArgs f{};
+    f.a = a;
+    f.p = pl.p; f.top = pl.top; f.tail = pl.tail;
+    f.nmid = pl.nstages - 1;
+    for (int s = 0; s < f.nmid; ++s) f.mid_t[s] = pl.D[s];
+    const int grid = ctx->num_cu;
+    const int64_t wmax = ((((int64_t)1 << (pl.top - pl.tail)) + grid - 1) / grid);
+    int sh = pl.tail, sha = sh, shb = 0;
+    for (int s = 0; s < f.nmid; ++s) {
+      sh += pl.D[s];
+      if (s % 2 == 0) { if (sh > shb) shb = sh; }
+      else { if (sh > sha) sha = sh; }
+    }
+    f.buf[0] = bufn[0]; f.buf[1] = bufn[1];
+    f.wg_cap[0] = wmax << sha; f.wg_cap[1] = f.nmid ? (wmax << shb) : 0;
+    if (f.wg_cap[0] * grid <= pl.cap_a && f.wg_cap[1] * grid <= pl.cap_b) {
+      int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st);
+      if (rc != FSS_AMD_OK) return rc;
+      fused = true;
+    }
+  }
   // frontier at depth p + top
   a.level0 = pl.p + pl.top;
   a.out_nodes = bufn[0];
   a.out_v = bufv[0];
-  {
+  if (!fused) {
     int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, k.seed, k.cws, a, pl.top, pl.tail);
     if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = (int64_t)1 << pl.top;
   int level = pl.p + pl.top;
   int cur = 0;
-  for (int s = 0; s < pl.nstages; ++s) {
+  for (int s = 0; s < pl.nstages && !fused; ++s) {
     bool leaf = (s == pl.nstages - 1);
     a.level0 = level;
     a.n_in = f;

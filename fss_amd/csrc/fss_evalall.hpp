@@ -26,6 +26,9 @@
 #ifndef FSS_HT_PAIR
 #define FSS_HT_PAIR 1
 #endif
+#ifndef FSS_LEAF_PAIR_LINES
+#define FSS_LEAF_PAIR_LINES 1
+#endif
 
 namespace fssamd {
 
@@ -240,17 +243,16 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
 }
 
 // -- frontier with the AES tables: one walk per quad of lanes (fss_quad.hpp) ---------------------------------
+// The walks j_first, j_first + j_stride, ... < j_end of this lane's quad (j counts walks: quads of lanes).
 template <class LT, int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
-__global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
-                                                            const uint32_t* __restrict__ k_seed,
-                                                            const uint32_t* __restrict__ k_cws, ExpandArgs a, int top,
-                                                            int tail) {
+__device__ __forceinline__ void quad_frontier_walks(const LT& L, const DevCtx* __restrict__ c,
+                                                    const uint32_t* __restrict__ k_seed,
+                                                    const uint32_t* __restrict__ k_cws, const ExpandArgs& a, int top,
+                                                    int tail, int64_t j_first, int64_t j_end, int64_t j_stride) {
   // `top` levels are produced per key: top - tail walked, then (tail = 2, DPF / Grotto / Half-Tree) the quad expands
   // its node two levels in registers and stores the four grandchildren -- the first, thinnest expansion stage
   // without its launch.  a.level0 = depth of the stored nodes.
   static_assert(SCHEME == S_DPF || SCHEME == S_DCF || SCHEME == S_HT, "quad frontier: DPF / Grotto / DCF / Half-Tree");
-  const DevCtx* c = first_kernarg(K);
-  FSS_PRG_PROLOGUE(LT, te0);
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
   QuadPrg<LT, SCHEME> P;
@@ -258,8 +260,6 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
   const Grp g = make_grp(a.group, c);
   const int depth = a.level0 - tail;  // levels walked: p + top - tail
   top -= tail;
-  const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << top;  // walks
-  const int64_t nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
   // one node -> both children at tree level lv (dpf_expand / ht_expand), a word per lane
   auto expand = [&](const uint32_t* kc, int lv, uint32_t node, uint32_t& left, uint32_t& right) {
     const uint32_t w = kc[8 * lv + q];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
       left = right = node;  // no tail for DCF
     }
   };
-  for (int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; j < nout; j += nquads) {
+  for (int64_t j = j_first; j < j_end; j += j_stride) {
     const int64_t key = BATCH ? (j >> top) : 0;
     const uint64_t path = BATCH ? (uint64_t)(j & (((int64_t)1 << top) - 1)) : ((top >= 64 ? 0ull : (a.prefix << top)) | (uint64_t)j);
     const uint32_t* kc = BATCH ? k_cws + 8 * key * a.key_slots : k_cws;
@@ -304,6 +304,19 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
   }
 }
 
+template <class LT, int SCHEME, bool BATCH>
+__global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                            const uint32_t* __restrict__ k_seed,
+                                                            const uint32_t* __restrict__ k_cws, ExpandArgs a, int top,
+                                                            int tail) {
+  const DevCtx* c = first_kernarg(K);
+  FSS_PRG_PROLOGUE(LT, te0);
+  const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << (top - tail);  // walks
+  quad_frontier_walks<LT, SCHEME, BATCH>(L, c, k_seed, k_cws, a, top, tail,
+                                         ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2, nout,
+                                         ((int64_t)gridDim.x * blockDim.x) >> 2);
+}
+
 // -- expansion stage ------------------------------------------------------------
 // Lane j takes input node j at level `level0` and writes its descendants E + D levels down at
 // (j << (E + D)) + k.  The last D levels are expanded in registers (all 2^D nodes live); the E levels
@@ -317,9 +330,10 @@ struct OuterLevels {
   static __device__ __forceinline__ void run(const LT& L, const DevCtx* __restrict__ c, const Grp& g,
                                              const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
                                              int lvl, const uint32_t node[4], const Acc& v, int64_t ob, int sub_log2,
-                                             Body& body) {
+                                             Body& body, int half = -1) {
+    // half: which child of the innermost rolled level this subtree is (0 / 1), -1 with no rolled level above the body
     if constexpr (E == 0) {
-      body(k_cws, k_ocw, node, v, lvl, ob);
+      body(k_cws, k_ocw, node, v, lvl, ob, half);
     } else {
       uint32_t l[4], r[4];
       Acc vl, vr;
@@ -337,7 +351,7 @@ struct OuterLevels {
           if constexpr (SCHEME == S_DCF) cv.v[q] = h ? vr.v[q] : vl.v[q];
         }
         OuterLevels<LT, SCHEME, E - 1>::run(L, c, g, k_cws, k_ocw, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
-                                            sub_log2 - 1, body);
+                                            sub_log2 - 1, body, h);
       }
     }
   }
@@ -346,21 +360,24 @@ struct OuterLevels {
 // OW (leaf stages of DPF / Half-Tree with the AES tables): 4 = any output group; 2 = the group reads only the low
 // 8 bytes of a leaf seed (Uint<uint8_t .. uint64_t>, uint.cuh:49-68), so the leaf-level blocks compute words 0, 1 and
 // the control bit only -- 7 of their last round's 16 lookups vanish (aes_fin), about 2 % of a DPF tree's lookups.
-template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0, bool BATCH = false, int OW = 4>
-__global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
-                                                    const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
-                                                    const uint32_t* __restrict__ k_ocw,  // Half-Tree
-                                                    ExpandArgs a) {
-  const DevCtx* c = first_kernarg(K);
-  FSS_WAVEQ_PROLOGUE();
-  FSS_PRG_PROLOGUE(LT, te0);
-  const Grp g = make_grp(a.group, c);
-  const int party = a.party;
-
-  constexpr int NN = 1 << D;
-  // the D levels expanded in registers, from one node at level `lvl` to outputs ob .. ob + 2^D - 1
-  auto body = [&](const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc, const uint32_t nin[4],
-                  const Acc& vin, int lvl, int64_t ob) {
+//
+// StageBody: the D levels expanded in registers, from one node at level `lvl` to outputs ob .. ob + 2^D - 1
+// (a.out_nodes / a.out_v, or the converted leaves in a.ys).
+template <class LT, int SCHEME, int D, bool LEAF, int OW>
+struct StageBody {
+  const LT& L;
+  const DevCtx* __restrict__ c;
+  const Grp& g;
+  const ExpandArgs& a;
+  // DPF leaves under a rolled level: the 64 bytes of the first half are held back and stored together with the
+  // second half -- the lane's eight 16-byte stores then fall on one 128-byte line within a few cycles instead of half
+  // a line now and half after six more AES blocks (FSS_LEAF_PAIR_LINES, A/B)
+  static constexpr bool kHold = FSS_LEAF_PAIR_LINES && LEAF && SCHEME == S_DPF && D == 2;
+  uint4 held[kHold ? 4 : 1];
+  __device__ __forceinline__ void operator()(const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc,
+                                             const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob, int half) {
+    constexpr int NN = 1 << D;
+    const int party = a.party;
     uint32_t nodes[NN][4];
     Acc vs[SCHEME == S_DCF ? NN : 1];
     nodes[0][0] = nin[0]; nodes[0][1] = nin[1]; nodes[0][2] = nin[2]; nodes[0][3] = nin[3];
@@ -454,23 +471,31 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
         if constexpr (SCHEME == S_DCF) y = vs[k];
         y.add(g, s);
         y.add_if(g, tm, oc);
-#if defined(FSS_EXP_ONE_STORE)
-        // timing experiment only: fold the leaves into one store per lane
-        uint4 yy = y.finish(g, party != 0);
-        if (k == 0) ys[ob] = yy; else if (yy.x == 0x12345u && yy.y == 7u) ys[ob + k] = yy;
-#else
-        ys[ob + k] = y.finish(g, party != 0);
-#endif
+        if constexpr (kHold) {
+          const uint4 yy = y.finish(g, party != 0);
+          if (half == 0) {
+            held[k] = yy;
+          } else {
+            if (half == 1) ys[ob - NN + k] = held[k];
+            ys[ob + k] = yy;
+          }
+        } else {
+          ys[ob + k] = y.finish(g, party != 0);
+        }
       }
     }
-  };
+  }
+};
 
-#if FSS_DIAG_STAMPS
-  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1, a.gq, a.static_chunks);
+// One stage over the input nodes [j_lo, j_hi) handed out 64 at a time by `next` (WaveQ / LocalQ): lane j loads
+// node j, walks E levels depth-first and expands the last D in registers.
+template <class LT, int SCHEME, int D, bool LEAF, int E, bool BATCH, int OW, class Queue>
+__device__ __forceinline__ void run_stage(const LT& L, const DevCtx* __restrict__ c, const Grp& g, const ExpandArgs& a,
+                                          const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
+                                          Queue& q, int64_t j_hi) {
+  StageBody<LT, SCHEME, D, LEAF, OW> body{L, c, g, a, {}};
   for (int64_t j; q.next(j);) {
-    if (j >= a.n_in) continue;  // ragged last chunk
+    if (j >= j_hi) continue;  // ragged last chunk
     uint32_t n0[4];
     Acc v0;
     {
@@ -487,6 +512,23 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
     const uint32_t* koc = (BATCH && k_ocw) ? k_ocw + 4 * key : k_ocw;
     OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
   }
+}
+
+template <class LT, int SCHEME, int D, bool LEAF, int BS, int E = 0, bool BATCH = false, int OW = 4>
+__global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                    const uint32_t* __restrict__ k_cws,  // raw Cw slots of the key
+                                                    const uint32_t* __restrict__ k_ocw,  // Half-Tree
+                                                    ExpandArgs a) {
+  const DevCtx* c = first_kernarg(K);
+  FSS_WAVEQ_PROLOGUE();
+  FSS_PRG_PROLOGUE(LT, te0);
+  const Grp g = make_grp(a.group, c);
+
+#if FSS_DIAG_STAMPS
+  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  WaveQ q(a.dyn, &waveq_ctr_, a.n_in, 1, a.gq, a.static_chunks);
+  run_stage<LT, SCHEME, D, LEAF, E, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, a.n_in);
 #if FSS_DIAG_STAMPS
   if (LEAF && (threadIdx.x & 63) == 0 && a.stamps) {
     uint64_t* o = a.stamps + 4 * ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
@@ -496,6 +538,95 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
   q.done();
 }
 
+// -- the whole chain in one launch ------------------------------------------------------------------------------
+// Every workgroup owns a contiguous share of the frontier walks and takes it all the way down by itself: its walks,
+// its intermediate stages (through a private slice of the two workspace buffers), its leaves.  No workgroup ever
+// reads what another wrote, so the phases are separated by workgroup barriers only -- one launch, one table fill and
+// no drain / ramp between the stages of a plan (2^25-leaf block: four launches of 25 + 12 + 42 + 585 us become one;
+// the thin stages were 12 % of the time for 6 % of the blocks).  The nodes a workgroup reads back were written by its
+// own CU, so they also come from its own XCD's L2.
+struct FusedArgs {
+  ExpandArgs a;       // scheme, in_bits, party, group, prefix, ys; level0 / in / out are set per phase
+  int p;              // depth of the block's root
+  int top, tail;      // frontier depth below p (tail levels of it expanded in registers after the walk)
+  int nmid;           // intermediate stages
+  int mid_t[6];       // their depths: 1, 2 (in registers) or 3 (one rolled level above two)
+  uint4* buf[2];      // workspace halves; workgroup b owns [b * wg_cap[i], (b + 1) * wg_cap[i])
+  int64_t wg_cap[2];
+};
+
+// The workgroup's own 64-node chunks of [lo, hi), handed to its waves through the LDS counter.
+struct LocalQ {
+  uint32_t* ctr;
+  int64_t lo, n, cur;
+  __device__ __forceinline__ int64_t fetch() {
+    uint32_t v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1u);
+    return (int64_t)__builtin_amdgcn_readfirstlane(v);
+  }
+  __device__ __forceinline__ LocalQ(uint32_t* lds_ctr, int64_t lo_, int64_t hi_) : ctr(lds_ctr), lo(lo_), n(hi_ - lo_) {
+    cur = fetch();
+  }
+  __device__ __forceinline__ bool next(int64_t& j) {
+    if (cur * 64 >= n) return false;
+    j = lo + cur * 64 + (threadIdx.x & 63);
+    cur = fetch();
+    return true;
+  }
+};
+
+template <class LT, int SCHEME, int LD, int LE, int OW>
+__global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
+                                                            const uint32_t* __restrict__ k_seed,
+                                                            const uint32_t* __restrict__ k_cws,
+                                                            const uint32_t* __restrict__ k_ocw, FusedArgs f) {
+  static_assert(SCHEME == S_DPF || SCHEME == S_GROTTO || SCHEME == S_HT);
+  constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
+  const DevCtx* c = first_kernarg(K);
+  FSS_WAVEQ_PROLOGUE();
+  FSS_PRG_PROLOGUE(LT, te0);
+  const Grp g = make_grp(f.a.group, c);
+  // this workgroup's walks [w_lo, w_hi) of the 2^(top - tail)
+  const int64_t walks = (int64_t)1 << (f.top - f.tail);
+  const int64_t w_lo = walks * blockIdx.x / gridDim.x, w_hi = walks * (blockIdx.x + 1) / gridDim.x;
+  uint4* const mine[2] = {f.buf[0] + (int64_t)blockIdx.x * f.wg_cap[0], f.buf[1] + (int64_t)blockIdx.x * f.wg_cap[1]};
+  int64_t lo = w_lo << f.tail, hi = w_hi << f.tail;  // node range of the current level (indices within the block)
+  int level = f.p + f.top;
+  ExpandArgs a = f.a;
+  {  // ---- frontier: nodes [lo, hi) at depth p + top into mine[0]
+    a.level0 = level;
+    a.out_nodes = mine[0] - lo;
+    quad_frontier_walks<LT, WS, false>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> 2), w_hi,
+                                       blockDim.x >> 2);
+  }
+  int cur = 0;
+  for (int s = 0; s < f.nmid; ++s) {  // ---- intermediate stages: mine[cur] -> mine[cur ^ 1]
+    __syncthreads();  // the nodes of the phase before are in place (same CU: same L1), the chunk counter is idle
+    if (threadIdx.x == 0) waveq_ctr_ = 0;
+    __syncthreads();
+    const int t = f.mid_t[s];
+    a.level0 = level;
+    a.in_nodes = mine[cur] - lo;
+    a.out_nodes = mine[cur ^ 1] - (lo << t);
+    LocalQ q(&waveq_ctr_, lo, hi);
+    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    else if (t == 2) run_stage<LT, SCHEME, 2, false, 0, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    else run_stage<LT, SCHEME, 2, false, 1, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    lo <<= t; hi <<= t; level += t;
+    cur ^= 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) waveq_ctr_ = 0;
+  __syncthreads();
+  {  // ---- leaf stage: mine[cur] -> ys
+    a.level0 = level;
+    a.in_nodes = mine[cur] - lo;
+    LocalQ q(&waveq_ctr_, lo, hi);
+    run_stage<LT, SCHEME, LD, true, LE, false, OW>(L, c, g, a, k_cws, k_ocw, q, hi);
+  }
+}
+
+#ifndef FSS_EVALALL_TEMPLATES_ONLY  // the plain (non-template) kernels below belong to one unit: fss_abi_evalall.hip
 // Grotto EvalAll phase 2 (grotto_dcf.cuh:158-162): in-place running XOR over the
 // leaf control bits.  Three passes: per-chunk parity, scan of the chunk parities,
 // per-chunk running XOR seeded with the carry.
@@ -604,5 +735,7 @@ __global__ __launch_bounds__(256) void grotto_table_eval_kernel(const uint8_t* _
     ys[i] = (uint8_t)(pi & 1u);
   }
 }
+
+#endif  // FSS_EVALALL_TEMPLATES_ONLY
 
 }  // namespace fssamd

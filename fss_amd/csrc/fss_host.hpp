@@ -1,6 +1,6 @@
 // Host-side plumbing shared by the translation units of libfss_amd.so (fss_amd.hip, fss_abi_evalall.hip,
-// fss_abi_gen.hip): the context, error recording, launch geometry and work-distribution heuristics, PRG dispatch.
-// The library is split so that hipcc compiles the three kernel families in parallel.
+// fss_abi_gen.hip, fss_abi_fused.hip): the context, error recording, launch geometry and work-distribution heuristics,
+// PRG dispatch.  The library is split so that hipcc compiles the kernel families in parallel.
 #pragma once
 #include "../../include/fss_amd.h"
 
