@@ -299,7 +299,9 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
     f.p = pl.p; f.top = pl.top; f.tail = pl.tail;
     f.nmid = pl.nstages - 1;
     for (int s = 0; s < f.nmid; ++s) f.mid_t[s] = pl.D[s];
-    const int grid = ctx->num_cu;
+    // one workgroup per CU (the AES tables leave room for one); FSS_AMD_FUSED_GRID overrides, for tests of uneven shares
+    static const int grid_env = [] { const char* e = getenv("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
+    const int grid = grid_env ? grid_env : ctx->num_cu;
     const int64_t wmax = ((((int64_t)1 << (pl.top - pl.tail)) + grid - 1) / grid);
     int sh = pl.tail, sha = sh, shb = 0;
     for (int s = 0; s < f.nmid; ++s) {

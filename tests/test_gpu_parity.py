@@ -2,6 +2,7 @@
 with the reference's known answers.  Bit-exact: everything on this path is integer /
 XOR arithmetic."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -776,6 +777,23 @@ def test_eval_all_batch_vs_oracle(engine, O, scheme, n, nkeys, g):
     one = engine.eval_all(scheme, n, g, 1, T(s0s[nkeys - 1, 1].copy()), T(cws[nkeys - 1]),
                           ocw=None if ocws is None else T(ocws[nkeys - 1])).cpu().numpy()
     assert (got[nkeys - 1] == one).all()
+
+
+@pytest.mark.parametrize("grid", [77, 304])
+def test_eval_all_one_launch_with_uneven_workgroup_shares(grid):
+    """evalall_fused_kernel splits the frontier walks over the workgroups as [w * b / G, w * (b + 1) / G): with a
+    workgroup count that does not divide 2^16 (FSS_AMD_FUSED_GRID, read once per process, hence the child process) the
+    shares are ragged and the private workspace slices are sized by the largest one.  Same oracle comparisons as
+    test_eval_all_planner_shapes_vs_oracle (DPF n = 20 .. 22, Grotto n = 21, Half-Tree n = 21 take the one-launch form)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FSS_AMD_FUSED_GRID=str(grid), FSS_AMD_FUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_eval_all_planner_shapes_vs_oracle or test_grotto_eval_all_vs_oracle"],
+                       capture_output=True, text=True, timeout=900, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
 
 
 def test_cxx_dropin_boundary():

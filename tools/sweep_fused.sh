@@ -1,0 +1,11 @@
+#!/bin/bash
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
+run() { echo -n "[$1] "; env $1 python3 tools/bench_evalall.py --scheme $2 --n $3 --log2-leaves $4 --steady 2>/dev/null | tail -1; }
+for rep in 1 2; do
+for cfg in "dpf 28 25" "ht 28 25" "dpf 24 24" "ht 24 24"; do
+  set -- $cfg
+  for e in "FSS_AMD_FUSED=1" "FSS_AMD_TOPMAX=14" "FSS_AMD_TOPMAX=15" "FSS_AMD_TOPMAX=17" "FSS_AMD_MID_E=0" "FSS_AMD_MID_E=1" "FSS_AMD_LEAF_E=1" "FSS_AMD_LEAF_E=2" "FSS_AMD_LEAF_E=0"; do
+    run "$e" $1 $2 $3
+  done
+done
+done
