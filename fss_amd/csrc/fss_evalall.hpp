@@ -29,6 +29,10 @@
 #ifndef FSS_LEAF_PAIR_LINES
 #define FSS_LEAF_PAIR_LINES 1
 #endif
+// FSS_HT_HOLD = 1: the Half-Tree leaf stage stores a lane's four leaves together (A/B: 0 = as they are converted).
+#ifndef FSS_HT_HOLD
+#define FSS_HT_HOLD 1
+#endif
 
 namespace fssamd {
 
@@ -371,7 +375,8 @@ struct StageBody {
   const ExpandArgs& a;
   // DPF leaves under a rolled level: the 64 bytes of the first half are held back and stored together with the
   // second half -- the lane's eight 16-byte stores then fall on one 128-byte line within a few cycles instead of half
-  // a line now and half after six more AES blocks (FSS_LEAF_PAIR_LINES, A/B)
+  // a line now and half after six more AES blocks (FSS_LEAF_PAIR_LINES, A/B).  The same for DCF (two leaves per
+  // half) measured flat to slightly worse and is not taken.
   static constexpr bool kHold = FSS_LEAF_PAIR_LINES && LEAF && SCHEME == S_DPF && D == 2;
   uint4 held[kHold ? 4 : 1];
   __device__ __forceinline__ void operator()(const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc,
@@ -434,6 +439,16 @@ struct StageBody {
     } else if constexpr (SCHEME == S_HT) {
       const uint32_t* cw = kc + 8 * (a.in_bits - 1);
       uint4* ys = reinterpret_cast<uint4*>(a.ys);
+#if FSS_HT_PAIR && FSS_HT_HOLD
+      if constexpr (DE == 1) {  // the lane's four leaves (64 bytes) stored together
+        uint4 y[4];
+        ht_convert2<LT, OW>(L, c, g, party, cw, koc, nodes[0], y[0], y[1]);
+        ht_convert2<LT, OW>(L, c, g, party, cw, koc, nodes[1], y[2], y[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ys[ob + k] = y[k];
+        return;
+      }
+#endif
 #pragma unroll
       for (int k = 0; k < (1 << DE); ++k) {
 #if FSS_HT_PAIR
