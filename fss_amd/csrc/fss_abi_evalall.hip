@@ -148,7 +148,7 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
   return true;
 }
 
-// The plan as one launch (fss_abi_fused.hip): AES tables, DPF / Grotto / Half-Tree, a capped quad frontier with at
+// The plan as one launch (fss_abi_fused.hip): AES tables, DPF / Grotto / Half-Tree / DCF, a quad frontier with at
 // least 16 walks per workgroup, stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
 // launches (A/B).
 inline bool fused_on() {
@@ -157,11 +157,11 @@ inline bool fused_on() {
 }
 bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl) {
   if (!fused_on() || !quad_frontier() || ctx->prg == FSS_AMD_PRG_CHACHA) return false;
-  if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT) return false;
+  if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT && scheme != S_DCF) return false;
   if (pl.nstages < 1 || pl.nstages > 7) return false;
   if (pl.top - pl.tail < 12 || (((int64_t)1 << (pl.top - pl.tail)) < (int64_t)16 * ctx->num_cu)) return false;
-  const int leaf = pl.D[pl.nstages - 1];
-  if (leaf < 2 || leaf > 4 || (scheme == S_HT && leaf != 2)) return false;
+  const int leaf = pl.D[pl.nstages - 1], dm = dmax_for(scheme);
+  if (leaf < dm || leaf > dm + 2 || (scheme == S_HT && leaf != 2)) return false;
   for (int s = 0; s + 1 < pl.nstages; ++s)
     if (pl.D[s] < 1 || pl.D[s] > 3) return false;
   return true;
@@ -310,6 +310,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
       else { if (sh > sha) sha = sh; }
     }
     f.buf[0] = bufn[0]; f.buf[1] = bufn[1];
+    f.bufv[0] = bufv[0]; f.bufv[1] = bufv[1];
     f.wg_cap[0] = wmax << sha; f.wg_cap[1] = f.nmid ? (wmax << shb) : 0;
     if (f.wg_cap[0] * grid <= pl.cap_a && f.wg_cap[1] * grid <= pl.cap_b) {
       int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st);

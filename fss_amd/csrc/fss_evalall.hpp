@@ -565,8 +565,9 @@ struct FusedArgs {
   int p;              // depth of the block's root
   int top, tail;      // frontier depth below p (tail levels of it expanded in registers after the walk)
   int nmid;           // intermediate stages
-  int mid_t[6];       // their depths: 1, 2 (in registers) or 3 (one rolled level above two)
+  int mid_t[6];       // their depths, 1 .. 3: up to two levels in registers (DCF: one), the rest rolled above them
   uint4* buf[2];      // workspace halves; workgroup b owns [b * wg_cap[i], (b + 1) * wg_cap[i])
+  uint4* bufv[2];     // DCF: the running values of those nodes, same slices
   int64_t wg_cap[2];
 };
 
@@ -595,8 +596,9 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
                                                             const uint32_t* __restrict__ k_seed,
                                                             const uint32_t* __restrict__ k_cws,
                                                             const uint32_t* __restrict__ k_ocw, FusedArgs f) {
-  static_assert(SCHEME == S_DPF || SCHEME == S_GROTTO || SCHEME == S_HT);
+  static_assert(SCHEME == S_DPF || SCHEME == S_GROTTO || SCHEME == S_HT || SCHEME == S_DCF);
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
+  constexpr int DM = SCHEME == S_DCF ? 1 : 2;  // levels a stage expands in registers
   const DevCtx* c = first_kernarg(K);
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
@@ -605,12 +607,14 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   const int64_t walks = (int64_t)1 << (f.top - f.tail);
   const int64_t w_lo = walks * blockIdx.x / gridDim.x, w_hi = walks * (blockIdx.x + 1) / gridDim.x;
   uint4* const mine[2] = {f.buf[0] + (int64_t)blockIdx.x * f.wg_cap[0], f.buf[1] + (int64_t)blockIdx.x * f.wg_cap[1]};
+  uint4* const minev[2] = {f.bufv[0] + (int64_t)blockIdx.x * f.wg_cap[0], f.bufv[1] + (int64_t)blockIdx.x * f.wg_cap[1]};
   int64_t lo = w_lo << f.tail, hi = w_hi << f.tail;  // node range of the current level (indices within the block)
   int level = f.p + f.top;
   ExpandArgs a = f.a;
   {  // ---- frontier: nodes [lo, hi) at depth p + top into mine[0]
     a.level0 = level;
     a.out_nodes = mine[0] - lo;
+    a.out_v = minev[0] - lo;
     quad_frontier_walks<LT, WS, false>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> 2), w_hi,
                                        blockDim.x >> 2);
   }
@@ -622,11 +626,13 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     const int t = f.mid_t[s];
     a.level0 = level;
     a.in_nodes = mine[cur] - lo;
+    a.in_v = minev[cur] - lo;
     a.out_nodes = mine[cur ^ 1] - (lo << t);
+    a.out_v = minev[cur ^ 1] - (lo << t);
     LocalQ q(&waveq_ctr_, lo, hi);
     if (t == 1) run_stage<LT, SCHEME, 1, false, 0, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
-    else if (t == 2) run_stage<LT, SCHEME, 2, false, 0, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
-    else run_stage<LT, SCHEME, 2, false, 1, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    else run_stage<LT, SCHEME, DM, false, 3 - DM, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
     lo <<= t; hi <<= t; level += t;
     cur ^= 1;
   }
@@ -636,6 +642,7 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   {  // ---- leaf stage: mine[cur] -> ys
     a.level0 = level;
     a.in_nodes = mine[cur] - lo;
+    a.in_v = minev[cur] - lo;
     LocalQ q(&waveq_ctr_, lo, hi);
     run_stage<LT, SCHEME, LD, true, LE, false, OW>(L, c, g, a, k_cws, k_ocw, q, hi);
   }
