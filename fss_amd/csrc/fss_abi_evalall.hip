@@ -5,7 +5,7 @@
 
 // fss_abi_fused.hip
 int launch_fused_evalall(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* seed, const uint32_t* cws,
-                         const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st);
+                         const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st, bool batch);
 
 namespace {
 
@@ -89,6 +89,20 @@ inline int mid_extra(int scheme) {
   return (scheme == S_DPF || scheme == S_GROTTO) ? 1 : 0;
 }
 
+// Room (in nodes) the one-launch form needs in the two buffers beyond the plan's own sizes: every workgroup's private
+// slice is ceil(walks / grid) walks wide; `slack_walks` covers the rounding of up to 1024 workgroups.
+inline void fused_room(const Plan& pl, int64_t walks, int64_t* room_a, int64_t* room_b) {
+  int sh = pl.tail;
+  *room_a = walks << sh;
+  *room_b = 0;
+  for (int s = 0; s + 1 < pl.nstages; ++s) {
+    sh += pl.D[s];
+    const int64_t v = walks << sh;
+    if (s % 2 == 0) { if (v > *room_b) *room_b = v; }
+    else { if (v > *room_a) *room_a = v; }
+  }
+}
+
 bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl) {
   if (in_bits < 1 || in_bits > 62 || nleaves < 1 || first_leaf < 0) return false;
   if (nleaves & (nleaves - 1)) return false;
@@ -128,22 +142,12 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
     if (s % 2 == 0) { if (f > pl->cap_b) pl->cap_b = f; }
     else { if (f > pl->cap_a) pl->cap_a = f; }
   }
-  // The one-launch form (evalall_fused_kernel) gives every workgroup a private slice, ceil(walks / grid) walks wide:
-  // room for the rounding of up to 1024 workgroups (a few hundred KiB at most).
-  {
-    const int64_t slack = 1023;
-    int sh = pl->tail;
-    int64_t fa = (((int64_t)1 << (top - pl->tail)) + slack) << sh, fb = 0;
-    for (int s = 0; s + 1 < pl->nstages; ++s) {
-      sh += pl->D[s];
-      const int64_t v = (((int64_t)1 << (top - pl->tail)) + slack) << sh;
-      if (s % 2 == 0) { if (v > fb) fb = v; }
-      else { if (v > fa) fa = v; }
-    }
-    if (top - pl->tail >= 12) {  // only plans the fused form takes (fused_ok)
-      if (fa > pl->cap_a) pl->cap_a = fa;
-      if (fb > pl->cap_b) pl->cap_b = fb;
-    }
+  // the one-launch form (evalall_fused_kernel): room for the rounding of the workgroups' slices, a few hundred KiB
+  if (top - pl->tail >= 12) {  // only plans it takes (fused_ok)
+    int64_t fa, fb;
+    fused_room(*pl, ((int64_t)1 << (top - pl->tail)) + 1023, &fa, &fb);
+    if (fa > pl->cap_a) pl->cap_a = fa;
+    if (fb > pl->cap_b) pl->cap_b = fb;
   }
   return true;
 }
@@ -155,11 +159,26 @@ inline bool fused_on() {
   static const bool v = [] { const char* e = getenv("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
   return v;
 }
-bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl) {
+// one workgroup per CU (the AES tables leave room for one); FSS_AMD_FUSED_GRID overrides, for tests of uneven shares
+inline int fused_grid(const fss_amd_ctx* ctx) {
+  static const int grid_env = [] { const char* e = getenv("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
+  return grid_env ? grid_env : ctx->num_cu;
+}
+// The workgroups' private slices of the two buffers, for `nkeys` trees side by side.
+inline void fused_slices(const Plan& pl, int64_t nkeys, int grid, uint4* const bufn[2], uint4* const bufv[2], FusedArgs* f) {
+  f->p = pl.p; f->top = pl.top; f->tail = pl.tail;
+  f->nmid = pl.nstages - 1;
+  for (int s = 0; s < f->nmid; ++s) f->mid_t[s] = pl.D[s];
+  const int64_t wmax = (((nkeys << (pl.top - pl.tail)) + grid - 1) / grid);
+  fused_room(pl, wmax, &f->wg_cap[0], &f->wg_cap[1]);
+  f->buf[0] = bufn[0]; f->buf[1] = bufn[1];
+  f->bufv[0] = bufv[0]; f->bufv[1] = bufv[1];
+}
+bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys) {
   if (!fused_on() || !quad_frontier() || ctx->prg == FSS_AMD_PRG_CHACHA) return false;
   if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT && scheme != S_DCF) return false;
   if (pl.nstages < 1 || pl.nstages > 7) return false;
-  if (pl.top - pl.tail < 12 || (((int64_t)1 << (pl.top - pl.tail)) < (int64_t)16 * ctx->num_cu)) return false;
+  if ((nkeys << (pl.top - pl.tail)) < (int64_t)16 * ctx->num_cu) return false;
   const int leaf = pl.D[pl.nstages - 1], dm = dmax_for(scheme);
   if (leaf < dm || leaf > dm + 2 || (scheme == S_HT && leaf != 2)) return false;
   for (int s = 0; s + 1 < pl.nstages; ++s)
@@ -293,27 +312,13 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   a.ys = ys;
 
   bool fused = false;
-  if (fused_ok(ctx, SCHEME, pl)) {
+  if (fused_ok(ctx, SCHEME, pl, 1)) {
     FusedArgs f{};
     f.a = a;
-    f.p = pl.p; f.top = pl.top; f.tail = pl.tail;
-    f.nmid = pl.nstages - 1;
-    for (int s = 0; s < f.nmid; ++s) f.mid_t[s] = pl.D[s];
-    // one workgroup per CU (the AES tables leave room for one); FSS_AMD_FUSED_GRID overrides, for tests of uneven shares
-    static const int grid_env = [] { const char* e = getenv("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
-    const int grid = grid_env ? grid_env : ctx->num_cu;
-    const int64_t wmax = ((((int64_t)1 << (pl.top - pl.tail)) + grid - 1) / grid);
-    int sh = pl.tail, sha = sh, shb = 0;
-    for (int s = 0; s < f.nmid; ++s) {
-      sh += pl.D[s];
-      if (s % 2 == 0) { if (sh > shb) shb = sh; }
-      else { if (sh > sha) sha = sh; }
-    }
-    f.buf[0] = bufn[0]; f.buf[1] = bufn[1];
-    f.bufv[0] = bufv[0]; f.bufv[1] = bufv[1];
-    f.wg_cap[0] = wmax << sha; f.wg_cap[1] = f.nmid ? (wmax << shb) : 0;
+    const int grid = fused_grid(ctx);
+    fused_slices(pl, 1, grid, bufn, bufv, &f);
     if (f.wg_cap[0] * grid <= pl.cap_a && f.wg_cap[1] * grid <= pl.cap_b) {
-      int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st);
+      int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st, false);
       if (rc != FSS_AMD_OK) return rc;
       fused = true;
     }
@@ -403,9 +408,20 @@ bool make_batch_plan(int scheme, bool aes, int in_bits, int64_t nkeys, BatchPlan
   return true;
 }
 
+// Nodes in the two buffers: the plan's frontiers for all keys, or the one-launch form's slices (fused_room) if larger.
+inline void batch_caps(const BatchPlan& bp, int64_t* ca, int64_t* cb) {
+  int64_t fa, fb;
+  fused_room(bp.pl, (bp.nkeys << (bp.pl.top - bp.pl.tail)) + 1023, &fa, &fb);
+  *ca = bp.pl.cap_a * bp.nkeys;
+  *cb = bp.pl.cap_b * bp.nkeys;
+  if (fa > *ca) *ca = fa;
+  if (fb > *cb) *cb = fb;
+}
 size_t batch_workspace(int scheme, const BatchPlan& bp) {
   size_t per = (scheme == S_DCF) ? 32 : 16;
-  return align256((size_t)bp.pl.cap_a * bp.nkeys * per) + align256((size_t)bp.pl.cap_b * bp.nkeys * per);
+  int64_t ca, cb;
+  batch_caps(bp, &ca, &cb);
+  return align256((size_t)ca * per) + align256((size_t)cb * per);
 }
 
 template <int SCHEME>
@@ -422,7 +438,8 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   FSS_ON_DEVICE(ctx);
 
   const size_t per = (SCHEME == S_DCF) ? 32 : 16;
-  const int64_t ca = pl.cap_a * nkeys, cb = pl.cap_b * nkeys;
+  int64_t ca, cb;
+  batch_caps(bp, &ca, &cb);
   uint8_t* w = reinterpret_cast<uint8_t*>(workspace);
   uint4* bufn[2] = {reinterpret_cast<uint4*>(w), reinterpret_cast<uint4*>(w + align256((size_t)ca * per))};
   uint4* bufv[2] = {bufn[0] + ca, bufn[1] + cb};
@@ -437,6 +454,14 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   k.cws = reinterpret_cast<const uint32_t*>(cws);
   k.ocw = reinterpret_cast<const uint32_t*>(ocws);
 
+  if ((SCHEME == S_DPF || SCHEME == S_HT) && fused_ok(ctx, SCHEME, pl, nkeys)) {
+    FusedArgs fa{};
+    fa.a = a;
+    const int grid = fused_grid(ctx);
+    fused_slices(pl, nkeys, grid, bufn, bufv, &fa);
+    if (fa.wg_cap[0] * grid <= ca && fa.wg_cap[1] * grid <= cb)
+      return launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], nullptr, k.cws, k.ocw, fa, grid, st, true);
+  }
   a.level0 = pl.top;
   a.out_nodes = bufn[0];
   a.out_v = bufv[0];

@@ -591,7 +591,8 @@ struct LocalQ {
   }
 };
 
-template <class LT, int SCHEME, int LD, int LE, int OW>
+// BATCH: nkeys trees side by side (a.nkeys, a.seeds, a.key_slots; walk j belongs to key j >> (top - tail)).
+template <class LT, int SCHEME, int LD, int LE, int OW, bool BATCH = false>
 __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
                                                             const uint32_t* __restrict__ k_cws,
@@ -603,8 +604,8 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const Grp g = make_grp(f.a.group, c);
-  // this workgroup's walks [w_lo, w_hi) of the 2^(top - tail)
-  const int64_t walks = (int64_t)1 << (f.top - f.tail);
+  // this workgroup's walks [w_lo, w_hi) of the 2^(top - tail) per key
+  const int64_t walks = (BATCH ? f.a.nkeys : (int64_t)1) << (f.top - f.tail);
   const int64_t w_lo = walks * blockIdx.x / gridDim.x, w_hi = walks * (blockIdx.x + 1) / gridDim.x;
   uint4* const mine[2] = {f.buf[0] + (int64_t)blockIdx.x * f.wg_cap[0], f.buf[1] + (int64_t)blockIdx.x * f.wg_cap[1]};
   uint4* const minev[2] = {f.bufv[0] + (int64_t)blockIdx.x * f.wg_cap[0], f.bufv[1] + (int64_t)blockIdx.x * f.wg_cap[1]};
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     a.level0 = level;
     a.out_nodes = mine[0] - lo;
     a.out_v = minev[0] - lo;
-    quad_frontier_walks<LT, WS, false>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> 2), w_hi,
+    quad_frontier_walks<LT, WS, BATCH>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> 2), w_hi,
                                        blockDim.x >> 2);
   }
   int cur = 0;
@@ -630,9 +631,9 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     a.out_nodes = mine[cur ^ 1] - (lo << t);
     a.out_v = minev[cur ^ 1] - (lo << t);
     LocalQ q(&waveq_ctr_, lo, hi);
-    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
-    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
-    else run_stage<LT, SCHEME, DM, false, 3 - DM, false, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    else run_stage<LT, SCHEME, DM, false, 3 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
     lo <<= t; hi <<= t; level += t;
     cur ^= 1;
   }
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     a.in_nodes = mine[cur] - lo;
     a.in_v = minev[cur] - lo;
     LocalQ q(&waveq_ctr_, lo, hi);
-    run_stage<LT, SCHEME, LD, true, LE, false, OW>(L, c, g, a, k_cws, k_ocw, q, hi);
+    run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi);
   }
 }
 
