@@ -508,6 +508,79 @@ static void Batches() {
               g_fail == before ? "ok" : "FAILED");
 }
 
+// every built-in group through the per-thread walk: 1024 DPF keys, n = 16, against the engine's keys and shares
+template <typename G>
+static void GroupCase(const char* name) {
+  const int before = g_fail;
+  constexpr int kN = 1024, kBits = 16;
+  using Prg = fss::prg::Aes128Mmo<2>;
+  using Dpf = fss::Dpf<kBits, G, Prg, uint16_t>;
+  const unsigned char* keys[2] = {k0, k1};
+  Prg prg(keys);
+  Dpf dpf{prg};
+  std::vector<int4> seeds(2 * kN), seeds0(kN), seeds1(kN), betas(kN);
+  std::vector<uint16_t> alphas(kN), xs(kN);
+  std::vector<uint32_t> xs32(kN);
+  for (int i = 0; i < kN; ++i) {
+    seeds0[i] = seeds[2 * i] = RandSeed();
+    seeds1[i] = seeds[2 * i + 1] = RandSeed();
+    betas[i] = RandSeed();
+    alphas[i] = static_cast<uint16_t>(Next());
+    xs32[i] = xs[i] = i % 2 ? alphas[i] : static_cast<uint16_t>(Next());
+  }
+  int4* d_seeds = ToDevice(seeds.data(), 2 * kN);
+  int4* d_seeds0 = ToDevice(seeds0.data(), kN);
+  int4* d_seeds1 = ToDevice(seeds1.data(), kN);
+  int4* d_betas = ToDevice(betas.data(), kN);
+  uint16_t* d_alphas = ToDevice(alphas.data(), kN);
+  uint16_t* d_xs = ToDevice(xs.data(), kN);
+  uint32_t* d_xs32 = ToDevice(xs32.data(), kN);
+  typename Dpf::Cw* d_cws = DeviceBuf<typename Dpf::Cw>(size_t(kBits + 1) * kN);
+  typename Dpf::Cw* d_cws_e = DeviceBuf<typename Dpf::Cw>(size_t(kBits + 1) * kN);
+  int4* d_y0 = DeviceBuf<int4>(kN);
+  int4* d_y1 = DeviceBuf<int4>(kN);
+  int4* d_ye = DeviceBuf<int4>(kN);
+  GenKeysKernel<Dpf, uint16_t><<<kN / 128, 128>>>(dpf, d_cws, d_seeds, d_alphas, d_betas, kN);
+  EvalKeysKernel<Dpf, uint16_t><<<kN / 128, 128>>>(dpf, d_y0, false, d_seeds0, d_cws, d_xs, kN);
+  EvalKeysKernel<Dpf, uint16_t><<<kN / 128, 128>>>(dpf, d_y1, true, d_seeds1, d_cws, d_xs, kN);
+  HIP_OK(hipDeviceSynchronize());
+  auto y0 = ToHost(d_y0, kN), y1 = ToHost(d_y1, kN);
+  int bad = 0;
+  for (int i = 0; i < kN; ++i) {
+    int4 want = xs[i] == alphas[i] ? G::From(fss::util::SetLsb(betas[i], false)).Into() : kZero;
+    bad += !Same(Recon<G>(y0[i], y1[i]), want);
+  }
+  EXPECT(bad == 0);
+  dpf.GenBatch(d_cws_e, d_seeds, d_alphas, d_betas, kN);
+  auto a = ToHost(d_cws, size_t(kBits + 1) * kN), e = ToHost(d_cws_e, size_t(kBits + 1) * kN);
+  bad = 0;
+  for (size_t i = 0; i < a.size(); ++i) bad += !Same(a[i].s, e[i].s) || (i % (kBits + 1) != kBits && a[i].tr != e[i].tr);
+  EXPECT(bad == 0);
+  int4* cw_s = DeviceBuf<int4>(size_t(kBits) * kN);
+  uint32_t* extra = DeviceBuf<uint32_t>(kN);
+  int4* out_cw = DeviceBuf<int4>(kN);
+  fss::gpu::DpfRelayoutGpu<kBits, G, Prg, uint16_t>(d_cws, kN, cw_s, extra, out_cw);
+  fss::gpu::DpfEvalPointGpu<4>(true, d_seeds1, cw_s, extra, out_cw, d_xs32, d_ye, kN, dpf);
+  HIP_OK(hipDeviceSynchronize());
+  auto ye = ToHost(d_ye, kN);
+  bad = 0;
+  for (int i = 0; i < kN; ++i) bad += !Same(ye[i], y1[i]);
+  EXPECT(bad == 0);
+  for (void* p : {(void*)d_seeds, (void*)d_seeds0, (void*)d_seeds1, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_xs32,
+                  (void*)d_cws, (void*)d_cws_e, (void*)d_y0, (void*)d_y1, (void*)d_ye, (void*)cw_s, (void*)extra, (void*)out_cw})
+    HIP_OK(hipFree(p));
+  std::printf("AES-128-MMO  DPF n=16  %-22s 1024 keys per thread == engine, reconstructs: %s\n", name,
+              g_fail == before ? "ok" : "FAILED");
+}
+static void Groups() {
+  GroupCase<fss::group::Bytes>("Bytes");
+  GroupCase<fss::group::Uint<uint8_t>>("Uint<u8>");
+  GroupCase<fss::group::Uint<uint32_t>>("Uint<u32>");
+  GroupCase<fss::group::Uint<unsigned __int128, static_cast<unsigned __int128>(1) << 127>>("Uint<u128, 2^127>");
+  GroupCase<fss::group::Uint<uint32_t, 4294967291u>>("Uint<u32, 2^32 - 5>");
+  GroupCase<fss::group::Uint<uint64_t, 18446744073709551557ull>>("Uint<u64, 2^64 - 59>");
+}
+
 // what the compatibility form costs next to the engine: DPF n=32, 2^18 independent keys, one evaluation each
 static void Timing() {
   constexpr int kN = 1 << 18;
@@ -724,6 +797,7 @@ int main() {
     p1::Run();
     p2::Kats();
     p2::Batches();
+    p2::Groups();
     p2::Timing();
     p3::Run();
     fss::ReleaseEngines();
