@@ -3,9 +3,11 @@
 #include "fss_host.hpp"
 #include "fss_evalall.hpp"
 
-// fss_abi_fused.hip
+// fss_abi_fused.hip, fss_abi_fused_batch.hip
 int launch_fused_evalall(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* seed, const uint32_t* cws,
-                         const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st, bool batch);
+                         const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st);
+int launch_fused_evalall_batch(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* cws, const uint32_t* ocws,
+                               const fssamd::FusedArgs& f, int grid, hipStream_t st);
 
 namespace {
 
@@ -89,6 +91,13 @@ inline int mid_extra(int scheme) {
   return (scheme == S_DPF || scheme == S_GROTTO) ? 1 : 0;
 }
 
+// `walks` plus the rounding of the workgroups' shares: grid * ceil(walks / grid) <= walks + grid - 1 with at most one
+// workgroup per 256 walks and at most 1024 of them (fused_grid; the workspace queries have no context).
+inline int64_t fused_padded(int64_t walks) {
+  int64_t g = (walks + 255) / 256;
+  if (g > 1024) g = 1024;
+  return walks + (g < 1 ? 0 : g - 1);
+}
 // Room (in nodes) the one-launch form needs in the two buffers beyond the plan's own sizes: every workgroup's private
 // slice is ceil(walks / grid) walks wide; `slack_walks` covers the rounding of up to 1024 workgroups.
 inline void fused_room(const Plan& pl, int64_t walks, int64_t* room_a, int64_t* room_b) {
@@ -143,9 +152,9 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
     else { if (f > pl->cap_a) pl->cap_a = f; }
   }
   // the one-launch form (evalall_fused_kernel): room for the rounding of the workgroups' slices, a few hundred KiB
-  if (top - pl->tail >= 12) {  // only plans it takes (fused_ok)
+  {
     int64_t fa, fb;
-    fused_room(*pl, ((int64_t)1 << (top - pl->tail)) + 1023, &fa, &fb);
+    fused_room(*pl, fused_padded((int64_t)1 << (top - pl->tail)), &fa, &fb);
     if (fa > pl->cap_a) pl->cap_a = fa;
     if (fb > pl->cap_b) pl->cap_b = fb;
   }
@@ -153,16 +162,19 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
 }
 
 // The plan as one launch (fss_abi_fused.hip): AES tables, DPF / Grotto / Half-Tree / DCF, a quad frontier with at
-// least 16 walks per workgroup, stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
+// a workgroup per 256 walks (up to one per CU), stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
 // launches (A/B).
 inline bool fused_on() {
   static const bool v = [] { const char* e = getenv("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
   return v;
 }
-// one workgroup per CU (the AES tables leave room for one); FSS_AMD_FUSED_GRID overrides, for tests of uneven shares
-inline int fused_grid(const fss_amd_ctx* ctx) {
+// One workgroup per CU (the AES tables leave room for one), fewer when there are not 256 walks (1024 lanes) for each;
+// FSS_AMD_FUSED_GRID overrides, for tests of uneven shares.
+inline int fused_grid(const fss_amd_ctx* ctx, int64_t walks) {
   static const int grid_env = [] { const char* e = getenv("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
-  return grid_env ? grid_env : ctx->num_cu;
+  if (grid_env) return grid_env;
+  const int64_t want = (walks + 255) / 256;
+  return (int)(want < ctx->num_cu ? (want < 1 ? 1 : want) : ctx->num_cu);
 }
 // The workgroups' private slices of the two buffers, for `nkeys` trees side by side.
 inline void fused_slices(const Plan& pl, int64_t nkeys, int grid, uint4* const bufn[2], uint4* const bufv[2], FusedArgs* f) {
@@ -178,9 +190,9 @@ bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys)
   if (!fused_on() || !quad_frontier() || ctx->prg == FSS_AMD_PRG_CHACHA) return false;
   if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT && scheme != S_DCF) return false;
   if (pl.nstages < 1 || pl.nstages > 7) return false;
-  if ((nkeys << (pl.top - pl.tail)) < (int64_t)16 * ctx->num_cu) return false;
+  (void)nkeys;
   const int leaf = pl.D[pl.nstages - 1], dm = dmax_for(scheme);
-  if (leaf < dm || leaf > dm + 2 || (scheme == S_HT && leaf != 2)) return false;
+  if (leaf < 0 || leaf > dm + 2 || (scheme == S_HT && (leaf < 1 || leaf > 2))) return false;
   for (int s = 0; s + 1 < pl.nstages; ++s)
     if (pl.D[s] < 1 || pl.D[s] > 3) return false;
   return true;
@@ -315,10 +327,10 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   if (fused_ok(ctx, SCHEME, pl, 1)) {
     FusedArgs f{};
     f.a = a;
-    const int grid = fused_grid(ctx);
+    const int grid = fused_grid(ctx, (int64_t)1 << (pl.top - pl.tail));
     fused_slices(pl, 1, grid, bufn, bufv, &f);
     if (f.wg_cap[0] * grid <= pl.cap_a && f.wg_cap[1] * grid <= pl.cap_b) {
-      int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st, false);
+      int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st);
       if (rc != FSS_AMD_OK) return rc;
       fused = true;
     }
@@ -411,7 +423,7 @@ bool make_batch_plan(int scheme, bool aes, int in_bits, int64_t nkeys, BatchPlan
 // Nodes in the two buffers: the plan's frontiers for all keys, or the one-launch form's slices (fused_room) if larger.
 inline void batch_caps(const BatchPlan& bp, int64_t* ca, int64_t* cb) {
   int64_t fa, fb;
-  fused_room(bp.pl, (bp.nkeys << (bp.pl.top - bp.pl.tail)) + 1023, &fa, &fb);
+  fused_room(bp.pl, fused_padded(bp.nkeys << (bp.pl.top - bp.pl.tail)), &fa, &fb);
   *ca = bp.pl.cap_a * bp.nkeys;
   *cb = bp.pl.cap_b * bp.nkeys;
   if (fa > *ca) *ca = fa;
@@ -457,10 +469,10 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   if ((SCHEME == S_DPF || SCHEME == S_HT) && fused_ok(ctx, SCHEME, pl, nkeys)) {
     FusedArgs fa{};
     fa.a = a;
-    const int grid = fused_grid(ctx);
+    const int grid = fused_grid(ctx, nkeys << (pl.top - pl.tail));
     fused_slices(pl, nkeys, grid, bufn, bufv, &fa);
     if (fa.wg_cap[0] * grid <= ca && fa.wg_cap[1] * grid <= cb)
-      return launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], nullptr, k.cws, k.ocw, fa, grid, st, true);
+      return launch_fused_evalall_batch(ctx, SCHEME, pl.D[pl.nstages - 1], k.cws, k.ocw, fa, grid, st);
   }
   a.level0 = pl.top;
   a.out_nodes = bufn[0];

@@ -779,6 +779,39 @@ def test_eval_all_batch_vs_oracle(engine, O, scheme, n, nkeys, g):
     assert (got[nkeys - 1] == one).all()
 
 
+@pytest.mark.parametrize("scheme,n", [(DPF, 1), (DPF, 8), (DPF, 17), (DPF, 20), (HT, 1), (HT, 12), (HT, 21), (DCF, 16),
+                                      (GROTTO, 10), (GROTTO, 21)])
+def test_eval_all_is_one_launch(engine, O, scheme, n):
+    """With the AES tables a single-key EvalAll of every scheme and size is ONE kernel launch (evalall_fused_kernel:
+    walks, stages and leaves of a workgroup's share in one go), and so are the batched DPF / Half-Tree forms -- the
+    parity tests above therefore exercise that kernel, not the chain of launches it replaced (FSS_AMD_FUSED=0)."""
+    if os.environ.get("FSS_AMD_FUSED") == "0":
+        pytest.skip("the chain of launches was asked for")
+    rng = SplitMix64(777 + 100 * scheme + n)
+    g = G.BYTES if scheme == GROTTO else G.U64
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1, GROTTO: 2}[scheme])
+    s = [rng.i4(), rng.i4()]
+    alpha, beta, ocw = rng.below(n), beta_for(rng), None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 0, s, alpha, beta)
+    elif scheme == HT:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    else:
+        cws = O.grotto_gen(p, n, s, alpha)
+    # (Grotto: the tree is the one launch; the running-XOR scan kernels behind it do not record themselves)
+    engine.eval_all(scheme, n, g, 0, T(s[0]), T(cws), ocw=None if ocw is None else T(ocw))
+    assert engine.last_kernel()[0] == "evalall_fused", engine.last_kernel()
+    if scheme in (DPF, HT):
+        nk = 5
+        s0s = torch.stack([T(s[0])] * nk)
+        cwb = torch.stack([T(cws)] * nk)
+        ocb = None if ocw is None else torch.stack([T(ocw)] * nk)
+        engine.eval_all_batch(scheme, n, g, 0, s0s, cwb, ocws=ocb)
+        assert engine.last_kernel()[0] == "evalall_fused", engine.last_kernel()
+
+
 @pytest.mark.parametrize("grid", [77, 304])
 def test_eval_all_one_launch_with_uneven_workgroup_shares(grid):
     """evalall_fused_kernel splits the frontier walks over the workgroups as [w * b / G, w * (b + 1) / G): with a
