@@ -675,6 +675,36 @@ __device__ __forceinline__ void rotate_prio(int step) {
   }
 }
 
+// Progress-ranked wave priority (rot_prio = 2): closed loop instead of taking turns.  Every wave publishes how many
+// levels it has walked; its priority is the number of waves of its SIMD that are ahead of it, so whoever falls behind
+// is preferred until it has caught up.  Per-wave stamps showed why turns are not enough: with fixed shares the four
+// waves of a SIMD still leave in order of age, 72 / 55 / 27 / 8 us before the end of a 320 us launch (2^20 points),
+// and the LDS is not kept busy by the ones that remain.
+#define FSS_PROGRESS_PROLOGUE()                                   \
+  __shared__ __attribute__((aligned(16))) uint32_t wave_prog_[16]; \
+  if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0
+__device__ __forceinline__ void rank_prio(uint32_t* prog, uint32_t& mine, uint32_t slack) {
+  // The LDS is the pipe this kernel is bound by, so the exchange is made cheap: every fourth level, one single-lane
+  // write and one four-lane read (a full-wave 16-byte broadcast read per level cost 3.6 % at 2^24 points).
+  ++mine;
+  if (mine & 3u) return;
+  const int w = threadIdx.x >> 6, simd = w & 3, age = w >> 2;  // waves w, w+4, w+8, w+12 of a workgroup share a SIMD
+  const int lane = threadIdx.x & 63;
+  uint32_t other = 0;
+  if (lane < 4) {
+    if (lane == age) prog[simd * 4 + age] = mine;
+    other = *reinterpret_cast<const volatile uint32_t*>(prog + simd * 4 + lane);
+  }
+  // waves within `slack` levels of each other are left to the arbiter
+  const int ahead = __popcll(__ballot(other > mine + slack));
+  switch (ahead) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 // ------------------------------------------------------------------ BLAKE3 (VDPF hashes)
 // fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): one keyed-hash compression (7 rounds) of a
 // single block, flags CHUNK_START | CHUNK_END | ROOT | KEYED_HASH, counter 0; out = first 8 words of the

@@ -112,12 +112,18 @@ struct Tune {
   int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
   bool ilp_set = false;  // FSS_AMD_ILP given: do not second-guess it for small batches
   int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
-  int rot_prio = -1;  // FSS_AMD_ROTPRIO: 1 / 0 force; default: on for static launches
+  int rot_prio = -1;  // FSS_AMD_ROTPRIO: 0 none / 1 turns / 2 by progress; default: see launch_points_k
+  int prio_slack = 0;  // FSS_AMD_PRIO_SLACK
+  int static_prio = 2;  // FSS_AMD_STATIC_PRIO: wave priorities of launches with fixed shares (0 none / 1 turns / 2 by progress)
+  int64_t dyn_min = 65536;  // FSS_AMD_DYN_MIN: AES blocks per resident wave from which shares are handed out dynamically
   int tail_pct = 8;  // FSS_AMD_TAIL_PCT: share of a dynamic walk's chunks in the launch-wide tail queue (0: none)
   Tune() {
     if (const char* e = getenv("FSS_AMD_TAIL_PCT")) { tail_pct = atoi(e); if (tail_pct < 0 || tail_pct > 100) tail_pct = 8; }
-    if (const char* e = getenv("FSS_AMD_ROTPRIO")) rot_prio = atoi(e) != 0;
+    if (const char* e = getenv("FSS_AMD_ROTPRIO")) { rot_prio = atoi(e); if (rot_prio < 0 || rot_prio > 2) rot_prio = 1; }
     if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
+    if (const char* e = getenv("FSS_AMD_STATIC_PRIO")) { static_prio = atoi(e); if (static_prio < 0 || static_prio > 2) static_prio = 2; }
+    if (const char* e = getenv("FSS_AMD_DYN_MIN")) { dyn_min = atoll(e); if (dyn_min < 1) dyn_min = 65536; }
+    if (const char* e = getenv("FSS_AMD_PRIO_SLACK")) { prio_slack = atoi(e); if (prio_slack < 0) prio_slack = 0; }
     if (const char* e = getenv("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
     if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
     if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
@@ -229,12 +235,14 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   int grid = 0;
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
-  // dynamic distribution from 16 384 AES blocks per resident wave on (DPF n = 32: 2^21 points on the whole chip; DCF
-  // n = 32 and Half-Tree n = 64: 2^20); below that the chunks are too few or too short to even out and fixed shares
-  // with rotating priorities win (DPF 2^20 points: 0.320 ms static against 0.356 dynamic, 2^21: 0.629 against 0.616;
-  // DCF 2^20: 0.660 static against 0.616 dynamic; profiles/r2/points_ab.txt)
-  a.dyn = tune().dyn >= 0 ? tune().dyn : (a.n * blocks_per_eval >= (int64_t)16384 * grid * (bs / 64) ? 1 : 0);
-  a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : !a.dyn;
+  // dynamic distribution from 65 536 AES blocks per resident wave on (DPF n = 32: 2^23 points on the whole chip; DCF
+  // n = 32 and Half-Tree n = 64: 2^22); below that fixed shares with progress-ranked wave priorities (rank_prio) win:
+  // the waves of a SIMD finish together and there is no ragged last chunk (DPF 2^20 points: 0.344 -> 0.307 ms, 2^21:
+  // 0.624 -> 0.600, 2^22: 1.217 -> 1.194 against the earlier policy -- dynamic from 16 384 blocks, rotating priorities
+  // below; profiles/r2/points_prio_ab.txt)
+  a.dyn = tune().dyn >= 0 ? tune().dyn : (a.n * blocks_per_eval >= tune().dyn_min * grid * (bs / 64) ? 1 : 0);
+  a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : (a.dyn ? 0 : tune().static_prio);
+  a.prio_slack = tune().prio_slack;
   // the last tail_pct % of the chunks go to whichever workgroup asks first (WaveQ); shares stay whole rounds of the grid.
   // Only where a chunk is long enough: in the tail every chunk costs a request to one device-memory word, and those
   // serialise at a few tens of millions per second -- DPF n = 8, one evaluation per lane: 1.20 -> 1.39 ms WITH the tail;

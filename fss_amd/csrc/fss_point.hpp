@@ -53,7 +53,8 @@ struct EvalArgs {
   const uint4* pre_nodes;
   const uint4* pre_v;       // DCF: running group value of every node
   int dyn;                  // waves take chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
-  int rot_prio;             // statically distributed launches: rotate the wave priority every level (rotate_prio)
+  int prio_slack;           // rank_prio: levels a wave may be ahead of another before it yields
+  int rot_prio;             // wave priority per level: 1 = the waves of a SIMD take turns (rotate_prio), 2 = by progress (rank_prio)
   int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
   uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
   uint32_t* gq;             // WaveQ's launch-wide tail: {counter, waves done} of this stream, or nullptr
@@ -290,8 +291,10 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_ocw,   // Half-Tree
                                                          EvalArgs a) {
   const DevCtx* c = first_kernarg(K);
+  FSS_PROGRESS_PROLOGUE();
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
+  uint32_t my_prog = 0;
 
   const int in_bits = a.in_bits, party = a.party;
   const Grp g = make_grp(a.group, c);
@@ -341,7 +344,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
-        if (a.rot_prio) rotate_prio(i);
+        if (a.rot_prio == 1) rotate_prio(i);
+        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack);
         CwDpf cw[ILP];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
-        if (a.rot_prio) rotate_prio(i);
+        if (a.rot_prio == 1) rotate_prio(i);
+        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack);
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
           CwDcf cw;
@@ -421,7 +426,8 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits - 1; ++i) {
-        if (a.rot_prio) rotate_prio(i);
+        if (a.rot_prio == 1) rotate_prio(i);
+        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack);
         uint32_t cw[ILP][4];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {

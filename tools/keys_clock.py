@@ -78,6 +78,10 @@ if hasattr(L, "fss_amd_diag_read_stamps"):
     per_wg_end = r1.reshape(grid, -1).max(axis=1)
     line["workgroup_end_spread_us"] = round(float(per_wg_end.max() - per_wg_end.min()) / 100.0, 1)
     line["starts_spread_us"] = round(float(r0.max() - r0.min()) / 100.0, 1)
+    # by wave slot of the workgroup (slots s, s + 4, s + 8, s + 12 share a SIMD): how long before the launch's end
+    # the slot's waves leave their loop, averaged over the workgroups
+    slot = (r1.max() - r1).reshape(grid, -1).mean(axis=0) / 100.0
+    line["slot_done_before_end_us"] = [round(float(v), 1) for v in slot]
     ok = dreal > 0
     clk = dcyc[ok] / dreal[ok] * 0.1  # GHz: realtime ticks at 100 MHz
     line["in_kernel_clock_GHz_median"] = round(float(np.median(clk)), 4)
