@@ -683,11 +683,12 @@ __device__ __forceinline__ void rotate_prio(int step) {
 #define FSS_PROGRESS_PROLOGUE()                                   \
   __shared__ __attribute__((aligned(16))) uint32_t wave_prog_[16]; \
   if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0
-__device__ __forceinline__ void rank_prio(uint32_t* prog, uint32_t& mine, uint32_t slack) {
+// every_mask: the exchange happens when (steps done & every_mask) == 0 -- 3 for the point walks (a step = one level).
+__device__ __forceinline__ void rank_prio(uint32_t* prog, uint32_t& mine, uint32_t slack, uint32_t every_mask = 3u) {
   // The LDS is the pipe this kernel is bound by, so the exchange is made cheap: every fourth level, one single-lane
   // write and one four-lane read (a full-wave 16-byte broadcast read per level cost 3.6 % at 2^24 points).
   ++mine;
-  if (mine & 3u) return;
+  if (mine & every_mask) return;
   const int w = threadIdx.x >> 6, simd = w & 3, age = w >> 2;  // waves w, w+4, w+8, w+12 of a workgroup share a SIMD
   const int lane = threadIdx.x & 63;
   uint32_t other = 0;

@@ -373,6 +373,8 @@ struct StageBody {
   const DevCtx* __restrict__ c;
   const Grp& g;
   const ExpandArgs& a;
+  uint32_t* prog;  // fixed shares with progress-ranked wave priorities (rank_prio), or nullptr
+  uint32_t mine;
   // DPF leaves under a rolled level: the 64 bytes of the first half are held back and stored together with the
   // second half -- the lane's eight 16-byte stores then fall on one 128-byte line within a few cycles instead of half
   // a line now and half after six more AES blocks (FSS_LEAF_PAIR_LINES, A/B).  The same for DCF (two leaves per
@@ -383,6 +385,7 @@ struct StageBody {
                                              const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob, int half) {
     constexpr int NN = 1 << D;
     const int party = a.party;
+    if (prog != nullptr) rank_prio(prog, mine, 0u, 0u);  // a step = one body: the last D levels of one subtree
     uint32_t nodes[NN][4];
     Acc vs[SCHEME == S_DCF ? NN : 1];
     nodes[0][0] = nin[0]; nodes[0][1] = nin[1]; nodes[0][2] = nin[2]; nodes[0][3] = nin[3];
@@ -507,8 +510,8 @@ struct StageBody {
 template <class LT, int SCHEME, int D, bool LEAF, int E, bool BATCH, int OW, class Queue>
 __device__ __forceinline__ void run_stage(const LT& L, const DevCtx* __restrict__ c, const Grp& g, const ExpandArgs& a,
                                           const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
-                                          Queue& q, int64_t j_hi) {
-  StageBody<LT, SCHEME, D, LEAF, OW> body{L, c, g, a, {}};
+                                          Queue& q, int64_t j_hi, uint32_t* prog = nullptr) {
+  StageBody<LT, SCHEME, D, LEAF, OW> body{L, c, g, a, prog, 0u, {}};
   for (int64_t j; q.next(j);) {
     if (j >= j_hi) continue;  // ragged last chunk
     uint32_t n0[4];
@@ -569,18 +572,24 @@ struct FusedArgs {
   uint4* buf[2];      // workspace halves; workgroup b owns [b * wg_cap[i], (b + 1) * wg_cap[i])
   uint4* bufv[2];     // DCF: the running values of those nodes, same slices
   int64_t wg_cap[2];
+  int rank;           // 1: the stages hand a workgroup's chunks to its waves in fixed shares, priorities by progress
 };
 
 // The workgroup's own 64-node chunks of [lo, hi), handed to its waves through the LDS counter.
+// fixed = true: wave w takes chunks w, w + 16, ... (equal shares; run with rank_prio so that they also end together).
 struct LocalQ {
   uint32_t* ctr;
   int64_t lo, n, cur;
+  bool fixed;
   __device__ __forceinline__ int64_t fetch() {
+    if (fixed) return cur + (blockDim.x >> 6);
     uint32_t v = 0;
     if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1u);
     return (int64_t)__builtin_amdgcn_readfirstlane(v);
   }
-  __device__ __forceinline__ LocalQ(uint32_t* lds_ctr, int64_t lo_, int64_t hi_) : ctr(lds_ctr), lo(lo_), n(hi_ - lo_) {
+  __device__ __forceinline__ LocalQ(uint32_t* lds_ctr, int64_t lo_, int64_t hi_, bool fixed_ = false)
+      : ctr(lds_ctr), lo(lo_), n(hi_ - lo_), fixed(fixed_) {
+    cur = (int64_t)(threadIdx.x >> 6) - (blockDim.x >> 6);
     cur = fetch();
   }
   __device__ __forceinline__ bool next(int64_t& j) {
@@ -601,9 +610,11 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
   constexpr int DM = SCHEME == S_DCF ? 1 : 2;  // levels a stage expands in registers
   const DevCtx* c = first_kernarg(K);
+  FSS_PROGRESS_PROLOGUE();
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   const Grp g = make_grp(f.a.group, c);
+  uint32_t* const prog = f.rank ? wave_prog_ : nullptr;
   // this workgroup's walks [w_lo, w_hi) of the 2^(top - tail) per key
   const int64_t walks = (BATCH ? f.a.nkeys : (int64_t)1) << (f.top - f.tail);
   const int64_t w_lo = walks * blockIdx.x / gridDim.x, w_hi = walks * (blockIdx.x + 1) / gridDim.x;
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   for (int s = 0; s < f.nmid; ++s) {  // ---- intermediate stages: mine[cur] -> mine[cur ^ 1]
     __syncthreads();  // the nodes of the phase before are in place (same CU: same L1), the chunk counter is idle
     if (threadIdx.x == 0) waveq_ctr_ = 0;
+    if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0;
     __syncthreads();
     const int t = f.mid_t[s];
     a.level0 = level;
@@ -630,22 +642,23 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     a.in_v = minev[cur] - lo;
     a.out_nodes = mine[cur ^ 1] - (lo << t);
     a.out_v = minev[cur ^ 1] - (lo << t);
-    LocalQ q(&waveq_ctr_, lo, hi);
-    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
-    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
-    else run_stage<LT, SCHEME, DM, false, 3 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi);
+    LocalQ q(&waveq_ctr_, lo, hi, f.rank != 0);
+    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    else run_stage<LT, SCHEME, DM, false, 3 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
     lo <<= t; hi <<= t; level += t;
     cur ^= 1;
   }
   __syncthreads();
   if (threadIdx.x == 0) waveq_ctr_ = 0;
+  if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0;
   __syncthreads();
   {  // ---- leaf stage: mine[cur] -> ys
     a.level0 = level;
     a.in_nodes = mine[cur] - lo;
     a.in_v = minev[cur] - lo;
-    LocalQ q(&waveq_ctr_, lo, hi);
-    run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi);
+    LocalQ q(&waveq_ctr_, lo, hi, f.rank != 0);
+    run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
   }
 }
 
