@@ -519,7 +519,9 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
 template <int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
   const DevCtx* c = first_kernarg(K);
+  FSS_PROGRESS_PROLOGUE();
   FSS_WAVEQ_PROLOGUE();
+  uint32_t my_prog = 0;
   FSS_PRG_PROLOGUE(Lds, te0);
   constexpr int NW = BS / 64;
   __shared__ uint4 q_seed[NW][64];
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
     int pending = 0;  // jobs queued by this wave (wave-uniform)
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
+      if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, 0u);
       uint4 t[2];
       uint32_t m[2], tm[2], in[2][4], o[2][4];
 #pragma unroll
