@@ -2,13 +2,18 @@
 //
 // The evaluated block [first_leaf, first_leaf + 2^r) is the subtree under the
 // depth-p node whose path is `prefix` (p = in_bits - r): this is the unit a GPU
-// owns when the domain is sharded.  walk_kernel walks the p prefix levels once
-// (point-eval style), then every stage lets one lane take one node and expand it
-// D levels in registers into 2^D children (each node is expanded exactly once:
-// 2 AES per DPF node, 4 per DCF node, 1 per Half-Tree node, as the reference's
-// EvalTree).  The last stage converts leaves to group outputs and writes them in
-// index order with 64-bit indexing.  Intermediate frontiers live in the caller's
-// workspace (nodes of 16 B; 1/16 of the leaves for the last frontier).
+// owns when the domain is sharded.  The frontier kernel walks to 2^top nodes
+// (point-eval style, a quad of lanes per walk), then every stage lets one lane take
+// one node and expand it D levels in registers into 2^D children (each node is
+// expanded exactly once: 2 AES per DPF node, 4 per DCF node, 1 per Half-Tree node,
+// as the reference's EvalTree).  The last stage converts leaves to group outputs and
+// writes them in index order with 64-bit indexing.  Intermediate frontiers live in
+// the caller's workspace (nodes of 16 B; 1/16 of the leaves for the last frontier).
+//
+// With the AES tables the whole plan is ONE launch (evalall_fused_kernel below): every
+// workgroup takes its own share of the walks through all the stages to the leaves; the
+// separate frontier / stage kernels remain for ChaCha, DCF batches and the shared-prefix
+// point walks, and as the A/B reference (FSS_AMD_FUSED=0).
 //
 // Follows: fss::Dpf::EvalTree (include/fss/dpf.cuh:250-303), fss::Dcf::EvalTree
 // (include/fss/dcf.cuh:315-385), fss::HalfTreeDpf::EvalTree / ConvertLastLevel
