@@ -24,14 +24,18 @@ inline bool quad_frontier() {
   static const bool v = [] { const char* e = getenv("FSS_AMD_QUAD_FRONTIER"); return !(e && atoi(e) == 0); }();
   return v;
 }
-inline int top_max(int scheme, bool aes) {
+// single_key: the one-launch form of a single key's plan walks one level less -- its stages cost no launch, so the
+// balance between the walk's latency and the stages' work moves (DPF n = 18 / 20 / 22 / 24: 24 / 41 / 104 / 324 ->
+// 21 / 38 / 100 / 321 us; the 2^25-leaf block 0.624 -> 0.620 ms, Half-Tree 0.506 -> 0.503); batches and the
+// shared-prefix plans measured flat to slightly worse with 15 and keep 16.
+inline int top_max(int scheme, bool aes, bool single_key = false) {
   static int v = [] {
     const char* e = getenv("FSS_AMD_TOPMAX");
     int t = e ? atoi(e) : -1;
     return (t < 0 || t > 20) ? -1 : t;
   }();
   if (v >= 0) return v;
-  if (quad_frontier()) return 16;
+  if (quad_frontier()) return (single_key && aes) ? 15 : 16;
   if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return 18;
   return 15;
 }
@@ -92,10 +96,9 @@ inline int mid_extra(int scheme) {
 }
 
 // `walks` plus the rounding of the workgroups' shares: grid * ceil(walks / grid) <= walks + grid - 1 with at most one
-// workgroup per 256 walks and at most 1024 of them (fused_grid; the workspace queries have no context).
+// workgroup per walk and at most 1024 of them (fused_grid; the workspace queries have no context).
 inline int64_t fused_padded(int64_t walks) {
-  int64_t g = (walks + 255) / 256;
-  if (g > 1024) g = 1024;
+  const int64_t g = walks < 1024 ? walks : 1024;
   return walks + (g < 1 ? 0 : g - 1);
 }
 // Room (in nodes) the one-launch form needs in the two buffers beyond the plan's own sizes: every workgroup's private
@@ -124,7 +127,8 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
   pl->r = r;
   pl->p = in_bits - r;
   const int limit = r - (scheme == S_HT ? 1 : 0);
-  int top = limit < top_max(scheme, aes) ? limit : top_max(scheme, aes);
+  const int tmax = top_max(scheme, aes, true);
+  int top = limit < tmax ? limit : tmax;
   pl->tail = frontier_tail(scheme, aes, top < limit, limit - top);
   top += pl->tail;
   pl->top = top;
@@ -162,19 +166,19 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
 }
 
 // The plan as one launch (fss_abi_fused.hip): AES tables, DPF / Grotto / Half-Tree / DCF, a quad frontier with at
-// a workgroup per 256 walks (up to one per CU), stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
+// a workgroup per CU (or per walk when there are fewer), stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
 // launches (A/B).
 inline bool fused_on() {
   static const bool v = [] { const char* e = getenv("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
   return v;
 }
-// One workgroup per CU (the AES tables leave room for one), fewer when there are not 256 walks (1024 lanes) for each;
-// FSS_AMD_FUSED_GRID overrides, for tests of uneven shares.
+// One workgroup per CU (the AES tables leave room for one), fewer only when there are fewer walks than CUs: a small
+// domain is spread as wide as it goes (2^14 leaves on 256 workgroups 14.5 us, on 64 17, on 16 50: the stages below
+// the walks are what more CUs shorten).  FSS_AMD_FUSED_GRID overrides, for tests of uneven shares.
 inline int fused_grid(const fss_amd_ctx* ctx, int64_t walks) {
   static const int grid_env = [] { const char* e = getenv("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
   if (grid_env) return grid_env;
-  const int64_t want = (walks + 255) / 256;
-  return (int)(want < ctx->num_cu ? (want < 1 ? 1 : want) : ctx->num_cu);
+  return (int)(walks < ctx->num_cu ? (walks < 1 ? 1 : walks) : ctx->num_cu);
 }
 // The workgroups' private slices of the two buffers, for `nkeys` trees side by side.
 inline void fused_slices(const Plan& pl, int64_t nkeys, int grid, uint4* const bufn[2], uint4* const bufv[2], FusedArgs* f) {
