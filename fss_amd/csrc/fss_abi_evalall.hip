@@ -60,7 +60,8 @@ struct Plan {
 inline int dmax_for(int scheme) { return scheme == S_DCF ? 1 : 2; }  // levels expanded in registers
 // Extra levels the last stage of a plan walks depth-first above those (expand_kernel's E): the deeper the
 // last stage, the smaller and fewer the launches above it.  FSS_AMD_LEAF_E = 0 .. 2.
-// Measured at 2^24 leaves: DPF +3 %, DCF +5 % with two extra levels, Half-Tree -7 % (its nodes cost one AES).
+// Measured at 2^24 leaves: DPF +3 %, DCF +5 % with two extra levels; Half-Tree -7 % in round 1, +4-6 % once a lane's
+// leaves were held back and stored as whole 128-byte lines (the loss had been half-written lines falling out of L2).
 // A deep leaf stage needs enough input nodes to give every wave of the chip a chunk (64 nodes x 4096 waves =
 // 2^18): below that the launch is a latency chain run by a fraction of the waves, and a shallower last stage
 // on more nodes is faster (DPF n = 20: 136 -> 94 us with E = 0, tools/sweep_evalall_small.sh).
@@ -72,12 +73,12 @@ inline int leaf_extra(int scheme, int log2_leaves) {
     return (t < 0 || t > 3) ? -1 : t;
   }();
   if (v >= 0) return v;
-  int e = scheme == S_HT ? 0 : 2;
+  int e = 2;  // Half-Tree too, since its leaves go out as whole lines (round 2: 0.503 -> 0.481 ms on the 2^25-leaf block)
   const int room = log2_leaves - dmax_for(scheme) - 18;
   if (e > room) e = room < 0 ? 0 : room;
-  // DPF below 2^25 leaves: one rolled level (2^24: 0.343 ms against 0.355 with two; equal at 2^25, two ahead by
-  // 0.6 % at 2^26 -- gpurun_out/ab_evalall_3.txt, round 2)
-  if (scheme == S_DPF && log2_leaves < 25 && e > 1) e = 1;
+  // DPF at 2^23 and 2^24 leaves: one rolled level (0.175 / 0.320 ms against 0.177 / 0.322 with two; at 2^22 two are
+  // ahead, 0.095 against 0.100; equal at 2^25, two ahead by 0.6 % at 2^26)
+  if (scheme == S_DPF && (log2_leaves == 23 || log2_leaves == 24) && e > 1) e = 1;
   return e;
 }
 
@@ -200,7 +201,7 @@ bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys)
   if (pl.nstages < 1 || pl.nstages > 7) return false;
   (void)nkeys;
   const int leaf = pl.D[pl.nstages - 1], dm = dmax_for(scheme);
-  if (leaf < 0 || leaf > dm + 2 || (scheme == S_HT && (leaf < 1 || leaf > 2))) return false;
+  if (leaf < 0 || leaf > dm + 2 || (scheme == S_HT && leaf < 1)) return false;
   for (int s = 0; s + 1 < pl.nstages; ++s)
     if (pl.D[s] < 1 || pl.D[s] > 3) return false;
   return true;

@@ -384,7 +384,7 @@ struct StageBody {
   // second half -- the lane's eight 16-byte stores then fall on one 128-byte line within a few cycles instead of half
   // a line now and half after six more AES blocks (FSS_LEAF_PAIR_LINES, A/B).  The same for DCF (two leaves per
   // half) measured flat to slightly worse and is not taken.
-  static constexpr bool kHold = FSS_LEAF_PAIR_LINES && LEAF && SCHEME == S_DPF && D == 2;
+  static constexpr bool kHold = FSS_LEAF_PAIR_LINES && LEAF && (SCHEME == S_DPF || (SCHEME == S_HT && FSS_HT_PAIR && FSS_HT_HOLD)) && D == 2;
   uint4 held[kHold ? 4 : 1];
   __device__ __forceinline__ void operator()(const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc,
                                              const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob, int half) {
@@ -452,6 +452,15 @@ struct StageBody {
         uint4 y[4];
         ht_convert2<LT, OW>(L, c, g, party, cw, koc, nodes[0], y[0], y[1]);
         ht_convert2<LT, OW>(L, c, g, party, cw, koc, nodes[1], y[2], y[3]);
+        if (half == 0) {  // under a rolled level: with the other half, one 128-byte line at once
+#pragma unroll
+          for (int k = 0; k < 4; ++k) held[k] = y[k];
+          return;
+        }
+        if (half == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ys[ob - 4 + k] = held[k];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) ys[ob + k] = y[k];
         return;

@@ -30,10 +30,8 @@ int by_leaf(fss_amd_ctx* ctx, int leaf_t, const SharedKey& k, const FusedArgs& f
   if constexpr (DM == 2) {
     if (leaf_t == 2) return launch_one<SCHEME, 2, 0, OW, BATCH>(ctx, k, f, grid, st);
   }
-  if constexpr (SCHEME != S_HT) {
-    if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH>(ctx, k, f, grid, st);
-    if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH>(ctx, k, f, grid, st);
-  }
+  if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH>(ctx, k, f, grid, st);
+  if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH>(ctx, k, f, grid, st);
   return FSS_AMD_EINVAL;
 }
 
