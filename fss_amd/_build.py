@@ -5,7 +5,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.path.join(_HERE, "libfss_amd.so")
-UNITS = ["fss_amd.hip", "fss_abi_evalall.hip", "fss_abi_gen.hip", "fss_abi_fused.hip", "fss_abi_fused_batch.hip"]  # compiled in parallel, linked into one .so
+UNITS = ["fss_amd.hip", "fss_abi_evalall.hip", "fss_abi_gen.hip", "fss_abi_fused.hip", "fss_abi_fused_batch.hip",
+         "fss_abi_fused_chacha.hip"]  # compiled in parallel, linked into one .so
 HEADERS = ["fss_dev.hpp", "fss_point.hpp", "fss_quad.hpp", "fss_evalall.hpp", "fss_gen.hpp", "fss_vdpf.hpp", "fss_host.hpp",
            "fss_fused_launch.hpp"]
 OBJDIR = os.path.join(_HERE, "csrc", "build")

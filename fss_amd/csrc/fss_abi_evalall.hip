@@ -8,6 +8,8 @@ int launch_fused_evalall(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_
                          const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st);
 int launch_fused_evalall_batch(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* cws, const uint32_t* ocws,
                                const fssamd::FusedArgs& f, int grid, hipStream_t st);
+int launch_fused_evalall_chacha(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* seed, const uint32_t* cws,
+                                const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st, bool batch);
 
 namespace {
 
@@ -196,7 +198,8 @@ inline void fused_slices(const Plan& pl, int64_t nkeys, int grid, uint4* const b
   f->rank = rank;
 }
 bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys) {
-  if (!fused_on() || !quad_frontier() || ctx->prg == FSS_AMD_PRG_CHACHA) return false;
+  static const bool chacha_too = [] { const char* e = getenv("FSS_AMD_FUSED_CHACHA"); return !(e && atoi(e) == 0); }();
+  if (!fused_on() || !quad_frontier() || (ctx->prg == FSS_AMD_PRG_CHACHA && !chacha_too)) return false;
   if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT && scheme != S_DCF) return false;
   if (pl.nstages < 1 || pl.nstages > 7) return false;
   (void)nkeys;
@@ -339,7 +342,9 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
     const int grid = fused_grid(ctx, (int64_t)1 << (pl.top - pl.tail));
     fused_slices(pl, 1, grid, bufn, bufv, &f);
     if (f.wg_cap[0] * grid <= pl.cap_a && f.wg_cap[1] * grid <= pl.cap_b) {
-      int rc = launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st);
+      int rc = ctx->prg == FSS_AMD_PRG_CHACHA
+                   ? launch_fused_evalall_chacha(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st, false)
+                   : launch_fused_evalall(ctx, SCHEME, pl.D[pl.nstages - 1], k.seed, k.cws, k.ocw, f, grid, st);
       if (rc != FSS_AMD_OK) return rc;
       fused = true;
     }
@@ -475,7 +480,9 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   k.cws = reinterpret_cast<const uint32_t*>(cws);
   k.ocw = reinterpret_cast<const uint32_t*>(ocws);
 
-  if ((SCHEME == S_DPF || SCHEME == S_HT) && fused_ok(ctx, SCHEME, pl, nkeys)) {
+  // (ChaCha batches keep the chain: its stages run two workgroups per CU, the one-launch form one -- 64 keys x 2^20
+  // 1710 -> 1770 us with it; single ChaCha keys gain 1.5 - 5 %)
+  if ((SCHEME == S_DPF || SCHEME == S_HT) && ctx->prg != FSS_AMD_PRG_CHACHA && fused_ok(ctx, SCHEME, pl, nkeys)) {
     FusedArgs fa{};
     fa.a = a;
     const int grid = fused_grid(ctx, nkeys << (pl.top - pl.tail));

@@ -10,10 +10,10 @@
 // writes them in index order with 64-bit indexing.  Intermediate frontiers live in
 // the caller's workspace (nodes of 16 B; 1/16 of the leaves for the last frontier).
 //
-// With the AES tables the whole plan is ONE launch (evalall_fused_kernel below): every
-// workgroup takes its own share of the walks through all the stages to the leaves; the
-// separate frontier / stage kernels remain for ChaCha, DCF batches and the shared-prefix
-// point walks, and as the A/B reference (FSS_AMD_FUSED=0).
+// The whole plan of a single key (and of an AES batch) is ONE launch (evalall_fused_kernel
+// below): every workgroup takes its own share of the walks through all the stages to the
+// leaves; the separate frontier / stage kernels remain for ChaCha and DCF batches and the
+// shared-prefix point walks, and as the A/B reference (FSS_AMD_FUSED=0).
 //
 // Follows: fss::Dpf::EvalTree (include/fss/dpf.cuh:250-303), fss::Dcf::EvalTree
 // (include/fss/dcf.cuh:315-385), fss::HalfTreeDpf::EvalTree / ConvertLastLevel

@@ -1,5 +1,6 @@
-// Launch side of evalall_fused_kernel (fss_evalall.hpp), shared by the two units that instantiate it
-// (fss_abi_fused.hip: one key; fss_abi_fused_batch.hip: batches of keys) so that hipcc compiles them in parallel.
+// Launch side of evalall_fused_kernel (fss_evalall.hpp), shared by the units that instantiate it (fss_abi_fused.hip:
+// one key, AES tables; fss_abi_fused_batch.hip: batches of keys; fss_abi_fused_chacha.hip: the ChaCha PRG) so that
+// hipcc compiles them in parallel.
 #pragma once
 #include "fss_host.hpp"
 #define FSS_EVALALL_TEMPLATES_ONLY 1
@@ -7,9 +8,9 @@
 
 namespace {
 
-template <int SCHEME, int LD, int LE, int OW, bool BATCH>
+template <int SCHEME, int LD, int LE, int OW, bool BATCH, class LT>
 int launch_one(fss_amd_ctx* ctx, const SharedKey& k, const FusedArgs& f, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((evalall_fused_kernel<Lds, SCHEME, LD, LE, OW, BATCH>), dim3(grid), dim3(1024), 0, st, ctx->host, ctx->te0,
+  hipLaunchKernelGGL((evalall_fused_kernel<LT, SCHEME, LD, LE, OW, BATCH>), dim3(grid), dim3(1024), 0, st, ctx->host, ctx->te0,
                      k.seed, k.cws, k.ocw, f);
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = "evalall_fused";
@@ -20,18 +21,18 @@ int launch_one(fss_amd_ctx* ctx, const SharedKey& k, const FusedArgs& f, int gri
 
 // leaf_t levels in the leaf stage: up to DM in registers (DCF 1, the others 2; Half-Tree at least its conversion
 // level), then up to two rolled levels above them.
-template <int SCHEME, int OW, bool BATCH = false>
+template <int SCHEME, int OW, bool BATCH = false, class LT = Lds>
 int by_leaf(fss_amd_ctx* ctx, int leaf_t, const SharedKey& k, const FusedArgs& f, int grid, hipStream_t st) {
   constexpr int DM = SCHEME == S_DCF ? 1 : 2;
   if constexpr (SCHEME != S_HT) {
-    if (leaf_t == 0) return launch_one<SCHEME, 0, 0, 4, BATCH>(ctx, k, f, grid, st);  // conversion only: no block to narrow
+    if (leaf_t == 0) return launch_one<SCHEME, 0, 0, 4, BATCH, LT>(ctx, k, f, grid, st);  // conversion only: no block to narrow
   }
-  if (leaf_t == 1) return launch_one<SCHEME, 1, 0, OW, BATCH>(ctx, k, f, grid, st);
+  if (leaf_t == 1) return launch_one<SCHEME, 1, 0, OW, BATCH, LT>(ctx, k, f, grid, st);
   if constexpr (DM == 2) {
-    if (leaf_t == 2) return launch_one<SCHEME, 2, 0, OW, BATCH>(ctx, k, f, grid, st);
+    if (leaf_t == 2) return launch_one<SCHEME, 2, 0, OW, BATCH, LT>(ctx, k, f, grid, st);
   }
-  if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH>(ctx, k, f, grid, st);
-  if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH>(ctx, k, f, grid, st);
+  if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH, LT>(ctx, k, f, grid, st);
+  if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH, LT>(ctx, k, f, grid, st);
   return FSS_AMD_EINVAL;
 }
 

@@ -1,5 +1,5 @@
 // Host-side plumbing shared by the translation units of libfss_amd.so (fss_amd.hip, fss_abi_evalall.hip,
-// fss_abi_gen.hip, fss_abi_fused.hip): the context, error recording, launch geometry and work-distribution heuristics,
+// fss_abi_gen.hip, fss_abi_fused*.hip): the context, error recording, launch geometry and work-distribution heuristics,
 // PRG dispatch.  The library is split so that hipcc compiles the kernel families in parallel.
 #pragma once
 #include "../../include/fss_amd.h"
