@@ -781,6 +781,7 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
         const int64_t blocks = nkeys * (int64_t)(in_bits + in_bits / 2);
         a.dyn = tune().dyn >= 0 ? tune().dyn : (blocks >= tune().dyn_min * grid * (bs / 64) ? 1 : 0);
         a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : (a.dyn ? 0 : tune().static_prio);
+        a.prio_every = tune().prio_every;
         if (in_bits >= 16) set_tail(ctx, S(stream), a.dyn, nkeys, 128, grid, &a.gq, &a.static_chunks);
         return launch_grid(ctx, grotto_walk_defer_kernel<1024>, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
       }

@@ -114,6 +114,7 @@ struct Tune {
   int dyn = -1;  // FSS_AMD_DYN: 1 / 0 force dynamic / static work distribution; default: by batch size
   int rot_prio = -1;  // FSS_AMD_ROTPRIO: 0 none / 1 turns / 2 by progress; default: see launch_points_k
   int prio_slack = 0;  // FSS_AMD_PRIO_SLACK
+  int prio_every = 3;  // FSS_AMD_PRIO_EVERY: rank_prio exchanges when (levels done & this) == 0
   int static_prio = 2;  // FSS_AMD_STATIC_PRIO: wave priorities of launches with fixed shares (0 none / 1 turns / 2 by progress)
   int64_t dyn_min = 65536;  // FSS_AMD_DYN_MIN: AES blocks per resident wave from which shares are handed out dynamically
   int tail_pct = 8;  // FSS_AMD_TAIL_PCT: share of a dynamic walk's chunks in the launch-wide tail queue (0: none)
@@ -123,6 +124,7 @@ struct Tune {
     if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
     if (const char* e = getenv("FSS_AMD_STATIC_PRIO")) { static_prio = atoi(e); if (static_prio < 0 || static_prio > 2) static_prio = 2; }
     if (const char* e = getenv("FSS_AMD_DYN_MIN")) { dyn_min = atoll(e); if (dyn_min < 1) dyn_min = 65536; }
+    if (const char* e = getenv("FSS_AMD_PRIO_EVERY")) { prio_every = atoi(e); if (prio_every != 0 && prio_every != 1 && prio_every != 3 && prio_every != 7) prio_every = 3; }
     if (const char* e = getenv("FSS_AMD_PRIO_SLACK")) { prio_slack = atoi(e); if (prio_slack < 0) prio_slack = 0; }
     if (const char* e = getenv("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
     if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
@@ -243,6 +245,7 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   a.dyn = tune().dyn >= 0 ? tune().dyn : (a.n * blocks_per_eval >= tune().dyn_min * grid * (bs / 64) ? 1 : 0);
   a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : (a.dyn ? 0 : tune().static_prio);
   a.prio_slack = tune().prio_slack;
+  a.prio_every = tune().prio_every;
   // the last tail_pct % of the chunks go to whichever workgroup asks first (WaveQ); shares stay whole rounds of the grid.
   // Only where a chunk is long enough: in the tail every chunk costs a request to one device-memory word, and those
   // serialise at a few tens of millions per second -- DPF n = 8, one evaluation per lane: 1.20 -> 1.39 ms WITH the tail;

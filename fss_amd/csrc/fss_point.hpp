@@ -54,6 +54,7 @@ struct EvalArgs {
   const uint4* pre_v;       // DCF: running group value of every node
   int dyn;                  // waves take chunks from the workgroup's LDS counter (WaveQ, fss_dev.hpp)
   int prio_slack;           // rank_prio: levels a wave may be ahead of another before it yields
+  int prio_every;           // rank_prio: exchange when (levels done & prio_every) == 0
   int rot_prio;             // wave priority per level: 1 = the waves of a SIMD take turns (rotate_prio), 2 = by progress (rank_prio)
   int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
   uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
-        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack);
+        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack, (uint32_t)a.prio_every);
         CwDpf cw[ILP];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
-        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack);
+        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack, (uint32_t)a.prio_every);
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
           CwDcf cw;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #pragma unroll 1
       for (int i = lvl0; i < in_bits - 1; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
-        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack);
+        else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack, (uint32_t)a.prio_every);
         uint32_t cw[ILP][4];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
     int pending = 0;  // jobs queued by this wave (wave-uniform)
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
-      if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, 0u);
+      if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, 0u, (uint32_t)a.prio_every);
       uint4 t[2];
       uint32_t m[2], tm[2], in[2][4], o[2][4];
 #pragma unroll
