@@ -107,7 +107,12 @@ def test_python_layer_raises(raw):
 
 @pytest.mark.parametrize("env", [{"FSS_AMD_DYN": "1"}, {"FSS_AMD_DYN": "0", "FSS_AMD_ROTPRIO": "0", "FSS_AMD_QUAD_POINTS_MAX": "0"},
                                  {"FSS_AMD_ILP": "1", "FSS_AMD_BS": "256", "FSS_AMD_FRONTIER_TAIL": "0"}, {"FSS_AMD_LEAF_E": "1", "FSS_AMD_TOPMAX": "3"},
-                                 {"FSS_AMD_MID_E": "2", "FSS_AMD_GROTTO_DEFER": "0", "FSS_AMD_RELAYOUT": "0", "FSS_AMD_QUAD_FRONTIER": "0"}])
+                                 {"FSS_AMD_MID_E": "2", "FSS_AMD_GROTTO_DEFER": "0", "FSS_AMD_RELAYOUT": "0", "FSS_AMD_QUAD_FRONTIER": "0"},
+                                 # round 2: the chain of launches instead of the one-launch EvalAll; its stages on the chunk
+                                 # counter; rotating instead of ranked priorities, ranked ones under the dynamic queue
+                                 {"FSS_AMD_FUSED": "0", "FSS_AMD_STATIC_PRIO": "1", "FSS_AMD_DYN_MIN": "1"},
+                                 {"FSS_AMD_FUSED_RANK": "0", "FSS_AMD_FUSED_CHACHA": "0", "FSS_AMD_ROTPRIO": "2", "FSS_AMD_PRIO_EVERY": "0",
+                                  "FSS_AMD_LEAF_E": "2", "FSS_AMD_FUSED_GRID": "7"}])
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
     depths) pick by batch size, so the small oracle-checked cases would only ever see one of each; run the
