@@ -128,7 +128,3 @@ def build_dropin_test(force=False):
 def build_dropin_device_test(force=False):
     """Compile tests/cxx/dropin_device_test.cpp: Gen / Eval called per thread inside the caller's own kernels."""
     return _build_cxx_test("dropin_device_test", force)
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20", "-I" + os.path.join(_HERE, "..", "include"),
-                           DROPIN_SRC, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../../fss_amd", "-o", DROPIN_BIN])
-    return DROPIN_BIN

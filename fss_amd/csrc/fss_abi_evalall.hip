@@ -23,7 +23,7 @@ namespace {
 // lanes x 18 levels, every wave of the chip busy, the rest 15).  FSS_AMD_TOPMAX overrides (A/B).  The workspace
 // queries have no context and return the larger of the plans' needs.
 inline bool quad_frontier() {
-  static const bool v = [] { const char* e = getenv("FSS_AMD_QUAD_FRONTIER"); return !(e && atoi(e) == 0); }();
+  static const bool v = [] { const char* e = tune_env("FSS_AMD_QUAD_FRONTIER"); return !(e && atoi(e) == 0); }();
   return v;
 }
 // single_key: the one-launch form of a single key's plan walks one level less -- its stages cost no launch, so the
@@ -32,7 +32,7 @@ inline bool quad_frontier() {
 // shared-prefix plans measured flat to slightly worse with 15 and keep 16.
 inline int top_max(int scheme, bool aes, bool single_key = false) {
   static int v = [] {
-    const char* e = getenv("FSS_AMD_TOPMAX");
+    const char* e = tune_env("FSS_AMD_TOPMAX");
     int t = e ? atoi(e) : -1;
     return (t < 0 || t > 20) ? -1 : t;
   }();
@@ -46,7 +46,7 @@ inline int top_max(int scheme, bool aes, bool single_key = false) {
 // `walked` levels come from the walk, `room` more levels exist above the leaf stage's reach: the tail is used
 // when the walk was capped (it then replaces a launch; below the cap walking two more levels is cheaper).
 inline int frontier_tail(int scheme, bool aes, bool capped, int room) {
-  static const bool on = [] { const char* e = getenv("FSS_AMD_FRONTIER_TAIL"); return !(e && atoi(e) == 0); }();
+  static const bool on = [] { const char* e = tune_env("FSS_AMD_FRONTIER_TAIL"); return !(e && atoi(e) == 0); }();
   (void)aes;
   if (!on || !quad_frontier() || scheme == S_DCF || !capped || room < 2) return 0;
   return 2;
@@ -70,7 +70,7 @@ inline int dmax_for(int scheme) { return scheme == S_DCF ? 1 : 2; }  // levels e
 // log2_leaves = log2 of the leaves the stage produces in total (all keys of a batch).
 inline int leaf_extra(int scheme, int log2_leaves) {
   static int v = [] {
-    const char* e = getenv("FSS_AMD_LEAF_E");
+    const char* e = tune_env("FSS_AMD_LEAF_E");
     int t = e ? atoi(e) : -1;
     return (t < 0 || t > 3) ? -1 : t;
   }();
@@ -88,7 +88,7 @@ inline int leaf_extra(int scheme, int log2_leaves) {
 // deeper launches above the leaf stage.
 inline int mid_extra(int scheme) {
   static int v = [] {
-    const char* e = getenv("FSS_AMD_MID_E");
+    const char* e = tune_env("FSS_AMD_MID_E");
     int t = e ? atoi(e) : -1;
     return (t < 0 || t > 2) ? -1 : t;
   }();
@@ -172,14 +172,14 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
 // a workgroup per CU (or per walk when there are fewer), stages of the depths the fused kernel is built for.  FSS_AMD_FUSED=0: the chain of
 // launches (A/B).
 inline bool fused_on() {
-  static const bool v = [] { const char* e = getenv("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
+  static const bool v = [] { const char* e = tune_env("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
   return v;
 }
 // One workgroup per CU (the AES tables leave room for one), fewer only when there are fewer walks than CUs: a small
 // domain is spread as wide as it goes (2^14 leaves on 256 workgroups 14.5 us, on 64 17, on 16 50: the stages below
 // the walks are what more CUs shorten).  FSS_AMD_FUSED_GRID overrides, for tests of uneven shares.
 inline int fused_grid(const fss_amd_ctx* ctx, int64_t walks) {
-  static const int grid_env = [] { const char* e = getenv("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
+  static const int grid_env = [] { const char* e = tune_env("FSS_AMD_FUSED_GRID"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 1024) ? v : 0; }();
   if (grid_env) return grid_env;
   return (int)(walks < ctx->num_cu ? (walks < 1 ? 1 : walks) : ctx->num_cu);
 }
@@ -194,11 +194,11 @@ inline void fused_slices(const Plan& pl, int64_t nkeys, int grid, uint4* const b
   f->bufv[0] = bufv[0]; f->bufv[1] = bufv[1];
   // fixed shares + progress-ranked priorities inside the stages: DPF block 0.619 -> 0.616 ms, n = 24 0.325 -> 0.321,
   // Half-Tree 0 .. +0.6 % (FSS_AMD_FUSED_RANK=0: the per-workgroup chunk counter)
-  static const int rank = [] { const char* e = getenv("FSS_AMD_FUSED_RANK"); return e ? (atoi(e) != 0) : 1; }();
+  static const int rank = [] { const char* e = tune_env("FSS_AMD_FUSED_RANK"); return e ? (atoi(e) != 0) : 1; }();
   f->rank = rank;
 }
 bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys) {
-  static const bool chacha_too = [] { const char* e = getenv("FSS_AMD_FUSED_CHACHA"); return !(e && atoi(e) == 0); }();
+  static const bool chacha_too = [] { const char* e = tune_env("FSS_AMD_FUSED_CHACHA"); return !(e && atoi(e) == 0); }();
   if (!fused_on() || !quad_frontier() || (ctx->prg == FSS_AMD_PRG_CHACHA && !chacha_too)) return false;
   if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT && scheme != S_DCF) return false;
   if (pl.nstages < 1 || pl.nstages > 7) return false;
@@ -225,7 +225,7 @@ int launch_expand(fss_amd_ctx* ctx, const SharedKey& k, const ExpandArgs& a_in, 
   const ExpandArgs& a0 = a_in;
   int64_t want = (a0.n_in + BS - 1) / BS;
   // workgroups per CU: the AES tables (128 KiB) admit one; ChaCha needs no LDS
-  int64_t cap = (int64_t)ctx->num_cu * ((ctx->prg == FSS_AMD_PRG_CHACHA || kLdsWords <= 16384) ? 2 : 1);
+  int64_t cap = (int64_t)ctx->num_cu * (ctx->prg == FSS_AMD_PRG_CHACHA ? 2 : 1);
   int grid = (int)(want < cap ? want : cap);
   ExpandArgs a = a_in;
   a.dyn = use_dyn(a.n_in, 64, grid, BS);
@@ -235,8 +235,8 @@ int launch_expand(fss_amd_ctx* ctx, const SharedKey& k, const ExpandArgs& a_in, 
   // no launch-wide tail here: a stage's chunks last microseconds, and thousands of requests to one device-memory
   // word in that time serialise (Half-Tree 2^25 leaves: 0.53 -> 0.82 ms with it; the walks' chunks last 70 - 150 us)
   // narrow output groups: the leaf-level blocks skip the lookups of the seed words the group never reads
-  constexpr bool kCanNarrow = LEAF && D >= 1 && (SCHEME == S_DPF || SCHEME == S_HT) && FSS_T4;
-  static const bool narrow_on = [] { const char* e = getenv("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
+  constexpr bool kCanNarrow = LEAF && D >= 1 && (SCHEME == S_DPF || SCHEME == S_HT);
+  static const bool narrow_on = [] { const char* e = tune_env("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
   bool done = false;
   if constexpr (kCanNarrow) {
     if (narrow_on && ctx->prg != FSS_AMD_PRG_CHACHA && a.group >= G_U8 && a.group <= G_U64) {
@@ -268,9 +268,6 @@ int launch_stage(fss_amd_ctx* ctx, int T, bool leaf, const SharedKey& k, const E
     if constexpr (DM == 2) { if (T == 2) return launch_expand<SCHEME, 2, true, 0, BATCH>(ctx, k, a, st); }
     if (T == DM + 1) return launch_expand<SCHEME, DM, true, 1, BATCH>(ctx, k, a, st);
     if (T == DM + 2) return launch_expand<SCHEME, DM, true, 2, BATCH>(ctx, k, a, st);
-#if defined(FSS_EXP_LEAF_E3)
-    if constexpr (!BATCH && SCHEME == S_DPF) { if (T == DM + 3) return launch_expand<SCHEME, DM, true, 3, BATCH>(ctx, k, a, st); }
-#endif
   } else {
     if (T == 1) return launch_expand<SCHEME, 1, false, 0, BATCH>(ctx, k, a, st);
     if constexpr (DM == 2) { if (T == 2) return launch_expand<SCHEME, 2, false, 0, BATCH>(ctx, k, a, st); }
@@ -757,7 +754,7 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
   a.cw_s = reinterpret_cast<const uint4*>(cw_s);
   a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
   static const int bs = [] {
-    const char* e = getenv("FSS_AMD_GROTTO_BS");
+    const char* e = tune_env("FSS_AMD_GROTTO_BS");
     return (e && atoi(e) == 512) ? 512 : 1024;
   }();
   return FSS_BY_PRG(ctx, ([&] {
@@ -771,7 +768,7 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
     };
     // AES: taken child per level, siblings deferred to dense batches (FSS_AMD_GROTTO_DEFER=0: both children per level)
     if constexpr (std::is_same_v<LT, Lds>) {
-      static const bool defer = [] { const char* e = getenv("FSS_AMD_GROTTO_DEFER"); return !(e && atoi(e) == 0); }();
+      static const bool defer = [] { const char* e = tune_env("FSS_AMD_GROTTO_DEFER"); return !(e && atoi(e) == 0); }();
       if (defer && bs == 1024) {
         int grid = 0;
         int rc = persistent_grid(ctx, grotto_walk_defer_kernel<1024>, bs, (nkeys + 1) / 2, &grid);

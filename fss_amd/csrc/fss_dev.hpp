@@ -23,9 +23,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace fssamd {
+
+// Launch-plan tunables (FSS_AMD_ILP, FSS_AMD_DYN, FSS_AMD_FUSED, ... -- the A/B switches of tools/*.sh and of
+// tests/test_gpu_errors.py::test_parity_under_forced_tunables) are honoured only in a process that sets
+// FSS_AMD_TUNE=1.  A default process reads that one variable, once, and its launch plan does not depend on anything
+// else in the caller's environment.
+inline const char* tune_env(const char* name) {
+  static const bool on = [] { const char* e = getenv("FSS_AMD_TUNE"); return e != nullptr && atoi(e) == 1; }();
+  return on ? getenv(name) : nullptr;
+}
 
 // Group ids (shared with include/fss_amd.h).
 enum : int { G_BYTES = 0, G_U8 = 1, G_U16 = 2, G_U32 = 3, G_U64 = 4, G_U128M127 = 5 };
@@ -68,23 +78,20 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) {
   return __builtin_amdgcn_alignbit(x, x, 32 - n);
 }
 
-// ---- LDS table layouts --------------------------------------------------------
-// FSS_T4 = 1 (default): four tables T0..T3 (T_t = Te0 rotated left by 8t bits), each
-// replicated 32x so that lane l always reads bank l % 32 (conflict-free for any 64
-// indices); 128 KiB, one 1024-thread workgroup per CU.  Rows are 256 B:
+// ---- LDS table layout ---------------------------------------------------------
+// Four tables T0..T3 (T_t = Te0 rotated left by 8t bits), each replicated 32x so that
+// lane l always reads bank l % 32 (conflict-free for any 64 indices); 128 KiB, one
+// 1024-thread workgroup per CU.  Rows are 256 B:
 //   region A (first 64 KiB):  row idx = [T0[idx] x 32 lanes | T1[idx] x 32 lanes]
 //   region B (second 64 KiB): row idx = [T2[idx] x 32 lanes | T3[idx] x 32 lanes]
 // so a lookup address is  region << 16 | idx << 8 | half << 7 | (lane & 31) << 2  and
 // the round needs no rotate instructions.  On gfx950 v_perm_b32 / v_alignbit_b32 /
 // anything with an SGPR operand issue at 4 cycles per wave while v_bitop3_b32, shifts
 // and 2-input logic on VGPRs issue at 2 (tools/ubench/valu_rate.hip), and the walk is
-// VALU-issue bound, so dropping the 12 rotates per round is worth ~1.4x.
-// FSS_T4 = 0: one table Te0 x 64 lanes (64 KiB, two workgroups per CU), rotates in VALU.
-#ifndef FSS_T4
-#define FSS_T4 1
-#endif
-
-constexpr int kLdsWords = FSS_T4 ? 32768 : 16384;
+// VALU-issue bound, so dropping the 12 rotates per round is worth ~1.4x (the single-table
+// form with rotates, and the other variants measured and rejected, are listed in
+// tools/ubench/REJECTED_VARIANTS.md).
+constexpr int kLdsWords = 32768;
 
 // a ? b : c bitwise  (a = 0xF0, b = 0xCC, c = 0xAA)
 constexpr uint32_t kSelect = (0xF0 & 0xCC) | (~0xF0 & 0xAA & 0xFF);
@@ -97,45 +104,23 @@ __device__ __forceinline__ uint32_t vconst(uint32_t v) {
   return v;
 }
 
-// FSS_VKEYS = 1 (experiment, measured 11 % SLOWER than scalar keys on MI355X: the 2 x 1 KiB of
-// return data per round saturate the L1 -> VGPR path): round keys are fetched with vector loads (global_load_dwordx4, every lane
-// the same address, L1-resident) into VGPRs instead of scalar loads into SGPRs: a VALU op with
-// an SGPR operand issues at 4 cycles per wave, with VGPR operands at 2, and vector loads use
-// vmcnt, leaving lgkmcnt to the LDS lookups alone (counted waits instead of full drains).
-#ifndef FSS_VKEYS
-#define FSS_VKEYS 0
-#endif
-
 struct Lds {
   const uint8_t* tab;  // LDS table base
-  const uint32_t* kbase;  // &K (kernel-argument copy of DevCtx), as words
-  const uint32_t* gk;     // K.self_dev + an opaque per-lane zero
-#if FSS_T4
   uint32_t lo[4];      // per table: region << 16 | half << 7 | (lane & 31) << 2
   uint32_t m_ff00, m_00ff, m_ff0000, m_ffff;
-#else
-  uint32_t lo;         // (lane & 63) * 4
-#endif
 };
 
-__device__ __forceinline__ Lds make_lds(const uint32_t* lds, const DevCtx& K) {
+__device__ __forceinline__ Lds make_lds(const uint32_t* lds) {
   Lds L;
   L.tab = reinterpret_cast<const uint8_t*>(lds);
-  L.kbase = reinterpret_cast<const uint32_t*>(&K);
-  L.gk = K.self_dev + vconst(0u);
-#if FSS_T4
   const uint32_t l4 = (threadIdx.x & 31u) << 2;
   L.lo[0] = l4; L.lo[1] = l4 | 0x80u; L.lo[2] = l4 | 0x10000u; L.lo[3] = l4 | 0x10080u;
   L.m_ff00 = vconst(0xff00u); L.m_00ff = vconst(0xffu); L.m_ff0000 = vconst(0xff0000u); L.m_ffff = vconst(0xffffu);
-#else
-  L.lo = (threadIdx.x & 63u) * 4u;
-#endif
   return L;
 }
 
 // Fill the workgroup's LDS tables.  Call from every thread, then __syncthreads().
 __device__ __forceinline__ void lds_table_fill(uint32_t* lds, const uint32_t* __restrict__ te0) {
-#if FSS_T4
   if (blockDim.x == 1024) {
     // word i = tid + 1024 k holds entry ((tid >> 6) + 16 k) & 255 of table ((k >> 4) << 1) | ((tid >> 5) & 1):
     // 16 distinct entries per lane, requested together (one memory latency instead of 32 in turn;
@@ -156,16 +141,13 @@ __device__ __forceinline__ void lds_table_fill(uint32_t* lds, const uint32_t* __
     int tbl = ((i >> 14) << 1) | ((i >> 5) & 1);
     lds[i] = tbl ? __builtin_amdgcn_alignbit(t, t, 32 - 8 * tbl) : t;
   }
-#else
-  for (int i = threadIdx.x; i < 256 * 64; i += blockDim.x) lds[i] = te0[i >> 6];
-#endif
 }
 
 #define FSS_LDS_PROLOGUE(te0)                                              \
   __shared__ __attribute__((aligned(16))) uint32_t lds_te[kLdsWords];     \
   lds_table_fill(lds_te, te0);                                            \
   __syncthreads();                                                        \
-  const Lds L = make_lds(lds_te, K)
+  const Lds L = make_lds(lds_te)
 
 // Stands in for `Lds` in kernels instantiated for the ChaCha PRG: no tables, no LDS.
 struct ChaChaL {};
@@ -177,13 +159,12 @@ struct ChaChaL {};
     __shared__ __attribute__((aligned(16))) uint32_t lds_te[kLdsWords];     \
     lds_table_fill(lds_te, te0);                                            \
     __syncthreads();                                                        \
-    L = make_lds(lds_te, K);                                                \
+    L = make_lds(lds_te);                                                \
   }
 
 // One table lookup: T_T[byte K of w]  (T_T = Te0 rotated left by 8T bits).
 template <int K, int T>
 __device__ __forceinline__ uint32_t lk(const Lds& L, uint32_t w) {
-#if FSS_T4
   uint32_t addr;
   if (K == 1) {
     addr = __builtin_amdgcn_bitop3_b32(w, L.m_ff00, L.lo[T], kAndOr);  // byte 1 is already at idx << 8
@@ -192,16 +173,7 @@ __device__ __forceinline__ uint32_t lk(const Lds& L, uint32_t w) {
     constexpr uint32_t sel = 0x0c020000u | ((4u + K) << 8);
     addr = __builtin_amdgcn_perm(w, L.lo[T], sel);
   }
-#if defined(FSS_EXP_NOLDS)
-  return addr;
-#endif
   return *reinterpret_cast<const uint32_t*>(L.tab + addr);
-#else
-  constexpr uint32_t sel = 0x0c0c0000u | ((4u + K) << 8);
-  uint32_t addr = __builtin_amdgcn_perm(w, L.lo, sel);
-  uint32_t v = *reinterpret_cast<const uint32_t*>(L.tab + addr);
-  return T ? __builtin_amdgcn_alignbit(v, v, 32 - 8 * T) : v;
-#endif
 }
 
 // Opaque zero in an SGPR that depends on a lane value: placed at the head of an
@@ -220,23 +192,9 @@ __device__ __forceinline__ uint32_t round_anchor(uint32_t dep) {
 // SEL = false: `key` = 44 round-key words of one wave-uniform key.
 // SEL = true:  `key` = DevCtx::selXY, per lane k = key A where mask == 0 and key B
 // where mask == ~0.
-// Opaque per-lane zero that depends on a lane value (same purpose as round_anchor, for
-// vector-loaded keys).
-__device__ __forceinline__ uint32_t lane_anchor(uint32_t dep) {
-  uint32_t z = 0;
-  asm volatile("" : "+v"(z) : "v"(dep));
-  return z;
-}
-
 // Pointer to the key words of round r, readable one round at a time.
-__device__ __forceinline__ const uint32_t* round_key(const Lds& L, const uint32_t* key, int word, uint32_t dep) {
-#if defined(FSS_EXP_NOKEYLOAD)
-  return key;  // timing experiment only (wrong results): every round uses round 0's key, loaded once
-#elif FSS_VKEYS
-  return L.gk + (key - L.kbase) + word + lane_anchor(dep);
-#else
+__device__ __forceinline__ const uint32_t* round_key(const Lds&, const uint32_t* key, int word, uint32_t dep) {
   return key + word + round_anchor(dep);
-#endif
 }
 
 // LSB3: only bit 0 of out[3] (the control bit of a child) is wanted; out[3]'s other bits and out[0..2] are
@@ -293,13 +251,12 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
     for (int j = 0; j < RS; ++j) kc[j] = knx[j];
   }
   // Last round: S-box only, ShiftRows, AddRoundKey, then ^ in.
-  if constexpr (LSB3 && FSS_T4) {
+  if constexpr (LSB3) {
     static_assert(!SEL || !LSB3, "control-bit-only blocks use one key");
     out[0] = out[1] = out[2] = 0u;
     out[3] = xor3(lk<0, 2>(L, s3), in[3], kc[3]);  // byte 0 of word 3 = S(byte 0 of s3) ^ k ^ in
   } else {
     const uint32_t* k = kc;
-#if FSS_T4
     // T2 has S in byte 0, T3 in byte 1, T0 in byte 2, T1 in byte 3: each lookup already
     // holds its S-box byte in place; three bitwise selects assemble the column.
     uint32_t a0 = lk<0, 2>(L, s0), a1 = lk<0, 2>(L, s1), a2 = lk<0, 2>(L, s2), a3 = lk<0, 2>(L, s3);
@@ -312,21 +269,6 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
     uint32_t p0 = FSS_COL(a0, b0, c0, d0), p1 = FSS_COL(a1, b1, c1, d1), p2 = FSS_COL(a2, b2, c2, d2),
              p3 = FSS_COL(a3, b3, c3, d3);
 #undef FSS_COL
-#else
-    uint32_t a0 = lk<0, 0>(L, s0), a1 = lk<0, 0>(L, s1), a2 = lk<0, 0>(L, s2), a3 = lk<0, 0>(L, s3);
-    uint32_t b0 = lk<1, 0>(L, s1), b1 = lk<1, 0>(L, s2), b2 = lk<1, 0>(L, s3), b3 = lk<1, 0>(L, s0);
-    uint32_t c0 = lk<2, 0>(L, s2), c1 = lk<2, 0>(L, s3), c2 = lk<2, 0>(L, s0), c3 = lk<2, 0>(L, s1);
-    uint32_t d0 = lk<3, 0>(L, s3), d1 = lk<3, 0>(L, s0), d2 = lk<3, 0>(L, s1), d3 = lk<3, 0>(L, s2);
-    // byte 1 of a Te0 entry is S: p = S(a) | S(b) << 8 ; q = S(c) << 16 | S(d) << 24
-    constexpr uint32_t selp = 0x0c0c0501u, selq = 0x05010c0cu;
-    uint32_t p0 = __builtin_amdgcn_perm(b0, a0, selp), q0 = __builtin_amdgcn_perm(d0, c0, selq);
-    uint32_t p1 = __builtin_amdgcn_perm(b1, a1, selp), q1 = __builtin_amdgcn_perm(d1, c1, selq);
-    uint32_t p2 = __builtin_amdgcn_perm(b2, a2, selp), q2 = __builtin_amdgcn_perm(d2, c2, selq);
-    uint32_t p3 = __builtin_amdgcn_perm(b3, a3, selp), q3 = __builtin_amdgcn_perm(d3, c3, selq);
-#endif
-#if !FSS_T4
-    p0 ^= q0; p1 ^= q1; p2 ^= q2; p3 ^= q3;
-#endif
     if (SEL) {
       out[0] = xor3(and_xor(mask, k[4], p0), in[0], k[0]);
       out[1] = xor3(and_xor(mask, k[5], p1), in[1], k[1]);
@@ -352,19 +294,9 @@ __device__ __forceinline__ void aes_mmo(const Lds& L, const uint32_t* __restrict
 // order (its own waitcnt pass then has nothing left to insert).
 template <int K, int T>
 __device__ __forceinline__ uint32_t lk_addr(const Lds& L, uint32_t w) {
-#if FSS_T4
   if (K == 1) return __builtin_amdgcn_bitop3_b32(w, L.m_ff00, L.lo[T], kAndOr);
-#if defined(FSS_ADDR_FAST)
-  // shift + (a & b) | c, both on the 2-cycle path, instead of one 4-cycle v_perm
-  const uint32_t sh = K == 0 ? (w << 8) : (K == 2 ? (w >> 8) : (w >> 16));
-  return __builtin_amdgcn_bitop3_b32(sh, L.m_ff00, L.lo[T], kAndOr);
-#endif
   constexpr uint32_t sel = 0x0c020000u | ((4u + K) << 8);
   return __builtin_amdgcn_perm(w, L.lo[T], sel);
-#else
-  constexpr uint32_t sel = 0x0c0c0000u | ((4u + K) << 8);
-  return __builtin_amdgcn_perm(w, L.lo, sel);
-#endif
 }
 
 // Addresses of the 16 lookups of one round: [0..3] byte 0 of s0..s3, [4..7] byte 1 of s1,s2,s3,s0,
@@ -372,11 +304,7 @@ __device__ __forceinline__ uint32_t lk_addr(const Lds& L, uint32_t w) {
 // S in the output byte position.
 template <bool LAST>
 __device__ __forceinline__ void aes_addr16(const Lds& L, const uint32_t s[4], uint32_t ad[16]) {
-#if FSS_T4
   constexpr int T0 = LAST ? 2 : 0, T1 = LAST ? 3 : 1, T2 = LAST ? 0 : 2, T3 = LAST ? 1 : 3;
-#else
-  constexpr int T0 = 0, T1 = 0, T2 = 0, T3 = 0;
-#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     ad[j] = lk_addr<0, T0>(L, s[j]);
@@ -388,11 +316,7 @@ __device__ __forceinline__ void aes_addr16(const Lds& L, const uint32_t s[4], ui
 
 __device__ __forceinline__ void aes_load16(const Lds& L, const uint32_t ad[16], uint32_t v[16]) {
 #pragma unroll
-#if defined(FSS_EXP_NOLDS)
-  for (int j = 0; j < 16; ++j) v[j] = ad[j];  // timing experiment only: no lookups
-#else
   for (int j = 0; j < 16; ++j) v[j] = *reinterpret_cast<const uint32_t*>(L.tab + ad[j]);
-#endif
 }
 
 template <bool SEL>
@@ -400,43 +324,35 @@ __device__ __forceinline__ void aes_mix(const uint32_t v[16], const uint32_t* k,
                                         uint32_t s[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-#if FSS_T4
     uint32_t x = xor3(v[j], v[4 + j], v[8 + j]), d = v[12 + j];
-#else
-    uint32_t x = xor3(v[j], rotl32(v[4 + j], 8), rotl32(v[8 + j], 16)), d = rotl32(v[12 + j], 24);
-#endif
     s[j] = SEL ? xor3(x, and_xor(mask, kd[j], d), k[j]) : xor3(x, d, k[j]);
   }
 }
 
-// OW (output words wanted, FSS_T4 only): 4 = all of out[0..3]; 2 / 1 = out[0..OW-1] whole plus bit 0 of out[3]
+// OW (output words wanted): 4 = all of out[0..3]; 2 / 1 = out[0..OW-1] whole plus bit 0 of out[3]
 // (the control bit) -- what a leaf needs when the output group reads only the low 8 / 4 bytes of the seed
 // (Uint<uint64_t> and narrower, uint.cuh:49-68).  The other outputs are unspecified and their last-round
 // lookups (7 resp. 11 of the 16) disappear as dead code.
 template <bool SEL, bool LSB3 = false, int OW = 4>
 __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], const uint32_t* k, const uint32_t* kd,
                                         uint32_t mask, const uint32_t in[4], uint32_t out[4]) {
-  if constexpr (LSB3 && FSS_T4) {  // see aes_mmo: v[3] = the last-round lookup of byte 0 of s3
+  if constexpr (LSB3) {  // see aes_mmo: v[3] = the last-round lookup of byte 0 of s3
     out[0] = out[1] = out[2] = 0u;
     out[3] = xor3(v[3], in[3], k[3]);
     return;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if constexpr (OW < 4 && FSS_T4) {
+    if constexpr (OW < 4) {
       static_assert(!SEL || OW == 4, "narrow outputs are for uniform-key blocks");
       if (j >= OW) {
         out[j] = j == 3 ? xor3(v[3], in[3], k[3]) : 0u;  // byte 0 of word 3 only (as LSB3)
         continue;
       }
     }
-#if FSS_T4
     uint32_t p = __builtin_amdgcn_bitop3_b32(L.m_ffff, __builtin_amdgcn_bitop3_b32(L.m_00ff, v[j], v[4 + j], kSelect),
                                              __builtin_amdgcn_bitop3_b32(L.m_ff0000, v[8 + j], v[12 + j], kSelect),
                                              kSelect);
-#else
-    uint32_t p = __builtin_amdgcn_perm(v[4 + j], v[j], 0x0c0c0501u) ^ __builtin_amdgcn_perm(v[12 + j], v[8 + j], 0x05010c0cu);
-#endif
     out[j] = SEL ? xor3(and_xor(mask, kd[j], p), in[j], k[j]) : xor3(p, in[j], k[j]);
   }
 }
@@ -451,16 +367,13 @@ __device__ __forceinline__ void aes_fin(const Lds& L, const uint32_t v[16], cons
 
 // outA = AES_{keyA}(inA) ^ inA and outB = AES_{keyB}(inB) ^ inB, interleaved.  keyA / keyB and
 // maskA / maskB as for aes_mmo<SEL>; they may be the same or different key schedules.
-// RESD (two-key schedules only, keyA == keyB): the 44 (rkA ^ rkB) words come from `kdv`, registers
-// loaded once per kernel, so half of the key operands are VGPRs (2-cycle issue instead of 4).
-template <bool SEL, bool RESD = false, bool LSB3 = false, int OW = 4>
+template <bool SEL, bool LSB3 = false, int OW = 4>
 __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restrict__ keyA,
                                          const uint32_t* __restrict__ keyB, uint32_t maskA, uint32_t maskB,
                                          const uint32_t inA[4], const uint32_t inB[4], uint32_t outA[4],
-                                         uint32_t outB[4], const uint32_t* kdv = nullptr) {
+                                         uint32_t outB[4]) {
   constexpr int RS = SEL ? 8 : 4;
-  constexpr int RL = (SEL && !RESD) ? 8 : 4;  // words fetched per main round by the scalar loads
-  // kdv covers rounds 1..9 (36 words); rounds 0 and 10 read the D words from the scalar copy.
+  constexpr int RL = RS;  // words fetched per main round by the scalar loads
   uint32_t sA[4], sB[4], vA[16], vB[16], kA[RL], kB[RL];
   {
     const uint32_t* k0 = round_key(L, keyA, 0, inA[0]);
@@ -491,7 +404,7 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
       for (int j = 0; j < RL; ++j) kB[j] = kn[j];
     }
     FSS_FENCE();
-    aes_mix<SEL>(vA, kA, RESD ? kdv + 4 * (r - 1) : kA + 4, maskA, sA);  // B's lookups fly during A's VALU
+    aes_mix<SEL>(vA, kA, kA + 4, maskA, sA);  // B's lookups fly during A's VALU
     if (r < 9) aes_addr16<false>(L, sA, vA);
     else aes_addr16<true>(L, sA, vA);
     FSS_DRAIN_LGKM();  // B's round-r lookups and keys
@@ -502,7 +415,7 @@ __device__ __forceinline__ void aes_mmo2(const Lds& L, const uint32_t* __restric
       for (int j = 0; j < RL; ++j) kA[j] = kn[j];
     }
     FSS_FENCE();
-    aes_mix<SEL>(vB, kB, RESD ? kdv + 4 * (r - 1) : kB + 4, maskB, sB);
+    aes_mix<SEL>(vB, kB, kB + 4, maskB, sB);
     if (r < 9) aes_addr16<false>(L, sB, vB);
     else aes_addr16<true>(L, sB, vB);
   }
@@ -880,12 +793,12 @@ __device__ __forceinline__ void prg_hash2(const Lds& L, const DevCtx* __restrict
 template <int OW>
 __device__ __forceinline__ void prg_gen2_narrow(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t l[4],
                                                 uint32_t r[4]) {
-  aes_mmo2<false, false, false, OW>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
+  aes_mmo2<false, false, OW>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
 }
 template <int OW>
 __device__ __forceinline__ void prg_hash2_narrow(const Lds& L, const DevCtx* __restrict__ c, const uint32_t ia[4],
                                                  const uint32_t ib[4], uint32_t ha[4], uint32_t hb[4]) {
-  aes_mmo2<false, false, false, OW>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
+  aes_mmo2<false, false, OW>(L, c->rk[0], c->rk[0], 0, 0, ia, ib, ha, hb);
 }
 // Control bits only (Grotto: leaves of the tree, left siblings of the path walk): bit 0 of the results is
 // bit 0 of word 3 of Gen(s)[0] / Gen(s)[1]; the other bits are unspecified.
@@ -897,7 +810,7 @@ __device__ __forceinline__ uint32_t prg_tbit_left(const Lds& L, const DevCtx* __
 __device__ __forceinline__ void prg_tbits2(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], uint32_t& tl,
                                            uint32_t& tr) {
   uint32_t l[4], r[4];
-  aes_mmo2<false, false, true>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
+  aes_mmo2<false, true>(L, c->rk[0], c->rk[1], 0, 0, s, s, l, r);
   tl = l[3]; tr = r[3];
 }
 

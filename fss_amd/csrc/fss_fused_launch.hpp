@@ -42,7 +42,7 @@ namespace {
 // Narrow output groups (Uint<u8 .. u64>) take the leaf-level blocks that compute words 0, 1 and the control bit only
 // (expand_kernel's OW).
 inline bool fused_narrow(const FusedArgs& f) {
-  static const bool narrow_on = [] { const char* e = getenv("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
-  return FSS_T4 && narrow_on && f.a.group >= G_U8 && f.a.group <= G_U64;
+  static const bool narrow_on = [] { const char* e = tune_env("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
+  return narrow_on && f.a.group >= G_U8 && f.a.group <= G_U64;
 }
 }  // namespace

@@ -254,7 +254,7 @@ __global__ void key_major_flat_kernel(int in_bits, int slots, const uint4* __res
 // every other shape -- the 33-slot DPF / DCF keys first of all -- takes the flat kernel (DPF n = 32: relayout 4.4 ->
 // 5.4 TB/s, key_major 2.9 -> 5.4 TB/s).  FSS_AMD_RELAYOUT = 2 / 1 / 0 forces flat / tiled / one key per lane (A/B).
 inline int relayout_mode(int slots) {
-  static const int forced = [] { const char* e = getenv("FSS_AMD_RELAYOUT"); return e ? atoi(e) : -1; }();
+  static const int forced = [] { const char* e = tune_env("FSS_AMD_RELAYOUT"); return e ? atoi(e) : -1; }();
   if (forced >= 0) return forced;
   return slots % 4 == 0 ? 1 : 2;
 }

@@ -107,7 +107,8 @@ bool x_ok(int in_bits, int x_bytes) {
   return false;
 }
 
-// Tunables (env, read once): FSS_AMD_ILP in {1,2}, FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU.
+// Tunables (read once, and only when the process sets FSS_AMD_TUNE=1 -- tune_env, fss_dev.hpp): FSS_AMD_ILP in {1,2},
+// FSS_AMD_BS in {256,512,1024}, FSS_AMD_WGS_PER_CU, ...  A default process runs the plan below whatever its environment.
 struct Tune {
   int ilp = 2, bs = 1024, wgs_per_cu = 0;  // ilp 2 = two staggered AES streams per lane (aes_mmo2)
   bool ilp_set = false;  // FSS_AMD_ILP given: do not second-guess it for small batches
@@ -119,16 +120,16 @@ struct Tune {
   int64_t dyn_min = 65536;  // FSS_AMD_DYN_MIN: AES blocks per resident wave from which shares are handed out dynamically
   int tail_pct = 8;  // FSS_AMD_TAIL_PCT: share of a dynamic walk's chunks in the launch-wide tail queue (0: none)
   Tune() {
-    if (const char* e = getenv("FSS_AMD_TAIL_PCT")) { tail_pct = atoi(e); if (tail_pct < 0 || tail_pct > 100) tail_pct = 8; }
-    if (const char* e = getenv("FSS_AMD_ROTPRIO")) { rot_prio = atoi(e); if (rot_prio < 0 || rot_prio > 2) rot_prio = 1; }
-    if (const char* e = getenv("FSS_AMD_DYN")) dyn = atoi(e) != 0;
-    if (const char* e = getenv("FSS_AMD_STATIC_PRIO")) { static_prio = atoi(e); if (static_prio < 0 || static_prio > 2) static_prio = 2; }
-    if (const char* e = getenv("FSS_AMD_DYN_MIN")) { dyn_min = atoll(e); if (dyn_min < 1) dyn_min = 65536; }
-    if (const char* e = getenv("FSS_AMD_PRIO_EVERY")) { prio_every = atoi(e); if (prio_every != 0 && prio_every != 1 && prio_every != 3 && prio_every != 7) prio_every = 3; }
-    if (const char* e = getenv("FSS_AMD_PRIO_SLACK")) { prio_slack = atoi(e); if (prio_slack < 0) prio_slack = 0; }
-    if (const char* e = getenv("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
-    if (const char* e = getenv("FSS_AMD_BS")) bs = atoi(e);
-    if (const char* e = getenv("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
+    if (const char* e = tune_env("FSS_AMD_TAIL_PCT")) { tail_pct = atoi(e); if (tail_pct < 0 || tail_pct > 100) tail_pct = 8; }
+    if (const char* e = tune_env("FSS_AMD_ROTPRIO")) { rot_prio = atoi(e); if (rot_prio < 0 || rot_prio > 2) rot_prio = 1; }
+    if (const char* e = tune_env("FSS_AMD_DYN")) dyn = atoi(e) != 0;
+    if (const char* e = tune_env("FSS_AMD_STATIC_PRIO")) { static_prio = atoi(e); if (static_prio < 0 || static_prio > 2) static_prio = 2; }
+    if (const char* e = tune_env("FSS_AMD_DYN_MIN")) { dyn_min = atoll(e); if (dyn_min < 1) dyn_min = 65536; }
+    if (const char* e = tune_env("FSS_AMD_PRIO_EVERY")) { prio_every = atoi(e); if (prio_every != 0 && prio_every != 1 && prio_every != 3 && prio_every != 7) prio_every = 3; }
+    if (const char* e = tune_env("FSS_AMD_PRIO_SLACK")) { prio_slack = atoi(e); if (prio_slack < 0) prio_slack = 0; }
+    if (const char* e = tune_env("FSS_AMD_ILP")) { ilp = atoi(e); ilp_set = true; }
+    if (const char* e = tune_env("FSS_AMD_BS")) bs = atoi(e);
+    if (const char* e = tune_env("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
     if (ilp != 1 && ilp != 2) ilp = 2;
     if (bs != 256 && bs != 512 && bs != 1024) bs = 1024;
   }
@@ -280,7 +281,7 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   const int walked = a.in_bits - (PREFIX ? a.start_level : 0);
   if (!tune().ilp_set && walked >= 24) ilp = 1;
   const int blocks_per_eval = walked * (SCHEME == S_DCF ? 2 : 1);
-  static const int tail_minwork = [] { const char* e = getenv("FSS_AMD_TAIL_MINWORK"); return e ? atoi(e) : 24; }();
+  static const int tail_minwork = [] { const char* e = tune_env("FSS_AMD_TAIL_MINWORK"); return e ? atoi(e) : 24; }();
   const bool tail_ok = blocks_per_eval * ilp >= tail_minwork;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
@@ -302,7 +303,7 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
 constexpr int kQuadPointsMax = 131072;
 inline int64_t quad_points_max() {
   static const int64_t v = [] {
-    const char* e = getenv("FSS_AMD_QUAD_POINTS_MAX");
+    const char* e = tune_env("FSS_AMD_QUAD_POINTS_MAX");
     return e ? (int64_t)atoll(e) : (int64_t)kQuadPointsMax;
   }();
   return v;

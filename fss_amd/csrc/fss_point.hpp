@@ -7,12 +7,6 @@
 #pragma once
 #include "fss_dev.hpp"
 
-// FSS_RESD = 1 (experiment, measured 1 % slower: the extra 36 registers spill at the 128-VGPR cap of
-// 16 waves/CU): the DPF two-stream walk keeps the (rk0 ^ rk1) words of rounds 1..9 in VGPRs.
-#ifndef FSS_RESD
-#define FSS_RESD 0
-#endif
-
 // Correction words of independent keys are read exactly once: FSS_NT_CW = 1 (default) marks those loads
 // non-temporal (+1 % on the 2^24-key walks, which stream 1.7 TB/s and run power-limited).
 #ifndef FSS_NT_CW
@@ -130,18 +124,11 @@ struct DpfWalk {
   // Two walks, one level, the two AES blocks interleaved (aes_mmo2).
   template <class LT>
   static __device__ __forceinline__ void level2(const LT& L, const DevCtx* __restrict__ c, int in_bits, int i,
-                                                DpfWalk& a, const CwDpf& cwa, DpfWalk& b, const CwDpf& cwb,
-                                                const uint32_t* kdv) {
+                                                DpfWalk& a, const CwDpf& cwa, DpfWalk& b, const CwDpf& cwb) {
     uint32_t ma = bit_mask(a.x, in_bits - 1 - i), mb = bit_mask(b.x, in_bits - 1 - i);
     uint32_t ia[4] = {a.st[0], a.st[1], a.st[2], a.st[3] & ~1u}, ib[4] = {b.st[0], b.st[1], b.st[2], b.st[3] & ~1u};
     uint32_t oa[4], ob[4];
-#if FSS_RESD
-    if constexpr (std::is_same_v<LT, Lds>) aes_mmo2<true, true>(L, &c->sel01[0][0], &c->sel01[0][0], ma, mb, ia, ib, oa, ob, kdv);
-    else prg_take2x2(L, c, ma, mb, ia, ib, oa, ob);
-#else
-    (void)kdv;
     prg_take2x2(L, c, ma, mb, ia, ib, oa, ob);
-#endif
     a.apply(ma, oa, cwa);
     b.apply(mb, ob, cwb);
   }
@@ -317,13 +304,6 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
     }
 
     if constexpr (SCHEME == S_DPF) {
-      uint32_t kdv[36];  // (rk0 ^ rk1) of rounds 1..9, resident (FSS_RESD); dead otherwise
-#if FSS_RESD
-      if constexpr (ILP == 2) {
-#pragma unroll
-        for (int q = 0; q < 36; ++q) kdv[q] = vconst(c->sel01[1 + (q >> 2)][4 + (q & 3)]);
-      }
-#endif
       DpfWalk w[ILP];
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {
@@ -359,7 +339,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
             cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
           }
         }
-        if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1], kdv);
+        if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1]);
         else w[0].level(L, c, in_bits, i, cw[0]);
       }
 #pragma unroll

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BS) void vdpf_points_kernel(const DevCtx K, const u
           cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
         }
       }
-      if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1], nullptr);
+      if constexpr (ILP == 2) DpfWalk::level2(L, c, in_bits, i, w[0], cw[0], w[1], cw[1]);
       else w[0].level(L, c, in_bits, i, cw[0]);
     }
 #pragma unroll

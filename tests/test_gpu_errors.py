@@ -116,7 +116,8 @@ def test_python_layer_raises(raw):
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
     depths) pick by batch size, so the small oracle-checked cases would only ever see one of each; run the
-    oracle comparisons again with the other choices forced (the tunables are read once per process)."""
+    oracle comparisons again with the other choices forced (the tunables are read once per process, and only by a
+    process that sets FSS_AMD_TUNE=1)."""
     import os
     import subprocess
     import sys
@@ -125,7 +126,7 @@ def test_parity_under_forced_tunables(env):
                         os.path.join(root, "tests", "test_gpu_parity.py"), os.path.join(root, "tests", "test_gpu_vdpf.py"),
                         os.path.join(root, "tests", "test_gpu_chacha.py"),
                         "-k", "vs_oracle or kats or subblocks or deep_prefix or chacha"],
-                       env={**os.environ, **env}, cwd=root, capture_output=True, text=True, timeout=900)
+                       env={**os.environ, "FSS_AMD_TUNE": "1", **env}, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 

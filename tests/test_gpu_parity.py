@@ -785,7 +785,7 @@ def test_eval_all_is_one_launch(engine, O, scheme, n):
     """With the AES tables a single-key EvalAll of every scheme and size is ONE kernel launch (evalall_fused_kernel:
     walks, stages and leaves of a workgroup's share in one go), and so are the batched DPF / Half-Tree forms -- the
     parity tests above therefore exercise that kernel, not the chain of launches it replaced (FSS_AMD_FUSED=0)."""
-    if os.environ.get("FSS_AMD_FUSED") == "0" or os.environ.get("FSS_AMD_FUSED_GRID"):
+    if os.environ.get("FSS_AMD_TUNE") == "1" and (os.environ.get("FSS_AMD_FUSED") == "0" or os.environ.get("FSS_AMD_FUSED_GRID")):
         pytest.skip("the chain of launches was asked for (or a workgroup count the workspace was not sized for)")
     rng = SplitMix64(777 + 100 * scheme + n)
     g = G.BYTES if scheme == GROTTO else G.U64
@@ -820,7 +820,7 @@ def test_eval_all_one_launch_with_uneven_workgroup_shares(grid):
     test_eval_all_planner_shapes_vs_oracle (DPF n = 20 .. 22, Grotto n = 21, Half-Tree n = 21 take the one-launch form)."""
     import subprocess
     import sys
-    env = dict(os.environ, FSS_AMD_FUSED_GRID=str(grid), FSS_AMD_FUSED="1")
+    env = dict(os.environ, FSS_AMD_TUNE="1", FSS_AMD_FUSED_GRID=str(grid), FSS_AMD_FUSED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_eval_all_planner_shapes_vs_oracle or test_grotto_eval_all_vs_oracle"],
                        capture_output=True, text=True, timeout=900, env=env,

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # A/B of EvalAll library variants (FSS_AMD_LIB): steady-state times of the configs[3] block and whole domains.
 # usage: tools/ab_evalall.sh <variant tags...>   ("main" = the product library)
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Interleaved A/B of the EvalAll launch forms on one box: the chain of launches (FSS_AMD_FUSED=0) against the one-launch
 # form, and the library without whole-line leaf stores (libfss_amd_nopair.so, -DFSS_LEAF_PAIR_LINES=0) against the product.
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Rolled levels in the leaf stage (FSS_AMD_LEAF_E = 0 / 1 / 2) for Half-Tree and DPF, interleaved.
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
 for r in 1 2; do

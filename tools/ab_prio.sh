@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Launch policy of the point walks below the dynamic-distribution threshold: the round-2 policy (dynamic from 16 384 AES
 # blocks per wave, fixed shares with rotating priorities below) against fixed shares with progress-ranked priorities
 # up to 65 536 blocks per wave (the default), interleaved.  usage: tools/ab_prio.sh

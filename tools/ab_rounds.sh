@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Interleaved A/B: ROUNDS rounds over "ENV=... ENV=..." variant strings (use "-" for none) on one workload.
 # usage: ROUNDS=3 tools/ab_rounds.sh "<bench_evalall args>" "<variant1 env>" "<variant2 env>" ...
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"

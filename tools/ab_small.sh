@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Small-domain EvalAll: the chain of launches (FSS_AMD_FUSED=0) against the one-launch form, interleaved.
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
 for rep in 1 2; do

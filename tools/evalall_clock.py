@@ -3,6 +3,7 @@
 the workgroups of one launch finish and the clock the stage runs at.  The stamps are taken by expand_kernel's leaf stage,
 so the plan runs as the chain of launches here (FSS_AMD_FUSED=0), not as the one-launch form the product uses."""
 import argparse, ctypes as C, json, os, sys
+os.environ["FSS_AMD_TUNE"] = "1"
 os.environ["FSS_AMD_FUSED"] = "0"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, fss_amd

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # In-kernel clocks of the shared-key and independent-key walks and the launch variants that trade occupancy / ILP
 # for power.  Output: gpurun_out/keys_clock.txt (copy to profiles/r2/keys_clock.txt).
 R="${GRAFT_REPO_ROOT:-/root/repo}"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # BASELINE configs[1] (DPF n = 32, one key, 2^20 points): per-slot stamps (diagnostic library) under fixed shares with
 # rotating priorities (FSS_AMD_STATIC_PRIO=1) and under the default, fixed shares with progress-ranked priorities.
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # BASELINE configs[1] / [2] (one key, 2^20 points): LDS-busy fraction of the launch under rotating (STATIC_PRIO=1) and
 # progress-ranked (default) wave priorities.  One PMC pass each, 400 launches -> gpurun_out/points_2e20_pmc.txt
 R="${GRAFT_REPO_ROOT:-/root/repo}"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # A/B the EvalAll planner knobs (frontier depth, depth of the stages between frontier and leaf stage).
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 for sch in ${SCHEMES:-dpf ht dcf}; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Small domains are latency-bound: sweep the planner knobs (frontier depth, leaf-stage depth) for them.
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 for sch in ${SCHEMES:-dpf}; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
 run() { echo -n "[$1] "; env $1 python3 tools/bench_evalall.py --scheme $2 --n $3 --log2-leaves $4 --steady 2>/dev/null | tail -1; }
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FSS_AMD_TUNE=1  # the library reads its A/B tunables only under this switch (fss_dev.hpp: tune_env)
 # Sweep the launch tunables of the point-eval kernels (one process per setting).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for bs in 1024 512 256; do for ilp in 1 2; do for w in 0 1; do
