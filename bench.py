@@ -669,20 +669,62 @@ def run_suite(args):
         json.dump(res, f, indent=1)
 
 
+def visible_gpus_without_hip():
+    """GPUs this process could use, counted WITHOUT the HIP runtime (the launcher must not initialise it before it
+    forks its ranks; torch.cuda.device_count() only avoids HIP while amdsmi discovery works): KFD topology nodes with
+    SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES lists.  None = cannot tell
+    (no sysfs): then there is no pre-check and a rank without a device fails by itself, which ends the run."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(f) if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def _die_with_parent():
+    """preexec_fn of the ranks: SIGTERM when the launcher dies, however it dies (PR_SET_PDEATHSIG)."""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # 1 = PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes, spawned before
-    this one has touched the GPU -- nothing here calls into HIP), one per GPU, rendezvous on 127.0.0.1.  Rank 0's
+    this one has touched the GPU -- nothing here calls into HIP: the devices are counted from sysfs), one per GPU,
+    rendezvous on 127.0.0.1.  Rank 0's
     stdout (the one JSON line) passes through.  If a rank exits non-zero, or the run outlives --launch-timeout, the
     remaining ranks are killed and the exit code is non-zero: a failed rank can never leave the others in a barrier."""
+    import signal
     import socket
     import subprocess
     n = args.gpus
     share = os.environ.get("FSS_AMD_BENCH_SHARE_GPU") == "1"
     dry = os.environ.get("FSS_AMD_BENCH_DRY_RUN") == "1"
     if not (share or dry):
-        have = torch.cuda.device_count()  # counts devices without initialising the HIP runtime in this process
-        if have < n:
+        have = visible_gpus_without_hip()
+        if have is not None and have < n:
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+
+    # SIGTERM / SIGHUP / SIGINT to the launcher (`timeout N python bench.py --gpus 8`, a harness kill) must unwind
+    # into the `finally` below: the ranks sit in their own sessions and would otherwise outlive it on the GPUs.
+    def _on_signal(signum, _frame):
+        raise SystemExit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+        signal.signal(sg, _on_signal)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -691,7 +733,8 @@ def launch_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True,
+                                      preexec_fn=_die_with_parent))
     deadline = time.monotonic() + args.launch_timeout
     rc = 0
     try:
@@ -734,6 +777,7 @@ def run_dry(args, rank, world, dist):
     """FSS_AMD_BENCH_DRY_RUN=1: the launch / rendezvous / barrier / max-over-ranks / one-JSON-line control flow with an
     empty step and no GPU -- a test hook for boxes without one (tests/test_bench_launch.py).  Its line says
     "dry_run": true and measures nothing."""
+    print(f"bench.py dry rank {rank} pid {os.getpid()}", file=sys.stderr, flush=True)
     fail = os.environ.get("FSS_AMD_BENCH_FAIL_RANK")
     if fail is not None and int(fail) == rank:
         raise SystemExit(f"rank {rank}: failure injected by FSS_AMD_BENCH_FAIL_RANK")

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "fss_amd_dpf_relayout_u32": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_dpf_eval_keys_u32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_ctx_scratch": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "fss_amd_ctx_scratch_release": (_i, [_vp, _vp]),
     "fss_amd_upload": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "fss_amd_ctx_read_te0": (_i, [_vp, _vp]),
 }

@@ -100,12 +100,15 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
   if (e == hipSuccess) e = hipMalloc(&c->tail_pairs, fss_amd_ctx::kTailPairs * 2 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(c->tail_pairs, 0, fss_amd_ctx::kTailPairs * 2 * sizeof(uint32_t));
 #if FSS_DIAG_STAMPS
-  if (e == hipSuccess) e = hipMalloc(&c->diag_stamps, 4096 * 4 * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMemset(c->diag_stamps, 0, 4096 * 4 * sizeof(uint64_t));
+  // one record per wave of the largest grid any stamped kernel launches: two workgroups of 16 waves per CU (ChaCha)
+  if (e == hipSuccess) e = hipMalloc(&c->diag_stamps, kDiagStampRecords * 5 * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMemset(c->diag_stamps, 0, kDiagStampRecords * 5 * sizeof(uint64_t));
 #endif
   if (e != hipSuccess) {
     g_last_hip = (int)e;
     if (c->te0) (void)hipFree(c->te0);
+    if (c->tail_pairs) (void)hipFree(c->tail_pairs);
+    if (c->diag_stamps) (void)hipFree(c->diag_stamps);
     delete c;
     return FSS_AMD_EHIP;
   }
@@ -117,10 +120,19 @@ int fss_amd_ctx_create(fss_amd_ctx** out, int device, const uint8_t aes_keys[64]
 // diagnostic library only (not declared in fss_amd.h): the stamps of the last point-walk launch, 4 x uint64 per
 // workgroup {memtime0, realtime0, memtime1, realtime1}; synchronises the device
 int fss_amd_diag_read_stamps(fss_amd_ctx* ctx, uint64_t* out_host, int workgroups) {
-  if (!ctx || !out_host || workgroups < 1 || workgroups > 4096) return FSS_AMD_EINVAL;  // `workgroups` = records (waves)
+  if (!ctx || !out_host || workgroups < 1 || workgroups > kDiagStampRecords) return FSS_AMD_EINVAL;  // `workgroups` = records (waves)
   FSS_ON_DEVICE(ctx);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out_host, ctx->diag_stamps, (size_t)workgroups * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return FSS_AMD_OK;
+}
+// s_memrealtime of every wave's first instruction (before the table fill), point walks only
+int fss_amd_diag_read_entry_stamps(fss_amd_ctx* ctx, uint64_t* out_host, int records) {
+  if (!ctx || !out_host || records < 1 || records > kDiagStampRecords) return FSS_AMD_EINVAL;
+  FSS_ON_DEVICE(ctx);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out_host, ctx->diag_stamps + 4 * (size_t)kDiagStampRecords, (size_t)records * sizeof(uint64_t),
+                    hipMemcpyDeviceToHost));
   return FSS_AMD_OK;
 }
 #endif
@@ -140,7 +152,7 @@ int fss_amd_ctx_scratch(fss_amd_ctx* ctx, void* stream, size_t bytes, void** out
   *out = nullptr;
   FSS_ON_DEVICE(ctx);
   std::lock_guard<std::mutex> lk(ctx->scratch_mu);
-  fss_amd_ctx::Scratch& s = ctx->scratch[stream];
+  fss_amd_ctx::Scratch& s = ctx->scratch[stream_key(stream)];
   if (s.bytes < bytes || !s.p) {
     // hipFree waits for the device, so work still queued on the old buffer has finished before it goes away
     if (s.p) HIP_TRY(hipFree(s.p));
@@ -151,6 +163,18 @@ int fss_amd_ctx_scratch(fss_amd_ctx* ctx, void* stream, size_t bytes, void** out
     s.bytes = want;
   }
   *out = s.p;
+  return FSS_AMD_OK;
+}
+
+int fss_amd_ctx_scratch_release(fss_amd_ctx* ctx, void* stream) {
+  if (!ctx) return FSS_AMD_EINVAL;
+  FSS_ON_DEVICE(ctx);
+  std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+  auto it = ctx->scratch.find(stream_key(stream));
+  if (it == ctx->scratch.end()) return FSS_AMD_OK;
+  void* p = it->second.p;
+  ctx->scratch.erase(it);
+  if (p) HIP_TRY(hipFree(p));  // waits for the device: work still queued on the buffer has finished
   return FSS_AMD_OK;
 }
 

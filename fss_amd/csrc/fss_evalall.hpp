@@ -563,7 +563,8 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
   run_stage<LT, SCHEME, D, LEAF, E, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, a.n_in);
 #if FSS_DIAG_STAMPS
   if (LEAF && (threadIdx.x & 63) == 0 && a.stamps) {
-    uint64_t* o = a.stamps + 4 * ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
+    const int64_t rec = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    uint64_t* o = a.stamps + 4 * (rec < kDiagStampRecords ? rec : 0);
     o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif

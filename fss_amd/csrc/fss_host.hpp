@@ -9,9 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <unordered_map>
+#include <utility>
 
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
@@ -20,6 +23,16 @@
 using namespace fssamd;
 
 // ------------------------------------------------------------------ context
+// What per-stream state (scratch buffers, WaveQ's tail counters) is keyed by.  A stream handle names one real stream
+// except hipStreamPerThread, one handle value that stands for a different stream in every host thread: there the
+// calling thread is part of the key, so two threads launching on "their" per-thread stream never share a counter pair
+// or a scratch buffer.  (The null stream is one real stream for the whole process -- this library is not compiled
+// with -fgpu-default-stream=per-thread -- so launches on it run one after the other and may share.)
+using StreamKey = std::pair<void*, std::thread::id>;
+inline StreamKey stream_key(void* stream) {
+  return StreamKey(stream, stream == (void*)hipStreamPerThread ? std::this_thread::get_id() : std::thread::id());
+}
+
 struct fss_amd_ctx {
   int device;
   int num_cu;
@@ -31,21 +44,23 @@ struct fss_amd_ctx {
   // fss_amd_ctx_scratch: one grow-only device buffer per stream that asked for one
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   std::mutex scratch_mu;
-  std::unordered_map<void*, Scratch> scratch;
+  std::map<StreamKey, Scratch> scratch;
   uint64_t* diag_stamps = nullptr;  // FSS_DIAG_STAMPS builds: 4 x uint64 per workgroup of the last point-walk launch
-  // WaveQ's launch-wide tail counters: one {counter, waves done} pair per stream that launched a dynamic walk
-  // (launches on one stream run one after the other, and the kernel hands its pair back zeroed); nothing is
-  // allocated after creation, so a first launch may sit inside a stream capture
+  // WaveQ's launch-wide tail counters: one {counter, waves done} pair per real stream that launched a dynamic walk
+  // (launches on one stream run one after the other, and the kernel hands its pair back zeroed; StreamKey tells the
+  // per-thread streams behind hipStreamPerThread apart); nothing is allocated after creation, so a first launch may
+  // sit inside a stream capture
   static constexpr int kTailPairs = 1024;
   uint32_t* tail_pairs = nullptr;   // device: kTailPairs x 2 words, zero
   std::mutex tail_mu;
-  std::unordered_map<void*, int> tail_slot;
+  std::map<StreamKey, int> tail_slot;
   uint32_t* tail_pair(void* stream) {
+    const StreamKey key = stream_key(stream);
     std::lock_guard<std::mutex> lk(tail_mu);
-    auto it = tail_slot.find(stream);
+    auto it = tail_slot.find(key);
     if (it == tail_slot.end()) {
       if ((int)tail_slot.size() >= kTailPairs) return nullptr;  // more streams than pairs: those launch without a tail
-      it = tail_slot.emplace(stream, (int)tail_slot.size()).first;
+      it = tail_slot.emplace(key, (int)tail_slot.size()).first;
     }
     return tail_pairs + 2 * it->second;
   }
@@ -131,7 +146,11 @@ struct Tune {
     if (const char* e = tune_env("FSS_AMD_BS")) bs = atoi(e);
     if (const char* e = tune_env("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
     if (ilp != 1 && ilp != 2) ilp = 2;
+#if defined(FSS_EXP_BS768)
+    if (bs != 256 && bs != 512 && bs != 768 && bs != 1024) bs = 1024;  // round-3 experiment: 12 waves per CU
+#else
     if (bs != 256 && bs != 512 && bs != 1024) bs = 1024;
+#endif
   }
 };
 const Tune& tune() {
@@ -289,6 +308,9 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;
+#if defined(FSS_EXP_BS768)
+  if constexpr (!SHARED) { FSS_L(1, 768); }
+#endif
   FSS_L(1, 512);
   FSS_L(2, 512);
   FSS_L(1, 256);

@@ -62,6 +62,8 @@ struct EvalArgs {
 #ifndef FSS_DIAG_STAMPS
 #define FSS_DIAG_STAMPS 0
 #endif
+// records of the context's stamp buffer (one per wave of a launch; 256 CUs x 2 workgroups x 16 waves fit twice)
+constexpr int kDiagStampRecords = 16384;
 
 // tr bits of key i: uint64_t per key, or the reference's 32-bit packing (wave-uniform choice)
 __device__ __forceinline__ uint64_t load_tr(const uint64_t* tr_bits, int tr32, int64_t i) {
@@ -279,10 +281,18 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
                                                          const uint32_t* __restrict__ k_ocw,   // Half-Tree
                                                          EvalArgs a) {
   const DevCtx* c = first_kernarg(K);
+#if FSS_DIAG_STAMPS
+  const uint64_t stamp_re = __builtin_amdgcn_s_memrealtime();  // the wave's first instruction: before the table fill
+#endif
   FSS_PROGRESS_PROLOGUE();
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   uint32_t my_prog = 0;
+#if defined(FSS_EXP_CW_LDSDMA)
+  // round-3 experiment: the level's 64 correction words of a wave arrive by LDS-DMA
+  // (global_load_lds_dwordx4, no VGPR return path) in a 1 KiB slab per wave beside the tables
+  __shared__ __attribute__((aligned(16))) uint4 cw_slab_[BS / 64][64];
+#endif
 
   const int in_bits = a.in_bits, party = a.party;
   const Grp g = make_grp(a.group, c);
@@ -323,6 +333,14 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           trbh[j] = in_bits > 64 ? a.tr_bits[n + idx[j]] : 0ull;
         }
       }
+#if defined(FSS_EXP_CW_LDSDMA)
+      constexpr bool kDma = !SHARED && ILP == 1 && std::is_same_v<LT, Lds>;
+      if constexpr (kDma) {
+        __builtin_amdgcn_global_load_lds(a.cw_s + (int64_t)lvl0 * n + idx[0], &cw_slab_[threadIdx.x >> 6][0], 16, 0, 2);
+      }
+#else
+      constexpr bool kDma = false;
+#endif
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
@@ -333,6 +351,20 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           if constexpr (SHARED) {
             const uint32_t* p = k_cws + 8 * i;
             cw[j].x = p[0]; cw[j].y = p[1]; cw[j].z = p[2]; cw[j].wl = p[3]; cw[j].tr = p[4];
+#if defined(FSS_EXP_CW_LDSDMA)
+          } else if constexpr (kDma) {
+            FSS_FENCE();
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this level's slab has landed
+            FSS_FENCE();
+            uint4 t = cw_slab_[threadIdx.x >> 6][threadIdx.x & 63];
+            FSS_FENCE();
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slab is in registers before it is refilled
+            FSS_FENCE();
+            if (i + 1 < in_bits)
+              __builtin_amdgcn_global_load_lds(a.cw_s + (int64_t)(i + 1) * n + idx[0], &cw_slab_[threadIdx.x >> 6][0], 16, 0, 2);
+            cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
+            cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
+#endif
           } else {
             uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * n + idx[j]);
             cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
@@ -439,8 +471,10 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   }
 #if FSS_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave, taken as the wave leaves its loop (before done()'s barrier)
-    uint64_t* o = a.stamps + 4 * ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
+    const int64_t rec = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    uint64_t* o = a.stamps + 4 * (rec < kDiagStampRecords ? rec : 0);
     o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+    a.stamps[4 * (int64_t)kDiagStampRecords + (rec < kDiagStampRecords ? rec : 0)] = stamp_re;  // second region: entry times
   }
 #endif
   q.done();

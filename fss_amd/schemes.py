@@ -17,6 +17,7 @@ include/fss/grotto_dcf.cuh), which the reference does not bind to Python.
 import torch
 
 from . import engine as E
+from ._int import split_uint128
 from ._validate import (validate_alpha, validate_beta, validate_cpu_only, validate_cws, validate_device_match,
                         validate_domain_value, validate_group, validate_in_bits, validate_party, validate_pred,
                         validate_prg, validate_s0, validate_s0s)
@@ -34,7 +35,7 @@ def _xs_tensor(values, in_bits, device):
         return torch.tensor([v - (1 << 32) if v >= (1 << 31) else v for v in values], dtype=torch.int32, device=device)
     if in_bits <= 64:
         return torch.tensor([s64(v) for v in values], dtype=torch.int64, device=device)
-    return torch.tensor([[s64(v & ((1 << 64) - 1)), s64(v >> 64)] for v in values], dtype=torch.int64, device=device)
+    return torch.tensor([[s64(h) for h in split_uint128(v)] for v in values], dtype=torch.int64, device=device)
 
 
 def _x_tensor(x, in_bits, device):

@@ -312,11 +312,16 @@ int fss_amd_dpf_eval_keys_u32(fss_amd_ctx *ctx, int in_bits, int group, int part
  *   fss_amd_ctx_scratch  device scratch owned by the context, one grow-only buffer per stream: *out is valid
  *                        until a later call for the same (ctx, stream) asks for more, or the context is destroyed.
  *                        Growing frees the old buffer with hipFree (which waits for the device first).
- *                        This is the only call after creation that allocates.  Thread-safe.
+ *                        This is the only call after creation that allocates.  Thread-safe.  `stream` is only the
+ *                        key here (any pointer value may serve as one); for hipStreamPerThread the calling thread is
+ *                        part of the key, as for the per-stream work-distribution counters of the eval calls.
+ *   fss_amd_ctx_scratch_release  frees the buffer of (ctx, stream) (hipFree: waits for the device), e.g. before the
+ *                        stream is destroyed; a later fss_amd_ctx_scratch for the same key allocates afresh.
  *   fss_amd_upload       stream-ordered copy of a small host value (<= 1 MiB; meant for seeds and single keys) to
  *                        device memory.  The bytes travel as kernel arguments, so `src_host` may be pageable and
  *                        may be reused as soon as the call returns; nothing synchronises. */
 int fss_amd_ctx_scratch(fss_amd_ctx *ctx, void *stream, size_t bytes, void **out);
+int fss_amd_ctx_scratch_release(fss_amd_ctx *ctx, void *stream);
 int fss_amd_upload(fss_amd_ctx *ctx, void *dst, const void *src_host, size_t bytes, void *stream);
 
 /* ---- tuning / introspection -------------------------------------------------------- */

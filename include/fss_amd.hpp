@@ -215,6 +215,7 @@ struct Registry {
   std::mutex mu;
   std::map<std::string, fss_amd_ctx*> ctxs;
   std::mutex stage_mu;  // the host-buffer methods share one staging area per context: one at a time
+  std::mutex launch_mu;  // the asynchronous launchers enqueue "small arguments, then the kernel" as one unit
 };
 inline Registry& Reg() {
   static Registry* r = new Registry;  // never destroyed: contexts must not outlive the HIP runtime's own teardown
@@ -239,12 +240,21 @@ inline fss_amd_ctx* Engine(Spec s) {
   r.ctxs.emplace(key, c);
   return c;
 }
-// Drop every context (and its scratch) the value types created so far, e.g. before hipDeviceReset.
+// Drop every context (and its scratch) the value types created so far, e.g. before hipDeviceReset.  The registry
+// holds one context (about 10 KiB of device memory plus its scratch) per distinct (device, PRG keys / nonce, hash
+// key, modulus) ever used and never evicts by itself: a program that rotates key material calls this between epochs.
 inline void ReleaseEngines() {
   Registry& r = Reg();
   std::lock_guard<std::mutex> lk(r.mu);
   for (auto& kv : r.ctxs) fss_amd_ctx_destroy(kv.second);
   r.ctxs.clear();
+}
+// Free the scratch the asynchronous launchers keep for `stream` (every context); call before destroying the stream.
+// Waits for the device (hipFree).
+inline void ReleaseStreamScratch(hipStream_t stream) {
+  Registry& r = Reg();
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (auto& kv : r.ctxs) Check(fss_amd_ctx_scratch_release(kv.second, stream), "fss_amd_ctx_scratch_release");
 }
 
 template <typename In>
@@ -266,12 +276,15 @@ inline bool OnDevice(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeUnified;
 }
 
-// Staging area for the host-buffer (reference-signature) methods: slices of the context's scratch for the null
-// stream.  Blocking copies on the null stream keep the reference's synchronous semantics.
+// Staging area for the host-buffer (reference-signature) methods: slices of a scratch buffer of the context that is
+// the stage's alone (its own key: the asynchronous launchers' scratch of the null stream is a different buffer, so a
+// launcher running on stream 0 in another thread never sees its slots overwritten by a staged call).  One staged
+// call at a time (stage_mu); blocking copies on the null stream keep the reference's synchronous semantics.
+inline char kStageKey;  // its address is the scratch key
 class Stage {
  public:
   Stage(fss_amd_ctx* ctx, size_t bytes) : lock_(Reg().stage_mu), ctx_(ctx) {
-    Check(fss_amd_ctx_scratch(ctx, nullptr, bytes + 256, &base_), "fss_amd_ctx_scratch");  // + alignment slack
+    Check(fss_amd_ctx_scratch(ctx, &kStageKey, bytes + 256, &base_), "fss_amd_ctx_scratch");  // + alignment slack
   }
   // the next `bytes` of the area (32-byte aligned)
   void* Take(size_t bytes) {
@@ -321,9 +334,14 @@ class Stage {
 };
 
 // Scratch of (ctx, stream) for the asynchronous launchers: [0, 256) small by-value arguments, then the workspace.
+// One buffer per stream (per thread for hipStreamPerThread).  A launcher holds launch_mu from taking the buffer until
+// its kernel is enqueued, so two host threads launching on the same stream (the default stream = 0 in particular)
+// enqueue "upload, kernel" pairs whole: stream order then keeps one call's small arguments and workspace intact until
+// its kernel has read them.
 struct Scratch {
+  std::lock_guard<std::mutex> lock_;
   char* base;
-  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) {
+  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) : lock_(Reg().launch_mu) {
     void* p = nullptr;
     Check(fss_amd_ctx_scratch(ctx, stream, ws_bytes + 256, &p), "fss_amd_ctx_scratch");
     base = static_cast<char*>(p);
@@ -338,6 +356,7 @@ inline const int4* PutInt4(fss_amd_ctx* ctx, const Scratch& s, int slot, int4 v,
 }  // namespace detail
 
 using detail::ReleaseEngines;
+using detail::ReleaseStreamScratch;
 
 namespace detail {
 template <typename P>

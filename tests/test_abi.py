@@ -87,3 +87,13 @@ def test_cxx_dropin_device_test_compiles():
     (tests/test_gpu_parity.py::test_cxx_dropin_device_side)."""
     from fss_amd import _build
     assert os.path.exists(_build.build_dropin_device_test())
+
+
+def test_makefile_stamp_equals_python_digest():
+    """`make -C fss_amd/csrc` stamps the library with sources_digest.sh; fss_amd/_build.py must accept that stamp
+    (same digest), or Python would rebuild a library make has just built."""
+    import subprocess
+    from fss_amd import _build
+    sh = os.path.join(os.path.dirname(_build.CSRC), "csrc", "sources_digest.sh")
+    out = subprocess.run(["sh", sh], capture_output=True, text=True, check=True).stdout.strip()
+    assert out == _build._sources_digest()

@@ -58,6 +58,56 @@ def test_a_hung_rank_is_stopped_by_the_launch_timeout():
     assert dt < 90
 
 
+def test_sigterm_to_the_launcher_takes_the_ranks_down():
+    """`timeout N python bench.py --gpus 8` sends SIGTERM to the launcher only; its ranks live in their own sessions.
+    The launcher's handler must unwind into the clean-up that kills them (and PR_SET_PDEATHSIG covers SIGKILL)."""
+    import re
+    import signal
+    e = dict(os.environ, FSS_AMD_BENCH_DRY_RUN="1", FSS_AMD_BENCH_HANG_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--steps", "2"], env=e, stdout=subprocess.DEVNULL,
+                         stderr=subprocess.PIPE)
+    pids, t0, buf = [], time.monotonic(), ""
+    os.set_blocking(p.stderr.fileno(), False)
+    while len(pids) < 2 and time.monotonic() - t0 < 120:
+        try:
+            buf += os.read(p.stderr.fileno(), 65536).decode(errors="replace")
+        except BlockingIOError:
+            pass
+        pids = [int(m) for m in re.findall(r"dry rank \d+ pid (\d+)", buf)]
+        time.sleep(0.1)
+    assert len(pids) == 2, buf[-2000:]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) != 0
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:  # a zombie of an already-reaped session still answers kill(0): look at its state
+            return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+        except OSError:
+            return False
+    t1 = time.monotonic()
+    while any(alive(q) for q in pids) and time.monotonic() - t1 < 20:
+        time.sleep(0.2)
+    assert not any(alive(q) for q in pids), pids
+
+
+def test_device_count_does_not_need_hip():
+    """The launcher counts GPUs from sysfs (or cannot tell), never through the HIP runtime."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    n = m.visible_gpus_without_hip()
+    assert n is None or n >= 0
+    import inspect
+    assert "torch.cuda" not in inspect.getsource(m.launch_ranks)
+
+
 @pytest.mark.gpu
 def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
     r, _ = run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "20", "--no-cpu"],

@@ -92,6 +92,32 @@ if hasattr(L, "fss_amd_diag_read_stamps"):
     line["lds_floor_cycles"] = int(floor)
     line["lds_floor_over_cycles"] = round(floor / float(np.median(dcyc[ok])), 4)
     line["lds_frac_at_measured_clock"] = round(line["lds_frac_at_2.4GHz"] * 2.4 / line["in_kernel_clock_GHz_median"], 4)
+    if hasattr(L, "fss_amd_diag_read_entry_stamps"):
+        # where a launch's time goes (round 3, profiles/r3/points_2e20_breakdown.txt), in us on the 100 MHz clock:
+        #   launch -> first wave's first instruction and last wave's last instruction -> completion (what HIP events see
+        #   beyond the in-kernel span), entry -> after the table fill, the walk loop, the idle tail of waves that are done
+        ent = np.zeros(nrec, dtype=np.uint64)
+        L.fss_amd_diag_read_entry_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        assert L.fss_amd_diag_read_entry_stamps(eng._h, ent.ctypes.data_as(C.c_void_p), nrec) == 0
+        re_ = ent.astype(np.float64)
+        kernel_us = kms * 1e3
+        inkernel = (r1.max() - re_.min()) / 100.0
+        fill = (r0 - re_) / 100.0
+        busy = (r1 - r0) / 100.0
+        idle_tail = (r1.max() - r1) / 100.0
+        floor_us = floor / (line["in_kernel_clock_GHz_median"] * 1e3)
+        line["breakdown_us"] = {
+            "kernel_ms_x1000 (HIP events / launches)": round(kernel_us, 2),
+            "outside_in_kernel_span (launch, dispatch of 256 workgroups, completion)": round(kernel_us - inkernel, 2),
+            "entry_spread (first wave's entry -> last wave's entry)": round(float(re_.max() - re_.min()) / 100.0, 2),
+            "table_fill_mean (entry -> loop, per wave)": round(float(fill.mean()), 2),
+            "walk_loop_mean (per wave)": round(float(busy.mean()), 2),
+            "idle_tail_mean (wave done -> launch's last wave done)": round(float(idle_tail.mean()), 2),
+            "idle_tail_across_workgroups (mean over workgroups of: launch end - workgroup end)": round(float((r1.max() - per_wg_end).mean()) / 100.0, 2),
+            "idle_tail_inside_workgroup (mean over waves of: workgroup end - wave end)": round(float((per_wg_end.repeat(block // 64) - r1).mean()) / 100.0, 2),
+            "lds_floor_at_measured_clock": round(floor_us, 2),
+            "walk_loop_minus_floor (LDS idle while the wave's workgroup is walking)": round(float(busy.mean()) - floor_us, 2),
+        }
 else:
     line["note"] = "product library: no stamps (set FSS_AMD_LIB to the FSS_DIAG_STAMPS build)"
 import json
