@@ -193,9 +193,10 @@ def cpu_baseline(scheme, n, s0s, cws, ocw, xs_sample, gpu_sample, threads):
     xs64 = xs_sample.astype(np.uint64)
     oc = None if ocw is None else ocw.numpy()
     O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64[:1024], ocw=oc, nthreads=1)  # warm
-    # about 10 s of CPU work in all: the all-threads pass repeated until >= 6 s, a ~3 s single-thread sample, one AES-NI pass
+    # the all-threads pass repeated until >= 4 s, a ~1 s single-thread sample, one AES-NI pass (the sub-records'
+    # CPU legs add about as much again: ~15 s of CPU work in the whole default run)
     reps, dt = 0, 0.0
-    while dt < 6.0 and reps < 64:
+    while dt < 4.0 and reps < 64:
         t0 = time.perf_counter()
         ys = O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64, ocw=oc, nthreads=threads)
         dt += time.perf_counter() - t0
@@ -241,6 +242,144 @@ def _sub_record(desc, scheme, n, shared, units, wall, kernel_ms, world, steps, k
             "kernel_ms": kernel_ms, "per_gpu_evals_per_s": rate, "aes_blocks_per_eval": aes,
             "roofline": {"bound": "lds", "achieved": lds, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds / LDS_PEAK_GBS},
             "hbm_gbs_algorithmic": hbm, "hbm_frac": hbm / HBM_PEAK_GBS, "kernel": kname}
+
+
+def _small_batch_record(eng, scheme, log2_points, with_cpu):
+    """BASELINE configs[1] / configs[2] at their literal size (one key, kInBits=32, 2^20 random points, one GPU): a
+    0.3 - 0.6 ms launch, timed at steady clocks (time_steady) like every short launch in this file."""
+    import fss_amd
+    G, n, batch = fss_amd.U64, 32, 1 << log2_points
+    sid, s0s, cws, _, _, _ = make_key(eng, scheme, n, G, 0x5EED0600 + (7 if scheme == "dcf" else 0))
+    xs = _rand_xs(n, batch, 0x5EED0700 + (7 if scheme == "dcf" else 0))
+    sd, cd = s0s[0].cuda(), cws.cuda()
+    ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
+    step = lambda: eng.eval_points(sid, n, G, 0, sd, cd, xs, out=ys)
+    _, kms = time_steady(step)
+    rec = _sub_record(f"{'DCF (Boyle 21, mul=4 PRG, kLt)' if scheme == 'dcf' else 'DPF (Boyle 16)'} kInBits=32, 1 key, "
+                      f"2^{log2_points} random eval points, 1 GPU (BASELINE configs[{2 if scheme == 'dcf' else 1}] at its "
+                      f"literal size), party 0, Uint<uint64_t>; >= 150 ms of back-to-back launches after 60 ms of warm-up",
+                      scheme, n, True, batch, kms * 1e-3, kms, 1, 1, eng.last_kernel()[0])
+    rep = replayed_counters("dpf_2e20" if scheme == "dpf" else "dcf_2e20", batch)
+    rec["roofline"].update({"traffic": rep["traffic"], "traffic_replayed_from": rep["traffic_replayed_from"],
+                            "replay_matches_kernel_sources": rep["replay_matches_kernel_sources"]})
+    if "lds_busy_pmc" in rep:
+        rec["roofline"]["lds_busy_pmc"] = rep["lds_busy_pmc"]
+    if with_cpu:
+        from oracle import oracle as O
+        p = O.Prg(2 if scheme == "dpf" else 4, use_evp=True)
+        osid = O.DPF if scheme == "dpf" else O.DCF
+        x64 = xs.cpu().numpy().view(np.uint32).astype(np.uint64)
+        threads = usable_cores()
+        res = {}
+
+        def all_threads():
+            res["y"] = O.eval_points(p, osid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), x64, nthreads=threads)
+        reps, dt = _timed_cpu(all_threads, 1.0)
+        m1 = 1 << 17
+        t1 = time.perf_counter()
+        O.eval_points(p, osid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), x64[:m1], nthreads=1)
+        dt1 = time.perf_counter() - t1
+        ok = bool((res["y"] == ys.cpu().numpy()).all())
+        rec["cpu_baseline"] = {"value": reps * batch / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+                               "sample": f"all 2^{log2_points} points of the timed batch x {reps} passes, party 0, oracle with OpenSSL "
+                                         f"EVP AES-128-ECB PRG (reference call pattern), {threads} OpenMP threads, {dt:.1f} s; "
+                                         f"single thread: {m1} points",
+                               "single_thread_value": m1 / dt1, "gpu_matches_oracle_on_sample": ok}
+        rec["gpu_matches_oracle_on_sample"] = ok
+    return rec
+
+
+def _e2e_pcie_record(eng, log2_batch):
+    """The PCIe-inclusive rate SURVEY 8(d) asks to state separately (never `value`): x from and y back to pinned host
+    memory around the headline kernel -- serial on one stream, and pipelined in 8 chunks over three streams."""
+    import fss_amd
+    G, n, N, chunks = fss_amd.U64, 32, 1 << log2_batch, 8
+    sid, s0s, cws, _, _, _ = make_key(eng, "dpf", n, G, 0x5EED0002)
+    sd, cd = s0s[0].cuda(), cws.cuda()
+    xs_h = torch.randint(-2**31, 2**31, (N,), dtype=torch.int32).pin_memory()
+    ys_h = torch.empty((N, 4), dtype=torch.int32).pin_memory()
+    xs_d = torch.empty((N,), dtype=torch.int32, device="cuda")
+    ys_d = torch.empty((N, 4), dtype=torch.int32, device="cuda")
+
+    def serial():
+        xs_d.copy_(xs_h, non_blocking=True)
+        eng.eval_points(sid, n, G, 0, sd, cd, xs_d, out=ys_d)
+        ys_h.copy_(ys_d, non_blocking=True)
+
+    streams = [torch.cuda.Stream() for _ in range(3)]
+
+    def pipelined():
+        c_sz = N // chunks
+        for c in range(chunks):
+            sl = slice(c * c_sz, (c + 1) * c_sz)
+            with torch.cuda.stream(streams[c % 3]):
+                xs_d[sl].copy_(xs_h[sl], non_blocking=True)
+                eng.eval_points(sid, n, G, 0, sd, cd, xs_d[sl], out=ys_d[sl])
+                ys_h[sl].copy_(ys_d[sl], non_blocking=True)
+
+    out = {"workload": f"the headline batch (DPF kInBits=32, 1 key, 2^{log2_batch} points) with x read from and y written back to "
+                       "pinned host memory: 4 B up + 16 B down per evaluation; NOT the metric's value (inputs are not resident)",
+           "unit": "evals/s"}
+    reps = 5
+    for key, fn in (("serial_one_stream", serial), (f"pipelined_{chunks}_chunks_3_streams", pipelined)):
+        torch.cuda.synchronize()
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[key] = {"value": N / dt, "ms_per_batch": dt * 1e3, "pcie_GBs_both_directions": N * 20 / dt / 1e9}
+    ref = torch.empty_like(ys_d)
+    eng.eval_points(sid, n, G, 0, sd, cd, xs_d, out=ref)
+    out["outputs_identical_to_resident_run"] = bool((ys_h.cuda() == ref).all())
+    return out
+
+
+def c1_cpu_record(eng, threads):
+    """BASELINE configs[0]: DPF kInBits=8, one key, full-domain 256-point evaluation on the CPU with the OpenSSL
+    AES-128-MMO PRG (samples/dpf_dcf_cpu.cu:48-89: alpha = 42, beta = {7,0,0,0}, the sample's seeds and AES keys).
+    The oracle runs it -- in the reference's task shape on all threads, and sequentially on one -- its outputs are
+    checked against the reference's recorded SHA-256, and the GPU's EvalAll of the same key against it."""
+    import hashlib
+    import fss_amd
+    from oracle import oracle as O
+    n = 8
+    seeds = np.array([[0x11111111, 0x22222222, 0x33333333, 0x44444440], [0x55555555, 0x66666666, 0x77777777, 0x88888880]],
+                     dtype=np.uint32).view(np.int32)
+    beta = np.array([7, 0, 0, 0], dtype=np.int32)
+    p = O.Prg(2, use_evp=True)
+    cws = O.dpf_gen(p, n, O.BYTES, seeds, 42, beta)
+    want_sha = ("1745bb7f478e5ee9a9ef8709c6d6450d65bd440e145098d6a24515df15860cbd",
+                "02067d0b4346ff98b23fff0bc989bf8a4b4f58074426ba15fa77085fb3bd47cc")
+    ok_kat, ok_gpu = True, True
+    for b in (0, 1):
+        y = O.dpf_eval_all(p, n, O.BYTES, b, seeds[b], cws, task_threads=threads)
+        ok_kat &= hashlib.sha256(y.tobytes()).hexdigest() == want_sha[b]
+        g = eng.eval_all(fss_amd.DPF, n, fss_amd.BYTES, b, torch.from_numpy(seeds[b]), torch.from_numpy(cws)).cpu().numpy()
+        ok_gpu &= bool((g == y).all())
+    reps = 2000
+    t0 = time.perf_counter()
+    O.dpf_eval_all_repeat(p, n, O.BYTES, 0, seeds[0], cws, threads, reps)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    O.dpf_eval_all_repeat(p, n, O.BYTES, 0, seeds[0], cws, 1, reps)
+    dt1 = time.perf_counter() - t1
+    sd, cd = torch.from_numpy(seeds[0]).cuda(), torch.from_numpy(cws).cuda()
+    yg = torch.empty((1 << n, 4), dtype=torch.int32, device="cuda")
+    _, gms = time_steady(lambda: eng.eval_all(fss_amd.DPF, n, fss_amd.BYTES, 0, sd, cd, out=yg), steps=50, min_ms=50.0, warm_ms=20.0)
+    return {"workload": "DPF kInBits=8, 1 key, full-domain 256-point EvalAll, Bytes, party 0 (BASELINE configs[0]: the reference's "
+                        "CPU-runnable case, samples/dpf_dcf_cpu.cu constants)",
+            "cpu_baseline": {"value": reps * 256 / dt, "unit": "leaves/s", "cores": threads, "kind": "port",
+                             "us_per_evalall": dt / reps * 1e6,
+                             "sample": f"{reps} EvalAll calls: oracle in the reference's task-recursion shape, OpenSSL EVP PRG, "
+                                       f"{threads} threads; single thread: {reps} calls",
+                             "single_thread_value": reps * 256 / dt1, "single_thread_us_per_evalall": dt1 / reps * 1e6,
+                             "oracle_matches_reference_sha256": bool(ok_kat), "gpu_matches_oracle_on_sample": bool(ok_gpu and ok_kat)},
+            "gpu_us_per_evalall": gms * 1e3, "value": 256 / (gms * 1e-3), "unit": "leaves/s",
+            "gpu_matches_oracle_on_sample": bool(ok_gpu and ok_kat)}
 
 
 def run_headline(args, rank, world, dist):
@@ -290,8 +429,29 @@ def run_headline(args, rank, world, dist):
     if not args.only_headline:
         _keys_subrecord(args, rank, world, dist, eng, G, batch, ys, pick, subs, checks)
     eng.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys)  # the headline outputs again, for the CPU comparison below
+    # the headline's own CPU leg needs the first cpu_sample points and their outputs only: free the batch before the
+    # configs[3] / configs[4] sub-records take their 4 - 17 GiB
+    mm = min(batch, args.cpu_sample)
+    head_xs, head_ys = xs[:mm].cpu().numpy().view(np.uint32), ys[:mm].cpu().numpy()
+    del xs, ys
+    torch.cuda.empty_cache()
+    if not args.only_headline:
+        with_cpu = world == 1 and not args.no_cpu
+        if world == 1:
+            for key, sch in (("dpf_2e20", "dpf"), ("dcf_2e20", "dcf")):
+                subs[key] = _small_batch_record(eng, sch, 20, with_cpu)
+        for name in ("evalall_c4", "ht_c5", "grotto_c5"):
+            rec, _ = sharded_record(args, name, rank, world, dist, eng, with_cpu)
+            subs[name] = rec
+            del _
+            torch.cuda.empty_cache()
+        if world == 1 and rank == 0:
+            subs["e2e_pcie"] = _e2e_pcie_record(eng, args.log2_batch)
+            if with_cpu:
+                subs["c1_cpu"] = c1_cpu_record(eng, usable_cores())
     if rank != 0:
         return
+    xs, ys = head_xs, head_ys
     _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, kernel_ms, wall_sp, kernel_ms_sp, same,
                     kname, grid, block, subs, checks)
 
@@ -377,10 +537,12 @@ def _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, 
     if world == 1 and not args.no_cpu:
         threads = usable_cores()
         mm = min(batch, args.cpu_sample)
-        out["cpu_baseline"] = cpu_baseline(scheme, n, s0s, cws, ocw, xs[:mm].cpu().numpy().view(np.uint32),
-                                           ys[:mm].cpu().numpy(), threads)
+        out["cpu_baseline"] = cpu_baseline(scheme, n, s0s, cws, ocw, xs[:mm], ys[:mm], threads)
         for key, ok in cpu_check_subrecords(checks).items():  # part of the cpu_baseline leg: the oracle as checker
             out[key]["gpu_matches_oracle_on_sample"] = ok
+        gates = {k: v["gpu_matches_oracle_on_sample"] for k, v in out.items()
+                 if isinstance(v, dict) and "gpu_matches_oracle_on_sample" in v}
+        out["parity_gates"] = {"all_true": all(gates.values()), "gates": gates}
     print(json.dumps(out), flush=True)
 
 
@@ -400,36 +562,181 @@ def cpu_check_subrecords(checks):
     return res
 
 
-def run_sharded(args, rank, world, dist):
-    """BASELINE.json configs[3] and configs[4] as multi-GPU workloads with the same one-line contract:
-      evalall_c4: DPF EvalAll kInBits=28; the 2^28-leaf domain is cut into `world` aligned blocks, rank r expands
-                  block r into its own HBM (strong scaling, no collective);
-      ht_c5 / grotto_c5: kInBits=64, 2^24 independent keys x 1 point, key batch split across ranks (strong)."""
+def _workload_pmc(name):
+    """Counters of one workload's dominant kernel REPLAYED from profiles/r<N>/pmc_workloads.json (highest N first; written
+    by tools/profile_workloads.sh from separate rocprofv3 --pmc passes of `bench.py --workload <name>`): bench.py cannot
+    read PMCs itself.  Returns (record, path relative to the repo) or (None, None)."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_workloads.json"))
+    rnd = lambda f: int(re.search(r"profiles[/\\]r(\d+)", f).group(1))
+    for f in sorted(files, key=rnd, reverse=True):
+        try:
+            d = json.load(open(f))
+            if name in d:
+                return d[name], os.path.relpath(f, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
+def replayed_counters(name, units_per_launch):
+    """HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, MI355X_MICROARCH.md's gfx950 correction) and LDS busy
+    fraction per launch of the committed profile of this workload -- valid only for the launch size profiled and
+    labelled with whether the profile was captured for the sources this library's kernel is compiled from."""
+    rec, src = _workload_pmc(name)
+    out = {"traffic": None, "traffic_replayed_from": src, "replay_matches_kernel_sources": False}
+    if not rec or rec.get("units_per_launch") != units_per_launch:
+        return out
+    from fss_amd import _build
+    out["replay_matches_kernel_sources"] = rec.get("_captured_for") == _build.workload_digest(name)
+    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+        out["traffic"] = (2 * rec["FETCH_SIZE"]["mean_per_launch"] + rec["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
+    if "GRBM_GUI_ACTIVE" in rec and "SQ_LDS_IDX_ACTIVE" in rec:
+        out["lds_busy_pmc"] = rec["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / (rec["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0)
+    return out
+
+
+def _timed_cpu(fn, min_s, max_reps=64):
+    """fn() repeated until min_s seconds have been spent: (repetitions, seconds)."""
+    reps, dt = 0, 0.0
+    while dt < min_s and reps < max_reps:
+        t0 = time.perf_counter()
+        fn()
+        dt += time.perf_counter() - t0
+        reps += 1
+    return reps, dt
+
+
+def cpu_evalall(eng, threads, n_cpu):
+    """CPU baseline of the full-domain workload: the oracle's EvalAll in the reference's own
+    execution shape -- depth-first, one OpenMP task per child above ceil(log2(threads)) levels (dpf.cuh:232-303,
+    util.cuh:40-45), OpenSSL EVP PRG -- on a 2^n_cpu-leaf domain, all threads and one thread; the GPU's EvalAll of
+    the same key is compared with it leaf for leaf."""
+    import fss_amd
+    from oracle import oracle as O
+    G = fss_amd.U64
+    sid, s0s, cws, _, _, _ = make_key(eng, "dpf", n_cpu, G, 0x5EED0400 + n_cpu)
+    got = eng.eval_all(sid, n_cpu, G, 0, s0s[0].cuda(), cws.cuda()).cpu().numpy()
+    p = O.Prg(2, use_evp=True)
+    out = np.zeros((1 << n_cpu, 4), dtype=np.int32)
+    s0, cw = s0s[0].numpy(), cws.numpy()
+    reps, dt = _timed_cpu(lambda: O.dpf_eval_all(p, n_cpu, O.U64, 0, s0, cw, task_threads=threads, out=out), 1.5)
+    parity = bool((out == got).all())
+    t1 = time.perf_counter()
+    O.dpf_eval_all(p, n_cpu, O.U64, 0, s0, cw, task_threads=1, out=out)
+    dt1 = time.perf_counter() - t1
+    return {"value": reps * (1 << n_cpu) / dt, "unit": "leaves/s", "cores": threads, "kind": "port",
+            "sample": f"DPF EvalAll kInBits={n_cpu} (2^{n_cpu} leaves) x {reps} passes, party 0, Uint<uint64_t>: oracle in the "
+                      f"reference's task-recursion shape (one OpenMP task per child above ceil(log2(threads)) levels), OpenSSL "
+                      f"EVP AES-128-ECB PRG, {threads} threads, {dt:.1f} s; single thread: one pass, {dt1:.1f} s",
+            "single_thread_value": (1 << n_cpu) / dt1,
+            "gpu_matches_oracle_on_sample": parity and bool((out == got).all()),
+            "gpu_sample": f"the GPU's EvalAll of the same kInBits={n_cpu} key, all 2^{n_cpu} leaves"}
+
+
+def cpu_keys(eng, scheme, n, keys, seeds0, xs, ocws, ys, threads, m):
+    """CPU baseline of the independent-keys workloads (C5): a strided subset of m keys brought back key-major, the
+    oracle's per-key Eval (Half-Tree: Aes128Mmo<1> hashes; Grotto: the path walk, both children per level as the
+    reference's ExpandTreeRec computes them) with the OpenSSL EVP PRG, all threads and one thread; the GPU's outputs
+    for those keys are compared with it."""
+    import fss_amd
+    from fss_amd.engine import LevelMajorKeys
+    from oracle import oracle as O
+    nk = keys.nkeys
+    m = min(m, nk)
+    pick = torch.arange(0, nk, max(1, nk // m), device="cuda")[:m]
+    m = int(pick.numel())
+    if scheme == "ht":
+        sub = LevelMajorKeys(fss_amd.HT, n, m, keys.cw_s[:, pick].contiguous(), extra=keys.extra[pick].contiguous())
+        osid, mul, oc = O.HT, 1, ocws[pick].cpu().numpy()
+    else:
+        sub = LevelMajorKeys(fss_amd.DPF, n, m, keys.cw_s[:, pick].contiguous(), tr_bits=keys.tr_bits[pick].contiguous(),
+                             out_cw=keys.out_cw[pick].contiguous())
+        osid, mul, oc = O.GROTTO, 2, None
+    km = eng.key_major(sub).cpu().numpy()
+    sd = seeds0[pick].cpu().numpy()
+    xh = xs[pick].cpu().numpy().view(np.uint64)
+    got = ys[pick].cpu().numpy()
+    p = O.Prg(mul, use_evp=True)
+    res = {}
+
+    def all_threads():
+        res["y"] = O.eval_keys(p, osid, n, O.U64 if scheme == "ht" else O.BYTES, 0, sd, km, xh, ocws=oc, nthreads=threads)
+    reps, dt = _timed_cpu(all_threads, 1.5)
+    m1 = min(m, 1 << 16)
+    t1 = time.perf_counter()
+    O.eval_keys(p, osid, n, O.U64 if scheme == "ht" else O.BYTES, 0, sd[:m1], km[:m1], xh[:m1],
+                ocws=None if oc is None else oc[:m1], nthreads=1)
+    dt1 = time.perf_counter() - t1
+    want = res["y"] if scheme == "ht" else res["y"][:, 0].astype(np.uint8)
+    return {"value": reps * m / dt, "unit": "evals/s", "cores": threads, "kind": "port",
+            "sample": f"{m} of the timed batch's keys (every {max(1, nk // m)}th, brought back key-major) x {reps} passes, party 0: "
+                      f"oracle {'HalfTreeDpf::Eval (Aes128Mmo<1>)' if scheme == 'ht' else 'Grotto path walk (both children per level)'}"
+                      f" with the OpenSSL EVP AES-128-ECB PRG, {threads} OpenMP threads, {dt:.1f} s; single thread: {m1} keys",
+            "single_thread_value": m1 / dt1,
+            "gpu_matches_oracle_on_sample": bool((want == got).all())}
+
+
+def sharded_record(args, name, rank, world, dist, eng, with_cpu):
+    """BASELINE.json configs[3] / configs[4] under the same launch contract (barrier + synchronize, max over ranks):
+      evalall_c4: DPF EvalAll kInBits=--log2-domain (28); the domain is cut into `world` aligned blocks
+                  (shard.domain_block), rank r expands block r into its own HBM (strong scaling, no collective);
+      ht_c5 / grotto_c5: kInBits=64, 2^--log2-keys (24) independent keys x 1 point, key batch split across the ranks
+                  (shard.batch_slice; strong).
+    On one GPU with the CPU leg enabled the record also carries cpu_baseline (and its parity gate).  Returns the
+    record (meaningful on rank 0) and the outputs (for callers that hash them)."""
     import fss_amd
     from fss_amd import shard
-    eng = fss_amd.default_engine(torch.cuda.current_device())
     G = fss_amd.U64
-    if args.workload == "evalall_c4":
-        n = 28
+    cpu = None
+    if name == "evalall_c4":
+        n = args.log2_domain
         sid, s0s, cws, ocw, _, _ = make_key(eng, "dpf", n, G, 0x5EED0004)
         first, nleaves = shard.domain_block(n, rank, world)
         sd, cd = s0s[0].cuda(), cws.cuda()
         ys = torch.empty((nleaves, 4), dtype=torch.int32, device="cuda")
         step = lambda: eng.eval_all(sid, n, G, 0, sd, cd, first_leaf=first, nleaves=nleaves, out=ys)
         units_total, units_rank, unit, aes_per_unit = 1 << n, nleaves, "leaves/s", 2.0
-        desc = (f"DPF full-domain EvalAll kInBits=28 (2^28 outputs), domain-sharded x{world}: "
+        desc = (f"DPF full-domain EvalAll kInBits={n} (2^{n} outputs), domain-sharded x{world}: "
                 f"2^{nleaves.bit_length() - 1} leaves per GPU, Uint<uint64_t>, party 0")
-        hbm_unit = 16
+        hbm_unit, hbm_note = 16, "16 B written per leaf (SURVEY 8d); the PMC traffic also holds the frontier nodes written and read back"
+    elif name == "grotto_evalall":
+        # Grotto DCF full domain, domain-sharded: the one workload of the path with an exchange step -- the running XOR
+        # crosses block boundaries, one parity byte per rank all-gathered per step (shard.grotto_fix_shard).  Not part
+        # of the default line; tests/test_bench_launch.py runs it with 8 ranks on one GPU.
+        n = args.log2_domain
+        g0 = torch.Generator().manual_seed(0x5EED0006)
+        s0s = torch.randint(-2**31, 2**31, (1, 2, 4), dtype=torch.int32, generator=g0)
+        s0s[..., 3] &= ~1
+        alpha = torch.randint(0, 2**31, (1,), dtype=torch.int32, generator=g0) & ((1 << min(n, 31)) - 1)
+        cws1, _ = eng.gen(fss_amd.DPF, n, fss_amd.BYTES, s0s, alpha, torch.zeros((1, 4), dtype=torch.int32))
+        first, nleaves = shard.domain_block(n, rank, world)
+        sd, cd = s0s[0, 0].cuda(), cws1[0]
+        ys = torch.empty((nleaves,), dtype=torch.uint8, device="cuda")
+
+        def step():
+            eng.eval_all(fss_amd.GROTTO, n, fss_amd.BYTES, 0, sd, cd, first_leaf=first, nleaves=nleaves, out=ys)
+            shard.grotto_fix_shard(ys, dist)
+        units_total, units_rank, unit, aes_per_unit = 1 << n, nleaves, "leaves/s", 2.0
+        desc = (f"Grotto DCF full-domain EvalAll kInBits={n}, domain-sharded x{world} with the cross-block parity carry "
+                f"(one byte per rank all-gathered per step), 1 B per leaf, party 0")
+        hbm_unit, hbm_note = 1, "1 B written per leaf"
     else:
-        n, total = 64, 1 << 24
-        scheme = "ht" if args.workload == "ht_c5" else "grotto"
+        n, total = 64, 1 << args.log2_keys
+        scheme = "ht" if name == "ht_c5" else "grotto"
         lo, hi = shard.batch_slice(total, rank, world)
         nk = hi - lo
-        gen = torch.Generator(device="cuda").manual_seed(0x5EED0005 + rank)
-        s0s = torch.randint(-2**31, 2**31, (nk, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
-        betas = torch.randint(-2**31, 2**31, (nk, 4), dtype=torch.int32, device="cuda", generator=gen)
-        alphas = torch.randint(-2**63, 2**63 - 1, (nk,), dtype=torch.int64, device="cuda", generator=gen)
-        xs = torch.randint(-2**63, 2**63 - 1, (nk,), dtype=torch.int64, device="cuda", generator=gen)
+        # every key of the batch is a function of its global index: a rank's slice equals the same slice of a
+        # single-GPU run (tests/test_bench_launch.py hashes both)
+        gen = torch.Generator(device="cuda").manual_seed(0x5EED0005)
+        s0s = torch.randint(-2**31, 2**31, (total, 2, 4), dtype=torch.int32, device="cuda", generator=gen)[lo:hi].contiguous()
+        betas = torch.randint(-2**31, 2**31, (total, 4), dtype=torch.int32, device="cuda", generator=gen)[lo:hi].contiguous()
+        alphas = torch.randint(-2**63, 2**63 - 1, (total,), dtype=torch.int64, device="cuda", generator=gen)
+        xs = torch.randint(-2**63, 2**63 - 1, (total,), dtype=torch.int64, device="cuda", generator=gen)
+        xs[::2] = alphas[::2]  # half of the points hit their key's alpha
+        alphas, xs = alphas[lo:hi].contiguous(), xs[lo:hi].contiguous()
+        torch.cuda.empty_cache()
         sid = fss_amd.HT if scheme == "ht" else fss_amd.GROTTO
         gg = G if scheme == "ht" else fss_amd.BYTES
         if scheme == "grotto":
@@ -442,27 +749,78 @@ def run_sharded(args, rank, world, dist):
         step = lambda: eng.eval_keys(keys, gg, 0, seeds0, xs, ocws=ocws, out=ys)
         units_total, units_rank, unit = total, nk, "evals/s"
         aes_per_unit = 64.0 if scheme == "ht" else 96.0
-        desc = (f"{'Half-Tree DPF' if scheme == 'ht' else 'Grotto DCF (path walk)'} kInBits=64, 2^24 independent "
+        desc = (f"{'Half-Tree DPF' if scheme == 'ht' else 'Grotto DCF (path walk)'} kInBits=64, 2^{args.log2_keys} independent "
                 f"level-major keys x 1 point each, key batch sharded x{world} ({nk} keys per GPU), party 0")
         hbm_unit = 1084 if scheme == "ht" else 1057
+        hbm_note = ("16 seed + 8 x + 64 x 16 cw_s + 4 extra + 16 ocw + 16 y per key" if scheme == "ht"
+                    else "16 seed + 8 x + 64 x 16 cw_s + 8 tr bits + 1 y per key")
     wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
     kname, grid, block = eng.last_kernel()
-    if rank != 0:
-        return
+    if with_cpu and rank == 0 and world == 1:
+        threads = usable_cores()
+        if name == "evalall_c4":
+            cpu = cpu_evalall(eng, threads, min(22, n))
+            # the timed outputs themselves: a strided sample of the 2^n leaves (and both ends) against the oracle's
+            # per-point Eval -- EvalAll's leaf x is Eval(x) (dpf.cuh:232-303 vs :170-214)
+            from oracle import oracle as O
+            m = min(1 << n, 4096)
+            idx = torch.cat([torch.arange(0, 1 << n, max(1, (1 << n) // m), device="cuda")[:m],
+                             torch.tensor([(1 << n) - 1], device="cuda")])
+            want = O.eval_points(O.Prg(2), O.DPF, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), idx.cpu().numpy().astype(np.uint64), nthreads=4)
+            cpu["timed_outputs_match_oracle_on_strided_sample"] = bool((ys[idx].cpu().numpy() == want).all())
+            cpu["gpu_matches_oracle_on_sample"] = bool(cpu["gpu_matches_oracle_on_sample"] and cpu["timed_outputs_match_oracle_on_strided_sample"])
+        elif name in ("ht_c5", "grotto_c5"):
+            cpu = cpu_keys(eng, scheme, n, keys, seeds0, xs, ocws, ys, threads, 1 << 18)
     rate = units_rank / (kernel_ms * 1e-3)
     lds_gbs = rate * aes_per_unit * LOOKUP_BYTES_PER_AES / 1e9
-    print(json.dumps({
-        "metric": f"{args.workload}: {unit[:-2]} per second", "value": units_total * args.steps / wall, "unit": unit,
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": desc, "kernel": kname, "grid": grid, "block": block,
-                   "parallelism": f"sharded x{world}, no collective"},
+    rep = replayed_counters(name, units_rank)
+    rec = {
+        "workload": desc, "value": units_total * args.steps / wall, "unit": unit, "ms_per_step": wall / args.steps * 1e3,
+        "kernel_ms": kernel_ms, "per_gpu_units_per_s": rate, "scaling": "strong", "kernel": kname, "grid": grid, "block": block,
+        "aes_blocks_per_unit": aes_per_unit,
         "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds_gbs / LDS_PEAK_GBS,
-                     "traffic": None, "kernel_ms": kernel_ms,
-                     "algorithmic": f"{aes_per_unit:g} AES blocks per unit x 160 LDS lookups x 4 B (rank 0's share)"},
+                     "traffic": rep["traffic"], "traffic_replayed_from": rep["traffic_replayed_from"],
+                     "replay_matches_kernel_sources": rep["replay_matches_kernel_sources"], "kernel_ms": kernel_ms,
+                     "algorithmic": f"{aes_per_unit:g} AES blocks per unit x 160 LDS lookups x 4 B (rank 0's share of {units_rank} units)"},
         "roofline_hbm": {"bound": "hbm", "achieved": rate * hbm_unit / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": rate * hbm_unit / 1e9 / HBM_PEAK_GBS, "traffic": None},
-    }), flush=True)
+                         "frac": rate * hbm_unit / 1e9 / HBM_PEAK_GBS, "traffic": rep["traffic"],
+                         "traffic_replayed_from": rep["traffic_replayed_from"],
+                         "algorithmic_bytes_per_launch": units_rank * hbm_unit, "algorithmic": hbm_note},
+    }
+    if "lds_busy_pmc" in rep:
+        rec["roofline"]["lds_busy_pmc"] = rep["lds_busy_pmc"]
+    if cpu is not None:
+        rec["cpu_baseline"] = cpu
+        rec["gpu_matches_oracle_on_sample"] = cpu["gpu_matches_oracle_on_sample"]
+    return rec, ys
+
+
+def run_sharded(args, rank, world, dist):
+    """`--workload evalall_c4 | ht_c5 | grotto_c5`: one of configs[3] / configs[4] as the whole run, one JSON line."""
+    import fss_amd
+    eng = fss_amd.default_engine(torch.cuda.current_device())
+    rec, ys = sharded_record(args, args.workload, rank, world, dist, eng, with_cpu=not args.no_cpu)
+    if args.hash_out:
+        # tests/test_bench_launch.py: every rank leaves the SHA-256 of its outputs, cut into --hash-blocks equal blocks
+        # (an 8-rank run's eight digests must equal the eight block digests of a single-rank run)
+        import hashlib
+        from fss_amd import shard
+        arr = ys.cpu().numpy()
+        with open(f"{args.hash_out}.rank{rank}", "w") as f:
+            for b in range(max(1, args.hash_blocks)):
+                lo, hi = shard.batch_slice(arr.shape[0], b, max(1, args.hash_blocks))
+                f.write(hashlib.sha256(arr[lo:hi].tobytes()).hexdigest() + f" {hi - lo}\n")
+    if rank != 0:
+        return
+    line = {"metric": f"{args.workload}: {rec['unit'][:-2]} per second", "value": rec["value"], "unit": rec["unit"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": rec["workload"], "kernel": rec["kernel"], "grid": rec["grid"], "block": rec["block"],
+                       "parallelism": f"sharded x{world}, no collective"},
+            "roofline": rec["roofline"], "roofline_hbm": rec["roofline_hbm"]}
+    if "cpu_baseline" in rec:
+        line["cpu_baseline"] = rec["cpu_baseline"]
+    print(json.dumps(line), flush=True)
 
 
 def run_suite(args):
@@ -811,8 +1169,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=(1 << 24) if (os.cpu_count() or 1) >= 8 else (1 << 22), help="points of the batch timed on the CPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--suite", action="store_true")
-    ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "evalall_c4", "ht_c5", "grotto_c5"],
+    ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "evalall_c4", "ht_c5", "grotto_c5", "grotto_evalall"],
                     help="dpf_points = the headline (BASELINE metric); the others are configs[3] / configs[4], sharded")
+    ap.add_argument("--log2-domain", type=int, default=28, help="evalall_c4: kInBits of the full domain (configs[3]: 28)")
+    ap.add_argument("--log2-keys", type=int, default=24, help="ht_c5 / grotto_c5: log2 of the key batch (configs[4]: 24)")
+    ap.add_argument("--hash-out", default="", help="--workload runs: every rank writes the SHA-256 of its outputs to <this>.rank<r>")
+    ap.add_argument("--hash-blocks", type=int, default=1, help="with --hash-out: digests of this many equal blocks of the rank's outputs")
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the sub-records (DCF, independent keys, kInBits 16 / 64): the PMC passes of tools/profile.sh "
                          "use this so that one kernel template means one workload")

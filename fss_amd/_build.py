@@ -29,16 +29,38 @@ def _sources_digest():
 HEADLINE_SOURCES = ("fss_dev.hpp", "fss_point.hpp", "fss_host.hpp", "fss_amd.hip")
 
 
+# Sources the kernels of bench.py's other workloads (and their launch plans) are compiled from: the full-domain
+# evaluation is the one-launch form of fss_abi_fused.hip over fss_evalall.hpp; the independent-key walks are the point
+# walk's kernel; the Grotto path walk's launch lives in fss_abi_evalall.hip.
+_EVALALL_SOURCES = ("fss_dev.hpp", "fss_point.hpp", "fss_quad.hpp", "fss_evalall.hpp", "fss_host.hpp",
+                    "fss_fused_launch.hpp", "fss_abi_fused.hip", "fss_abi_evalall.hip")
+WORKLOAD_SOURCES = {
+    "headline": HEADLINE_SOURCES, "dpf_2e20": HEADLINE_SOURCES, "dcf_2e20": HEADLINE_SOURCES,
+    "evalall_c4": _EVALALL_SOURCES,
+    "ht_c5": HEADLINE_SOURCES,
+    "grotto_c5": HEADLINE_SOURCES + ("fss_abi_evalall.hip",),
+}
+
+
+def _digest_of(files):
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()
+
+
 def headline_digest():
     """SHA-256 over the sources (and flags) the point-walk kernels and their launch plan are compiled from: the
     rocprofv3 PMC summaries under profiles/ carry it, and bench.py says whether the counters it replays were
     captured for these sources."""
-    import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in HEADLINE_SOURCES:
-        h.update(f.encode())
-        h.update(open(os.path.join(CSRC, f), "rb").read())
-    return h.hexdigest()
+    return _digest_of(HEADLINE_SOURCES)
+
+
+def workload_digest(name):
+    """The same for one of bench.py's workloads (WORKLOAD_SOURCES); profiles/r<N>/pmc_workloads.json carries it."""
+    return _digest_of(WORKLOAD_SOURCES[name])
 
 
 def _stale():

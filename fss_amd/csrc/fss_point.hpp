@@ -23,6 +23,18 @@ __device__ __forceinline__ uint4 fss_ld_stream(const uint4* p) {
 #define FSS_LD_STREAM(p) (*(p))
 #endif
 
+#if defined(FSS_EXP_CW_LDSDMA)
+// 16 bytes per lane from `src` (per lane) to `dst` + 16 * lane (wave-uniform base), non-temporal; device pass only
+// (the host pass has no such builtin and would silently drop the kernel's launch stub)
+__device__ __forceinline__ void fss_glds16(const uint4* src, uint4* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);
+#else
+  (void)src; (void)dst;
+#endif
+}
+#endif
+
 namespace fssamd {
 
 struct EvalArgs {
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #if defined(FSS_EXP_CW_LDSDMA)
       constexpr bool kDma = !SHARED && ILP == 1 && std::is_same_v<LT, Lds>;
       if constexpr (kDma) {
-        __builtin_amdgcn_global_load_lds(a.cw_s + (int64_t)lvl0 * n + idx[0], &cw_slab_[threadIdx.x >> 6][0], 16, 0, 2);
+        fss_glds16(a.cw_s + (int64_t)lvl0 * n + idx[0], &cw_slab_[threadIdx.x >> 6][0]);
       }
 #else
       constexpr bool kDma = false;
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slab is in registers before it is refilled
             FSS_FENCE();
             if (i + 1 < in_bits)
-              __builtin_amdgcn_global_load_lds(a.cw_s + (int64_t)(i + 1) * n + idx[0], &cw_slab_[threadIdx.x >> 6][0], 16, 0, 2);
+              fss_glds16(a.cw_s + (int64_t)(i + 1) * n + idx[0], &cw_slab_[threadIdx.x >> 6][0]);
             cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
             cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
 #endif

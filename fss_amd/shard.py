@@ -46,6 +46,8 @@ def grotto_fix_shard(ys_local, dist=None):
         return ys_local
     world, rank = dist.get_world_size(), dist.get_rank()
     mine = ys_local[-1:].to(torch.uint8).clone()
+    if dist.get_backend() == "gloo":
+        mine = mine.cpu()  # gloo gathers host tensors only (the CPU tests, and ranks sharing one GPU)
     parts = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(parts, mine)
     carry = grotto_carries([int(p.item()) for p in parts])[rank]

@@ -444,6 +444,67 @@ void fo_dpf_eval_all(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, c
   for (size_t j = 0; j < n; ++j) ys[j] = dpf_leaf(group, b, set_lsb(ys[j], 0), get_lsb(ys[j]), &cws[in_bits]);
 }
 
+/* The same evaluation in the reference's own execution shape (dpf.cuh:232-303): a depth-first recursion over
+ * [l, r) that spawns one OpenMP task per child above par_depth = ceil(log2(threads)) (util.cuh:40-45,
+ * dpf.cuh:293-298) and runs sequentially below it.  Used as the CPU baseline of the full-domain workloads
+ * (bench.py); the leaves are the ones fo_dpf_eval_all writes (tests/test_oracle_properties.py).  The reference
+ * shares its EVP contexts between the tasks; here every thread has its own set (prgs[thread]). */
+static void dpf_eval_tree(const fo_prg *prgs, int in_bits, int group, int b, fo_i4 st, const fo_cw *cws, fo_i4 *ys,
+                          size_t l, size_t r, int i, int par_depth) {
+  const int t = get_lsb(st);
+  const fo_i4 s = set_lsb(st, 0);
+  if (i == in_bits) { /* dpf.cuh:253-263 */
+    ys[l] = dpf_leaf(group, b, s, t, &cws[in_bits]);
+    return;
+  }
+#ifdef _OPENMP
+  const fo_prg *p = &prgs[omp_get_thread_num()];
+#else
+  const fo_prg *p = &prgs[0];
+#endif
+  fo_i4 sl, sr; int tl, tr;
+  dpf_expand(p, s, t, &cws[i], &sl, &tl, &sr, &tr);
+  const fo_i4 stl = set_lsb(sl, tl), str = set_lsb(sr, tr);
+  const size_t mid = (l + r) / 2;
+  if (i < par_depth) {
+#pragma omp task
+    dpf_eval_tree(prgs, in_bits, group, b, stl, cws, ys, l, mid, i + 1, par_depth);
+#pragma omp task
+    dpf_eval_tree(prgs, in_bits, group, b, str, cws, ys, mid, r, i + 1, par_depth);
+#pragma omp taskwait
+  } else {
+    dpf_eval_tree(prgs, in_bits, group, b, stl, cws, ys, l, mid, i + 1, par_depth);
+    dpf_eval_tree(prgs, in_bits, group, b, str, cws, ys, mid, r, i + 1, par_depth);
+  }
+}
+
+static void prg_thread_copy(const fo_prg *src, fo_prg *dst);
+
+void fo_dpf_eval_all_tasks(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
+                           int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  int par_depth = 0; /* util.cuh:40-45 (ResolveParDepth): ceil(log2(threads)) */
+  while ((1 << par_depth) < nthreads) ++par_depth;
+  if (par_depth > in_bits) par_depth = in_bits;
+  fo_prg *prgs = (fo_prg *)malloc((size_t)nthreads * sizeof(fo_prg));
+  for (int k = 0; k < nthreads; ++k) prg_thread_copy(p, &prgs[k]);
+#pragma omp parallel num_threads(nthreads)
+#pragma omp single
+  dpf_eval_tree(prgs, in_bits, group, b, set_lsb(s0, b), cws, ys, 0, (size_t)1 << in_bits, 0, par_depth);
+  for (int k = 0; k < nthreads; ++k) fo_prg_free(&prgs[k]);
+  free(prgs);
+}
+
+/* `reps` back-to-back calls (timing small domains without a foreign-function call per evaluation) */
+void fo_dpf_eval_all_repeat(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
+                            int nthreads, int reps) {
+  for (int r = 0; r < reps; ++r) {
+    if (nthreads >= 1) fo_dpf_eval_all_tasks(p, in_bits, group, b, s0, cws, ys, nthreads);
+    else fo_dpf_eval_all(p, in_bits, group, b, s0, cws, ys);
+  }
+}
+
 /* ------------------------------------------------------------------ DCF */
 /* dcf.cuh:108-194 */
 void fo_dcf_gen(const fo_prg *p, int in_bits, int group, int pred, fo_cw *cws, const fo_i4 s0s[2], uint64_t a_lo,

@@ -94,6 +94,13 @@ void fo_dpf_gen(const fo_prg *p, int in_bits, int group, fo_cw *cws /* in_bits+1
 fo_i4 fo_dpf_eval(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, uint64_t x_lo,
                   uint64_t x_hi);
 void fo_dpf_eval_all(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys);
+/* fo_dpf_eval_all in the reference's execution shape: depth-first, one OpenMP task per child above
+ * ceil(log2(nthreads)) levels (dpf.cuh:232-303, util.cuh:40-45) */
+void fo_dpf_eval_all_tasks(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
+                           int nthreads);
+/* reps calls of fo_dpf_eval_all_tasks (nthreads >= 1) or fo_dpf_eval_all (nthreads = 0) */
+void fo_dpf_eval_all_repeat(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
+                            int nthreads, int reps);
 
 /* ---- DCF (include/fss/dcf.cuh) ---- */
 void fo_dcf_gen(const fo_prg *p, int in_bits, int group, int pred, fo_cw *cws /* in_bits+1 */, const fo_i4 s0s[2],

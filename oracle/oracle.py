@@ -74,6 +74,8 @@ def lib():
         L.fo_dpf_eval.argtypes = [P, i, i, i, _I4, vp, u64, u64]
         L.fo_dpf_eval.restype = _I4
         L.fo_dpf_eval_all.argtypes = [P, i, i, i, _I4, vp, vp]
+        L.fo_dpf_eval_all_tasks.argtypes = [P, i, i, i, _I4, vp, vp, i]
+        L.fo_dpf_eval_all_repeat.argtypes = [P, i, i, i, _I4, vp, vp, i, i]
         L.fo_dcf_gen.argtypes = [P, i, i, i, vp, vp, u64, u64, _I4]
         L.fo_dcf_eval.argtypes = [P, i, i, i, _I4, vp, u64, u64]
         L.fo_dcf_eval.restype = _I4
@@ -209,10 +211,23 @@ def dpf_eval(prg, in_bits, group, b, s0, cws, x):
     return _arr(lib().fo_dpf_eval(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), lo, hi))
 
 
-def dpf_eval_all(prg, in_bits, group, b, s0, cws):
+def dpf_eval_all(prg, in_bits, group, b, s0, cws, task_threads=0, out=None):
+    """task_threads = 0: the flattened breadth-first form; >= 1: the reference's depth-first recursion with OpenMP
+    tasks above ceil(log2(task_threads)) levels (dpf.cuh:232-303) -- same leaves."""
+    ys = np.zeros((1 << in_bits, 4), dtype=np.int32) if out is None else out
+    cws = np.ascontiguousarray(cws, dtype=np.int32)
+    if task_threads:
+        lib().fo_dpf_eval_all_tasks(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(ys), int(task_threads))
+    else:
+        lib().fo_dpf_eval_all(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(ys))
+    return ys
+
+
+def dpf_eval_all_repeat(prg, in_bits, group, b, s0, cws, task_threads, reps):
+    """`reps` EvalAll calls inside one foreign call (timing of small domains); returns the last outputs."""
     ys = np.zeros((1 << in_bits, 4), dtype=np.int32)
     cws = np.ascontiguousarray(cws, dtype=np.int32)
-    lib().fo_dpf_eval_all(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(ys))
+    lib().fo_dpf_eval_all_repeat(prg.ref, in_bits, group, int(b), _i4(s0), _ptr(cws), _ptr(ys), int(task_threads), int(reps))
     return ys
 
 

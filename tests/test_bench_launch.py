@@ -58,6 +58,15 @@ def test_a_hung_rank_is_stopped_by_the_launch_timeout():
     assert dt < 90
 
 
+def test_bare_gpus_8_dry_run():
+    """The driver's largest launch (8 ranks) through the launcher, rendezvous, barriers and the max-over-ranks
+    reduction, without a GPU."""
+    r, _ = run(["--gpus", "8", "--steps", "2", "--warmup", "1"], {"FSS_AMD_BENCH_DRY_RUN": "1"}, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["dry_run"] is True
+
+
 def test_sigterm_to_the_launcher_takes_the_ranks_down():
     """`timeout N python bench.py --gpus 8` sends SIGTERM to the launcher only; its ranks live in their own sessions.
     The launcher's handler must unwind into the clean-up that kills them (and PR_SET_PDEATHSIG covers SIGKILL)."""
@@ -125,9 +134,24 @@ def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
 def test_default_line_carries_the_whole_metric():
     """The driver's command at a small batch: headline + DCF / independent keys / kInBits 16, 64, each with its own
     kernel time and LDS fraction, each checked against the oracle on a sample inside the cpu_baseline leg."""
-    r, _ = run(["--steps", "3", "--warmup", "1", "--log2-batch", "18", "--cpu-sample", "65536"], {}, timeout=900)
+    r, _ = run(["--steps", "3", "--warmup", "1", "--log2-batch", "18", "--cpu-sample", "65536", "--log2-domain", "24",
+                "--log2-keys", "20"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json_lines(r.stdout)[0]
+    # round 3: BASELINE configs[0], [1], [2] at their literal sizes and configs[3], [4] (here at reduced sizes), each
+    # with its own CPU leg and parity gate, and the PCIe-inclusive figure, all in the one line
+    for key in ("dpf_2e20", "dcf_2e20", "evalall_c4", "ht_c5", "grotto_c5", "c1_cpu"):
+        rec = d[key]
+        assert rec["gpu_matches_oracle_on_sample"] is True, key
+        cb = rec["cpu_baseline"]
+        assert cb["value"] > 0 and cb["single_thread_value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port", key
+    for key in ("dpf_2e20", "dcf_2e20", "evalall_c4", "ht_c5", "grotto_c5"):
+        assert d[key]["kernel_ms"] > 0 and 0 < d[key]["roofline"]["frac"] < 1.2, key
+        assert "traffic" in d[key]["roofline"] and "replay_matches_kernel_sources" in d[key]["roofline"], key
+    assert d["evalall_c4"]["cpu_baseline"]["timed_outputs_match_oracle_on_strided_sample"] is True
+    assert d["c1_cpu"]["cpu_baseline"]["oracle_matches_reference_sha256"] is True
+    assert d["e2e_pcie"]["outputs_identical_to_resident_run"] is True and d["e2e_pcie"]["serial_one_stream"]["value"] > 0
+    assert d["parity_gates"]["all_true"] is True and len(d["parity_gates"]["gates"]) >= 11
     assert d["n_gpus"] == 1 and d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     for key in ("dcf_points", "dpf_keys", "dpf_n16", "dpf_n64"):
@@ -137,3 +161,34 @@ def test_default_line_carries_the_whole_metric():
     assert d["dcf_points"]["aes_blocks_per_eval"] == 64 and d["dpf_n16"]["aes_blocks_per_eval"] == 16
     assert d["shared_prefix"]["identical_to_plain_walk"] is True
     assert "clock_ghz_in_pmc_run" not in json.dumps(d)
+
+
+def _digests(prefix, ranks):
+    out = []
+    for r in range(ranks):
+        with open(f"{prefix}.rank{r}") as f:
+            out += [ln.split()[0] for ln in f if ln.strip()]
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,size", [("evalall_c4", ["--log2-domain", "22"]), ("ht_c5", ["--log2-keys", "18"]),
+                                           ("grotto_c5", ["--log2-keys", "18"]), ("grotto_evalall", ["--log2-domain", "20"])])
+def test_sharded_workloads_with_8_ranks_on_one_gpu(workload, size, tmp_path):
+    """BASELINE configs[3] / configs[4] as the driver's 8-GPU box would run them -- `bench.py --gpus 8 --workload ...`,
+    the domain cut by shard.domain_block, the key batch by shard.batch_slice -- with the eight ranks sharing this box's
+    one GPU (FSS_AMD_BENCH_SHARE_GPU: gloo instead of RCCL) at a reduced size.  Every rank writes the SHA-256 of its
+    block of outputs; the eight digests must be the digests of the eight blocks of a single-rank run (for the Grotto
+    full domain that includes the cross-block parity carry of shard.grotto_fix_shard)."""
+    common = ["--workload", workload, *size, "--steps", "2", "--warmup", "1", "--no-cpu"]
+    one = str(tmp_path / "one")
+    r, _ = run(common + ["--hash-out", one, "--hash-blocks", "8"], {}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    want = _digests(one, 1)
+    assert len(want) == 8 and len(set(want)) > 1
+    eight = str(tmp_path / "eight")
+    r, _ = run(["--gpus", "8"] + common + ["--hash-out", eight], {"FSS_AMD_BENCH_SHARE_GPU": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json_lines(r.stdout)
+    assert len(d) == 1 and d[0]["n_gpus"] == 8 and d[0]["value"] > 0 and d[0]["scaling"] == "strong"
+    assert _digests(eight, 8) == want

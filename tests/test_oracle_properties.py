@@ -48,6 +48,23 @@ def test_dpf_eval_all_matches_eval_and_reconstructs(O, rng, g):
     assert (r == want).all()
 
 
+@pytest.mark.parametrize("threads", [1, 2, 3, 8])
+@pytest.mark.parametrize("n", [1, 2, 9, 13])
+def test_dpf_eval_all_in_the_reference_task_shape(O, rng, n, threads):
+    """The depth-first recursion with OpenMP tasks above ceil(log2(threads)) levels (dpf.cuh:232-303) writes the
+    leaves the flattened form writes, for thread counts that are and are not powers of two and for domains
+    shallower than the task depth; with the EVP PRG (one context set per thread) as bench.py's CPU leg runs it."""
+    for use_evp in (False, True):
+        p = O.Prg(2, use_evp=use_evp)
+        s = [rng.i4(), rng.i4()]
+        cws = O.dpf_gen(p, n, G.U64, s, ALPHA & ((1 << n) - 1), beta_for(G.U64))
+        for b in (0, 1):
+            want = O.dpf_eval_all(p, n, G.U64, b, s[b], cws)
+            assert (O.dpf_eval_all(p, n, G.U64, b, s[b], cws, task_threads=threads) == want).all()
+            assert (O.dpf_eval_all_repeat(p, n, G.U64, b, s[b], cws, threads, 3) == want).all()
+            assert (O.dpf_eval_all_repeat(p, n, G.U64, b, s[b], cws, 0, 2) == want).all()
+
+
 @pytest.mark.parametrize("pred", [0, 1])
 @pytest.mark.parametrize("g", GROUPS)
 @pytest.mark.parametrize("n", [1, 8, 16, 64])
