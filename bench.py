@@ -46,6 +46,8 @@ N_CU, CLK_HZ = 256, 2.4e9
 LDS_PEAK_GBS = 128 * N_CU * CLK_HZ / 1e9   # 78 643 GB/s of 4-byte table lookups
 HBM_PEAK_GBS = 8000.0
 LOOKUP_BYTES_PER_AES = 160 * 4              # 144 Te0 + 16 S-box lookups, 4 B each
+CHACHA_VALU_PER_WAVE_BLOCK = 1003           # measured wave-instructions per 64 ChaCha20 blocks (960 in the rounds)
+VALU_ISSUE_PEAK_GINSTR = N_CU * 4 * CLK_HZ / 4.0 / 1e9   # 614.4 G wave64-instr/s at 4 clocks per instruction
 
 
 def aes_blocks_per_eval(scheme, n):
@@ -259,6 +261,7 @@ def _small_batch_record(eng, scheme, log2_points, with_cpu):
                       f"2^{log2_points} random eval points, 1 GPU (BASELINE configs[{2 if scheme == 'dcf' else 1}] at its "
                       f"literal size), party 0, Uint<uint64_t>; >= 150 ms of back-to-back launches after 60 ms of warm-up",
                       scheme, n, True, batch, kms * 1e-3, kms, 1, 1, eng.last_kernel()[0])
+    rec["units_per_launch"] = batch
     rep = replayed_counters("dpf_2e20" if scheme == "dpf" else "dcf_2e20", batch)
     rec["roofline"].update({"traffic": rep["traffic"], "traffic_replayed_from": rep["traffic_replayed_from"],
                             "replay_matches_kernel_sources": rep["replay_matches_kernel_sources"]})
@@ -776,7 +779,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
     rep = replayed_counters(name, units_rank)
     rec = {
         "workload": desc, "value": units_total * args.steps / wall, "unit": unit, "ms_per_step": wall / args.steps * 1e3,
-        "kernel_ms": kernel_ms, "per_gpu_units_per_s": rate, "scaling": "strong", "kernel": kname, "grid": grid, "block": block,
+        "kernel_ms": kernel_ms, "per_gpu_units_per_s": rate, "units_per_launch": units_rank, "scaling": "strong",
+        "kernel": kname, "grid": grid, "block": block,
         "aes_blocks_per_unit": aes_per_unit,
         "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": lds_gbs / LDS_PEAK_GBS,
                      "traffic": rep["traffic"], "traffic_replayed_from": rep["traffic_replayed_from"],
@@ -816,7 +820,7 @@ def run_sharded(args, rank, world, dist):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": rec["workload"], "kernel": rec["kernel"], "grid": rec["grid"], "block": rec["block"],
-                       "parallelism": f"sharded x{world}, no collective"},
+                       "units_per_launch": rec["units_per_launch"], "parallelism": f"sharded x{world}, no collective"},
             "roofline": rec["roofline"], "roofline_hbm": rec["roofline_hbm"]}
     if "cpu_baseline" in rec:
         line["cpu_baseline"] = rec["cpu_baseline"]
@@ -829,13 +833,25 @@ def run_suite(args):
     eng = fss_amd.default_engine(0)
     res = []
 
-    def record(name, units, fn, aes_per_unit, hbm_per_unit, steps=10, e=None):
+    def record(name, units, fn, aes_per_unit, hbm_per_unit, steps=10, e=None, chacha_per_unit=0):
         wall, kms = time_steady(fn, steps)
         rate = units / (kms * 1e-3)
         res.append({"config": name, "units_per_launch": units, "kernel_ms": kms, "units_per_s": rate,
                     "aes_blocks_per_s": rate * aes_per_unit,
                     "lds_frac": rate * aes_per_unit * LOOKUP_BYTES_PER_AES / 1e9 / LDS_PEAK_GBS,
                     "hbm_gbs_algorithmic": rate * hbm_per_unit / 1e9, "kernel": (e or eng).last_kernel()})
+        if chacha_per_unit:
+            # ChaCha lines: neither LDS (unused) nor HBM (< 1 %) binds them but VALU issue: a ChaCha20
+            # block is 10 double rounds x 96 instructions (32 add, 32 xor, 32 rotate; the rotates put the whole stream
+            # in the 4-clock issue class), 1 003 wave-instructions per wave-block with the feed-forward and the walk
+            # (SQ_INSTS_VALU, profiles/r1/chacha_dpf_n32_counters.txt).  peak = 256 CU x 4 SIMD x 2.4 GHz / 4 clk.
+            wave_instr = rate * chacha_per_unit / 64.0 * CHACHA_VALU_PER_WAVE_BLOCK
+            res[-1].pop("lds_frac")
+            res[-1]["chacha_blocks_per_s"] = rate * chacha_per_unit
+            res[-1]["roofline"] = {"bound": "valu_issue", "achieved": wave_instr / 1e9, "peak": VALU_ISSUE_PEAK_GINSTR,
+                                   "unit": "G wave64-instr/s", "frac": wave_instr / 1e9 / VALU_ISSUE_PEAK_GINSTR,
+                                   "algorithmic": f"{chacha_per_unit:g} ChaCha20 blocks per unit x {CHACHA_VALU_PER_WAVE_BLOCK} "
+                                                  "wave-instructions per 64 blocks; peak = 256 CU x 4 SIMD x 2.4 GHz / 4 clk"}
         print(json.dumps(res[-1]), file=sys.stderr, flush=True)
 
     G = fss_amd.U64
@@ -921,7 +937,8 @@ def run_suite(args):
         od = None if ocw is None else ocw.cuda()
         ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
         record(f"chacha {scheme} n={n} 1 key x 2^{lb} points", batch,
-               lambda: ceng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys), 0, hbm_bytes_per_eval(scheme, n, True), e=ceng)
+               lambda: ceng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys), 0, hbm_bytes_per_eval(scheme, n, True), e=ceng,
+               chacha_per_unit=n)
     for scheme, n, lk in (("dpf", 20, 22), ("dcf", 20, 21), ("ht", 20, 22)):
         nk = 1 << lk
         gen = torch.Generator(device="cuda").manual_seed(200 + n)
@@ -934,7 +951,8 @@ def run_suite(args):
         seeds0 = s0s[:, 0].contiguous()
         ys = torch.empty((nk, 4), dtype=torch.int32, device="cuda")
         record(f"chacha {scheme} n={n} 2^{lk} independent keys x 1 point", nk,
-               lambda: ceng.eval_keys(keys, G, 0, seeds0, xs, ocws=ocws, out=ys), 0, hbm_bytes_per_eval(scheme, n, False), e=ceng)
+               lambda: ceng.eval_keys(keys, G, 0, seeds0, xs, ocws=ocws, out=ys), 0, hbm_bytes_per_eval(scheme, n, False), e=ceng,
+               chacha_per_unit=n)
         del keys, ys
     # verifiable DPF: walk + one keyed-BLAKE3 XorHash per evaluation; the reference's GPU number
     # is ChaCha + BLAKE3 at n = 20 (README.md:389, BM_VdpfEvalPointGpu: 945 M eval/s on RTX PRO 5000)
@@ -957,7 +975,8 @@ def run_suite(args):
     sid, s0s, cws, ocw, _, _ = make_key(ceng, "dpf", 24, G, 5)
     sd, cd = s0s[0].cuda(), cws.cuda()
     ys = torch.empty((1 << 24, 4), dtype=torch.int32, device="cuda")
-    record("chacha dpf EvalAll n=24", 1 << 24, lambda: ceng.eval_all(sid, 24, G, 0, sd, cd, out=ys), 0, 16, steps=5, e=ceng)
+    record("chacha dpf EvalAll n=24", 1 << 24, lambda: ceng.eval_all(sid, 24, G, 0, sd, cd, out=ys), 0, 16, steps=5, e=ceng,
+           chacha_per_unit=1.0)  # one permutation per internal node = per leaf
     del ys
 
     # Grotto DCF full domain: the DPF tree over Bytes with beta = 0, leaf control bits, then the running-XOR scan
@@ -979,7 +998,7 @@ def run_suite(args):
     for beng, tag in ((eng, "aes"), (ceng, "chacha")):
         for mul in (1, 2, 4):
             record(f"{tag} prg Gen mul={mul}, 2^24 seeds", 1 << 24, lambda: beng.prg_gen(mul, seeds),
-                   mul if tag == "aes" else 0, 16 + 16 * mul, steps=5, e=beng)
+                   mul if tag == "aes" else 0, 16 + 16 * mul, steps=5, e=beng, chacha_per_unit=0 if tag == "aes" else 1.0)
     del seeds
 
     # key-major <-> level-major transpositions (fss::gpu::*RelayoutGpu, point_eval_gpu.cuh:324-375, and the inverse):
@@ -1010,7 +1029,8 @@ def run_suite(args):
             yb = torch.empty((nk, 1 << n, 4), dtype=torch.int32, device="cuda")
             record(f"{tag} {scheme} EvalAll batch n={n} x {nk} keys", nk << n,
                    lambda: beng.eval_all_batch(sid, n, G, 0, seeds0, cws, ocws=ocws, out=yb),
-                   (2 if scheme == "dpf" else 1.5) if tag == "aes" else 0, 16, steps=5, e=beng)
+                   (2 if scheme == "dpf" else 1.5) if tag == "aes" else 0, 16, steps=5, e=beng,
+                   chacha_per_unit=0 if tag == "aes" else (1.0 if scheme == "dpf" else 1.5))
             del yb
 
     # full domain
@@ -1169,7 +1189,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=(1 << 24) if (os.cpu_count() or 1) >= 8 else (1 << 22), help="points of the batch timed on the CPU")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--suite", action="store_true")
-    ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "evalall_c4", "ht_c5", "grotto_c5", "grotto_evalall"],
+    ap.add_argument("--workload", default="dpf_points", choices=["dpf_points", "dpf_2e20", "dcf_2e20", "evalall_c4", "ht_c5", "grotto_c5", "grotto_evalall"],
                     help="dpf_points = the headline (BASELINE metric); the others are configs[3] / configs[4], sharded")
     ap.add_argument("--log2-domain", type=int, default=28, help="evalall_c4: kInBits of the full domain (configs[3]: 28)")
     ap.add_argument("--log2-keys", type=int, default=24, help="ht_c5 / grotto_c5: log2 of the key batch (configs[4]: 24)")
@@ -1229,6 +1249,18 @@ def main():
         run_dry(args, rank, world, dist)
     elif args.workload == "dpf_points":
         run_headline(args, rank, world, dist)
+    elif args.workload in ("dpf_2e20", "dcf_2e20"):
+        # configs[1] / configs[2] at their literal size as the whole run (one GPU; the profiling passes use this)
+        if world != 1:
+            raise SystemExit(f"--workload {args.workload} is a one-GPU workload")
+        import fss_amd
+        rec = _small_batch_record(fss_amd.default_engine(torch.cuda.current_device()), args.workload[:3], 20, not args.no_cpu)
+        print(json.dumps({"metric": f"{args.workload}: evals per second", "value": rec["value"], "unit": "evals/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                          "config": {"workload": rec["workload"], "kernel": rec["kernel"], "units_per_launch": rec["units_per_launch"]},
+                          "roofline": rec["roofline"], **({"cpu_baseline": rec["cpu_baseline"]} if "cpu_baseline" in rec else {})}),
+              flush=True)
     else:
         run_sharded(args, rank, world, dist)
     if args.suite and world == 1 and not dry:

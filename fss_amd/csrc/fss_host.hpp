@@ -134,7 +134,12 @@ struct Tune {
   int static_prio = 2;  // FSS_AMD_STATIC_PRIO: wave priorities of launches with fixed shares (0 none / 1 turns / 2 by progress)
   int64_t dyn_min = 65536;  // FSS_AMD_DYN_MIN: AES blocks per resident wave from which shares are handed out dynamically
   int tail_pct = 8;  // FSS_AMD_TAIL_PCT: share of a dynamic walk's chunks in the launch-wide tail queue (0: none)
+  // "two, then one" (eval_points_kernel): what runs ONE evaluation per lane at the end of a two-per-lane launch --
+  int mix_mid_pct = 6;   // FSS_AMD_MIX_MID_PCT: dynamic launches: % of the batch dealt per workgroup, before the tail_pct % launch-wide
+  int mix_tail_units = 2;  // FSS_AMD_MIX_TAIL_UNITS: fixed shares: chunks of 64 per wave (0 with either: two per lane throughout)
   Tune() {
+    if (const char* e = tune_env("FSS_AMD_MIX_MID_PCT")) { mix_mid_pct = atoi(e); if (mix_mid_pct < 0 || mix_mid_pct > 90) mix_mid_pct = 6; }
+    if (const char* e = tune_env("FSS_AMD_MIX_TAIL_UNITS")) { mix_tail_units = atoi(e); if (mix_tail_units < 0) mix_tail_units = 2; }
     if (const char* e = tune_env("FSS_AMD_TAIL_PCT")) { tail_pct = atoi(e); if (tail_pct < 0 || tail_pct > 100) tail_pct = 8; }
     if (const char* e = tune_env("FSS_AMD_ROTPRIO")) { rot_prio = atoi(e); if (rot_prio < 0 || rot_prio > 2) rot_prio = 1; }
     if (const char* e = tune_env("FSS_AMD_DYN")) dyn = atoi(e) != 0;
@@ -146,11 +151,7 @@ struct Tune {
     if (const char* e = tune_env("FSS_AMD_BS")) bs = atoi(e);
     if (const char* e = tune_env("FSS_AMD_WGS_PER_CU")) wgs_per_cu = atoi(e);
     if (ilp != 1 && ilp != 2) ilp = 2;
-#if defined(FSS_EXP_BS768)
-    if (bs != 256 && bs != 512 && bs != 768 && bs != 1024) bs = 1024;  // round-3 experiment: 12 waves per CU
-#else
     if (bs != 256 && bs != 512 && bs != 1024) bs = 1024;
-#endif
   }
 };
 const Tune& tune() {
@@ -253,7 +254,7 @@ struct SharedKey {
 
 template <typename K>
 int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int bs, const SharedKey& k, EvalArgs a,
-                    hipStream_t st, bool tail_ok, int blocks_per_eval) {
+                    hipStream_t st, bool tail_ok, bool mix_ok, int blocks_per_eval) {
   int grid = 0;
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
@@ -272,7 +273,38 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   // from about 24 AES blocks per lane and chunk on it pays (n = 24: 3.53 -> 3.49 ms, n = 32: 4.66 -> 4.62).
   a.gq = nullptr;
   a.static_chunks = 0;
-  if (tail_ok) set_tail(ctx, st, a.dyn, a.n, 64 * (int64_t)ilp, grid, &a.gq, &a.static_chunks);
+  a.n_body = 0;
+  a.tail_on_body = 0;
+  if (ilp == 2 && !mix_ok) {
+    // two per lane throughout (short walks: a one-evaluation chunk would be too short to end the launch on)
+    a.n_body = a.n;
+    a.tail_on_body = 1;
+    if (tail_ok) set_tail(ctx, st, a.dyn, a.n, 128, grid, &a.gq, &a.static_chunks);
+  } else if (ilp == 2) {
+    // two per lane over [0, n_body), one per lane over the rest (eval_points_kernel)
+    const int64_t units = (a.n + 63) / 64, waves = (int64_t)grid * (bs / 64);  // units of 64 evaluations
+    int64_t tail_units = 0;
+    if (a.dyn) tail_units = units * (tune().mix_mid_pct + tune().tail_pct) / 100;
+    else tail_units = units >= 2 * tune().mix_tail_units * waves ? tune().mix_tail_units * waves : 0;
+    int64_t body_units = units - tail_units;
+    body_units -= body_units & 1;
+    a.n_body = tail_units > 0 ? body_units * 64 : a.n;
+    if (a.n_body > a.n) a.n_body = a.n;
+    if (a.dyn && a.n_body < a.n) {
+      // of the one-per-lane region the last tail_pct % OF THE BATCH go to whichever workgroup asks first
+      const int64_t r2 = (a.n - a.n_body + 63) / 64;
+      int64_t stat = r2 - units * tune().tail_pct / 100;
+      if (stat < 0) stat = 0;
+      stat -= stat % grid;
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+      (void)hipGetLastError();
+      if (!capturing && tune().tail_pct > 0 && ctx->tail_pairs && stat < r2 && (a.gq = ctx->tail_pair((void*)st)) != nullptr)
+        a.static_chunks = stat;
+    }
+  } else if (tail_ok) {
+    set_tail(ctx, st, a.dyn, a.n, 64, grid, &a.gq, &a.static_chunks);
+  }
 #if FSS_DIAG_STAMPS
   a.stamps = ctx->diag_stamps;
 #endif
@@ -297,20 +329,24 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   // walked): one shared DPF key 2^24 points 4.62 against 4.69 ms, 2^22 1.186 against 1.237, equal at 2^19 .. 2^21;
   // independent DPF keys 5.28 against 5.34 ms, Half-Tree keys 10.155 against 10.176 (profiles/r2/keys_clock.txt,
   // tail_queue_ab.txt).  Short walks (n < 24, the shared-prefix walks) keep two.
+  // Round 3: not either-or.  The two-per-lane kernel walks most of the batch two per lane and ENDS on one-per-lane
+  // chunks ("two, then one", eval_points_kernel): the interleaved streams' busier LDS for the body, the finer chunks
+  // for the end (launch_points_k sets the split).  FSS_AMD_ILP=1 / 2 with FSS_AMD_MIX_*=0 give the pure forms back.
   const int walked = a.in_bits - (PREFIX ? a.start_level : 0);
-  if (!tune().ilp_set && walked >= 24) ilp = 1;
   const int blocks_per_eval = walked * (SCHEME == S_DCF ? 2 : 1);
   static const int tail_minwork = [] { const char* e = tune_env("FSS_AMD_TAIL_MINWORK"); return e ? atoi(e) : 24; }();
-  const bool tail_ok = blocks_per_eval * ilp >= tail_minwork;
+  const bool tail_ok = blocks_per_eval * ilp >= tail_minwork;  // a chunk of `ilp` evaluations per lane is long enough for the launch-wide queue
+  const bool mix_ok = blocks_per_eval >= tail_minwork && (tune().mix_mid_pct > 0 || tune().mix_tail_units > 0);  // ... and so is a one-evaluation chunk
+  // fewer than four units of 64 per resident wave: nothing to split; one per lane as before (equal at 2^19 points, r2)
+  if (!tune().ilp_set && mix_ok && a.n < 256 * resident_waves) ilp = 1;
+  // ChaCha (pure VALU, no LDS to keep busy) keeps round 2's choice: one per lane from 24 walked levels on
+  if (!tune().ilp_set && ctx->prg == FSS_AMD_PRG_CHACHA && walked >= 24) ilp = 1;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
-  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, blocks_per_eval)))
+  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, mix_ok, blocks_per_eval)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;
-#if defined(FSS_EXP_BS768)
-  if constexpr (!SHARED) { FSS_L(1, 768); }
-#endif
   FSS_L(1, 512);
   FSS_L(2, 512);
   FSS_L(1, 256);

@@ -23,18 +23,6 @@ __device__ __forceinline__ uint4 fss_ld_stream(const uint4* p) {
 #define FSS_LD_STREAM(p) (*(p))
 #endif
 
-#if defined(FSS_EXP_CW_LDSDMA)
-// 16 bytes per lane from `src` (per lane) to `dst` + 16 * lane (wave-uniform base), non-temporal; device pass only
-// (the host pass has no such builtin and would silently drop the kernel's launch stub)
-__device__ __forceinline__ void fss_glds16(const uint4* src, uint4* dst) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);
-#else
-  (void)src; (void)dst;
-#endif
-}
-#endif
-
 namespace fssamd {
 
 struct EvalArgs {
@@ -65,7 +53,9 @@ struct EvalArgs {
   int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
   uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
   uint32_t* gq;             // WaveQ's launch-wide tail: {counter, waves done} of this stream, or nullptr
-  int64_t static_chunks;    // chunks dealt out per workgroup before the launch-wide tail starts
+  int64_t static_chunks;    // chunks (of the one-per-lane region) dealt out per workgroup before the launch-wide tail starts
+  int64_t n_body;           // two-per-lane kernels: evaluations [0, n_body) run two per lane (a multiple of 128), the rest one
+  int tail_on_body;         // two-per-lane kernels without a one-per-lane region: the launch-wide tail deals two-per-lane chunks
 };
 
 // Diagnostic build (-DFSS_DIAG_STAMPS=1, a separate library: in the product no stamp executes): lane 0 of every
@@ -286,7 +276,13 @@ struct HtWalk {
 // are read with scalar loads.
 // PREFIX: start every walk from the level-`start_level` node table (shared-prefix entry points);
 // a separate instantiation so profiles tell the two paths apart.
-template <class LT, int SCHEME, bool SHARED, int ILP, int BS, bool PREFIX = false>
+//
+// ILPT = 2, "two, then one": evaluations [0, n_body) are walked two per lane -- two interleaved AES streams (aes_mmo2)
+// keep the LDS busier than one: the stamped wave spends 2.5 % of the launch above the lookup floor instead of 4.3 % --
+// and the rest, [n_body, n), one per lane, so that the launch ends on chunks half as long (the idle tail of waves that
+// are done was 125-150 us of a 4.8 ms launch with two per lane throughout, 65-70 us with one).  Measured round 3:
+// profiles/r3/points_2e24_ilp_raw.txt (each alone), DESIGN.md 4.4 (combined).  n_body = n: two per lane throughout.
+template <class LT, int SCHEME, bool SHARED, int ILPT, int BS, bool PREFIX = false>
 __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                          const uint32_t* __restrict__ k_seed,  // uint32[4]
                                                          const uint32_t* __restrict__ k_cws,   // raw Cw slots
@@ -297,14 +293,11 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   const uint64_t stamp_re = __builtin_amdgcn_s_memrealtime();  // the wave's first instruction: before the table fill
 #endif
   FSS_PROGRESS_PROLOGUE();
+  __shared__ uint32_t waveq_ctr2_;  // chunk counter of the one-per-lane region (zeroed before FSS_WAVEQ_PROLOGUE's barrier)
+  if (threadIdx.x == 64) waveq_ctr2_ = 0;
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   uint32_t my_prog = 0;
-#if defined(FSS_EXP_CW_LDSDMA)
-  // round-3 experiment: the level's 64 correction words of a wave arrive by LDS-DMA
-  // (global_load_lds_dwordx4, no VGPR return path) in a 1 KiB slab per wave beside the tables
-  __shared__ __attribute__((aligned(16))) uint4 cw_slab_[BS / 64][64];
-#endif
 
   const int in_bits = a.in_bits, party = a.party;
   const Grp g = make_grp(a.group, c);
@@ -316,8 +309,9 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #if FSS_DIAG_STAMPS
   const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  WaveQ q(a.dyn, &waveq_ctr_, n, ILP, a.gq, a.static_chunks);
-  for (int64_t base; q.next(base);) {
+  // one chunk: 64 * ILP consecutive evaluations from `base` on, ILP per lane
+  auto walk_chunk = [&](auto ilp_tag, const int64_t base) {
+    constexpr int ILP = decltype(ilp_tag)::value;
     int64_t idx[ILP];
 #pragma unroll
     for (int j = 0; j < ILP; ++j) {
@@ -345,14 +339,6 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           trbh[j] = in_bits > 64 ? a.tr_bits[n + idx[j]] : 0ull;
         }
       }
-#if defined(FSS_EXP_CW_LDSDMA)
-      constexpr bool kDma = !SHARED && ILP == 1 && std::is_same_v<LT, Lds>;
-      if constexpr (kDma) {
-        fss_glds16(a.cw_s + (int64_t)lvl0 * n + idx[0], &cw_slab_[threadIdx.x >> 6][0]);
-      }
-#else
-      constexpr bool kDma = false;
-#endif
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
@@ -363,20 +349,6 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           if constexpr (SHARED) {
             const uint32_t* p = k_cws + 8 * i;
             cw[j].x = p[0]; cw[j].y = p[1]; cw[j].z = p[2]; cw[j].wl = p[3]; cw[j].tr = p[4];
-#if defined(FSS_EXP_CW_LDSDMA)
-          } else if constexpr (kDma) {
-            FSS_FENCE();
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this level's slab has landed
-            FSS_FENCE();
-            uint4 t = cw_slab_[threadIdx.x >> 6][threadIdx.x & 63];
-            FSS_FENCE();
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the slab is in registers before it is refilled
-            FSS_FENCE();
-            if (i + 1 < in_bits)
-              fss_glds16(a.cw_s + (int64_t)(i + 1) * n + idx[0], &cw_slab_[threadIdx.x >> 6][0]);
-            cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
-            cw[j].tr = (uint32_t)((i >= 64 ? trbh[j] : trb[j]) >> (i & 63));
-#endif
           } else {
             uint4 t = FSS_LD_STREAM(a.cw_s + (int64_t)i * n + idx[j]);
             cw[j].x = t.x; cw[j].y = t.y; cw[j].z = t.z; cw[j].wl = t.w;
@@ -480,7 +452,18 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         if (base + (int64_t)j * SJ < n) ys[idx[j]] = y;
       }
     }
+  };
+  // two per lane over [0, n_body): this workgroup's chunks through its LDS counter (or the wave's fixed share) ...
+  const int64_t n_body = ILPT == 2 ? a.n_body : 0;
+  if constexpr (ILPT == 2) {
+    WaveQ qb(a.dyn, &waveq_ctr_, n_body, 2, a.tail_on_body ? a.gq : nullptr, a.static_chunks);
+    for (int64_t base; qb.next(base);) walk_chunk(std::integral_constant<int, 2>{}, base);
+    qb.done();
   }
+  // ... then one per lane over [n_body, n): the first static_chunks chunks per workgroup, the rest launch-wide
+  WaveQ q(a.dyn, ILPT == 2 ? &waveq_ctr2_ : &waveq_ctr_, n - n_body, 1, (ILPT == 2 && a.tail_on_body) ? nullptr : a.gq,
+          a.static_chunks);
+  for (int64_t base; q.next(base);) walk_chunk(std::integral_constant<int, 1>{}, n_body + base);
 #if FSS_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave, taken as the wave leaves its loop (before done()'s barrier)
     const int64_t rec = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);

@@ -375,23 +375,22 @@ struct AesKeyCtx {
 template <int mul>
 class Aes128Mmo {
   static_assert(mul == 1 || mul == 2 || mul == 4);
-  unsigned char keys_[mul][16];
-  uint32_t rk_[mul][44];  // the expanded keys, for Gen called on the device (the engine expands its own)
+  thread::AesSchedules<mul, false> ks_;  // raw keys + round keys (little-endian words), for Gen called on the device
+  mutable bool wave_tables_ready_ = false;  // device: has this thread's wave filled its LDS copy of the tables?
 
-  __host__ __device__ void SetKey(int i, const unsigned char* key) {
-    for (int j = 0; j < 16; ++j) keys_[i][j] = key[j];
-    thread::AesExpandKey(keys_[i], rk_[i]);
+  __host__ __device__ void SetKeys(const unsigned char* const* keys) {
+    ks_.Set(keys, [](uint32_t b) { return static_cast<uint32_t>(thread::kAes.sbox[b]); });
   }
 
  public:
   // ctxs: from CreateCtxs(); only read here, the caller frees them with FreeCtxs()  (aes128_mmo.cuh:40-42)
   Aes128Mmo(std::span<AesKeyCtx*, mul> ctxs) {
-    for (int i = 0; i < mul; ++i) SetKey(i, ctxs[i]->key);
+    const unsigned char* keys[mul];
+    for (int i = 0; i < mul; ++i) keys[i] = ctxs[i]->key;
+    SetKeys(keys);
   }
   // the key bytes directly (no context objects to manage); also constructible inside a kernel
-  __host__ __device__ explicit Aes128Mmo(const unsigned char* const keys[mul]) {
-    for (int i = 0; i < mul; ++i) SetKey(i, keys[i]);
-  }
+  __host__ __device__ explicit Aes128Mmo(const unsigned char* const keys[mul]) { SetKeys(keys); }
   static std::array<AesKeyCtx*, mul> CreateCtxs(const unsigned char* keys[mul]) {
     std::array<AesKeyCtx*, mul> ctxs;
     for (int i = 0; i < mul; ++i) {
@@ -404,20 +403,135 @@ class Aes128Mmo {
     for (AesKeyCtx* c : ctxs) delete c;
   }
   // Host: one seed through the engine (a batch of one on the GPU; fss_amd_prg_gen is the batched form).
-  // Device: computed by the calling thread (the reference's OpenSSL-backed Gen traps there, aes128_mmo.cuh:75-77).
+  // Device: computed by the calling thread (the reference's OpenSSL-backed Gen traps there, aes128_mmo.cuh:75-77)
+  // on its wave's LDS copy of the tables, round keys in scalar registers (fss_amd_thread.hpp).
   __device__ std::array<int4, mul> Gen(int4 seed) const {
-    std::array<int4, mul> out;
-    for (int i = 0; i < mul; ++i) out[i] = thread::AesMmo(rk_[i], seed);
-    return out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ks_.Gen(thread::WaveTables(wave_tables_ready_), seed);
+#else
+    return {};
+#endif
   }
   __host__ std::array<int4, mul> Gen(int4 seed) const {
     return detail::GenOne(*this, seed);
+  }
+  // Device only: the outputs a tree level takes for one side -- {Gen(seed)[right]} for mul = 2, {Gen(seed)[2 right],
+  // Gen(seed)[2 right + 1]} for mul = 4 -- at one block per output instead of two (the per-thread Eval uses it).
+  __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ks_.GenSide(thread::WaveTables(wave_tables_ready_), seed, right);
+#else
+    return {};
+#endif
   }
 
   static constexpr int kMul = mul;
   void Describe(detail::Spec& s) const {
     s.prg = FSS_AMD_PRG_AES128_MMO;
-    std::memcpy(s.aes, keys_, sizeof keys_);
+    for (int i = 0; i < mul; ++i) ks_.KeyBytes(i, s.aes + 16 * i);
+  }
+};
+
+// ---------------------------------------------------------------- software AES-128-MMO with caller-held tables
+// fss::prg::aes_detail and fss::prg::Aes128Soft<mul> (include/fss/prg/aes128_mmo_soft.cuh:32-218): the PRG the
+// reference's GPU kernels construct per thread from tables in shared memory,
+//     __shared__ uint32_t s_te0[256]; __shared__ uint8_t s_sbox[256];   // filled with ComputeTe0 / Sbox
+//     fss::prg::Aes128Soft<2> prg(keys, s_te0, s_sbox);  fss::Dpf<...> dpf{prg};  ys[tid] = dpf.Eval(...);
+// (src/bench_gpu.cu:100-138).  Same names, same arguments, same table contents (big-endian Te0, te0[0] = c66363a5).
+// Behind them: ds_read lookups on the caller's LDS tables, wave-uniform round keys in scalar registers instead of a
+// 176-byte-per-key array per thread, all nine table rounds unrolled, and -- through GenSide, which Dpf / Dcf::Eval use
+// -- only the child a level takes.
+namespace aes_detail {
+constexpr int kNb = 4;
+constexpr int kNk = 4;
+constexpr int kNr = 10;
+constexpr int kRoundKeySize = kNb * (kNr + 1) * 4;  // 176 bytes
+
+__host__ __device__ inline uint8_t Sbox(uint8_t idx) { return thread::kAes.sbox[idx]; }
+__host__ __device__ inline uint8_t Rcon(int idx) {  // 0x8d, then the powers of x in GF(2^8)
+  uint8_t r = 0x8d;
+  for (int i = 0; i < idx; ++i) r = thread::Times2(r);
+  return r;
+}
+// Te0[idx] as a big-endian column (2 S, S, S, 3 S)
+__host__ __device__ inline uint32_t ComputeTe0(uint8_t idx) { return thread::ByteSwap(thread::kAes.te0[idx]); }
+__host__ __device__ inline void InitTe0(uint32_t* dst) {
+  for (int i = 0; i < 256; ++i) dst[i] = ComputeTe0(static_cast<uint8_t>(i));
+}
+__host__ __device__ inline void InitSbox(uint8_t* dst) {
+  for (int i = 0; i < 256; ++i) dst[i] = Sbox(static_cast<uint8_t>(i));
+}
+__host__ __device__ inline uint32_t RotWord8(uint32_t x) { return thread::AesRot<true>(x, 1); }
+__host__ __device__ inline uint32_t RotWord16(uint32_t x) { return thread::AesRot<true>(x, 2); }
+__host__ __device__ inline uint32_t RotWord24(uint32_t x) { return thread::AesRot<true>(x, 3); }
+__host__ __device__ inline uint32_t LoadBE32(const uint8_t* p) {
+  return static_cast<uint32_t>(p[0]) << 24 | static_cast<uint32_t>(p[1]) << 16 | static_cast<uint32_t>(p[2]) << 8 | p[3];
+}
+__host__ __device__ inline void StoreBE32(uint8_t* p, uint32_t v) {
+  for (int i = 0; i < 4; ++i) p[i] = static_cast<uint8_t>(v >> (24 - 8 * i));
+}
+// 176 bytes of round keys from a 16-byte key, S-box lookups through `sbox`
+__host__ __device__ inline void KeyExpansion(uint8_t* round_key, const uint8_t* key, const uint8_t* sbox) {
+  uint32_t w[44];
+  thread::AesExpandKeyWords<true>(key, w, [sbox](uint32_t b) { return static_cast<uint32_t>(sbox[b]); });
+  for (int i = 0; i < 44; ++i) StoreBE32(round_key + 4 * i, w[i]);
+}
+// buf = AES-128(buf) in place, round keys as KeyExpansion wrote them
+__host__ __device__ inline void Encrypt(uint8_t* buf, const uint8_t* round_key, const uint32_t* te0, const uint8_t* sbox) {
+  uint32_t rk[44], in[4], out[4];
+  for (int i = 0; i < 44; ++i) rk[i] = LoadBE32(round_key + 4 * i);
+  for (int j = 0; j < 4; ++j) in[j] = LoadBE32(buf + 4 * j);
+  thread::AesEncrypt<true>(thread::PlainTables{te0, sbox}, thread::AesKeyWords{rk}, in, out);
+  for (int j = 0; j < 4; ++j) StoreBE32(buf + 4 * j, out[j]);
+}
+}  // namespace aes_detail
+
+template <int mul>
+class Aes128Soft {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+  thread::AesSchedules<mul, true> ks_;
+  const uint32_t* te0_;
+  const uint8_t* sbox_;
+
+ public:
+  // keys: mul 16-byte AES-128 keys; te0: the 256-entry round table (InitTe0 / ComputeTe0); sbox: the S-box (InitSbox /
+  // Sbox).  On the device both tables belong in __shared__ memory, filled by the workgroup before any thread
+  // constructs its PRG (aes128_mmo_soft.cuh:191-207); on the host, arrays of the caller.
+  __host__ __device__ Aes128Soft(const uint8_t keys[][16], const uint32_t* te0, const uint8_t* sbox)
+      : te0_(te0), sbox_(sbox) {
+    const unsigned char* kp[mul];
+    for (int i = 0; i < mul; ++i) kp[i] = keys[i];
+    ks_.Set(kp, [sbox](uint32_t b) { return static_cast<uint32_t>(sbox[b]); });
+  }
+
+  __host__ __device__ std::array<int4, mul> Gen(int4 seed) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_is_shared(te0_) && __builtin_amdgcn_is_shared(sbox_))
+      return ks_.Gen(thread::LdsTables{(const __attribute__((address_space(3))) uint32_t*)te0_,
+                                       (const __attribute__((address_space(3))) uint8_t*)sbox_}, seed);
+#endif
+    return ks_.Gen(thread::PlainTables{te0_, sbox_}, seed);
+  }
+  // the outputs of one side of a tree level (see Aes128Mmo::GenSide)
+  __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_is_shared(te0_) && __builtin_amdgcn_is_shared(sbox_))
+      return ks_.GenSide(thread::LdsTables{(const __attribute__((address_space(3))) uint32_t*)te0_,
+                                           (const __attribute__((address_space(3))) uint8_t*)sbox_}, seed, right);
+#endif
+    return ks_.GenSide(thread::PlainTables{te0_, sbox_}, seed, right);
+  }
+
+  // The engine runs the same function (AES-128-MMO with these keys): schemes over Aes128Soft take the batched entry
+  // points and the fss::gpu launchers like schemes over Aes128Mmo.
+  static constexpr int kMul = mul;
+  void Describe(detail::Spec& s) const {
+    s.prg = FSS_AMD_PRG_AES128_MMO;
+    for (int i = 0; i < mul; ++i) ks_.KeyBytes(i, s.aes + 16 * i);
   }
 };
 
@@ -490,6 +604,7 @@ auto GenOne(const Prg& prg, int4 seed) -> std::array<int4, Prg::kMul> {
 
 namespace prg {
 static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Aes128Mmo<4>, 4>);
+static_assert(Prgable<Aes128Soft<1>, 1> && Prgable<Aes128Soft<2>, 2> && Prgable<Aes128Soft<4>, 4>);
 static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
 }  // namespace prg
 

@@ -4,9 +4,11 @@
 //
 // Everything below is __device__ code written against the two hooks only -- Prgable (`prg.Gen(seed)`) and Groupable
 // (`From / + / - / Into`) -- so a caller's own PRG or group type works as well as the built-in ones, provided its
-// members are callable on the device.  It is the compatibility form: one thread walks one key with its PRG in
-// registers and tables in constant memory.  The engine's batched kernels behind EvalPoints / fss::gpu::* (LDS-resident
-// tables, two AES streams per lane, level-major keys) are the fast forms; nothing here is used by them.
+// members are callable on the device.  It is the per-thread form: one thread walks one key.  With the AES PRGs the
+// tables are in LDS (the caller's for fss::prg::Aes128Soft, a per-wave copy for fss::prg::Aes128Mmo), the round keys in
+// scalar registers, and a level computes only the child it takes (GenSide).  The engine's batched kernels behind
+// EvalPoints / fss::gpu::* (bank-conflict-free replicated tables, level-major keys) remain the fast forms; nothing here
+// is used by them.
 //
 // Correction-word slots are addressed as raw int4 pairs (slot i = words 2i, 2i+1), the layout all three Cw structs
 // share: word 0 = s, word 1 = v (DCF) or the flag byte tr / extra at byte 16 (DPF, Half-Tree).
@@ -33,8 +35,9 @@ __host__ __device__ inline bool BitAt(In x, int pos) {
 }
 
 // ---------------------------------------------------------------- AES-128 (FIPS-197), tables built at compile time
-// Little-endian words throughout: the int4's x, y, z, w are the four state columns, byte 0 of the block in the low
-// byte of x (the byte order of aes128_mmo.cuh:80-84, which encrypts the int4's bytes in memory order).
+// Little-endian words: the int4's x, y, z, w are the four state columns, byte 0 of the block in the low byte of x
+// (the byte order of aes128_mmo.cuh:80-84, which encrypts the int4's bytes in memory order).  kAes is the source the
+// LDS copies are filled from (WaveTables) and what aes_detail::ComputeTe0 / Sbox return.
 struct AesTables {
   uint32_t te0[256];  // column (2, 1, 1, 3) * S[i], row 0 in the low byte
   uint8_t sbox[256];
@@ -63,51 +66,276 @@ constexpr AesTables BuildAesTables() {
 inline constexpr AesTables kAes = BuildAesTables();
 static_assert(kAes.sbox[0x53] == 0xed && kAes.te0[0] == 0xa56363c6u);  // FIPS-197 fig. 7; Te0[0] = c66363a5 big-endian
 
-// Round keys as 44 little-endian words (FIPS-197 5.2), computed wherever the PRG object is constructed.
-__host__ __device__ constexpr void AesExpandKey(const unsigned char key[16], uint32_t rk[44]) {
-  for (int i = 0; i < 4; ++i)
-    rk[i] = static_cast<uint32_t>(key[4 * i]) | static_cast<uint32_t>(key[4 * i + 1]) << 8 |
-            static_cast<uint32_t>(key[4 * i + 2]) << 16 | static_cast<uint32_t>(key[4 * i + 3]) << 24;
-  uint32_t rcon = 1;
-  for (int i = 4; i < 44; ++i) {
-    uint32_t w = rk[i - 1];
-    if (i % 4 == 0) {
-      w = w >> 8 | w << 24;  // RotWord on a little-endian word
-      w = static_cast<uint32_t>(kAes.sbox[w & 0xff]) | static_cast<uint32_t>(kAes.sbox[w >> 8 & 0xff]) << 8 |
-          static_cast<uint32_t>(kAes.sbox[w >> 16 & 0xff]) << 16 | static_cast<uint32_t>(kAes.sbox[w >> 24]) << 24;
-      w ^= rcon;
-      rcon = Times2(static_cast<uint8_t>(rcon));
-    }
-    rk[i] = rk[i - 4] ^ w;
-  }
-}
-
 __device__ inline uint32_t RotL(uint32_t v, int n) { return __builtin_rotateleft32(v, n); }
 
-// out = AES_rk(seed) ^ seed  (Matyas-Meyer-Oseas, aes128_mmo.cuh:79-89)
-__device__ inline int4 AesMmo(const uint32_t rk[44], int4 seed) {
-  const uint32_t in[4] = {static_cast<uint32_t>(seed.x), static_cast<uint32_t>(seed.y), static_cast<uint32_t>(seed.z),
-                          static_cast<uint32_t>(seed.w)};
-  uint32_t c[4] = {in[0] ^ rk[0], in[1] ^ rk[1], in[2] ^ rk[2], in[3] ^ rk[3]};
-#pragma unroll 1
+// ---------------------------------------------------------------- AES-128 on tables in LDS, one block per thread
+// The per-thread form of the cipher for calls from inside a caller's kernel (fss::prg::Aes128Soft, and the device
+// side of fss::prg::Aes128Mmo): the round table Te0 (1 KiB) and the S-box (256 B) are read from wherever the caller
+// keeps them -- LDS in every case that matters (include/fss/prg/aes128_mmo_soft.cuh:197-207 asks for __shared__
+// tables; Aes128Mmo fills a private copy per wave, WaveAesTables below) -- and the round keys are wave-uniform values
+// (scalar registers), never per-thread byte arrays.
+//
+// BE = the word order of the state and of the table.  The reference's software AES works on big-endian words
+// (LoadBE32, aes128_mmo_soft.cuh:113-129) with Te0[i] = 2S << 24 | S << 16 | S << 8 | 3S (ComputeTe0, :55-60);
+// this header's own tables (kAes) are the little-endian mirror image.  The cipher is the same: output byte k of
+// column j is byte k of column j + k run through the table and rotated by k bytes -- to the right for big-endian words,
+// to the left for little-endian ones.
+template <bool BE>
+__host__ __device__ constexpr int AesBytePos(int k) { return BE ? 24 - 8 * k : 8 * k; }
+template <bool BE>
+__host__ __device__ inline uint32_t AesRot(uint32_t v, int k) {  // the table entry for row k
+  if (k == 0) return v;
+  return BE ? (v >> (8 * k) | v << (32 - 8 * k)) : (v << (8 * k) | v >> (32 - 8 * k));
+}
+__host__ __device__ inline uint32_t ByteSwap(uint32_t v) { return __builtin_bswap32(v); }
+
+// How a table is addressed: a plain pointer (host code, or tables somewhere else than LDS), or a 32-bit LDS address
+// (the form the device path converts the caller's pointers to: ds_read_b32 / ds_read_u8 instead of flat loads).
+struct PlainTables {
+  const uint32_t* te0;
+  const uint8_t* sbox;
+  __host__ __device__ uint32_t T(uint32_t i) const { return te0[i]; }
+  __host__ __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+struct LdsTables {
+  const __attribute__((address_space(3))) uint32_t* te0;
+  const __attribute__((address_space(3))) uint8_t* sbox;
+  __device__ uint32_t T(uint32_t i) const { return te0[i]; }
+  __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
+};
+#endif
+
+// One block: out = AES_k(in).  `Key` supplies the round-key words: key.W(r, j) = word j of round r's key, in the word
+// order of the state.  The nine table rounds are unrolled (the reference's loop is `#pragma unroll 1`,
+// aes128_mmo_soft.cuh:131, and reloads its key bytes from the stack every round).
+template <bool BE, typename Tab, typename Key>
+__host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const uint32_t in[4], uint32_t out[4]) {
+  uint32_t c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = in[j] ^ key.W(0, j);
+#pragma unroll
   for (int r = 1; r < 10; ++r) {
-    uint32_t n[4];
+    uint32_t t[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)  // column j takes row k from column j + k (ShiftRows), Te_k = Te0 rotated by k bytes
-      n[j] = kAes.te0[c[j] & 0xff] ^ RotL(kAes.te0[c[(j + 1) & 3] >> 8 & 0xff], 8) ^
-             RotL(kAes.te0[c[(j + 2) & 3] >> 16 & 0xff], 16) ^ RotL(kAes.te0[c[(j + 3) & 3] >> 24], 24) ^ rk[4 * r + j];
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = n[j];
+      for (int k = 0; k < 4; ++k) t[j][k] = tab.T(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);  // 16 lookups in flight
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      c[j] = t[j][0] ^ AesRot<BE>(t[j][1], 1) ^ AesRot<BE>(t[j][2], 2) ^ AesRot<BE>(t[j][3], 3) ^ key.W(r, j);
   }
-  uint32_t o[4];
+  uint32_t u[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    o[j] = (static_cast<uint32_t>(kAes.sbox[c[j] & 0xff]) | static_cast<uint32_t>(kAes.sbox[c[(j + 1) & 3] >> 8 & 0xff]) << 8 |
-            static_cast<uint32_t>(kAes.sbox[c[(j + 2) & 3] >> 16 & 0xff]) << 16 |
-            static_cast<uint32_t>(kAes.sbox[c[(j + 3) & 3] >> 24]) << 24) ^
-           rk[40 + j] ^ in[j];
-  return int4{static_cast<int>(o[0]), static_cast<int>(o[1]), static_cast<int>(o[2]), static_cast<int>(o[3])};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[j][k] = tab.S(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    out[j] = (u[j][0] << AesBytePos<BE>(0) | u[j][1] << AesBytePos<BE>(1) | u[j][2] << AesBytePos<BE>(2) |
+              u[j][3] << AesBytePos<BE>(3)) ^ key.W(10, j);
 }
+
+// Round keys as 44 words (one wave-uniform schedule), and the per-lane choice between two schedules A and B given as
+// A and D = A ^ B:  k = A ^ (mask & D), mask = 0 or ~0 per lane -- the taken child of a tree level without computing
+// the other one (the engine's aes_mmo<SEL>, fss_amd/csrc/fss_dev.hpp).
+struct AesKeyWords {
+  const uint32_t* rk;
+  __host__ __device__ uint32_t W(int r, int j) const { return rk[4 * r + j]; }
+};
+struct AesKeySelect {
+  const uint32_t* a;
+  const uint32_t* d;
+  uint32_t mask;
+  __host__ __device__ uint32_t W(int r, int j) const { return a[4 * r + j] ^ (mask & d[4 * r + j]); }
+};
+
+// Key schedule in state word order from 16 key bytes (FIPS-197 5.2), S-box lookups through `S`.
+template <bool BE, typename SboxFn>
+__host__ __device__ inline void AesExpandKeyWords(const unsigned char key[16], uint32_t rk[44], SboxFn S) {
+  uint32_t w[44];  // little-endian words while expanding
+  for (int i = 0; i < 4; ++i)
+    w[i] = static_cast<uint32_t>(key[4 * i]) | static_cast<uint32_t>(key[4 * i + 1]) << 8 |
+           static_cast<uint32_t>(key[4 * i + 2]) << 16 | static_cast<uint32_t>(key[4 * i + 3]) << 24;
+  uint32_t rcon = 1;
+  for (int i = 4; i < 44; ++i) {
+    uint32_t t = w[i - 1];
+    if (i % 4 == 0) {
+      t = t >> 8 | t << 24;
+      t = S(t & 0xff) | S(t >> 8 & 0xff) << 8 | S(t >> 16 & 0xff) << 16 | S(t >> 24) << 24;
+      t ^= rcon;
+      rcon = Times2(static_cast<uint8_t>(rcon));
+    }
+    w[i] = w[i - 4] ^ t;
+  }
+  for (int i = 0; i < 44; ++i) rk[i] = BE ? ByteSwap(w[i]) : w[i];
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Linear index of the calling thread in its workgroup, and the wave it belongs to.
+__device__ inline unsigned LinearTid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
+
+// The lanes of a wave hand LDS contents to each other: order the wave's own LDS accesses around the hand-over.
+__device__ inline void WaveLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A value every active lane holds identically, moved to a scalar register.
+__device__ inline uint32_t Uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// Do all active lanes hold the same 16 words?
+__device__ inline bool SameInAllLanes(const uint32_t* w, int n) {
+  uint32_t diff = 0;
+  for (int i = 0; i < n; ++i) diff |= w[i] ^ Uniform(w[i]);
+  return __ballot(diff != 0) == 0;
+}
+
+// fss::prg::Aes128Mmo on the device has no table arguments (the reference's class is host-only, aes128_mmo.cuh:75-77):
+// every wave keeps a private copy of Te0 and the S-box in LDS -- 1 280 B per wave, 20 KiB for the largest workgroup --
+// filled by the lanes that make the wave's first call (no workgroup barrier: a kernel may call Gen from divergent
+// code, after some of its threads have returned).  `ready` is the caller's per-thread flag; lanes that arrive later
+// than their wave's first call fill the same values again, which is harmless.
+struct WaveAesTables {
+  uint32_t te0[256];
+  uint8_t sbox[256];
+};
+__device__ inline LdsTables WaveTables(bool& ready) {
+  __shared__ WaveAesTables tabs[16];
+  WaveAesTables* mine = &tabs[(LinearTid() >> 6) & 15];
+  if (!ready) {
+    const uint64_t act = __ballot(1);
+    const int cnt = __popcll(act);
+    const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(act >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(act), 0u));
+    for (int i = rank; i < 256; i += cnt) {
+      mine->te0[i] = kAes.te0[i];
+      mine->sbox[i] = kAes.sbox[i];
+    }
+    WaveLdsSync();
+    ready = true;
+  }
+  return LdsTables{(const __attribute__((address_space(3))) uint32_t*)(mine->te0),
+                   (const __attribute__((address_space(3))) uint8_t*)(mine->sbox)};
+}
+#endif
+
+// The round keys of a PRG object with `mul` AES keys, as the per-thread cipher wants them.
+//  * Layout: schedules that a tree level chooses between per lane are stored as A and D = A ^ B, so the taken child
+//    costs one block (AesKeySelect) and the other child's key is A ^ D:
+//      mul = 1: [k0]      mul = 2: [k0, k0 ^ k1]      mul = 4 (DCF, outputs sl, vl, sr, vr): [k0, k1, k0 ^ k2, k1 ^ k3]
+//  * On the device the words are wave-uniform values in scalar registers when every lane of the wave was constructed
+//    from the same keys (`uniform`; the normal case: one key set per kernel).  Lanes with keys of their own fall back
+//    to expanding their key per call.
+template <int mul, bool BE>
+struct AesSchedules {
+  uint32_t keyw[mul][4];  // the raw keys, little-endian words (per lane)
+  uint32_t rk[mul][44];   // A / D layout above, state word order
+  bool uniform;
+
+  template <typename SboxFn>
+  __host__ __device__ void Set(const unsigned char* const* keys, SboxFn S) {
+    uint32_t full[mul][44];
+    for (int i = 0; i < mul; ++i) {
+      for (int j = 0; j < 4; ++j)
+        keyw[i][j] = static_cast<uint32_t>(keys[i][4 * j]) | static_cast<uint32_t>(keys[i][4 * j + 1]) << 8 |
+                     static_cast<uint32_t>(keys[i][4 * j + 2]) << 16 | static_cast<uint32_t>(keys[i][4 * j + 3]) << 24;
+      AesExpandKeyWords<BE>(keys[i], full[i], S);
+    }
+    for (int w = 0; w < 44; ++w) {
+      rk[0][w] = full[0][w];
+      if constexpr (mul == 2) rk[1][w] = full[0][w] ^ full[1][w];
+      if constexpr (mul == 4) {
+        rk[1][w] = full[1][w];
+        rk[2][w] = full[0][w] ^ full[2][w];
+        rk[3][w] = full[1][w] ^ full[3][w];
+      }
+    }
+    uniform = true;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uniform = SameInAllLanes(&keyw[0][0], 4 * mul);
+    for (int i = 0; i < mul; ++i)
+      for (int w = 0; w < 44; ++w) rk[i][w] = Uniform(rk[i][w]);  // scalar registers (lane 0's when not uniform: unused then)
+#endif
+  }
+  __host__ __device__ void KeyBytes(int i, unsigned char out[16]) const {
+    for (int j = 0; j < 16; ++j) out[j] = static_cast<unsigned char>(keyw[i][j >> 2] >> (8 * (j & 3)));
+  }
+
+  struct KeyXor {  // A ^ D
+    const uint32_t* a;
+    const uint32_t* d;
+    __host__ __device__ uint32_t W(int r, int j) const { return a[4 * r + j] ^ d[4 * r + j]; }
+  };
+  static __host__ __device__ void Words(int4 v, uint32_t w[4]) {
+    w[0] = static_cast<uint32_t>(v.x); w[1] = static_cast<uint32_t>(v.y); w[2] = static_cast<uint32_t>(v.z); w[3] = static_cast<uint32_t>(v.w);
+    if constexpr (BE) for (int j = 0; j < 4; ++j) w[j] = ByteSwap(w[j]);
+  }
+  static __host__ __device__ int4 Mmo(const uint32_t o[4], int4 seed) {  // ciphertext ^ plaintext (aes128_mmo.cuh:79-89)
+    uint32_t c[4] = {o[0], o[1], o[2], o[3]};
+    if constexpr (BE) for (int j = 0; j < 4; ++j) c[j] = ByteSwap(c[j]);
+    return int4{static_cast<int>(c[0]) ^ seed.x, static_cast<int>(c[1]) ^ seed.y, static_cast<int>(c[2]) ^ seed.z,
+                static_cast<int>(c[3]) ^ seed.w};
+  }
+
+  // out[i] = AES_{key i}(seed) ^ seed for every key
+  template <typename Tab>
+  __host__ __device__ std::array<int4, mul> Gen(const Tab& tab, int4 seed) const {
+    std::array<int4, mul> out;
+    uint32_t in[4], o[4];
+    Words(seed, in);
+    if (uniform) {
+#pragma unroll
+      for (int i = 0; i < mul; ++i) {
+        const bool direct = mul == 1 || i == 0 || (mul == 4 && i == 1);
+        if (direct) AesEncrypt<BE>(tab, AesKeyWords{rk[i]}, in, o);
+        else AesEncrypt<BE>(tab, KeyXor{rk[mul == 2 ? 0 : i - 2], rk[i]}, in, o);
+        out[i] = Mmo(o, seed);
+      }
+    } else {
+      for (int i = 0; i < mul; ++i) {
+        AesEncrypt<BE>(tab, AesKeyWords{PerLane(tab, i).w}, in, o);
+        out[i] = Mmo(o, seed);
+      }
+    }
+    return out;
+  }
+  // The outputs of one side only: mul = 2: {right ? out[1] : out[0]};  mul = 4: {right ? out[2] : out[0], right ? out[3] : out[1]}
+  template <typename Tab>
+  __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(const Tab& tab, int4 seed, bool right) const {
+    static_assert(mul == 2 || mul == 4);
+    constexpr int half = mul / 2;
+    std::array<int4, half> out;
+    uint32_t in[4], o[4];
+    Words(seed, in);
+    if (uniform) {
+      const uint32_t mask = right ? ~0u : 0u;
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        AesEncrypt<BE>(tab, AesKeySelect{rk[i], rk[half + i], mask}, in, o);
+        out[i] = Mmo(o, seed);
+      }
+    } else {
+      for (int i = 0; i < half; ++i) {
+        AesEncrypt<BE>(tab, AesKeyWords{PerLane(tab, (right ? half : 0) + i).w}, in, o);
+        out[i] = Mmo(o, seed);
+      }
+    }
+    return out;
+  }
+
+ private:
+  struct Expanded {
+    uint32_t w[44];
+  };
+  template <typename Tab>
+  __host__ __device__ Expanded PerLane(const Tab& tab, int i) const {  // this lane's own key i, expanded for one call
+    unsigned char kb[16];
+    KeyBytes(i, kb);
+    Expanded e;
+    AesExpandKeyWords<BE>(kb, e.w, [&tab](uint32_t b) { return tab.S(b); });
+    return e;
+  }
+};
 
 // ---------------------------------------------------------------- ChaCha (chacha.cuh:24-128)
 // State rows: [constant | seed | seed | 0, 0, nonce]; `rounds` rounds; every row XORed with its input row.
@@ -183,12 +411,14 @@ __device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slot
   int4 s = WithCtl(s0, false);
   bool t = b;
   for (int i = 0; i < in_bits; ++i) {
-    const std::array<int4, 2> g = prg.Gen(s);
     const int side = BitAt(x, in_bits - 1 - i);
+    int4 taken;  // Gen(s)[side]; a PRG that can compute one side alone is asked for just that
+    if constexpr (requires { prg.GenSide(s, true); }) taken = prg.GenSide(s, side != 0)[0];
+    else taken = prg.Gen(s)[side];
     const int4 cw = slots[2 * i];
     const bool side_cw = side ? (slots[2 * i + 1].x & 0xff) != 0 : Ctl(cw);
-    int4 child = WithCtl(g[side], false);
-    bool ct = Ctl(g[side]);
+    int4 child = WithCtl(taken, false);
+    bool ct = Ctl(taken);
     if (t) {
       child = X4(child, WithCtl(cw, false));
       ct ^= side_cw;
@@ -249,13 +479,20 @@ __device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slot
   Group acc;
   auto add = [b](Group sum, Group term) { return b ? sum + (-term) : sum + term; };  // party 1 subtracts
   for (int i = 0; i < in_bits; ++i) {
-    const std::array<int4, 4> g = prg.Gen(s);
     const int side = BitAt(x, in_bits - 1 - i);
+    int4 ts, tv;  // Gen(s)[2 side], Gen(s)[2 side + 1]
+    if constexpr (requires { prg.GenSide(s, true); }) {
+      const std::array<int4, 2> g = prg.GenSide(s, side != 0);
+      ts = g[0]; tv = g[1];
+    } else {
+      const std::array<int4, 4> g = prg.Gen(s);
+      ts = g[2 * side]; tv = g[2 * side + 1];
+    }
     const int4 cw_s = slots[2 * i], cw_v = slots[2 * i + 1];
-    acc = add(acc, Group::From(WithCtl(g[2 * side + 1], false)));
+    acc = add(acc, Group::From(WithCtl(tv, false)));
     if (t) acc = add(acc, Group::From(WithCtl(cw_v, false)));
-    int4 child = WithCtl(g[2 * side], false);
-    bool ct = Ctl(g[2 * side]);
+    int4 child = WithCtl(ts, false);
+    bool ct = Ctl(ts);
     if (t) {
       child = X4(child, WithCtl(cw_s, false));
       ct ^= side ? Ctl(cw_v) : Ctl(cw_s);

@@ -9,7 +9,9 @@
 //           reference's known answers (DPF n=8 Bytes, DCF n=8, DPF n=32 Uint<u64>, Half-Tree n=64) and
 //           against the engine on random DCF (kGt) and Half-Tree n=64 batches;
 //   part 3  a caller-defined Prgable and Groupable: per thread in a kernel, and through the host signatures
-//           (Gen / Eval / EvalAll / GenBatch / EvalPoints -> the generic per-thread kernels), reconstructed.
+//           (Gen / Eval / EvalAll / GenBatch / EvalPoints -> the generic per-thread kernels), reconstructed;
+//   part 4  fss::prg::Aes128Soft / aes_detail in the reference's GPU kernel shape (src/bench_gpu.cu:100-138): tables in
+//           shared memory, PRG per thread, 2^20 keys of n = 20 -- against the known answers, the engine, and timed.
 // Exit code 0 and a final "OK" line on success.
 #include <cstdio>
 #include <cstdlib>
@@ -787,6 +789,301 @@ static void Run() {
 }
 }  // namespace p3
 
+// ---------------------------------------------------------------------------------------------- part 4: Aes128Soft
+// fss::prg::Aes128Soft / fss::prg::aes_detail in the shape the reference's GPU benchmark uses them
+// (src/bench_gpu.cu:100-138: tables in shared memory filled from ComputeTe0 / Sbox, the PRG constructed per thread from
+// keys in constant memory, one key per thread, key-major correction words, 256 threads per block).
+namespace p4 {
+namespace ad = fss::prg::aes_detail;
+constexpr int kBits = 20;
+constexpr int kThreads = 256;
+using G = fss::group::Uint<uint64_t>;
+using Soft2 = fss::prg::Aes128Soft<2>;
+using Dpf = fss::Dpf<kBits, G, Soft2, uint32_t>;
+using Mmo2 = fss::prg::Aes128Mmo<2>;
+using DpfE = fss::Dpf<kBits, G, Mmo2, uint32_t>;  // the engine's view of the same function
+
+__constant__ uint8_t kSoftKeys[4][16] = {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16},
+                                         {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1},
+                                         {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+                                         {8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1}};
+// a second key pair, for threads that do NOT share their keys with the rest of their wave
+__constant__ uint8_t kOtherKeys[2][16] = {{9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6},
+                                          {0xa0, 0xa1, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xab, 0xac, 0xad, 0xae, 0xaf}};
+
+struct SharedTables {
+  uint32_t te0[256];
+  uint8_t sbox[256];
+};
+__device__ void FillTables(SharedTables& t) {  // the whole workgroup, then a barrier
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    t.te0[i] = ad::ComputeTe0(static_cast<uint8_t>(i));
+    t.sbox[i] = ad::Sbox(static_cast<uint8_t>(i));
+  }
+  __syncthreads();
+}
+
+__global__ void GenKernel(Dpf::Cw* cws, const int4* seeds, const uint32_t* alphas, const int4* betas, int n) {
+  __shared__ SharedTables tabs;
+  FillTables(tabs);
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  Soft2 prg(kSoftKeys, tabs.te0, tabs.sbox);
+  Dpf dpf{prg};
+  int4 s[2] = {seeds[2 * tid], seeds[2 * tid + 1]};
+  dpf.Gen(cws + size_t(tid) * (kBits + 1), s, alphas[tid], betas[tid]);
+}
+__global__ void EvalKernel(int4* ys, bool party, const int4* seeds, const Dpf::Cw* cws, const uint32_t* xs, int n) {
+  __shared__ SharedTables tabs;
+  FillTables(tabs);
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  Soft2 prg(kSoftKeys, tabs.te0, tabs.sbox);
+  Dpf dpf{prg};
+  ys[tid] = dpf.Eval(party, seeds[tid], cws + size_t(tid) * (kBits + 1), xs[tid]);
+}
+// odd threads use another key pair: the lanes of a wave do not agree on the round keys
+__global__ void MixedKeysEvalKernel(int4* ys, const int4* seeds, const Dpf::Cw* cws, const uint32_t* xs, int n) {
+  __shared__ SharedTables tabs;
+  FillTables(tabs);
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  Soft2 prg(tid & 1 ? kOtherKeys : kSoftKeys, tabs.te0, tabs.sbox);
+  Dpf dpf{prg};
+  ys[tid] = dpf.Eval(false, seeds[tid], cws + size_t(tid) * (kBits + 1), xs[tid]);
+}
+// raw PRG and the byte-level helpers on the device, tables in LDS and in global memory
+__global__ void PrgKernel(int4* out /* [4 + 4 + 1] */, const uint32_t* g_te0, const uint8_t* g_sbox, int4 seed) {
+  __shared__ SharedTables tabs;
+  FillTables(tabs);
+  if (threadIdx.x != 0) return;
+  fss::prg::Aes128Soft<4> lds_prg(kSoftKeys, tabs.te0, tabs.sbox);
+  auto a = lds_prg.Gen(seed);
+  fss::prg::Aes128Soft<4> glob_prg(kSoftKeys, g_te0, g_sbox);  // not LDS: the generic-pointer path
+  auto b = glob_prg.Gen(seed);
+  for (int i = 0; i < 4; ++i) { out[i] = a[i]; out[4 + i] = b[i]; }
+  uint8_t rk[ad::kRoundKeySize], buf[16];
+  ad::KeyExpansion(rk, kSoftKeys[0], tabs.sbox);
+  __builtin_memcpy(buf, &seed, 16);
+  ad::Encrypt(buf, rk, tabs.te0, tabs.sbox);
+  int4 c;
+  __builtin_memcpy(&c, buf, 16);
+  out[8] = int4{c.x ^ seed.x, c.y ^ seed.y, c.z ^ seed.z, c.w ^ seed.w};
+}
+// DCF over Aes128Soft<4>: a level takes {s, v} of one side (GenSide: two blocks instead of four)
+using DcfS = fss::Dcf<16, G, fss::prg::Aes128Soft<4>, uint32_t>;
+using DcfE = fss::Dcf<16, G, fss::prg::Aes128Mmo<4>, uint32_t>;
+__global__ void DcfEvalKernel(int4* ys, bool party, const int4* seeds, const DcfS::Cw* cws, const uint32_t* xs, int n) {
+  __shared__ SharedTables tabs;
+  FillTables(tabs);
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  fss::prg::Aes128Soft<4> prg(kSoftKeys, tabs.te0, tabs.sbox);
+  DcfS dcf{prg};
+  ys[tid] = dcf.Eval(party, seeds[tid], cws + size_t(tid) * DcfS::kSlots, xs[tid]);
+}
+
+static void Run() {
+  const int before = g_fail;
+  // ---- the helpers' values: the reference's table constants and FIPS-197
+  EXPECT(ad::ComputeTe0(0) == 0xc66363a5u && ad::ComputeTe0(1) == 0xf87c7c84u);
+  EXPECT(ad::Sbox(0x53) == 0xed && ad::Sbox(0) == 0x63);
+  EXPECT(ad::Rcon(0) == 0x8d && ad::Rcon(1) == 0x01 && ad::Rcon(9) == 0x1b && ad::Rcon(10) == 0x36);
+  EXPECT(ad::RotWord8(0x11223344u) == 0x44112233u && ad::RotWord16(0x11223344u) == 0x33441122u &&
+         ad::RotWord24(0x11223344u) == 0x22334411u);
+  static_assert(ad::kRoundKeySize == 176 && ad::kNr == 10 && ad::kNb == 4 && ad::kNk == 4);
+  uint32_t te0[256];
+  uint8_t sbox[256];
+  ad::InitTe0(te0);
+  ad::InitSbox(sbox);
+  {  // FIPS-197 appendix C.1 through KeyExpansion + Encrypt on the host
+    uint8_t key[16], pt[16], rk[ad::kRoundKeySize];
+    for (int i = 0; i < 16; ++i) { key[i] = static_cast<uint8_t>(i); pt[i] = static_cast<uint8_t>(i * 0x11); }
+    ad::KeyExpansion(rk, key, sbox);
+    ad::Encrypt(pt, rk, te0, sbox);
+    const uint8_t want[16] = {0x69, 0xc4, 0xe0, 0xd8, 0x6a, 0x7b, 0x04, 0x30, 0xd8, 0xcd, 0xb7, 0x80, 0x70, 0xb4, 0xc5, 0x5a};
+    EXPECT(std::memcmp(pt, want, 16) == 0);
+    EXPECT(rk[160] == 0x13 && rk[161] == 0x11 && rk[162] == 0x1d && rk[163] == 0x7f && rk[174] == 0x30 && rk[175] == 0xc5);  // FIPS-197 C.1: w40 = 13111d7f, w43 = 4d2b30c5
+  }
+  const uint8_t hkeys[4][16] = {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16},
+                                {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1},
+                                {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+                                {8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1}};
+  const int4 kat_seed = I4(0x11111111, 0x22222222, 0x33333333, 0x44444440);
+  const int4 kat[4] = {I4(0x1423e6d2, 0x60533602, 0x813b3fbc, 0x412b31dc), I4(0x2d18cbe7, 0xa5eddcc9, 0xc691e4f6, 0x97831704),
+                       I4(0x2c046c24, 0x8a033811, 0xcb0335b6, 0x3d799ddb), I4(0x2413b69f, 0xffed7ac4, 0x314804c9, 0x595d2580)};
+  {  // host Gen / GenSide: the reference's PRG known answers
+    fss::prg::Aes128Soft<4> prg(hkeys, te0, sbox);
+    auto o = prg.Gen(kat_seed);
+    for (int i = 0; i < 4; ++i) EXPECT(Same(o[i], kat[i]));
+    auto l = prg.GenSide(kat_seed, false), r = prg.GenSide(kat_seed, true);
+    EXPECT(Same(l[0], kat[0]) && Same(l[1], kat[1]) && Same(r[0], kat[2]) && Same(r[1], kat[3]));
+    fss::prg::Aes128Soft<2> prg2(hkeys, te0, sbox);
+    auto o2 = prg2.Gen(kat_seed);
+    EXPECT(Same(o2[0], kat[0]) && Same(o2[1], kat[1]));
+    EXPECT(Same(prg2.GenSide(kat_seed, true)[0], kat[1]) && Same(prg2.GenSide(kat_seed, false)[0], kat[0]));
+    fss::prg::Aes128Soft<1> prg1(hkeys, te0, sbox);
+    EXPECT(Same(prg1.Gen(kat_seed)[0], kat[0]));
+  }
+  {  // the same on the device: LDS tables, tables in global memory, and the byte-level Encrypt
+    uint32_t* d_te0 = ToDevice(te0, 256);
+    uint8_t* d_sbox = ToDevice(sbox, 256);
+    int4* d_out = DeviceBuf<int4>(9);
+    PrgKernel<<<1, 64>>>(d_out, d_te0, d_sbox, kat_seed);
+    HIP_OK(hipDeviceSynchronize());
+    auto o = ToHost(d_out, 9);
+    for (int i = 0; i < 4; ++i) EXPECT(Same(o[i], kat[i]) && Same(o[4 + i], kat[i]));
+    EXPECT(Same(o[8], kat[0]));
+  }
+  // ---- 2^20 keys, one per thread: generated and evaluated in the reference's kernel shape, against the engine
+  constexpr int kN = 1 << 20;
+  std::vector<int4> seeds(2 * size_t(kN)), seeds0(kN), seeds1(kN), betas(kN);
+  std::vector<uint32_t> alphas(kN), xs(kN);
+  for (int i = 0; i < kN; ++i) {
+    seeds0[i] = seeds[2 * size_t(i)] = RandSeed();
+    seeds1[i] = seeds[2 * size_t(i) + 1] = RandSeed();
+    betas[i] = RandSeed();
+    alphas[i] = static_cast<uint32_t>(Next()) & ((1u << kBits) - 1);
+    xs[i] = i % 2 ? alphas[i] : static_cast<uint32_t>(Next()) & ((1u << kBits) - 1);
+  }
+  int4* d_seeds = ToDevice(seeds.data(), seeds.size());
+  int4* d_seeds0 = ToDevice(seeds0.data(), kN);
+  int4* d_seeds1 = ToDevice(seeds1.data(), kN);
+  int4* d_betas = ToDevice(betas.data(), kN);
+  uint32_t* d_alphas = ToDevice(alphas.data(), kN);
+  uint32_t* d_xs = ToDevice(xs.data(), kN);
+  Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(size_t(kBits + 1) * kN);
+  int4* d_y0 = DeviceBuf<int4>(kN);
+  int4* d_y1 = DeviceBuf<int4>(kN);
+  GenKernel<<<kN / kThreads, kThreads>>>(d_cws, d_seeds, d_alphas, d_betas, kN);
+  EvalKernel<<<kN / kThreads, kThreads>>>(d_y0, false, d_seeds0, d_cws, d_xs, kN);
+  EvalKernel<<<kN / kThreads, kThreads>>>(d_y1, true, d_seeds1, d_cws, d_xs, kN);
+  HIP_OK(hipDeviceSynchronize());
+  auto y0 = ToHost(d_y0, kN), y1 = ToHost(d_y1, kN);
+  int bad = 0;
+  for (int i = 0; i < kN; ++i) bad += !Same(Recon<G>(y0[i], y1[i]), xs[i] == alphas[i] ? G::From(betas[i]).Into() : kZero);
+  EXPECT(bad == 0);
+  // the engine on the same inputs: keys (every byte of every slot) and both parties' shares
+  const unsigned char* ekeys[2] = {p2::k0, p2::k1};
+  Mmo2 eprg(ekeys);
+  DpfE edpf{eprg};
+  DpfE::Cw* d_cws_e = DeviceBuf<DpfE::Cw>(size_t(kBits + 1) * kN);
+  edpf.GenBatch(d_cws_e, d_seeds, d_alphas, d_betas, kN);
+  HIP_OK(hipDeviceSynchronize());
+  {
+    auto a = ToHost(reinterpret_cast<const int4*>(d_cws), size_t(2) * (kBits + 1) * kN);
+    auto e = ToHost(reinterpret_cast<const int4*>(d_cws_e), size_t(2) * (kBits + 1) * kN);
+    EXPECT(std::memcmp(a.data(), e.data(), a.size() * sizeof(int4)) == 0);
+  }
+  int4* cw_s = DeviceBuf<int4>(size_t(kBits) * kN);
+  uint32_t* extra = DeviceBuf<uint32_t>(kN);
+  int4* out_cw = DeviceBuf<int4>(kN);
+  int4* d_ye = DeviceBuf<int4>(kN);
+  fss::gpu::DpfRelayoutGpu<kBits, G, Mmo2, uint32_t>(d_cws_e, kN, cw_s, extra, out_cw);
+  for (int b = 0; b < 2; ++b) {
+    fss::gpu::DpfEvalPointGpu<4>(b != 0, b ? d_seeds1 : d_seeds0, cw_s, extra, out_cw, d_xs, d_ye, kN, edpf);
+    HIP_OK(hipDeviceSynchronize());
+    auto ye = ToHost(d_ye, kN);
+    EXPECT(std::memcmp(ye.data(), (b ? y1 : y0).data(), sizeof(int4) * kN) == 0);
+  }
+  // a scheme over Aes128Soft is an engine scheme too: the launchers take it as they take Aes128Mmo
+  {
+    Soft2 hprg(hkeys, te0, sbox);
+    Dpf hdpf{hprg};
+    static_assert(Dpf::kEngine);
+    fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, cw_s, extra, out_cw, d_xs, d_ye, kN, hdpf);
+    HIP_OK(hipDeviceSynchronize());
+    auto ye = ToHost(d_ye, kN);
+    EXPECT(std::memcmp(ye.data(), y0.data(), sizeof(int4) * kN) == 0);
+  }
+  // ---- DCF over Aes128Soft<4> (GenSide takes {s, v} of one side): 4096 keys of n = 16 against the engine
+  {
+    constexpr int kM = 1 << 12;
+    const unsigned char* k4[4] = {p2::k0, p2::k1, p2::k2, p2::k3};
+    fss::prg::Aes128Mmo<4> eprg4(k4);
+    DcfE edcf{eprg4};
+    std::vector<uint32_t> a16(kM), x16(kM);
+    for (int i = 0; i < kM; ++i) {
+      a16[i] = alphas[i] & 0xffffu;
+      x16[i] = i % 3 == 0 ? a16[i] : static_cast<uint32_t>(Next()) & 0xffffu;
+    }
+    uint32_t* d_a16 = ToDevice(a16.data(), kM);
+    uint32_t* d_x16 = ToDevice(x16.data(), kM);
+    DcfE::Cw* d_c = DeviceBuf<DcfE::Cw>(size_t(17) * kM);
+    edcf.GenBatch(d_c, d_seeds, d_a16, d_betas, kM);
+    int4* d_s = DeviceBuf<int4>(size_t(16) * kM);
+    int4* d_v = DeviceBuf<int4>(size_t(16) * kM);
+    int4* d_o = DeviceBuf<int4>(kM);
+    int4* d_yt = DeviceBuf<int4>(kM);
+    int4* d_yw = DeviceBuf<int4>(kM);
+    fss::gpu::DcfRelayoutGpu<16, G, fss::prg::Aes128Mmo<4>, uint32_t>(d_c, kM, d_s, d_v, d_o);
+    for (int b = 0; b < 2; ++b) {
+      DcfEvalKernel<<<kM / kThreads, kThreads>>>(d_yt, b != 0, b ? d_seeds1 : d_seeds0, reinterpret_cast<const DcfS::Cw*>(d_c), d_x16, kM);
+      fss::gpu::DcfEvalPointGpu<4>(b != 0, b ? d_seeds1 : d_seeds0, d_s, d_v, d_o, d_x16, d_yw, kM, edcf);
+      HIP_OK(hipDeviceSynchronize());
+      auto yt = ToHost(d_yt, kM), yw = ToHost(d_yw, kM);
+      EXPECT(std::memcmp(yt.data(), yw.data(), sizeof(int4) * kM) == 0);
+    }
+  }
+  // ---- lanes with keys of their own (the per-lane fallback): odd threads on the other key pair
+  {
+    constexpr int kM = 1 << 12;
+    const unsigned char o0[16] = {9, 8, 7, 6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6};
+    unsigned char o1[16];
+    for (int i = 0; i < 16; ++i) o1[i] = static_cast<unsigned char>(0xa0 + i);
+    const unsigned char* okeys[2] = {o0, o1};
+    Mmo2 oprg(okeys);
+    DpfE odpf{oprg};
+    // keys of the odd threads are regenerated under the other key pair by the engine
+    DpfE::Cw* d_cws_o = DeviceBuf<DpfE::Cw>(size_t(kBits + 1) * kM);
+    odpf.GenBatch(d_cws_o, d_seeds, d_alphas, d_betas, kM);
+    HIP_OK(hipDeviceSynchronize());
+    auto ca = ToHost(d_cws_e, size_t(kBits + 1) * kM);
+    auto co = ToHost(d_cws_o, size_t(kBits + 1) * kM);
+    for (int i = 1; i < kM; i += 2)
+      std::memcpy(&ca[size_t(i) * (kBits + 1)], &co[size_t(i) * (kBits + 1)], sizeof(DpfE::Cw) * (kBits + 1));
+    Dpf::Cw* d_mix = reinterpret_cast<Dpf::Cw*>(ToDevice(ca.data(), ca.size()));
+    int4* d_ym = DeviceBuf<int4>(kM);
+    MixedKeysEvalKernel<<<kM / kThreads, kThreads>>>(d_ym, d_seeds0, d_mix, d_xs, kM);
+    HIP_OK(hipDeviceSynchronize());
+    auto ym = ToHost(d_ym, kM);
+    // expected: even keys from the run above, odd keys from the engine under the other pair
+    int4* c_s = DeviceBuf<int4>(size_t(kBits) * kM);
+    uint32_t* c_x = DeviceBuf<uint32_t>(kM);
+    int4* c_o = DeviceBuf<int4>(kM);
+    int4* d_yo = DeviceBuf<int4>(kM);
+    fss::gpu::DpfRelayoutGpu<kBits, G, Mmo2, uint32_t>(d_cws_o, kM, c_s, c_x, c_o);
+    fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, c_s, c_x, c_o, d_xs, d_yo, kM, odpf);
+    HIP_OK(hipDeviceSynchronize());
+    auto yo = ToHost(d_yo, kM);
+    bad = 0;
+    for (int i = 0; i < kM; ++i) bad += !Same(ym[i], i & 1 ? yo[i] : y0[i]);
+    EXPECT(bad == 0);
+  }
+  // ---- rate of the reference-shaped Eval kernel: n = 20, 2^20 keys, one per thread (the reference publishes
+  // 339.6 M evals/s for this kernel on an RTX PRO 5000, README.md:377)
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int rep = 0; rep < 8; ++rep) {
+    float ms = 0;
+    HIP_OK(hipEventRecord(e0));
+    for (int k = 0; k < 4; ++k) EvalKernel<<<kN / kThreads, kThreads>>>(d_y0, false, d_seeds0, d_cws, d_xs, kN);
+    HIP_OK(hipEventRecord(e1));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep >= 2 && ms / 4 < best) best = ms / 4;
+  }
+  const double rate = kN / (best * 1e-3);
+  EXPECT(rate >= 340e6);
+  std::printf("Aes128Soft  DPF n=20, 2^20 keys, the reference's per-thread kernel shape: == engine (keys, shares), reconstructs: %s\n",
+              g_fail == before ? "ok" : "FAILED");
+  std::printf("     (per-thread Eval kernel, 256 threads per block: %.3f ms = %.1f M evals/s = %.1f G AES blocks/s computed; "
+              "reference: 339.6 M evals/s)\n", best, rate / 1e6, rate * kBits / 1e9);
+}
+}  // namespace p4
+
 int main() {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -800,6 +1097,7 @@ int main() {
     p2::Groups();
     p2::Timing();
     p3::Run();
+    p4::Run();
     fss::ReleaseEngines();
   } catch (const fss::Error& e) {
     std::fprintf(stderr, "fss::Error: %s\n", e.what());
