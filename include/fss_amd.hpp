@@ -486,6 +486,13 @@ __host__ __device__ inline void Encrypt(uint8_t* buf, const uint8_t* round_key, 
   thread::AesEncrypt<true>(thread::PlainTables{te0, sbox}, thread::AesKeyWords{rk}, in, out);
   for (int j = 0; j < 4; ++j) StoreBE32(buf + 4 * j, out[j]);
 }
+// The bank-replicated form of the round table (Aes128SoftBanked below): kBankedTe0Words words, entry i repeated in
+// words 32 i .. 32 i + 31.  InitTe0Banked is called by every thread of the workgroup (its linear index and the
+// workgroup's size), followed by a barrier; on the host, InitTe0Banked(dst, 0, 1).
+constexpr int kBankedTe0Words = 256 * 32;
+__host__ __device__ inline void InitTe0Banked(uint32_t* dst, int tid, int nthreads) {
+  for (int w = tid; w < kBankedTe0Words; w += nthreads) dst[w] = ComputeTe0(static_cast<uint8_t>(w >> 5));
+}
 }  // namespace aes_detail
 
 template <int mul>
@@ -533,6 +540,55 @@ class Aes128Soft {
     s.prg = FSS_AMD_PRG_AES128_MMO;
     for (int i = 0; i < mul; ++i) ks_.KeyBytes(i, s.aes + 16 * i);
   }
+};
+
+// Aes128Soft on the bank-replicated table: the opt-in for callers who write their own kernels and want the per-thread
+// form without LDS bank conflicts -- 32 KiB of LDS per workgroup instead of 1 KiB,
+//     __shared__ uint32_t s_te0[fss::prg::aes_detail::kBankedTe0Words]; __shared__ uint8_t s_sbox[256];
+//     fss::prg::aes_detail::InitTe0Banked(s_te0, threadIdx.x, blockDim.x);  // + the S-box as before, then __syncthreads()
+//     fss::prg::Aes128SoftBanked<2> prg(keys, s_te0, s_sbox);
+// and everything else as with Aes128Soft (same function, same schemes, same engine routing).
+template <int mul>
+class Aes128SoftBanked {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+  thread::AesSchedules<mul, true> ks_;
+  const uint32_t* te0_;
+  const uint8_t* sbox_;
+
+ public:
+  __host__ __device__ Aes128SoftBanked(const uint8_t keys[][16], const uint32_t* te0_banked, const uint8_t* sbox)
+      : te0_(te0_banked), sbox_(sbox) {
+    const unsigned char* kp[mul];
+    for (int i = 0; i < mul; ++i) kp[i] = keys[i];
+    ks_.Set(kp, [sbox](uint32_t b) { return static_cast<uint32_t>(sbox[b]); });
+  }
+  __host__ __device__ std::array<int4, mul> Gen(int4 seed) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_is_shared(te0_) && __builtin_amdgcn_is_shared(sbox_)) return ks_.Gen(Lds(), seed);
+#endif
+    return ks_.Gen(thread::BankedPlainTables{te0_, sbox_}, seed);
+  }
+  __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_is_shared(te0_) && __builtin_amdgcn_is_shared(sbox_)) return ks_.GenSide(Lds(), seed, right);
+#endif
+    return ks_.GenSide(thread::BankedPlainTables{te0_, sbox_}, seed, right);
+  }
+  static constexpr int kMul = mul;
+  void Describe(detail::Spec& s) const {
+    s.prg = FSS_AMD_PRG_AES128_MMO;
+    for (int i = 0; i < mul; ++i) ks_.KeyBytes(i, s.aes + 16 * i);
+  }
+
+ private:
+#if defined(__HIP_DEVICE_COMPILE__)
+  __device__ thread::BankedLdsTables Lds() const {
+    return thread::BankedLdsTables{(const __attribute__((address_space(3))) uint32_t*)te0_ + (__lane_id() & 31),
+                                   (const __attribute__((address_space(3))) uint8_t*)sbox_};
+  }
+#endif
 };
 
 // ChaCha as the PRG (chacha.cuh:24-128): one permutation of [constant | seed | seed | 0, 0, nonce] per Gen.
@@ -605,6 +661,7 @@ auto GenOne(const Prg& prg, int4 seed) -> std::array<int4, Prg::kMul> {
 namespace prg {
 static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Aes128Mmo<4>, 4>);
 static_assert(Prgable<Aes128Soft<1>, 1> && Prgable<Aes128Soft<2>, 2> && Prgable<Aes128Soft<4>, 4>);
+static_assert(Prgable<Aes128SoftBanked<1>, 1> && Prgable<Aes128SoftBanked<2>, 2> && Prgable<Aes128SoftBanked<4>, 4>);
 static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
 }  // namespace prg
 

@@ -92,13 +92,32 @@ __host__ __device__ inline uint32_t ByteSwap(uint32_t v) { return __builtin_bswa
 // How a table is addressed: a plain pointer (host code, or tables somewhere else than LDS), or a 32-bit LDS address
 // (the form the device path converts the caller's pointers to: ds_read_b32 / ds_read_u8 instead of flat loads).
 struct PlainTables {
+  static constexpr bool kUnrollRounds = false;  // the general path: compact code (one rolled round), any address space
   const uint32_t* te0;
   const uint8_t* sbox;
   __host__ __device__ uint32_t T(uint32_t i) const { return te0[i]; }
   __host__ __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
 };
+// The round table with every entry repeated once per LDS bank: word 32 i + b holds Te0[i] for b = 0 .. 31 (32 KiB).  Lane
+// l reads copy l % 32, so the 64 lookups of a wave instruction never share a bank (the layout of the engine's own
+// tables, fss_amd/csrc/fss_dev.hpp, with one table and the rotations left to the VALU).
+struct BankedPlainTables {  // host code / tables outside LDS: copy 0
+  static constexpr bool kUnrollRounds = false;
+  const uint32_t* te0;
+  const uint8_t* sbox;
+  __host__ __device__ uint32_t T(uint32_t i) const { return te0[32 * i]; }
+  __host__ __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
+};
 #if defined(__HIP_DEVICE_COMPILE__)
+struct BankedLdsTables {
+  static constexpr bool kUnrollRounds = true;
+  const __attribute__((address_space(3))) uint32_t* te0_lane;  // table base + this lane's bank
+  const __attribute__((address_space(3))) uint8_t* sbox;
+  __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
+  __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
+};
 struct LdsTables {
+  static constexpr bool kUnrollRounds = true;  // the fast path: nine straight-line rounds, keys by constant index
   const __attribute__((address_space(3))) uint32_t* te0;
   const __attribute__((address_space(3))) uint8_t* sbox;
   __device__ uint32_t T(uint32_t i) const { return te0[i]; }
@@ -114,8 +133,7 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
   uint32_t c[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) c[j] = in[j] ^ key.W(0, j);
-#pragma unroll
-  for (int r = 1; r < 10; ++r) {
+  auto round = [&](int r) {
     uint32_t t[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -124,6 +142,13 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       c[j] = t[j][0] ^ AesRot<BE>(t[j][1], 1) ^ AesRot<BE>(t[j][2], 2) ^ AesRot<BE>(t[j][3], 3) ^ key.W(r, j);
+  };
+  if constexpr (Tab::kUnrollRounds) {
+#pragma unroll
+    for (int r = 1; r < 10; ++r) round(r);
+  } else {
+#pragma unroll 1
+    for (int r = 1; r < 10; ++r) round(r);
   }
   uint32_t u[4][4];
 #pragma unroll
@@ -381,6 +406,7 @@ template <int in_bits, typename Group, typename In, typename Prg>
 __device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In a, int4 beta) {
   int4 seed[2] = {WithCtl(s0s[0], false), WithCtl(s0s[1], false)};
   bool t[2] = {false, true};
+#pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
     const std::array<int4, 2> g[2] = {prg.Gen(seed[0]), prg.Gen(seed[1])};
     const int keep = BitAt(a, in_bits - 1 - i), lose = 1 - keep;
@@ -410,6 +436,7 @@ template <int in_bits, typename Group, typename In, typename Prg>
 __device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
   int4 s = WithCtl(s0, false);
   bool t = b;
+#pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
     const int side = BitAt(x, in_bits - 1 - i);
     int4 taken;  // Gen(s)[side]; a PRG that can compute one side alone is asked for just that
@@ -439,6 +466,7 @@ __device__ inline void DcfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
   bool t[2] = {false, true};
   const Group gbeta = Group::From(WithCtl(beta, false));
   Group acc;  // zero
+#pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
     const std::array<int4, 4> g[2] = {prg.Gen(seed[0]), prg.Gen(seed[1])};
     const int keep = BitAt(a, in_bits - 1 - i), lose = 1 - keep;
@@ -478,6 +506,7 @@ __device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slot
   bool t = b;
   Group acc;
   auto add = [b](Group sum, Group term) { return b ? sum + (-term) : sum + term; };  // party 1 subtracts
+#pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
     const int side = BitAt(x, in_bits - 1 - i);
     int4 ts, tv;  // Gen(s)[2 side], Gen(s)[2 side + 1]
@@ -516,6 +545,7 @@ __device__ inline int4 HtHash(const Prg& prg, int4 hash_key, int4 v) {
 template <int in_bits, typename Group, typename In, typename Prg>
 __device__ inline void HtGen(const Prg& prg, int4 hash_key, int4* slots, int4& ocw, const int4 s0s[2], In a, int4 beta) {
   int4 node[2] = {WithCtl(s0s[0], false), WithCtl(s0s[1], true)};
+#pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits - 1; ++i) {
     const int4 h[2] = {HtHash(prg, hash_key, node[0]), HtHash(prg, hash_key, node[1])};
     const bool a_bit = BitAt(a, in_bits - 1 - i);
@@ -544,6 +574,7 @@ __device__ inline void HtGen(const Prg& prg, int4 hash_key, int4* slots, int4& o
 template <int in_bits, typename Group, typename In, typename Prg>
 __device__ inline int4 HtEval(const Prg& prg, int4 hash_key, bool b, int4 s0, const int4* slots, int4 ocw, In x) {
   int4 node = WithCtl(s0, b);
+#pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits - 1; ++i) {
     const int4 h = HtHash(prg, hash_key, node);
     node = X4(X4(h, If(BitAt(x, in_bits - 1 - i), node)), If(Ctl(node), slots[2 * i]));

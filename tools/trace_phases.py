@@ -5,11 +5,15 @@ The default run times several workloads one after the other and three of them (D
 SAME kernel template, so rocprofv3's own per-name --stats average mixes them.  This splits the dispatches, in time
 order, into phases -- a phase starts at every key-generation launch (gen_kernel / ht_gen_kernel: bench.py makes a key
 before each workload) -- and prints calls / average / min / max per kernel name and phase.
-usage: tools/trace_phases.py <dir with *_kernel_trace.csv>"""
+The last column is the average over the LAST `timed` calls of the phase (default 20 = the driver's --steps): the
+launches bench.py's HIP events bracket, without the warm-up ones before them (the first launch after an idle GPU runs
+at a low clock and pulls the all-calls average up).
+usage: tools/trace_phases.py <dir with *_kernel_trace.csv> [timed]"""
 import csv
 import glob
 import sys
 
+TIMED = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -28,4 +32,6 @@ for st, en, name in rows:
     stats[key].append((en - st) / 1e3)
 for key in order:
     v = stats[key]
-    print("phase %2d  %-66s calls %4d  avg_us %9.2f  min_us %9.2f  max_us %9.2f" % (key[0], key[1][:66], len(v), sum(v) / len(v), min(v), max(v)))
+    t = v[-TIMED:]
+    print("phase %2d  %-66s calls %4d  avg_us %9.2f  min_us %9.2f  max_us %9.2f  last_%d_avg_us %9.2f" % (
+        key[0], key[1][:66], len(v), sum(v) / len(v), min(v), max(v), len(t), sum(t) / len(t)))
