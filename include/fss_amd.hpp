@@ -34,8 +34,10 @@
 // User-defined Groupable / Prgable types (members __host__ __device__ and trivially copyable, as the reference
 // requires of anything passed to a kernel): the prebuilt kernels cannot execute them, so Gen / Eval / EvalAll /
 // GenBatch / EvalPoints instantiate the per-thread walk in generic kernels of this header, compiled with the caller's
-// types -- still on the GPU, one thread per key or point, not the tuned path.  The level-major forms, EvalAllBlock and
-// the fss::gpu launchers need the built-in types (static_assert).  Nothing in this header computes on the CPU.
+// types -- still on the GPU, one thread per key or point, not the tuned path.  So do the fss::gpu launchers (the
+// reference's are templates over any PRG passed by value, point_eval_gpu.cuh:448-460, eval_all_gpu.cuh:478-488): on the
+// level-major arrays, one key per thread, coalesced.  GenLevelMajor and EvalAllBlock need the built-in types
+// (static_assert).  Nothing in this header computes on the CPU.
 // Errors throw fss::Error (the reference asserts).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -697,6 +699,43 @@ __global__ void ThreadEvalOcwKernel(S sch, bool b, const int4* s0, const typenam
   const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i < n) ys[i] = sch.Eval(b, *s0, cws, *ocw, xs ? xs[i] : static_cast<In>(i));
 }
+// Level-major keys (what *RelayoutGpu writes), one key per thread: the fss::gpu launchers for caller-defined types.
+template <int in_bits, typename Group, typename In, typename Prg, typename XT>
+__global__ void DpfLevelMajorEvalKernel(Prg prg, bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra,
+                                        const uint64_t* tr_bits, const int4* out_cw, const XT* xs, int4* ys, int64_t n) {
+  const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (k >= n) return;
+  thread::DpfLevelMajorView key{cw_s, out_cw, extra ? uint64_t(extra[k]) : tr_bits[k],
+                                (!extra && in_bits > 64) ? tr_bits[n + k] : uint64_t(0), n, k, in_bits};
+  ys[k] = thread::DpfEvalOn<in_bits, Group, In>(prg, b, seeds[k], key, static_cast<In>(xs[k]));
+}
+template <int in_bits, typename Group, typename In, typename Prg, typename XT>
+__global__ void DcfLevelMajorEvalKernel(Prg prg, bool b, const int4* seeds, const int4* cw_s, const int4* cw_v,
+                                        const int4* out_cw, const XT* xs, int4* ys, int64_t n) {
+  const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (k >= n) return;
+  thread::DcfLevelMajorView key{cw_s, cw_v, out_cw, n, k, in_bits};
+  ys[k] = thread::DcfEvalOn<in_bits, Group, In>(prg, b, seeds[k], key, static_cast<In>(xs[k]));
+}
+template <int in_bits, typename Group, typename In, typename Prg, typename XT>
+__global__ void HtLevelMajorEvalKernel(Prg prg, int4 hash_key, bool b, const int4* seeds, const int4* cw_s,
+                                       const uint32_t* extra, const int4* ocws, const XT* xs, int4* ys, int64_t n) {
+  const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (k >= n) return;
+  thread::HtLevelMajorView key{cw_s, extra[k], n, k};
+  ys[k] = thread::HtEvalOn<in_bits, Group, In>(prg, hash_key, b, seeds[k], key, ocws[k], static_cast<In>(xs[k]));
+}
+// the full domain of every key of a key-major batch, one thread per (key, x)
+template <typename S, typename In, int in_bits>
+__global__ void ThreadEvalAllBatchKernel(S sch, bool b, const int4* s0s, const typename S::Cw* cws, const int4* ocws,
+                                         int64_t nkeys, int4* ys) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= (nkeys << in_bits)) return;
+  const int64_t k = i >> in_bits;
+  const In x = static_cast<In>(i & ((int64_t(1) << in_bits) - 1));
+  if constexpr (requires { sch.hash_key; }) ys[i] = sch.Eval(b, s0s[k], cws + k * S::kSlots, ocws[k], x);
+  else ys[i] = sch.Eval(b, s0s[k], cws + k * S::kSlots, x);
+}
 template <typename K, typename... Args>
 void LaunchThreads(K kernel, int64_t n, hipStream_t stream, Args... args) {
   if (n <= 0) return;
@@ -1232,16 +1271,26 @@ void HalfTreeDpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const 
                              const uint32_t* xs, int4* ys, int nkeys,
                              const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
   static_assert(in_bits <= 32, "uint32_t xs cover in_bits <= 32; pass const In* xs");
-  Check(fss_amd_ht_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs, 4, nkeys, ys, stream),
-        "fss_amd_ht_eval_keys");
+  using S = HalfTreeDpf<in_bits, Group, Prg, In, par_depth>;
+  if constexpr (S::kEngine)
+    Check(fss_amd_ht_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs, 4, nkeys, ys, stream),
+          "fss_amd_ht_eval_keys");
+  else  // caller-defined PRG / group: one key per thread on the same level-major arrays
+    detail::LaunchThreads(detail::HtLevelMajorEvalKernel<in_bits, Group, In, Prg, uint32_t>, nkeys, stream, dpf.prg,
+                          dpf.hash_key, b, seeds, cw_s, extra, ocws, xs, ys, int64_t(nkeys));
 }
 template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
   requires(!std::is_same_v<In, uint32_t>)
 void HalfTreeDpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra, const int4* ocws,
                              const In* xs, int4* ys, int64_t nkeys,
                              const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
-  Check(fss_amd_ht_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs, detail::XBytes<In>(),
-                             nkeys, ys, stream), "fss_amd_ht_eval_keys");
+  using S = HalfTreeDpf<in_bits, Group, Prg, In, par_depth>;
+  if constexpr (S::kEngine)
+    Check(fss_amd_ht_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, ocws, xs, detail::XBytes<In>(),
+                               nkeys, ys, stream), "fss_amd_ht_eval_keys");
+  else
+    detail::LaunchThreads(detail::HtLevelMajorEvalKernel<in_bits, Group, In, Prg, In>, nkeys, stream, dpf.prg,
+                          dpf.hash_key, b, seeds, cw_s, extra, ocws, xs, ys, nkeys);
 }
 // point_eval_gpu.cuh:448-460  ys[k] = Dpf::Eval(b, seeds[k], key k, xs[k])
 template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
@@ -1249,15 +1298,25 @@ void DpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t
                      const uint32_t* xs, int4* ys, int nkeys, const Dpf<in_bits, Group, Prg, In, par_depth>& dpf,
                      hipStream_t stream = 0) {
   static_assert(in_bits <= 32, "uint32_t extra / xs cover in_bits <= 32; pass uint64_t* tr_bits and const In* xs");
-  Check(fss_amd_dpf_eval_keys_u32(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, out_cw, xs, 4, nkeys, ys,
-                                  stream), "fss_amd_dpf_eval_keys_u32");
+  using S = Dpf<in_bits, Group, Prg, In, par_depth>;
+  if constexpr (S::kEngine)
+    Check(fss_amd_dpf_eval_keys_u32(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, out_cw, xs, 4, nkeys, ys,
+                                    stream), "fss_amd_dpf_eval_keys_u32");
+  else
+    detail::LaunchThreads(detail::DpfLevelMajorEvalKernel<in_bits, Group, In, Prg, uint32_t>, nkeys, stream, dpf.prg, b,
+                          seeds, cw_s, extra, static_cast<const uint64_t*>(nullptr), out_cw, xs, ys, int64_t(nkeys));
 }
 template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, int par_depth>
 void DpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* out_cw,
                      const In* xs, int4* ys, int64_t nkeys, const Dpf<in_bits, Group, Prg, In, par_depth>& dpf,
                      hipStream_t stream = 0) {
-  Check(fss_amd_dpf_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, out_cw, xs,
-                              detail::XBytes<In>(), nkeys, ys, stream), "fss_amd_dpf_eval_keys");
+  using S = Dpf<in_bits, Group, Prg, In, par_depth>;
+  if constexpr (S::kEngine)
+    Check(fss_amd_dpf_eval_keys(dpf.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, out_cw, xs,
+                                detail::XBytes<In>(), nkeys, ys, stream), "fss_amd_dpf_eval_keys");
+  else
+    detail::LaunchThreads(detail::DpfLevelMajorEvalKernel<in_bits, Group, In, Prg, In>, nkeys, stream, dpf.prg, b, seeds,
+                          cw_s, static_cast<const uint32_t*>(nullptr), tr_bits, out_cw, xs, ys, nkeys);
 }
 // point_eval_gpu.cuh:479-491
 template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int par_depth>
@@ -1265,16 +1324,26 @@ void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw
                      const uint32_t* xs, int4* ys, int nkeys, const Dcf<in_bits, Group, Prg, In, pred, par_depth>& dcf,
                      hipStream_t stream = 0) {
   static_assert(in_bits <= 32, "uint32_t xs cover in_bits <= 32; pass const In* xs");
-  Check(fss_amd_dcf_eval_keys(dcf.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs, 4, nkeys, ys, stream),
-        "fss_amd_dcf_eval_keys");
+  using S = Dcf<in_bits, Group, Prg, In, pred, par_depth>;
+  if constexpr (S::kEngine)
+    Check(fss_amd_dcf_eval_keys(dcf.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs, 4, nkeys, ys, stream),
+          "fss_amd_dcf_eval_keys");
+  else
+    detail::LaunchThreads(detail::DcfLevelMajorEvalKernel<in_bits, Group, In, Prg, uint32_t>, nkeys, stream, dcf.prg, b,
+                          seeds, cw_s, cw_v, out_cw, xs, ys, int64_t(nkeys));
 }
 template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int par_depth>
   requires(!std::is_same_v<In, uint32_t>)
 void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw_v, const int4* out_cw, const In* xs,
                      int4* ys, int64_t nkeys, const Dcf<in_bits, Group, Prg, In, pred, par_depth>& dcf,
                      hipStream_t stream = 0) {
-  Check(fss_amd_dcf_eval_keys(dcf.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs, detail::XBytes<In>(),
-                              nkeys, ys, stream), "fss_amd_dcf_eval_keys");
+  using S = Dcf<in_bits, Group, Prg, In, pred, par_depth>;
+  if constexpr (S::kEngine)
+    Check(fss_amd_dcf_eval_keys(dcf.handle(), in_bits, Group::kId, b, seeds, cw_s, cw_v, out_cw, xs, detail::XBytes<In>(),
+                                nkeys, ys, stream), "fss_amd_dcf_eval_keys");
+  else
+    detail::LaunchThreads(detail::DcfLevelMajorEvalKernel<in_bits, Group, In, Prg, In>, nkeys, stream, dcf.prg, b, seeds,
+                          cw_s, cw_v, out_cw, xs, ys, nkeys);
 }
 
 // include/fss/vdpf point launchers (point_eval_gpu.cuh:389-396, :514-526), 64 tr bits per key
@@ -1297,32 +1366,44 @@ template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typ
 void HalfTreeDpfEvalAllGpu(bool b, int4 s0, const typename HalfTreeDpf<in_bits, Group, Prg, In, par_depth>::Cw* cws,
                            int4 ocw, int4* ys, const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf,
                            hipStream_t stream = 0) {
-  fss_amd_ctx* ctx = dpf.handle();
-  const size_t ws = dpf.EvalAllWorkspace();
+  using S = HalfTreeDpf<in_bits, Group, Prg, In, par_depth>;
+  fss_amd_ctx* ctx = dpf.StageCtx();
+  size_t ws = 0;
+  if constexpr (S::kEngine) ws = dpf.EvalAllWorkspace();
   const detail::Scratch sc(ctx, stream, ws);
   const int4* d_s0 = detail::PutInt4(ctx, sc, 0, s0, stream);
   const int4* d_ocw = detail::PutInt4(ctx, sc, 1, ocw, stream);
-  dpf.EvalAllBlock(b, d_s0, cws, d_ocw, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
+  if constexpr (S::kEngine) dpf.EvalAllBlock(b, d_s0, cws, d_ocw, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
+  else dpf.EvalPoints(b, d_s0, cws, d_ocw, static_cast<const In*>(nullptr), ys, int64_t(1) << in_bits, stream);  // one thread per leaf
 }
 // eval_all_gpu.cuh:478-488
 template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
 void DpfEvalAllGpu(bool b, int4 s0, const typename Dpf<in_bits, Group, Prg, In, par_depth>::Cw* cws, int4* ys,
                    const Dpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
-  fss_amd_ctx* ctx = dpf.handle();
-  const size_t ws = dpf.EvalAllWorkspace();
+  using S = Dpf<in_bits, Group, Prg, In, par_depth>;
+  fss_amd_ctx* ctx = dpf.StageCtx();
+  size_t ws = 0;
+  if constexpr (S::kEngine) ws = dpf.EvalAllWorkspace();
   const detail::Scratch sc(ctx, stream, ws);
   const int4* d_s0 = detail::PutInt4(ctx, sc, 0, s0, stream);
-  dpf.EvalAllBlock(b, d_s0, cws, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
+  if constexpr (S::kEngine) dpf.EvalAllBlock(b, d_s0, cws, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
+  else dpf.EvalPoints(b, d_s0, cws, static_cast<const In*>(nullptr), ys, int64_t(1) << in_bits, stream);
 }
 // eval_all_gpu.cuh:511-520: nkeys keys, the full domain of each; ys[k * 2^in_bits + x]
 template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
 void DpfEvalAllGpuBatch(bool b, const int4* s0s, const typename Dpf<in_bits, Group, Prg, In, par_depth>::Cw* cws,
                         int nkeys, int4* ys, const Dpf<in_bits, Group, Prg, In, par_depth>& dpf, hipStream_t stream = 0) {
-  fss_amd_ctx* ctx = dpf.handle();
-  const size_t ws = fss_amd_eval_all_batch_workspace(FSS_AMD_DPF, in_bits, nkeys);
-  const detail::Scratch sc(ctx, stream, ws);
-  Check(fss_amd_dpf_eval_all_batch(ctx, in_bits, Group::kId, b, s0s, cws, nkeys, ys, sc.Workspace(), ws, stream),
-        "fss_amd_dpf_eval_all_batch");
+  using S = Dpf<in_bits, Group, Prg, In, par_depth>;
+  if constexpr (S::kEngine) {
+    fss_amd_ctx* ctx = dpf.handle();
+    const size_t ws = fss_amd_eval_all_batch_workspace(FSS_AMD_DPF, in_bits, nkeys);
+    const detail::Scratch sc(ctx, stream, ws);
+    Check(fss_amd_dpf_eval_all_batch(ctx, in_bits, Group::kId, b, s0s, cws, nkeys, ys, sc.Workspace(), ws, stream),
+          "fss_amd_dpf_eval_all_batch");
+  } else {
+    detail::LaunchThreads(detail::ThreadEvalAllBatchKernel<S, In, in_bits>, int64_t(nkeys) << in_bits, stream, dpf, b, s0s,
+                          cws, static_cast<const int4*>(nullptr), int64_t(nkeys), ys);
+  }
 }
 // eval_all_gpu.cuh:526-535
 template <int z = -1, int b1 = 8, int bs = 256, int in_bits, typename Group, typename Prg, typename In, int par_depth>
@@ -1330,21 +1411,30 @@ void HalfTreeDpfEvalAllGpuBatch(bool b, const int4* s0s,
                                 const typename HalfTreeDpf<in_bits, Group, Prg, In, par_depth>::Cw* cws, const int4* ocws,
                                 int nkeys, int4* ys, const HalfTreeDpf<in_bits, Group, Prg, In, par_depth>& dpf,
                                 hipStream_t stream = 0) {
-  fss_amd_ctx* ctx = dpf.handle();
-  const size_t ws = fss_amd_eval_all_batch_workspace(FSS_AMD_HT, in_bits, nkeys);
-  const detail::Scratch sc(ctx, stream, ws);
-  Check(fss_amd_ht_eval_all_batch(ctx, in_bits, Group::kId, b, s0s, cws, ocws, nkeys, ys, sc.Workspace(), ws, stream),
-        "fss_amd_ht_eval_all_batch");
+  using S = HalfTreeDpf<in_bits, Group, Prg, In, par_depth>;
+  if constexpr (S::kEngine) {
+    fss_amd_ctx* ctx = dpf.handle();
+    const size_t ws = fss_amd_eval_all_batch_workspace(FSS_AMD_HT, in_bits, nkeys);
+    const detail::Scratch sc(ctx, stream, ws);
+    Check(fss_amd_ht_eval_all_batch(ctx, in_bits, Group::kId, b, s0s, cws, ocws, nkeys, ys, sc.Workspace(), ws, stream),
+          "fss_amd_ht_eval_all_batch");
+  } else {
+    detail::LaunchThreads(detail::ThreadEvalAllBatchKernel<S, In, in_bits>, int64_t(nkeys) << in_bits, stream, dpf, b, s0s,
+                          cws, ocws, int64_t(nkeys), ys);
+  }
 }
 // DCF full domain on the device (the reference has no such launcher; same shape as DpfEvalAllGpu)
 template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int par_depth>
 void DcfEvalAllGpu(bool b, int4 s0, const typename Dcf<in_bits, Group, Prg, In, pred, par_depth>::Cw* cws, int4* ys,
                    const Dcf<in_bits, Group, Prg, In, pred, par_depth>& dcf, hipStream_t stream = 0) {
-  fss_amd_ctx* ctx = dcf.handle();
-  const size_t ws = dcf.EvalAllWorkspace();
+  using S = Dcf<in_bits, Group, Prg, In, pred, par_depth>;
+  fss_amd_ctx* ctx = dcf.StageCtx();
+  size_t ws = 0;
+  if constexpr (S::kEngine) ws = dcf.EvalAllWorkspace();
   const detail::Scratch sc(ctx, stream, ws);
   const int4* d_s0 = detail::PutInt4(ctx, sc, 0, s0, stream);
-  dcf.EvalAllBlock(b, d_s0, cws, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
+  if constexpr (S::kEngine) dcf.EvalAllBlock(b, d_s0, cws, ys, sc.Workspace(), ws, 0, int64_t(1) << in_bits, stream);
+  else dcf.EvalPoints(b, d_s0, cws, static_cast<const In*>(nullptr), ys, int64_t(1) << in_bits, stream);
 }
 
 }  // namespace gpu

@@ -399,6 +399,44 @@ __device__ inline std::array<int4, mul> ChaChaGen(int nonce0, int nonce1, int4 s
   return out;
 }
 
+// ---------------------------------------------------------------- where a walk reads its key from
+// The evaluators below take the key through a small view: S(i) = the seed word of level i's slot, V(i) = its second
+// word (DCF), Flag(i) = the tr / extra flag of level i (DPF, Half-Tree's last level), Last() / LastV() = the output
+// correction word.  KeyMajor is the reference's Cw array (slot i = words 2i, 2i + 1); the level-major views are what
+// fss::gpu::*RelayoutGpu writes (include/fss/point_eval_gpu.cuh:39-91): cw_s[i * n + k], the flags of key k packed
+// into one word, out_cw[k] -- read by thread k, so the loads of a wave are coalesced.
+struct KeyMajorView {
+  const int4* slots;
+  __device__ int4 S(int i) const { return slots[2 * i]; }
+  __device__ int4 V(int i) const { return slots[2 * i + 1]; }
+  __device__ bool Flag(int i) const { return (slots[2 * i + 1].x & 0xff) != 0; }
+};
+struct DpfLevelMajorView {
+  const int4* cw_s;
+  const int4* out_cw;
+  uint64_t tr_lo, tr_hi;  // tr bits of key k: levels 0 .. 63 and 64 .. 127
+  int64_t n, k;
+  int in_bits;
+  __device__ int4 S(int i) const { return i == in_bits ? out_cw[k] : cw_s[i * n + k]; }
+  __device__ bool Flag(int i) const { return ((i < 64 ? tr_lo >> i : tr_hi >> (i - 64)) & 1) != 0; }
+};
+struct DcfLevelMajorView {
+  const int4* cw_s;
+  const int4* cw_v;
+  const int4* out_cw;  // the v word of slot in_bits
+  int64_t n, k;
+  int in_bits;
+  __device__ int4 S(int i) const { return cw_s[i * n + k]; }
+  __device__ int4 V(int i) const { return i == in_bits ? out_cw[k] : cw_v[i * n + k]; }
+};
+struct HtLevelMajorView {
+  const int4* cw_s;
+  uint32_t extra;  // bit 0: the flag of the last level
+  int64_t n, k;
+  __device__ int4 S(int i) const { return cw_s[i * n + k]; }
+  __device__ bool Flag(int) const { return (extra & 1) != 0; }
+};
+
 // ---------------------------------------------------------------- DPF (dpf.cuh:93-214)
 // Gen: both parties' paths towards alpha are walked together; per level the correction word cancels the seeds of
 // the child OFF the path and leaves the control bits differing exactly ON it.
@@ -432,8 +470,8 @@ __device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
   slots[2 * in_bits + 1] = int4{0, 0, 0, 0};
 }
 
-template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
+template <int in_bits, typename Group, typename In, typename Prg, typename Key>
+__device__ inline int4 DpfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
   int4 s = WithCtl(s0, false);
   bool t = b;
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
@@ -442,8 +480,8 @@ __device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slot
     int4 taken;  // Gen(s)[side]; a PRG that can compute one side alone is asked for just that
     if constexpr (requires { prg.GenSide(s, true); }) taken = prg.GenSide(s, side != 0)[0];
     else taken = prg.Gen(s)[side];
-    const int4 cw = slots[2 * i];
-    const bool side_cw = side ? (slots[2 * i + 1].x & 0xff) != 0 : Ctl(cw);
+    const int4 cw = key.S(i);
+    const bool side_cw = side ? key.Flag(i) : Ctl(cw);
     int4 child = WithCtl(taken, false);
     bool ct = Ctl(taken);
     if (t) {
@@ -454,9 +492,13 @@ __device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slot
     t = ct;
   }
   Group y = Group::From(s);
-  if (t) y = y + Group::From(slots[2 * in_bits]);
+  if (t) y = y + Group::From(key.S(in_bits));
   if (b) y = -y;
   return y.Into();
+}
+template <int in_bits, typename Group, typename In, typename Prg>
+__device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
+  return DpfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
 }
 
 // ---------------------------------------------------------------- DCF (dcf.cuh:108-276); PRG output [sl, vl, sr, vr]
@@ -500,8 +542,8 @@ __device__ inline void DcfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
   slots[2 * in_bits + 1] = last.Into();
 }
 
-template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
+template <int in_bits, typename Group, typename In, typename Prg, typename Key>
+__device__ inline int4 DcfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
   int4 s = WithCtl(s0, false);
   bool t = b;
   Group acc;
@@ -517,7 +559,7 @@ __device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slot
       const std::array<int4, 4> g = prg.Gen(s);
       ts = g[2 * side]; tv = g[2 * side + 1];
     }
-    const int4 cw_s = slots[2 * i], cw_v = slots[2 * i + 1];
+    const int4 cw_s = key.S(i), cw_v = key.V(i);
     acc = add(acc, Group::From(WithCtl(tv, false)));
     if (t) acc = add(acc, Group::From(WithCtl(cw_v, false)));
     int4 child = WithCtl(ts, false);
@@ -530,8 +572,12 @@ __device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slot
     t = ct;
   }
   acc = add(acc, Group::From(s));
-  if (t) acc = add(acc, Group::From(slots[2 * in_bits + 1]));
+  if (t) acc = add(acc, Group::From(key.V(in_bits)));
   return acc.Into();
+}
+template <int in_bits, typename Group, typename In, typename Prg>
+__device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
+  return DcfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
 }
 
 // ---------------------------------------------------------------- Half-Tree DPF (half_tree_dpf.cuh:68-231)
@@ -571,17 +617,17 @@ __device__ inline void HtGen(const Prg& prg, int4 hash_key, int4* slots, int4& o
   ocw = v.Into();
 }
 
-template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline int4 HtEval(const Prg& prg, int4 hash_key, bool b, int4 s0, const int4* slots, int4 ocw, In x) {
+template <int in_bits, typename Group, typename In, typename Prg, typename Key>
+__device__ inline int4 HtEvalOn(const Prg& prg, int4 hash_key, bool b, int4 s0, const Key& key, int4 ocw, In x) {
   int4 node = WithCtl(s0, b);
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits - 1; ++i) {
     const int4 h = HtHash(prg, hash_key, node);
-    node = X4(X4(h, If(BitAt(x, in_bits - 1 - i), node)), If(Ctl(node), slots[2 * i]));
+    node = X4(X4(h, If(BitAt(x, in_bits - 1 - i), node)), If(Ctl(node), key.S(i)));
   }
   const bool sigma = BitAt(x, 0), t = Ctl(node);
-  const int4 last = slots[2 * (in_bits - 1)];
-  const bool lcw = sigma ? (slots[2 * (in_bits - 1) + 1].x & 0xff) != 0 : Ctl(last);
+  const int4 last = key.S(in_bits - 1);
+  const bool lcw = sigma ? key.Flag(in_bits - 1) : Ctl(last);
   const int4 h = HtHash(prg, hash_key, WithCtl(node, sigma));
   const int4 high = X4(WithCtl(h, false), If(t, WithCtl(last, false)));
   const bool low = Ctl(h) ^ (t && lcw);
@@ -589,6 +635,10 @@ __device__ inline int4 HtEval(const Prg& prg, int4 hash_key, bool b, int4 s0, co
   if (low) y = y + Group::From(ocw);
   if (b) y = -y;
   return y.Into();
+}
+template <int in_bits, typename Group, typename In, typename Prg>
+__device__ inline int4 HtEval(const Prg& prg, int4 hash_key, bool b, int4 s0, const int4* slots, int4 ocw, In x) {
+  return HtEvalOn<in_bits, Group, In>(prg, hash_key, b, s0, KeyMajorView{slots}, ocw, x);
 }
 
 }  // namespace thread

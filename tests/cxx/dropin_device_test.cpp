@@ -784,7 +784,93 @@ static void Run() {
     }
     EXPECT(bad == 0);
   }
-  std::printf("caller-defined Prgable + Groupable  in a kernel and through the host signatures, reconstructs: %s\n",
+  {  // the fss::gpu launchers with the caller's types (the reference's are templates over any PRG passed by value,
+     // point_eval_gpu.cuh:448-460, eval_all_gpu.cuh:478-535): level-major arrays from *RelayoutGpu, one key per thread
+    constexpr int kKeys = 777;
+    std::vector<int4> sd(2 * kKeys), s0(kKeys), s1(kKeys), betas(kKeys);
+    std::vector<In> alphas(kKeys);
+    std::vector<uint32_t> xs(kKeys);
+    for (int i = 0; i < kKeys; ++i) {
+      s0[i] = sd[2 * i] = RandSeed();
+      s1[i] = sd[2 * i + 1] = RandSeed();
+      betas[i] = int4{(int)Next(), (int)Next(), (int)Next(), 0};
+      alphas[i] = static_cast<In>(Next() % n);
+      xs[i] = i % 2 ? alphas[i] : static_cast<uint32_t>(Next() % n);
+    }
+    int4* d_sd = ToDevice(sd.data(), 2 * kKeys);
+    int4* d_s0 = ToDevice(s0.data(), kKeys);
+    int4* d_s1 = ToDevice(s1.data(), kKeys);
+    int4* d_betas = ToDevice(betas.data(), kKeys);
+    In* d_alphas = ToDevice(alphas.data(), kKeys);
+    uint32_t* d_xs = ToDevice(xs.data(), kKeys);
+    int4* d_y0 = DeviceBuf<int4>(kKeys);
+    int4* d_y1 = DeviceBuf<int4>(kKeys);
+    int4* cw_s = DeviceBuf<int4>(size_t(kInBits) * kKeys);
+    int4* cw_v = DeviceBuf<int4>(size_t(kInBits) * kKeys);
+    uint32_t* extra = DeviceBuf<uint32_t>(kKeys);
+    int4* out_cw = DeviceBuf<int4>(kKeys);
+    int bad = 0;
+    {  // DPF: x == alpha on odd keys
+      Dpf dpf{MixPrg<2>{0xabcdef01u}};
+      Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(size_t(kInBits + 1) * kKeys);
+      dpf.GenBatch(d_cws, d_sd, d_alphas, d_betas, kKeys);
+      fss::gpu::DpfRelayoutGpu<kInBits, Vec3, MixPrg<2>, In>(d_cws, kKeys, cw_s, extra, out_cw);
+      fss::gpu::DpfEvalPointGpu<4>(false, d_s0, cw_s, extra, out_cw, d_xs, d_y0, kKeys, dpf);
+      fss::gpu::DpfEvalPointGpu<4>(true, d_s1, cw_s, extra, out_cw, d_xs, d_y1, kKeys, dpf);
+      HIP_OK(hipDeviceSynchronize());
+      auto y0 = ToHost(d_y0, kKeys), y1 = ToHost(d_y1, kKeys);
+      for (int i = 0; i < kKeys; ++i) bad += !Same(Recon<Vec3>(y0[i], y1[i]), xs[i] == alphas[i] ? betas[i] : kZero);
+      // the whole domain of a few keys, singly and as a batch, against the key-major per-point form
+      int4* d_all = DeviceBuf<int4>(size_t(3) * n);
+      auto hc = ToHost(d_cws, size_t(kInBits + 1) * kKeys);
+      fss::gpu::DpfEvalAllGpu<20, 12, 256>(true, s1[5], d_cws + size_t(5) * (kInBits + 1), d_all, dpf);
+      HIP_OK(hipDeviceSynchronize());
+      auto one = ToHost(d_all, n);
+      for (int x = 0; x < n; x += 37) bad += !Same(one[x], dpf.Eval(true, s1[5], &hc[size_t(5) * (kInBits + 1)], In(x)));
+      fss::gpu::DpfEvalAllGpuBatch<17, 9, 256>(false, d_s0 + 4, d_cws + size_t(4) * (kInBits + 1), 3, d_all, dpf);
+      HIP_OK(hipDeviceSynchronize());
+      auto three = ToHost(d_all, size_t(3) * n);
+      for (int k = 0; k < 3; ++k)
+        for (int x = 0; x < n; x += 101)
+          bad += !Same(three[size_t(k) * n + x], dpf.Eval(false, s0[4 + k], &hc[size_t(4 + k) * (kInBits + 1)], In(x)));
+    }
+    {  // DCF (x < alpha releases beta)
+      Dcf dcf{MixPrg<4>{0x1234u}};
+      Dcf::Cw* d_cws = DeviceBuf<Dcf::Cw>(size_t(kInBits + 1) * kKeys);
+      dcf.GenBatch(d_cws, d_sd, d_alphas, d_betas, kKeys);
+      fss::gpu::DcfRelayoutGpu<kInBits, Vec3, MixPrg<4>, In>(d_cws, kKeys, cw_s, cw_v, out_cw);
+      fss::gpu::DcfEvalPointGpu<4>(false, d_s0, cw_s, cw_v, out_cw, d_xs, d_y0, kKeys, dcf);
+      fss::gpu::DcfEvalPointGpu<4>(true, d_s1, cw_s, cw_v, out_cw, d_xs, d_y1, kKeys, dcf);
+      HIP_OK(hipDeviceSynchronize());
+      auto y0 = ToHost(d_y0, kKeys), y1 = ToHost(d_y1, kKeys);
+      for (int i = 0; i < kKeys; ++i) bad += !Same(Recon<Vec3>(y0[i], y1[i]), xs[i] < alphas[i] ? betas[i] : kZero);
+    }
+    {  // Half-Tree
+      Ht ht{MixPrg<1>{0x55u}, int4{1, 2, 3, 4}};
+      Ht::Cw* d_cws = DeviceBuf<Ht::Cw>(size_t(kInBits) * kKeys);
+      int4* d_ocws = DeviceBuf<int4>(kKeys);
+      ht.GenBatch(d_cws, d_ocws, d_sd, d_alphas, d_betas, kKeys);
+      fss::gpu::HalfTreeDpfRelayoutGpu<kInBits, Vec3, MixPrg<1>, In>(d_cws, kKeys, cw_s, extra);
+      fss::gpu::HalfTreeDpfEvalPointGpu<4>(false, d_s0, cw_s, extra, d_ocws, d_xs, d_y0, kKeys, ht);
+      fss::gpu::HalfTreeDpfEvalPointGpu<4>(true, d_s1, cw_s, extra, d_ocws, d_xs, d_y1, kKeys, ht);
+      HIP_OK(hipDeviceSynchronize());
+      auto y0 = ToHost(d_y0, kKeys), y1 = ToHost(d_y1, kKeys);
+      for (int i = 0; i < kKeys; ++i) bad += !Same(Recon<Vec3>(y0[i], y1[i]), xs[i] == alphas[i] ? betas[i] : kZero);
+      int4* d_all = DeviceBuf<int4>(size_t(2) * n);
+      auto ho = ToHost(d_ocws, kKeys);
+      fss::gpu::HalfTreeDpfEvalAllGpu<20, 12, 256>(false, s0[9], d_cws + size_t(9) * kInBits, ho[9], d_all, ht);
+      fss::gpu::HalfTreeDpfEvalAllGpu<20, 12, 256>(true, s1[9], d_cws + size_t(9) * kInBits, ho[9], d_all + n, ht);
+      HIP_OK(hipDeviceSynchronize());
+      auto two = ToHost(d_all, size_t(2) * n);
+      for (int x = 0; x < n; ++x) bad += !Same(Recon<Vec3>(two[x], two[n + x]), x == alphas[9] ? betas[9] : kZero);
+      fss::gpu::HalfTreeDpfEvalAllGpuBatch<17, 9, 256>(false, d_s0 + 9, d_cws + size_t(9) * kInBits, d_ocws + 9, 2, d_all, ht);
+      HIP_OK(hipDeviceSynchronize());
+      auto batch = ToHost(d_all, size_t(2) * n);
+      for (int x = 0; x < n; ++x) bad += !Same(batch[x], two[x]);
+    }
+    EXPECT(bad == 0);
+  }
+  std::printf("caller-defined Prgable + Groupable  in a kernel, through the host signatures and the fss::gpu launchers, reconstructs: %s\n",
               g_fail == before ? "ok" : "FAILED");
 }
 }  // namespace p3
