@@ -47,7 +47,7 @@ LDS_PEAK_GBS = 128 * N_CU * CLK_HZ / 1e9   # 78 643 GB/s of 4-byte table lookups
 HBM_PEAK_GBS = 8000.0
 LOOKUP_BYTES_PER_AES = 160 * 4              # 144 Te0 + 16 S-box lookups, 4 B each
 CHACHA_VALU_PER_WAVE_BLOCK = 1003           # measured wave-instructions per 64 ChaCha20 blocks (960 in the rounds)
-VALU_ISSUE_PEAK_GINSTR = N_CU * 4 * CLK_HZ / 4.0 / 1e9   # 614.4 G wave64-instr/s at 4 clocks per instruction
+VALU_ISSUE_PEAK_GINSTR = N_CU * 4 * CLK_HZ / 2.0 / 1e9   # 1 228.8 G wave64-instr/s: 32 lanes per SIMD and clock (the headline's roofline_valu peak)
 
 
 def aes_blocks_per_eval(scheme, n):
@@ -151,7 +151,8 @@ def time_steady(fn, steps=10, min_ms=150.0, warm_ms=60.0):
 
 def pre_warm(fn, ms=100.0):
     """Sub-records are timed between CPU legs during which the GPU sits idle and its clocks fall: run `ms` of the
-    step first (untimed), then the W warm-up and K timed steps follow as for the headline."""
+    step first (untimed), then the W warm-up and K timed steps follow as for the headline.  The number of repetitions
+    depends on this rank's own timing: `fn` must not contain a collective."""
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -732,8 +733,11 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         sd, cd = s0s[0, 0].cuda(), cws1[0]
         ys = torch.empty((nleaves,), dtype=torch.uint8, device="cuda")
 
-        def step():
+        def warm_step():  # the kernels alone: pre_warm's repetition count differs between ranks, a collective must not be in it
             eng.eval_all(fss_amd.GROTTO, n, fss_amd.BYTES, 0, sd, cd, first_leaf=first, nleaves=nleaves, out=ys)
+
+        def step():
+            warm_step()
             shard.grotto_fix_shard(ys, dist)
         units_total, units_rank, unit, aes_per_unit = 1 << n, nleaves, "leaves/s", 2.0
         desc = (f"Grotto DCF full-domain EvalAll kInBits={n}, domain-sharded x{world} with the cross-block parity carry "
@@ -771,7 +775,7 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         hbm_unit = 1084 if scheme == "ht" else 1057
         hbm_note = ("16 seed + 8 x + 64 x 16 cw_s + 4 extra + 16 ocw + 16 y per key" if scheme == "ht"
                     else "16 seed + 8 x + 64 x 16 cw_s + 8 tr bits + 1 y per key")
-    pre_warm(step)
+    pre_warm(warm_step if name == "grotto_evalall" else step)
     wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
     kname, grid, block = eng.last_kernel()
     if with_cpu and rank == 0 and world == 1:
@@ -857,16 +861,19 @@ def run_suite(args):
                     "hbm_gbs_algorithmic": rate * hbm_per_unit / 1e9, "kernel": (e or eng).last_kernel()})
         if chacha_per_unit:
             # ChaCha lines: neither LDS (unused) nor HBM (< 1 %) binds them but VALU issue: a ChaCha20
-            # block is 10 double rounds x 96 instructions (32 add, 32 xor, 32 rotate; the rotates put the whole stream
-            # in the 4-clock issue class), 1 003 wave-instructions per wave-block with the feed-forward and the walk
-            # (SQ_INSTS_VALU, profiles/r1/chacha_dpf_n32_counters.txt).  peak = 256 CU x 4 SIMD x 2.4 GHz / 4 clk.
+            # block is 10 double rounds x 96 instructions (32 add, 32 xor, 32 rotate), 1 003 wave-instructions per
+            # wave-block with the feed-forward and the walk (SQ_INSTS_VALU, profiles/r1/chacha_dpf_n32_counters.txt).
+            # peak = the chip's VALU rate, 256 CU x 4 SIMD x 32 lanes per clock = one wave64 instruction per 2 clocks
+            # and SIMD (MI355X_MICROARCH.md).  The rotates are slow-class instructions and drag the whole stream to
+            # ~3.8 clocks per instruction, so ~0.5 of this peak is where an add-rotate-xor cipher ends.
             wave_instr = rate * chacha_per_unit / 64.0 * CHACHA_VALU_PER_WAVE_BLOCK
             res[-1].pop("lds_frac")
             res[-1]["chacha_blocks_per_s"] = rate * chacha_per_unit
             res[-1]["roofline"] = {"bound": "valu_issue", "achieved": wave_instr / 1e9, "peak": VALU_ISSUE_PEAK_GINSTR,
                                    "unit": "G wave64-instr/s", "frac": wave_instr / 1e9 / VALU_ISSUE_PEAK_GINSTR,
                                    "algorithmic": f"{chacha_per_unit:g} ChaCha20 blocks per unit x {CHACHA_VALU_PER_WAVE_BLOCK} "
-                                                  "wave-instructions per 64 blocks; peak = 256 CU x 4 SIMD x 2.4 GHz / 4 clk"}
+                                                  "wave-instructions per 64 blocks; peak = 256 CU x 4 SIMD x 2.4 GHz / 2 clk",
+                                   "clk_per_instruction_and_simd": N_CU * 4 * CLK_HZ / wave_instr}
         print(json.dumps(res[-1]), file=sys.stderr, flush=True)
 
     G = fss_amd.U64

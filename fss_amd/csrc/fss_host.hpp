@@ -196,8 +196,9 @@ int use_dyn(int64_t units, int per_chunk, int grid, int bs) {
 
 // WaveQ's launch-wide tail for a dynamic launch of `units` units in chunks of `per_chunk` over `grid` workgroups:
 // the stream's counter pair and the number of chunks dealt out per workgroup before it takes over.
+// `tail_chunks` < 0: tail_pct % of the chunks; otherwise that many chunks (the caller's own split).
 inline void set_tail(fss_amd_ctx* ctx, hipStream_t st, int dyn, int64_t units, int64_t per_chunk, int grid, uint32_t** gq,
-                     int64_t* static_chunks) {
+                     int64_t* static_chunks, int64_t tail_chunks = -1) {
   *gq = nullptr;
   *static_chunks = 0;
   if (!dyn || tune().tail_pct <= 0 || !ctx->tail_pairs) return;
@@ -207,7 +208,8 @@ inline void set_tail(fss_amd_ctx* ctx, hipStream_t st, int dyn, int64_t units, i
   if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
   if (cap != hipStreamCaptureStatusNone) return;
   const int64_t nchunks = (units + per_chunk - 1) / per_chunk;
-  int64_t stat = nchunks - nchunks * tune().tail_pct / 100;
+  int64_t stat = nchunks - (tail_chunks < 0 ? nchunks * tune().tail_pct / 100 : tail_chunks);
+  if (stat < 0) stat = 0;
   stat -= stat % grid;
   if (stat < nchunks && (*gq = ctx->tail_pair((void*)st)) != nullptr) *static_chunks = stat;
 }
@@ -290,18 +292,8 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
     body_units -= body_units & 1;
     a.n_body = tail_units > 0 ? body_units * 64 : a.n;
     if (a.n_body > a.n) a.n_body = a.n;
-    if (a.dyn && a.n_body < a.n) {
-      // of the one-per-lane region the last tail_pct % OF THE BATCH go to whichever workgroup asks first
-      const int64_t r2 = (a.n - a.n_body + 63) / 64;
-      int64_t stat = r2 - units * tune().tail_pct / 100;
-      if (stat < 0) stat = 0;
-      stat -= stat % grid;
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      const bool capturing = hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-      (void)hipGetLastError();
-      if (!capturing && tune().tail_pct > 0 && ctx->tail_pairs && stat < r2 && (a.gq = ctx->tail_pair((void*)st)) != nullptr)
-        a.static_chunks = stat;
-    }
+    // of the one-per-lane region the last tail_pct % OF THE BATCH go to whichever workgroup asks first
+    if (a.n_body < a.n) set_tail(ctx, st, a.dyn, a.n - a.n_body, 64, grid, &a.gq, &a.static_chunks, units * tune().tail_pct / 100);
   } else if (tail_ok) {
     set_tail(ctx, st, a.dyn, a.n, 64, grid, &a.gq, &a.static_chunks);
   }

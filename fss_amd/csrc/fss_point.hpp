@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #endif
   FSS_PROGRESS_PROLOGUE();
   __shared__ uint32_t waveq_ctr2_;  // chunk counter of the one-per-lane region (zeroed before FSS_WAVEQ_PROLOGUE's barrier)
-  if (threadIdx.x == 64) waveq_ctr2_ = 0;
+  if (threadIdx.x == 0) waveq_ctr2_ = 0;
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   uint32_t my_prog = 0;
