@@ -209,7 +209,7 @@ __device__ inline void WaveLdsSync() {
 
 // A value every active lane holds identically, moved to a scalar register.
 __device__ inline uint32_t Uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-// Do all active lanes hold the same 16 words?
+// Do all active lanes hold the same n words?
 __device__ inline bool SameInAllLanes(const uint32_t* w, int n) {
   uint32_t diff = 0;
   for (int i = 0; i < n; ++i) diff |= w[i] ^ Uniform(w[i]);
