@@ -436,6 +436,21 @@ class Aes128Mmo {
   }
 };
 
+// fss::prg::Aes128MmoRaw<mul>(const uint8_t keys[][16]) (include/fss/prg/aes128_mmo_raw.cuh:39-110): the reference's
+// host-only AES-NI form of the same function, constructed from the key bytes directly.  Here it IS Aes128Mmo with that
+// constructor: Gen on the host goes to the engine, schemes over it are engine schemes, and on the device it works too.
+template <int mul>
+class Aes128MmoRaw : public Aes128Mmo<mul> {
+  static std::array<const unsigned char*, mul> Ptrs(const uint8_t keys[][16]) {
+    std::array<const unsigned char*, mul> p;
+    for (int i = 0; i < mul; ++i) p[i] = keys[i];
+    return p;
+  }
+
+ public:
+  Aes128MmoRaw(const uint8_t keys[][16]) : Aes128Mmo<mul>(Ptrs(keys).data()) {}
+};
+
 // ---------------------------------------------------------------- software AES-128-MMO with caller-held tables
 // fss::prg::aes_detail and fss::prg::Aes128Soft<mul> (include/fss/prg/aes128_mmo_soft.cuh:32-218): the PRG the
 // reference's GPU kernels construct per thread from tables in shared memory,
@@ -663,6 +678,7 @@ auto GenOne(const Prg& prg, int4 seed) -> std::array<int4, Prg::kMul> {
 namespace prg {
 static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Aes128Mmo<4>, 4>);
 static_assert(Prgable<Aes128Soft<1>, 1> && Prgable<Aes128Soft<2>, 2> && Prgable<Aes128Soft<4>, 4>);
+static_assert(Prgable<Aes128MmoRaw<1>, 1> && Prgable<Aes128MmoRaw<2>, 2> && Prgable<Aes128MmoRaw<4>, 4>);
 static_assert(Prgable<Aes128SoftBanked<1>, 1> && Prgable<Aes128SoftBanked<2>, 2> && Prgable<Aes128SoftBanked<4>, 4>);
 static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
 }  // namespace prg

@@ -113,8 +113,30 @@ static void HostSignatureDpf() {
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     std::printf("     (host-signature Eval: %.1f us per call, checksum %08x)\n", ms * 1000.0f / 200, (unsigned)acc.x);
   }
+  {  // the reference's other two spellings of the same PRG, host side: Aes128MmoRaw(keys) (aes128_mmo_raw.cuh:76) and
+     // Aes128Soft(keys, te0, sbox) with host tables (aes128_mmo_soft.cuh:197-207) -- same outputs, same keys, same shares
+    const uint8_t kk[2][16] = {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16}, {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1}};
+    fss::prg::Aes128MmoRaw<2> raw(kk);
+    auto o = raw.Gen(kSeeds[0]);
+    EXPECT(Same(o[0], out[0]) && Same(o[1], out[1]));
+    fss::Dpf<kInBits, Group, fss::prg::Aes128MmoRaw<2>, In> rdpf{raw};
+    EXPECT(Same(rdpf.Eval(false, seeds[0], reinterpret_cast<const decltype(rdpf)::Cw*>(cws), alpha), I4(0xa81892ad, 0xad2e583e, 0x272d1483, 0xd2bfa094)));
+    uint32_t te0[256];
+    uint8_t sbox[256];
+    fss::prg::aes_detail::InitTe0(te0);
+    fss::prg::aes_detail::InitSbox(sbox);
+    EXPECT(te0[0] == 0xc66363a5u && te0[1] == 0xf87c7c84u);
+    fss::prg::Aes128Soft<2> soft(kk, te0, sbox);
+    auto so = soft.Gen(kSeeds[0]);
+    EXPECT(Same(so[0], out[0]) && Same(so[1], out[1]));
+    fss::Dpf<kInBits, Group, fss::prg::Aes128Soft<2>, In> sdpf{soft};
+    decltype(sdpf)::Cw scws[kInBits + 1];
+    sdpf.Gen(scws, seeds, alpha, beta);  // the engine, keyed from the Aes128Soft object
+    EXPECT(std::memcmp(scws, cws, sizeof scws) == 0 || (Same(scws[0].s, cws[0].s) && Same(scws[8].s, cws[8].s)));
+    EXPECT(Same(sdpf.Eval(true, seeds[1], scws, alpha), I4(0xa81892aa, 0xad2e583e, 0x272d1483, 0xd2bfa094)));
+  }
   DpfPrg::FreeCtxs(ctxs);
-  std::printf("DPF  n=8  Bytes      host-signature Gen/Eval/EvalAll + PRG KAT: %s\n", g_fail ? "FAILED" : "ok");
+  std::printf("DPF  n=8  Bytes      host-signature Gen/Eval/EvalAll + PRG KAT (Aes128Mmo, Aes128MmoRaw, Aes128Soft): %s\n", g_fail ? "FAILED" : "ok");
 }
 
 static void HostSignatureDcf() {
