@@ -112,7 +112,14 @@ def test_python_layer_raises(raw):
                                  # counter; rotating instead of ranked priorities, ranked ones under the dynamic queue
                                  {"FSS_AMD_FUSED": "0", "FSS_AMD_STATIC_PRIO": "1", "FSS_AMD_DYN_MIN": "1"},
                                  {"FSS_AMD_FUSED_RANK": "0", "FSS_AMD_FUSED_CHACHA": "0", "FSS_AMD_ROTPRIO": "2", "FSS_AMD_PRIO_EVERY": "0",
-                                  "FSS_AMD_LEAF_E": "2", "FSS_AMD_FUSED_GRID": "7"}])
+                                  "FSS_AMD_LEAF_E": "2", "FSS_AMD_FUSED_GRID": "7"},
+                                 # round 3: "two, then one" forced onto the small oracle-checked batches -- the dynamic split
+                                 # with a large one-per-lane share, the fixed-share split, and two per lane throughout
+                                 {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_MIX_MID_PCT": "30", "FSS_AMD_QUAD_POINTS_MAX": "0"},
+                                 {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "0", "FSS_AMD_MIX_TAIL_UNITS": "1", "FSS_AMD_QUAD_POINTS_MAX": "0",
+                                  "FSS_AMD_TAIL_MINWORK": "1"},
+                                 {"FSS_AMD_ILP": "2", "FSS_AMD_MIX_MID_PCT": "0", "FSS_AMD_MIX_TAIL_UNITS": "0", "FSS_AMD_DYN": "1",
+                                  "FSS_AMD_QUAD_POINTS_MAX": "0"}])
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
     depths) pick by batch size, so the small oracle-checked cases would only ever see one of each; run the
