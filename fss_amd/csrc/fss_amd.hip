@@ -169,12 +169,20 @@ int fss_amd_ctx_scratch(fss_amd_ctx* ctx, void* stream, size_t bytes, void** out
 int fss_amd_ctx_scratch_release(fss_amd_ctx* ctx, void* stream) {
   if (!ctx) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
-  std::lock_guard<std::mutex> lk(ctx->scratch_mu);
-  auto it = ctx->scratch.find(stream_key(stream));
-  if (it == ctx->scratch.end()) return FSS_AMD_OK;
-  void* p = it->second.p;
-  ctx->scratch.erase(it);
-  if (p) HIP_TRY(hipFree(p));  // waits for the device: work still queued on the buffer has finished
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+    auto it = ctx->scratch.find(stream_key(stream));
+    if (it != ctx->scratch.end()) {
+      p = it->second.p;
+      ctx->scratch.erase(it);
+    }
+  }
+  // wait for the device either way: work still queued on the buffer (or using the stream's work-distribution
+  // counters, which are handed on below) has finished
+  if (p) HIP_TRY(hipFree(p));
+  else HIP_TRY(hipDeviceSynchronize());
+  ctx->tail_release(stream);
   return FSS_AMD_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <thread>
 #include <unordered_map>
 #include <utility>
+#include <vector>
 
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
@@ -54,15 +55,28 @@ struct fss_amd_ctx {
   uint32_t* tail_pairs = nullptr;   // device: kTailPairs x 2 words, zero
   std::mutex tail_mu;
   std::map<StreamKey, int> tail_slot;
+  std::vector<int> tail_free;  // pairs given back by fss_amd_ctx_scratch_release (a stream that is going away)
+  int tail_next = 0;
   uint32_t* tail_pair(void* stream) {
     const StreamKey key = stream_key(stream);
     std::lock_guard<std::mutex> lk(tail_mu);
     auto it = tail_slot.find(key);
     if (it == tail_slot.end()) {
-      if ((int)tail_slot.size() >= kTailPairs) return nullptr;  // more streams than pairs: those launch without a tail
-      it = tail_slot.emplace(key, (int)tail_slot.size()).first;
+      int idx;
+      if (!tail_free.empty()) { idx = tail_free.back(); tail_free.pop_back(); }
+      else if (tail_next < kTailPairs) idx = tail_next++;
+      else return nullptr;  // more live streams than pairs: those launch without a tail
+      it = tail_slot.emplace(key, idx).first;
     }
     return tail_pairs + 2 * it->second;
+  }
+  // The stream (this thread's, for hipStreamPerThread) is going away and the device is idle: its pair can serve another.
+  void tail_release(void* stream) {
+    std::lock_guard<std::mutex> lk(tail_mu);
+    auto it = tail_slot.find(stream_key(stream));
+    if (it == tail_slot.end()) return;
+    tail_free.push_back(it->second);
+    tail_slot.erase(it);
   }
 };
 

@@ -315,8 +315,10 @@ int fss_amd_dpf_eval_keys_u32(fss_amd_ctx *ctx, int in_bits, int group, int part
  *                        This is the only call after creation that allocates.  Thread-safe.  `stream` is only the
  *                        key here (any pointer value may serve as one); for hipStreamPerThread the calling thread is
  *                        part of the key, as for the per-stream work-distribution counters of the eval calls.
- *   fss_amd_ctx_scratch_release  frees the buffer of (ctx, stream) (hipFree: waits for the device), e.g. before the
- *                        stream is destroyed; a later fss_amd_ctx_scratch for the same key allocates afresh.
+ *   fss_amd_ctx_scratch_release  frees the buffer of (ctx, stream) and hands the stream's work-distribution counters on
+ *                        (waits for the device), e.g. before the stream is destroyed or a thread that used
+ *                        hipStreamPerThread ends; later calls for the same key start afresh.  A context serves up to
+ *                        1024 live streams with the launch-wide tail queue; beyond that launches go without it.
  *   fss_amd_upload       stream-ordered copy of a small host value (<= 1 MiB; meant for seeds and single keys) to
  *                        device memory.  The bytes travel as kernel arguments, so `src_host` may be pageable and
  *                        may be reused as soon as the call returns; nothing synchronises. */
