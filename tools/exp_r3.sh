@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the variant switches (FSS_EXP_CW_LDSDMA, FSS_EXP_BS768) were removed from the sources after this run (negative
+# results: profiles/r3/keys_clock.txt, tools/ubench/REJECTED_VARIANTS.md); the script documents what was measured and how.
 # Round 3, VERDICT r2 items 5 and 6: (a) where a 2^20-point launch's time goes (entry / fill / loop / tail stamps of the
 # diagnostic library), (b) independent keys with the level's correction words staged by LDS-DMA, (c) the same walk
 # with 12 waves per CU.  Variant libraries are built beforehand (they travel with the snapshot):

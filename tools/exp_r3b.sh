@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the dma variant library needs FSS_EXP_CW_LDSDMA, removed from the sources after this run (negative result).
 # Round 3, second batch: the LDS-DMA variant of the independent-key walk against the product's
 # walk, interleaved; the headline batch with two evaluations per lane (where the time goes, for the mixed-ILP idea).
 export FSS_AMD_TUNE=1

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: libfss_amd_pf.so was built from a working tree with the prefetch (WaveQ::peek); the change was not kept
+# (profiles/r3/prefetch_x_raw.txt, tools/ubench/REJECTED_VARIANTS.md).
 # Round 3, fourth batch: the next chunk's points requested a chunk ahead (libfss_amd_pf.so) against loading them at the
 # start of the chunk (libfss_amd_diag.so, the previous commit), interleaved; both diagnostic builds with stamps.
 export FSS_AMD_TUNE=1
