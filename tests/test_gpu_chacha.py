@@ -38,6 +38,19 @@ def test_chacha_prg_vs_oracle(ceng, O, mul):
         assert (got[i] == p.gen(seeds[i])).all()
 
 
+@pytest.mark.parametrize("mul", [1, 2, 4])
+@pytest.mark.parametrize("n", [1, 64, 65, 128, 129, 4097, (1 << 20) + 131])
+def test_chacha_prg_ragged_sizes(ceng, O, mul, n):
+    gen = torch.Generator(device="cuda").manual_seed(77 * mul + n % 997)
+    seeds = torch.randint(-2**31, 2**31, (n, 4), dtype=torch.int32, device="cuda", generator=gen)
+    got = ceng.prg_gen(mul, seeds).cpu().numpy()
+    sh = seeds.cpu().numpy()
+    p = cprg(O, mul)
+    idx = sorted(set(range(0, n, max(1, n // 64))) | set(range(max(0, n - 140), n)) | set(range(min(n, 140))))
+    for i in idx:
+        assert (got[i] == p.gen(sh[i])).all(), i
+
+
 @pytest.mark.parametrize("g", [G.BYTES, G.U32, G.U64, G.U128])
 @pytest.mark.parametrize("n", [1, 16, 32, 64, 128])
 @pytest.mark.parametrize("scheme", [DPF, DCF, HT])

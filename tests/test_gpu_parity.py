@@ -64,6 +64,26 @@ def test_prg_matches_oracle(engine, O, mul):
         assert (got[i] == p.gen(seeds[i])).all()
 
 
+@pytest.mark.parametrize("mul", [1, 2, 4])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 128, 129, 191, 1000, 4097, (1 << 16) + 77, (1 << 21) + 131])
+def test_prg_ragged_sizes(engine, O, mul, n):
+    """Every batch shape of the raw PRG launch: one seed, either side of a wave and of the two-seeds-per-lane chunk
+    (mul = 1), fixed shares and the dynamic hand-out; the ragged end is checked seed by seed."""
+    gen = torch.Generator(device="cuda").manual_seed(1000 * mul + n % 997)
+    seeds = torch.randint(-2**31, 2**31, (n, 4), dtype=torch.int32, device="cuda", generator=gen)
+    got = engine.prg_gen(mul, seeds).cpu().numpy()
+    assert got.shape == (n, mul, 4)
+    sh = seeds.cpu().numpy()
+    p = O.Prg(mul)
+    idx = sorted(set(range(0, n, max(1, n // 128))) | set(range(max(0, n - 200), n)) | set(range(min(n, 200))))
+    for i in idx:
+        assert (got[i] == p.gen(sh[i])).all(), i
+    if n > 4097:  # the same seeds through launches with fixed shares: every output
+        for lo in range(0, n, 1 << 14):
+            part = engine.prg_gen(mul, seeds[lo:lo + (1 << 14)].contiguous()).cpu().numpy()
+            assert (part == got[lo:lo + (1 << 14)]).all(), lo
+
+
 # ---------------------------------------------------------------- reference KATs on the GPU
 def test_reference_te0_on_gpu(engine):
     """The round table the kernels fill LDS from is the reference's Te0 (te0[0] = c66363a5, te0[1] =

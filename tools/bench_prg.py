@@ -1,15 +1,35 @@
-#!/usr/bin/env python3
-"""Time the raw PRG entry point (fss_amd_prg_gen; reference Aes128Soft<mul>::Gen bench, doc/bench_aes128_soft.md)."""
-import argparse, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, fss_amd
-from bench import time_steady
-ap = argparse.ArgumentParser()
-ap.add_argument("--log2-seeds", type=int, default=24); ap.add_argument("--prg", default="aes128_mmo")
-a = ap.parse_args()
-eng = fss_amd.Engine(0, prg=a.prg)
-n = 1 << a.log2_seeds
-seeds = torch.randint(-2**31, 2**31, (n, 4), dtype=torch.int32, device="cuda")
-for mul in (1, 2, 4):
-    _, kms = time_steady(lambda: eng.prg_gen(mul, seeds))
-    print(f"{a.prg} prg Gen mul={mul} 2^{a.log2_seeds} seeds: {kms:.3f} ms  {n/kms/1e6:.2f} G Gen/s  lds {n*mul/kms/1e6*640/78643.2:.2f}  hbm {n*16*(1+mul)/kms/1e6:.0f} GB/s")
+"""Raw PRG launch (fss_amd_prg_gen) timings: mul 1/2/4, AES and ChaCha, 2^20 and 2^24 seeds.  HIP events on the
+current stream; prints ms, G blocks/s and the LDS fraction for AES (160 lookups x 4 B per block, 78.6 TB/s)."""
+import sys
+import torch
+from fss_amd.engine import Engine
+
+LDS_PEAK = 256 * 128 * 2.4e9
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    for prg in ("aes128_mmo", "chacha"):
+        eng = Engine(prg=prg)
+        for lg in (20, 24):
+            n = 1 << lg
+            seeds = torch.randint(-2**31, 2**31, (n, 4), dtype=torch.int32, device="cuda")
+            for mul in (1, 2, 4):
+                for _ in range(5):
+                    eng.prg_gen(mul, seeds)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    eng.prg_gen(mul, seeds)
+                b.record()
+                torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / reps
+                blocks = n * mul / (ms * 1e-3)
+                frac = blocks * 640 / LDS_PEAK if prg == "aes128_mmo" else float("nan")
+                print(f"{prg:10s} 2^{lg} mul={mul}  {ms:8.4f} ms  {blocks / 1e9:7.2f} G blocks/s  lds_frac {frac:.3f}  "
+                      f"hbm {n * 16 * (1 + mul) / (ms * 1e-3) / 1e12:.2f} TB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
