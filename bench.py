@@ -471,7 +471,7 @@ def run_headline(args, rank, world, dist):
         return
     xs, ys = head_xs, head_ys
     _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, kernel_ms, wall_sp, kernel_ms_sp, same,
-                    kname, grid, block, subs, checks)
+                    kname, grid, block, subs, checks, dist.get_backend() if dist is not None else None)
 
 
 def _keys_subrecord(args, rank, world, dist, eng, G, batch, ys, pick, subs, checks):
@@ -501,7 +501,7 @@ def _keys_subrecord(args, rank, world, dist, eng, G, batch, ys, pick, subs, chec
 
 
 def _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, kernel_ms, wall_sp, kernel_ms_sp, same,
-                    kname, grid, block, subs, checks):
+                    kname, grid, block, subs, checks, process_group=None):
     evals = batch * world * args.steps
     value = evals / wall
     per_gpu_kernel_rate = batch / (kernel_ms * 1e-3)
@@ -521,7 +521,8 @@ def _print_headline(args, world, batch, scheme, n, s0s, cws, ocw, xs, ys, wall, 
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"DPF (Boyle'16) kInBits=32, 1 key, 2^{args.log2_batch} uniformly random eval points "
                                "per GPU per step (configs[1] shape at the metric's batch), party 0, Uint<uint64_t>",
-                   "kernel": kname, "grid": grid, "block": block, "parallelism": f"batch-sharded x{world}, no collective"},
+                   "kernel": kname, "grid": grid, "block": block, "parallelism": f"batch-sharded x{world}, no collective",
+                   "process_group": process_group},
         "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                      "frac": lds_gbs / LDS_PEAK_GBS, "traffic": measured_hbm_traffic(args.log2_batch),
                      "traffic_replayed_from": replay_src, "replay_matches_kernel_sources": replay_ok,
@@ -839,7 +840,8 @@ def run_sharded(args, rank, world, dist):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": rec["workload"], "kernel": rec["kernel"], "grid": rec["grid"], "block": rec["block"],
-                       "units_per_launch": rec["units_per_launch"], "parallelism": f"sharded x{world}, no collective"},
+                       "units_per_launch": rec["units_per_launch"], "parallelism": f"sharded x{world}, no collective",
+                       "process_group": dist.get_backend() if dist is not None else None},
             "roofline": rec["roofline"], "roofline_hbm": rec["roofline_hbm"]}
     if "cpu_baseline" in rec:
         line["cpu_baseline"] = rec["cpu_baseline"]
@@ -1245,7 +1247,9 @@ def main():
             local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # Under a launcher (torch.distributed.run sets RANK and MASTER_ADDR) the process group is formed even for one rank:
+    # `--nproc-per-node 1` then walks the same RCCL rendezvous, barriers and reduction as an 8-GPU run does.
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import datetime
         import torch.distributed as dist_mod
         # a rank that dies before the first barrier must not leave the others waiting for ever (under

@@ -131,6 +131,32 @@ def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--workload", "evalall_c4", "--log2-domain", "22"],
+                                   ["--workload", "grotto_evalall", "--log2-domain", "20"]])
+def test_one_rank_under_torch_distributed_run_goes_through_rccl(extra):
+    """The driver's multi-GPU command line with --nproc-per-node 1: the rank forms its process group over RCCL
+    (backend "nccl"), passes the barriers either side of the timed region and the max-over-ranks reduction on a device
+    tensor, and tears the group down -- the calls an 8-GPU run makes, on the one GPU of this box."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu",
+           "--log2-batch", "20"] + extra
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["process_group"] == "nccl"
+
+
+@pytest.mark.gpu
 def test_default_line_carries_the_whole_metric():
     """The driver's command at a small batch: headline + DCF / independent keys / kInBits 16, 64, each with its own
     kernel time and LDS fraction, each checked against the oracle on a sample inside the cpu_baseline leg."""
