@@ -1256,18 +1256,21 @@ def main():
         # torch.distributed.run the launcher ends them; under bench.py's own launcher launch_ranks does; this
         # bounds the remaining cases)
         tmo = datetime.timedelta(seconds=min(args.launch_timeout, 600.0))
-        if share or dry:
-            # gloo announces its connections on stdout; keep stdout for the one JSON line
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
+        # gloo announces its connections on stdout and RCCL prints a version banner when its communicator comes up:
+        # keep stdout for the one JSON line (the first barrier is inside, so that a lazily built communicator is too)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if share or dry:
                 dist_mod.init_process_group("gloo", timeout=tmo)
-            finally:
-                os.dup2(saved, 1)
-                os.close(saved)
-        else:
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
+            else:
+                dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
+            dist_mod.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         dist = dist_mod
     if args.gpus != world and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
