@@ -328,7 +328,8 @@ int fss_amd_upload(fss_amd_ctx *ctx, void *dst, const void *src_host, size_t byt
 
 /* ---- tuning / introspection -------------------------------------------------------- */
 /* Name and launch geometry of the kernel the last eval call on this ctx launched
- * (for bench.py / profiles). */
+ * (for bench.py / profiles).  Diagnostic: written without a lock, so with several threads
+ * launching on one ctx it names one of their launches. */
 const char *fss_amd_last_kernel(const fss_amd_ctx *ctx, int *grid, int *block);
 /* The 256-entry round table the AES kernels fill their LDS copies from, read back from the device: entry x holds
  * the bytes (2 S(x), S(x), S(x), 3 S(x)) in memory order, i.e. the reference's Te0 (ComputeTe0,

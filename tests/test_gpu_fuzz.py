@@ -2,7 +2,8 @@
 against the oracle bit for bit (shared key, shared prefix, independent keys through device Gen + level-major
 relayout), and the same for EvalAll (whole domains, aligned sub-blocks, key batches).  Complements the fixed
 matrices of test_gpu_parity.py with the sizes in between.  FSS_AMD_FUZZ_CASES=N widens every sweep to N seeded
-cases (48 / 40 by default; the 20000-case run is recorded in DESIGN.md section 2)."""
+cases (48 / 40 by default; the 20000-case run is recorded in DESIGN.md section 2) and FSS_AMD_FUZZ_SEED=S draws a
+different stream of them."""
 import os
 
 import numpy as np
@@ -17,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 GROUPS = [G.BYTES, G.U8, G.U16, G.U32, G.U64, G.U128]
 CASES = int(os.environ.get("FSS_AMD_FUZZ_CASES", "0"))
+SEED = int(os.environ.get("FSS_AMD_FUZZ_SEED", "0"), 0) << 32  # a different stream of cases per soak run
 
 
 def draw(rng):
@@ -29,7 +31,7 @@ def draw(rng):
 
 @pytest.mark.parametrize("case", range(CASES or 48))
 def test_random_configuration_vs_oracle(engine, O, case):
-    rng = SplitMix64(0xF5500000 + case)
+    rng = SplitMix64(SEED + 0xF5500000 + case)
     scheme, n, g, count = draw(rng)
     mul = {DPF: 2, DCF: 4, HT: 1}[scheme]
     p = O.Prg(mul)
@@ -79,7 +81,7 @@ def oracle_tree(O, p, scheme, n, g, b, s0, cws, ocw):
 @pytest.mark.parametrize("case", range(CASES or 40))
 def test_random_eval_all_vs_oracle(engine, O, case):
     """Whole domain and one random aligned power-of-two block of it, both parties; every third case a key batch."""
-    rng = SplitMix64(0xEA110000 + case)
+    rng = SplitMix64(SEED + 0xEA110000 + case)
     scheme = [DPF, DCF, HT, GROTTO][rng.next() % 4]
     n = 1 + rng.next() % 17
     g = G.BYTES if scheme == GROTTO else GROUPS[rng.next() % len(GROUPS)]
@@ -124,7 +126,7 @@ def test_random_eval_all_vs_oracle(engine, O, case):
 def test_random_grotto_walk_vs_oracle(engine, O, case):
     """Grotto path walk (fss_amd_grotto_eval_keys: taken child per level, siblings batched through the per-wave
     queue) against the oracle's walk and the predicate, random domain sizes and ragged key counts."""
-    rng = SplitMix64(0x6A077000 + case)
+    rng = SplitMix64(SEED + 0x6A077000 + case)
     n = 1 + rng.next() % 64
     nkeys = [1, 2, 63, 64, 65, 127, 128, 129, 200, 1000][rng.next() % 10]
     p = O.Prg(2)
