@@ -115,3 +115,54 @@ def test_many_short_lived_threads_release_their_per_thread_stream_state():
         t.start()
         t.join(120)
     assert not bad, bad[:10]
+
+
+def test_four_streams_mixed_workloads_on_one_context():
+    """One context, four streams, every kind of launch in flight at once (point walks with the launch-wide tail, keys,
+    the Grotto walk, one-launch EvalAll, batch EvalAll, device Gen): each output equals the one-stream result."""
+    import fss_amd
+    from fss_amd.engine import DPF, DCF, HT, GROTTO
+    eng = fss_amd.default_engine(0)
+    G64, GB = fss_amd.U64, fss_amd.BYTES
+    gen = torch.Generator(device="cuda").manual_seed(0x57EA)
+    ri = lambda *shape: torch.randint(-2**31, 2**31, shape, dtype=torch.int32, device="cuda", generator=gen)
+    r64 = lambda n: torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=gen)
+    s0s, al, be = ri(1, 2, 4), ri(1), ri(1, 4)
+    seed = s0s[0, 0].contiguous()
+    cw_dpf, _ = eng.gen(DPF, 32, G64, s0s, al, be)
+    cw_dcf, _ = eng.gen(DCF, 32, G64, s0s, al, be)
+    cw_20, _ = eng.gen(DPF, 20, G64, s0s, al & 0xFFFFF, be)
+    xs23, xs21 = ri(1 << 23), ri(1 << 21)
+    nk = 1 << 20
+    ks0, kbe, kx = ri(nk, 2, 4), ri(nk, 4), r64(nk)
+    kseeds = ks0[:, 0].contiguous()
+    hkeys, hocw = eng.gen_level_major(HT, 64, G64, ks0, r64(nk), kbe)
+    gkeys, _ = eng.gen_level_major(GROTTO, 64, GB, ks0, r64(nk), torch.zeros_like(kbe))
+    bk = 256
+    bcw, _ = eng.gen(DPF, 10, G64, ks0[:bk].contiguous(), ri(bk) & 0x3FF, kbe[:bk].contiguous())
+    bseeds = ks0[:bk, 0].contiguous()
+    ops = [
+        lambda: eng.eval_points(DPF, 32, G64, 0, seed, cw_dpf[0], xs23),                     # dynamic + tail
+        lambda: eng.eval_points(DCF, 32, G64, 0, seed, cw_dcf[0], xs21),
+        lambda: eng.eval_keys(hkeys, G64, 0, kseeds, kx, ocws=hocw),
+        lambda: eng.eval_keys(gkeys, GB, 0, kseeds, kx),                                    # Grotto walk (tail)
+        lambda: eng.eval_all(DPF, 20, G64, 0, seed, cw_20[0]),
+        lambda: eng.eval_all_batch(DPF, 10, G64, 0, bseeds, bcw),
+        lambda: eng.gen(DPF, 32, G64, ks0[:1 << 16].contiguous(), ri(1 << 16), kbe[:1 << 16].contiguous())[0],
+        lambda: eng.eval_points_shared(DPF, 32, G64, 0, seed, cw_dpf[0], xs21),
+    ]
+    # the Gen op draws its alphas anew on every call: fix them
+    al16 = ri(1 << 16)
+    ops[6] = lambda: eng.gen(DPF, 32, G64, ks0[:1 << 16].contiguous(), al16, kbe[:1 << 16].contiguous())[0]
+    want = [op().clone() for op in ops]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for rnd in range(3):
+        got = []
+        for i in range(len(ops) * 2):
+            j = (i + rnd) % len(ops)
+            with torch.cuda.stream(streams[i % 4]):
+                got.append((j, ops[j]()))
+        torch.cuda.synchronize()
+        for j, y in got:
+            assert torch.equal(y, want[j]), (rnd, j)
