@@ -3,7 +3,6 @@ launches that make a context allocate on demand (the tables, the per-stream coun
 queue, per-stream scratch)."""
 import gc
 
-import numpy as np
 import pytest
 
 import groups as G

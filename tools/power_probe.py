@@ -13,7 +13,7 @@ import time
 import torch
 
 import fss_amd
-from fss_amd.engine import DPF, DCF, HT, GROTTO
+from fss_amd.engine import DPF, DCF, HT
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import groups as G  # noqa: E402
