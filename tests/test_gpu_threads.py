@@ -5,7 +5,6 @@ tickets interleave, chunks are skipped, outputs stay unwritten).  The context ke
 import ctypes as C
 import threading
 
-import numpy as np
 import pytest
 import torch
 
