@@ -2,7 +2,7 @@
 process's GPU, found by its PCI address), beside the kernel time.  Backs DESIGN 4.8's statement that the
 independent-key walks run at the clock the power budget grants.
 
-    PYTHONPATH=. python tools/power_probe.py [seconds per workload]
+    PYTHONPATH=. python tools/power_probe.py [seconds per workload] [substring of the workload names to run]
 """
 import glob
 import os
@@ -72,6 +72,7 @@ def run_for(fn, seconds):
 
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
     eng = fss_amd.default_engine(0)
     mine, bdf, cands = my_hwmon()
     dirs = [d for _, d in cands]
@@ -106,6 +107,7 @@ def main():
     dst = torch.empty_like(src)
     work.append(("1 GiB device copy", lambda: dst.copy_(src)))
 
+    work = [w for w in work if only in w[0]]
     idx = dirs.index(mine) if mine in dirs else None
     print(f"{'workload':42s} {'ms':>8s} {'W':>7s} {'W max':>7s} {'MHz':>6s}  samples", flush=True)
     time.sleep(1.0)
