@@ -26,6 +26,7 @@ PROTOTYPES = {
     "fss_amd_dpf_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_dcf_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_ht_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_eval_points_host": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_eval_points_workspace": (_sz, [_i, _i, _i]),
     "fss_amd_dpf_eval_points_shared": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp, _sz, _vp]),
     "fss_amd_dcf_eval_points_shared": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp, _sz, _vp]),

@@ -180,9 +180,11 @@ int fss_amd_ctx_scratch_release(fss_amd_ctx* ctx, void* stream) {
   }
   // wait for the device either way: work still queued on the buffer (or using the stream's work-distribution
   // counters, which are handed on below) has finished
-  if (p) HIP_TRY(hipFree(p));
-  else HIP_TRY(hipDeviceSynchronize());
+  const hipError_t e = p ? hipFree(p) : hipDeviceSynchronize();
+  // the counter pair goes back to the pool whatever the device said: the buffer is already forgotten, and a pair that
+  // stayed with a dead stream would be lost for the life of the context
   ctx->tail_release(stream);
+  HIP_TRY(e);
   return FSS_AMD_OK;
 }
 
@@ -325,6 +327,37 @@ int fss_amd_dcf_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party,
 int fss_amd_ht_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
                            const void* ocw, const void* xs, int x_bytes, int64_t npoints, void* ys, void* stream) {
   return points_common(ctx, S_HT, in_bits, group, party, seed, cws, ocw, xs, x_bytes, npoints, ys, stream);
+}
+
+// ------------------------------------------------------------------ point eval, shared key, host-resident batch
+// A kernel-usable address of `p` when it is pinned (hipHostMalloc / hipHostRegister: mapped into the device's address
+// space) or device memory; nullptr for pageable host memory, which no kernel can touch.
+static void* device_view(const void* p) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();  // an unregistered host pointer is reported as an error
+    return nullptr;
+  }
+  if (at.type == hipMemoryTypeHost) return at.devicePointer;
+  if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged || at.type == hipMemoryTypeUnified) return const_cast<void*>(p);
+  return nullptr;
+}
+
+int fss_amd_eval_points_host(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seed,
+                             const void* cws, const void* ocw, const void* xs_host, int x_bytes, int64_t npoints,
+                             void* ys_host, void* stream) {
+  if (!ctx || (scheme != FSS_AMD_DPF && scheme != FSS_AMD_DCF && scheme != FSS_AMD_HT)) return FSS_AMD_EINVAL;
+  if (npoints > 0 && (!xs_host || !ys_host)) return FSS_AMD_EINVAL;
+  const void* xs = xs_host;
+  void* ys = ys_host;
+  if (npoints > 0) {
+    FSS_ON_DEVICE(ctx);
+    xs = device_view(xs_host);
+    ys = device_view(ys_host);
+    if (!xs || !ys) return FSS_AMD_EINVAL;  // pageable memory: pin it (hipHostRegister) or stage it yourself
+  }
+  const int s = scheme == FSS_AMD_DPF ? S_DPF : (scheme == FSS_AMD_DCF ? S_DCF : S_HT);
+  return points_common(ctx, s, in_bits, group, party, seed, cws, s == S_HT ? ocw : nullptr, xs, x_bytes, npoints, ys, stream);
 }
 
 // ------------------------------------------------------------------ relayout

@@ -302,8 +302,12 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
     int64_t tail_units = 0;
     if (a.dyn) tail_units = units * (tune().mix_mid_pct + tune().tail_pct) / 100;
     else tail_units = units >= 2 * tune().mix_tail_units * waves ? tune().mix_tail_units * waves : 0;
+    // FSS_AMD_MIX_MID_PCT + FSS_AMD_TAIL_PCT may exceed 100: the one-per-lane region is then the whole batch, never more
+    if (tail_units > units) tail_units = units;
+    if (tail_units < 0) tail_units = 0;
     int64_t body_units = units - tail_units;
     body_units -= body_units & 1;
+    if (body_units < 0) body_units = 0;
     a.n_body = tail_units > 0 ? body_units * 64 : a.n;
     if (a.n_body > a.n) a.n_body = a.n;
     // of the one-per-lane region the last tail_pct % OF THE BATCH go to whichever workgroup asks first

@@ -54,7 +54,7 @@ struct EvalArgs {
   uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
   uint32_t* gq;             // WaveQ's launch-wide tail: {counter, waves done} of this stream, or nullptr
   int64_t static_chunks;    // chunks (of the one-per-lane region) dealt out per workgroup before the launch-wide tail starts
-  int64_t n_body;           // two-per-lane kernels: evaluations [0, n_body) run two per lane (a multiple of 128), the rest one
+  int64_t n_body;           // two-per-lane kernels: evaluations [0, n_body) run two per lane, the rest one (a multiple of 128, or == n: two per lane throughout)
   int tail_on_body;         // two-per-lane kernels without a one-per-lane region: the launch-wide tail deals two-per-lane chunks
 };
 

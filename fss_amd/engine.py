@@ -173,6 +173,33 @@ class Engine:
         _lib.check(rc, "eval_points")
         return ys
 
+    def eval_points_host(self, scheme, in_bits, group, party, seed, cws, xs, ocw=None, out=None):
+        """eval_points on a batch that lives in PINNED host memory (the PCIe-inclusive path,
+        fss_amd_eval_points_host): the walk reads x from and writes y to the host tensors themselves, one launch, no
+        staging copies.  xs: a pinned CPU tensor; out: a pinned CPU int32[n, 4] tensor (allocated pinned when None).
+        The call is asynchronous on the current stream: synchronise before reading `out`."""
+        seed, cws = self._dev(seed, torch.int32), self._dev(cws, torch.int32)
+        if xs.device.type != "cpu" or not (xs.is_pinned() or xs.numel() == 0) or not xs.is_contiguous():
+            raise ValueError("eval_points_host: xs must be a contiguous pinned CPU tensor (tensor.pin_memory())")
+        xb = self._xbytes(xs, in_bits)
+        n = xs.shape[0] if xb == 16 else xs.numel()
+        self._need(seed, 4, "seed"); self._need(cws, 8 * self._slots(scheme, in_bits), "cws")
+        if out is None:
+            out = torch.empty((n, 4), dtype=torch.int32, pin_memory=True)
+        if (not isinstance(out, torch.Tensor) or out.device.type != "cpu" or not (out.is_pinned() or n == 0) or not out.is_contiguous()
+                or out.dtype != torch.int32 or out.numel() < 4 * n):
+            raise ValueError(f"eval_points_host: out must be a contiguous pinned CPU int32 tensor of at least {4 * n} elements")
+        if scheme not in (DPF, DCF, HT):
+            raise ValueError("scheme")
+        if scheme == HT:
+            ocw = self._need(self._dev(self._need(ocw, 4, "ocw"), torch.int32), 4, "ocw")
+        with torch.cuda.device(self.device):
+            rc = self._L.fss_amd_eval_points_host(self._h, scheme, in_bits, group, party, _ptr(seed), _ptr(cws),
+                                                  _ptr(ocw) if scheme == HT else None, C.c_void_p(xs.data_ptr()), xb, n,
+                                                  C.c_void_p(out.data_ptr()), self._stream())
+        _lib.check(rc, "eval_points_host")
+        return out
+
     def eval_points_shared(self, scheme, in_bits, group, party, seed, cws, xs, ocw=None, out=None, prefix_bits=None):
         """eval_points with the shared top of the tree expanded once per launch (same outputs).
         prefix_bits=None picks ~log2(len(xs)), capped by in_bits and 26."""

@@ -93,6 +93,9 @@ int fss_amd_last_hip_error(void);
  * fss::prg::Aes128Mmo<mul>::Gen, include/fss/prg/aes128_mmo.cuh:72-93. */
 int fss_amd_prg_gen(fss_amd_ctx *ctx, int mul, const void *seeds, int64_t n, void *out, void *stream);
 
+/* Scheme ids of the entry points that take one. */
+enum fss_amd_scheme { FSS_AMD_DPF = 0, FSS_AMD_DCF = 1, FSS_AMD_HT = 2, FSS_AMD_GROTTO = 3 };
+
 /* ---- point evaluation, ONE key shared by all points --------------------------
  * ys[i] = Scheme::Eval(party, *seed, cws, xs[i]).
  * Replaces a user kernel calling fss::Dpf::Eval / fss::Dcf::Eval /
@@ -108,6 +111,21 @@ int fss_amd_dcf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party,
                             const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
 int fss_amd_ht_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
                            const void *ocw, const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
+
+/* ---- the same on a batch that lives in HOST memory (the PCIe-inclusive path) -------------
+ * What the reference's binding does around its kernel for host tensors -- copy in, evaluate, copy out
+ * (fss_crypto/_csrc/dpf_binding_impl.cuh:58-101) -- without the copies and without staging buffers: xs_host and
+ * ys_host are pinned host memory (hipHostMalloc, or hipHostRegister'ed) and the walk itself reads x from and
+ * writes y to them across PCIe, 4 (8, 16) bytes up and 16 down per evaluation, in ONE launch.  The batch then runs at
+ * the PCIe rate (2^24 points of DPF kInBits=32: 6.1 ms = 55 GB/s both directions summed, against 4.7 ms resident and
+ * 11.9 ms for copy, launch, copy on one stream; profiles/r4/e2e_trace.txt).  Outputs are those of
+ * fss_amd_*_eval_points.  scheme: FSS_AMD_DPF / _DCF / _HT; seed, cws, ocw (Half-Tree) are DEVICE pointers as
+ * above; y is complete when `stream` reaches the point after this call (hipStreamSynchronize / an event).
+ * Pageable host memory is refused (FSS_AMD_EINVAL): no kernel can address it.  Device pointers are accepted and
+ * make this the resident call. */
+int fss_amd_eval_points_host(fss_amd_ctx *ctx, int scheme, int in_bits, int group, int party, const void *seed,
+                             const void *cws, const void *ocw, const void *xs_host, int x_bytes, int64_t npoints,
+                             void *ys_host, void *stream);
 
 /* ---- the same, with the shared top of the tree expanded once per launch ------------------
  * All points of one key walk the same top levels.  These entry points first expand the top
@@ -180,7 +198,6 @@ int fss_amd_ht_eval_keys(fss_amd_ctx *ctx, int in_bits, int group, int party, co
  * device scratch of at least fss_amd_eval_all_workspace(scheme, in_bits, nleaves)
  * bytes.  64-bit indexing throughout (the reference's int indices overflow at
  * in_bits >= 31, eval_all_gpu.cuh:257,287). */
-enum fss_amd_scheme { FSS_AMD_DPF = 0, FSS_AMD_DCF = 1, FSS_AMD_HT = 2, FSS_AMD_GROTTO = 3 };
 size_t fss_amd_eval_all_workspace(int scheme, int in_bits, int64_t nleaves);
 int fss_amd_dpf_eval_all(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
                          int64_t first_leaf, int64_t nleaves, void *ys, void *workspace, size_t workspace_bytes,

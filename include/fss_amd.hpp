@@ -268,7 +268,7 @@ constexpr int XBytes() {
 template <typename In>
 concept InType = std::is_unsigned_v<In> || std::is_same_v<In, unsigned __int128>;
 
-// Is p usable by a kernel as it stands?  Plain (and pinned) host memory is staged instead.
+// Is p device memory?  Inputs that are not (keys, seeds: a few KiB) are staged.
 inline bool OnDevice(const void* p) {
   hipPointerAttribute_t a{};
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -276,6 +276,21 @@ inline bool OnDevice(const void* p) {
     return false;
   }
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeUnified;
+}
+// The address a kernel can use for p: p itself for device memory, the device mapping of pinned host memory
+// (hipHostMalloc / hipHostRegister), nullptr for pageable host memory.  Large OUTPUTS in pinned memory are written by
+// the kernels themselves across PCIe (no staging buffer, no copy afterwards; fss_amd_eval_points_host is the same idea
+// for a batch of points).
+template <typename T>
+inline T* DeviceView(T* p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (a.type == hipMemoryTypeHost) return static_cast<T*>(a.devicePointer);
+  if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeUnified) return p;
+  return nullptr;
 }
 
 // Staging area for the host-buffer (reference-signature) methods: slices of a scratch buffer of the context that is
@@ -308,15 +323,15 @@ class Stage {
     Put(d, &v, sizeof(T));
     return static_cast<const T*>(d);
   }
-  // device buffer for an output: the destination itself when it is device memory
+  // device buffer for an output: the destination itself when a kernel can write it (device memory, pinned host memory)
   template <typename T>
   T* Out(T* dst, size_t count) {
-    if (OnDevice(dst)) return dst;
+    if (T* v = DeviceView(dst)) return v;
     return static_cast<T*>(Take(count * sizeof(T)));
   }
   template <typename T>
   void Back(T* dst, const T* dev, size_t count) {
-    if (static_cast<const void*>(dst) == static_cast<const void*>(dev)) {
+    if (static_cast<const void*>(DeviceView(dst)) == static_cast<const void*>(dev)) {
       CheckHip(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
       return;
     }
@@ -821,7 +836,7 @@ class Dpf {
     const size_t n = size_t(1) << in_bits;
     size_t ws = 0;
     if constexpr (kEngine) ws = EvalAllWorkspace();
-    const bool direct = detail::OnDevice(ys);
+    const bool direct = detail::DeviceView(ys) != nullptr;
     detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
@@ -857,6 +872,13 @@ class Dpf {
                                     stream), "fss_amd_dpf_eval_points");
     else
       detail::LaunchThreads(detail::ThreadEvalKernel<Dpf, In>, n, stream, *this, b, d_s0, d_cws, d_xs, d_ys, n);
+  }
+  // The same on a batch in PINNED host memory: the walk reads xs_host and writes ys_host across PCIe itself, one launch,
+  // no staging copies (fss_amd_eval_points_host); d_s0 / d_cws stay device pointers; asynchronous on `stream`.
+  void EvalPointsHost(bool b, const int4* d_s0, const Cw* d_cws, const In* xs_host, int4* ys_host, int64_t n,
+                      hipStream_t stream = 0) const {
+    Check(fss_amd_eval_points_host(handle(), FSS_AMD_DPF, in_bits, Group::kId, b, d_s0, d_cws, nullptr, xs_host,
+                                   detail::XBytes<In>(), n, ys_host, stream), "fss_amd_eval_points_host");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_DPF, in_bits, nleaves);
@@ -923,7 +945,7 @@ class Dcf {
     const size_t n = size_t(1) << in_bits;
     size_t ws = 0;
     if constexpr (kEngine) ws = EvalAllWorkspace();
-    const bool direct = detail::OnDevice(ys);
+    const bool direct = detail::DeviceView(ys) != nullptr;
     detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + ws + 32 + (direct ? 0 : n * sizeof(int4)));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
@@ -955,6 +977,13 @@ class Dcf {
                                     stream), "fss_amd_dcf_eval_points");
     else
       detail::LaunchThreads(detail::ThreadEvalKernel<Dcf, In>, n, stream, *this, b, d_s0, d_cws, d_xs, d_ys, n);
+  }
+  // The same on a batch in PINNED host memory: the walk reads xs_host and writes ys_host across PCIe itself, one launch,
+  // no staging copies (fss_amd_eval_points_host); d_s0 / d_cws stay device pointers; asynchronous on `stream`.
+  void EvalPointsHost(bool b, const int4* d_s0, const Cw* d_cws, const In* xs_host, int4* ys_host, int64_t n,
+                      hipStream_t stream = 0) const {
+    Check(fss_amd_eval_points_host(handle(), FSS_AMD_DCF, in_bits, Group::kId, b, d_s0, d_cws, nullptr, xs_host,
+                                   detail::XBytes<In>(), n, ys_host, stream), "fss_amd_eval_points_host");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_DCF, in_bits, nleaves);
@@ -1023,7 +1052,7 @@ class HalfTreeDpf {
     const size_t n = size_t(1) << in_bits;
     size_t ws = 0;
     if constexpr (kEngine) ws = EvalAllWorkspace();
-    const bool direct = detail::OnDevice(ys);
+    const bool direct = detail::DeviceView(ys) != nullptr;
     detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 32 + ws + 32 + (direct ? 0 : n * sizeof(int4)));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
@@ -1057,6 +1086,12 @@ class HalfTreeDpf {
     else
       detail::LaunchThreads(detail::ThreadEvalOcwKernel<HalfTreeDpf, In>, n, stream, *this, b, d_s0, d_cws, d_ocw, d_xs,
                             d_ys, n);
+  }
+  // The same on a batch in PINNED host memory (fss_amd_eval_points_host): x read and y written across PCIe by the walk.
+  void EvalPointsHost(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_ocw, const In* xs_host, int4* ys_host,
+                      int64_t n, hipStream_t stream = 0) const {
+    Check(fss_amd_eval_points_host(handle(), FSS_AMD_HT, in_bits, Group::kId, b, d_s0, d_cws, d_ocw, xs_host,
+                                   detail::XBytes<In>(), n, ys_host, stream), "fss_amd_eval_points_host");
   }
   static size_t EvalAllWorkspace(int64_t nleaves = int64_t(1) << in_bits) {
     return fss_amd_eval_all_workspace(FSS_AMD_HT, in_bits, nleaves);
@@ -1104,7 +1139,7 @@ class GrottoDcf {
     static_assert(in_bits <= 40, "a parity table of 2^(in_bits + 1) bytes");
     fss_amd_ctx* ctx = handle();
     const size_t ws = PreprocessWorkspace();
-    const bool direct = detail::OnDevice(pt.p);
+    const bool direct = detail::DeviceView(pt.p) != nullptr;
     detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 64 + (direct ? 0 : ParityTreeBytes()));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
@@ -1136,7 +1171,7 @@ class GrottoDcf {
     static_assert(in_bits <= 40, "a full-domain output of 2^in_bits bools");
     const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
     fss_amd_ctx* ctx = handle();
-    const bool direct = detail::OnDevice(ys);
+    const bool direct = detail::DeviceView(ys) != nullptr;
     detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 64 + (direct ? 0 : n));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);

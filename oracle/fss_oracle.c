@@ -480,8 +480,10 @@ static void dpf_eval_tree(const fo_prg *prgs, int in_bits, int group, int b, fo_
 
 static void prg_thread_copy(const fo_prg *src, fo_prg *dst);
 
-void fo_dpf_eval_all_tasks(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
-                           int nthreads) {
+/* `reps` evaluations on ONE set of per-thread PRG copies: the reference builds its EVP contexts once (CreateCtxs,
+ * aes128_mmo.cuh:49-64) and then calls EvalAll as often as it likes, so context setup is outside the repetition. */
+static void dpf_eval_all_tasks_n(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
+                                 int nthreads, int reps) {
   if (nthreads < 1) nthreads = 1;
   if (nthreads > 256) nthreads = 256;
   int par_depth = 0; /* util.cuh:40-45 (ResolveParDepth): ceil(log2(threads)) */
@@ -489,20 +491,29 @@ void fo_dpf_eval_all_tasks(const fo_prg *p, int in_bits, int group, int b, fo_i4
   if (par_depth > in_bits) par_depth = in_bits;
   fo_prg *prgs = (fo_prg *)malloc((size_t)nthreads * sizeof(fo_prg));
   for (int k = 0; k < nthreads; ++k) prg_thread_copy(p, &prgs[k]);
+  for (int r = 0; r < reps; ++r) {
+    /* one parallel region per EvalAll, as dpf.cuh:244-246 opens one per call */
 #pragma omp parallel num_threads(nthreads)
 #pragma omp single
-  dpf_eval_tree(prgs, in_bits, group, b, set_lsb(s0, b), cws, ys, 0, (size_t)1 << in_bits, 0, par_depth);
+    dpf_eval_tree(prgs, in_bits, group, b, set_lsb(s0, b), cws, ys, 0, (size_t)1 << in_bits, 0, par_depth);
+  }
   for (int k = 0; k < nthreads; ++k) fo_prg_free(&prgs[k]);
   free(prgs);
+}
+
+void fo_dpf_eval_all_tasks(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
+                           int nthreads) {
+  dpf_eval_all_tasks_n(p, in_bits, group, b, s0, cws, ys, nthreads, 1);
 }
 
 /* `reps` back-to-back calls (timing small domains without a foreign-function call per evaluation) */
 void fo_dpf_eval_all_repeat(const fo_prg *p, int in_bits, int group, int b, fo_i4 s0, const fo_cw *cws, fo_i4 *ys,
                             int nthreads, int reps) {
-  for (int r = 0; r < reps; ++r) {
-    if (nthreads >= 1) fo_dpf_eval_all_tasks(p, in_bits, group, b, s0, cws, ys, nthreads);
-    else fo_dpf_eval_all(p, in_bits, group, b, s0, cws, ys);
+  if (nthreads >= 1) {
+    dpf_eval_all_tasks_n(p, in_bits, group, b, s0, cws, ys, nthreads, reps);
+    return;
   }
+  for (int r = 0; r < reps; ++r) fo_dpf_eval_all(p, in_bits, group, b, s0, cws, ys);
 }
 
 /* ------------------------------------------------------------------ DCF */

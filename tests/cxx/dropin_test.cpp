@@ -551,6 +551,57 @@ static void OnAStream() {
   std::printf("DpfEvalAllGpu on a side stream: %s\n", g_fail == before ? "ok" : "FAILED");
 }
 
+// buffers in PINNED host memory: EvalAll writes its leaves into them from the kernels (no staging buffer behind the
+// host-signature call), and EvalPointsHost walks a batch whose x and y both live on the host -- the same outputs as
+// through pageable memory (staged) and through device memory
+static void PinnedHostBuffers() {
+  int before = g_fail;
+  using DpfPrg = fss::prg::Aes128Mmo<2>;
+  using DpfType = fss::Dpf<16, UintGroup, DpfPrg, uint>;
+  const unsigned char* keys[2] = {k0, k1};
+  DpfType dpf{DpfPrg(keys)};
+  int4 seeds[2] = {kSeeds[0], kSeeds[1]};
+  DpfType::Cw cws[17];
+  dpf.Gen(cws, seeds, 4242u, int4{9, 1, 0, 0});
+  const size_t n = size_t(1) << 16;
+  std::vector<int4> pageable(n);
+  dpf.EvalAll(false, seeds[0], cws, pageable.data());
+  int4* pinned = nullptr;
+  HIP_OK(hipHostMalloc(&pinned, n * sizeof(int4)));
+  std::memset(pinned, 0xff, n * sizeof(int4));
+  dpf.EvalAll(false, seeds[0], cws, pinned);
+  EXPECT(std::memcmp(pinned, pageable.data(), n * sizeof(int4)) == 0);
+  // a registered (hipHostRegister) buffer is pinned memory too
+  std::vector<int4> reg(n + 1);
+  int4* reg_p = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(reg.data()) + 15) & ~uintptr_t(15));
+  HIP_OK(hipHostRegister(reg_p, n * sizeof(int4), hipHostRegisterDefault));
+  dpf.EvalAll(false, seeds[0], cws, reg_p);
+  EXPECT(std::memcmp(reg_p, pageable.data(), n * sizeof(int4)) == 0);
+  HIP_OK(hipHostUnregister(reg_p));
+  // a batch of points on the host: every x of the domain in a scrambled order, ragged length
+  const int64_t m = (int64_t)n - 37;
+  uint* xs = nullptr;
+  HIP_OK(hipHostMalloc(&xs, m * sizeof(uint)));
+  for (int64_t i = 0; i < m; ++i) xs[i] = (uint)((i * 40503u + 7u) & 0xffffu);
+  std::memset(pinned, 0xff, n * sizeof(int4));
+  DpfType::Cw* d_cws = ToDevice(cws, 17);
+  int4* d_s0 = ToDevice(&seeds[0], 1);
+  dpf.EvalPointsHost(false, d_s0, d_cws, xs, pinned, m);
+  HIP_OK(hipDeviceSynchronize());
+  int bad = 0;
+  for (int64_t i = 0; i < m; ++i)
+    if (!Same(pinned[i], pageable[xs[i]])) ++bad;
+  EXPECT(bad == 0);
+  EXPECT(pinned[m].x == -1);  // nothing written past the batch
+  // pageable memory cannot be walked in place: refused, not read
+  std::vector<uint> xs_pg(64, 1u);
+  EXPECT(fss_amd_eval_points_host(dpf.handle(), FSS_AMD_DPF, 16, UintGroup::kId, 0, d_s0, d_cws, nullptr, xs_pg.data(), 4, 64,
+                                  pinned, nullptr) == FSS_AMD_EINVAL);
+  HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_s0));
+  HIP_OK(hipHostFree(xs)); HIP_OK(hipHostFree(pinned));
+  std::printf("pinned host buffers (EvalAll in place, EvalPointsHost): %s\n", g_fail == before ? "ok" : "FAILED");
+}
+
 int main() {
   try {
     HostSignatureDpf();
@@ -568,6 +619,7 @@ int main() {
     HalfTreeLaunchers<20, UintGroup>(fss::prg::Aes128Mmo<1>(keys1), "Aes128Mmo<1>");
     HalfTreeLaunchers<12, UintGroup>(fss::prg::ChaCha<1>(kNonce), "ChaCha<1>   ");
     OnAStream();
+    PinnedHostBuffers();
     fss::ReleaseEngines();
   } catch (const fss::Error& e) {
     std::fprintf(stderr, "fss::Error: %s\n", e.what());

@@ -126,8 +126,10 @@ def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
     assert len(lines) == 1
     d = lines[0]
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
-    for key in ("dcf_points", "dpf_keys", "dpf_n16", "dpf_n64"):
-        assert d[key]["value"] > 0 and 0 < d[key]["roofline"]["frac"] < 1.2
+    for key in ("dcf_points", "dpf_keys", "dcf_keys", "dpf_n16", "dpf_n64", "dcf_n16", "dcf_n64", "dpf_keys_n16", "dpf_keys_n64"):
+        assert d["sub"][key]["v"] > 0 and 0 < d["sub"][key]["f"] < 1.2, key
+    # the one batch cut in two: half the points per rank, a rate of its own
+    assert d["strong"]["n"] == (1 << 19) and d["strong"]["v"] > 0 and d["strong"]["scaling"] == "strong"
 
 
 @pytest.mark.gpu
@@ -158,35 +160,41 @@ def test_one_rank_under_torch_distributed_run_goes_through_rccl(extra):
 
 @pytest.mark.gpu
 def test_default_line_carries_the_whole_metric():
-    """The driver's command at a small batch: headline + DCF / independent keys / kInBits 16, 64, each with its own
-    kernel time and LDS fraction, each checked against the oracle on a sample inside the cpu_baseline leg."""
+    """The driver's command at a small batch: the headline, every cell of the north-star grid (DCF, independent keys,
+    kInBits 16 / 64 for both), BASELINE configs[0..4] and the PCIe-inclusive figure -- each with its own kernel time and
+    LDS fraction, each checked against the oracle inside the cpu_baseline leg -- in ONE line short enough for the
+    driver's record (< 7 KB), whose every key bench_legend.json explains."""
     r, _ = run(["--steps", "3", "--warmup", "1", "--log2-batch", "18", "--cpu-sample", "65536", "--log2-domain", "24",
                 "--log2-keys", "20"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json_lines(r.stdout)[0]
-    # round 3: BASELINE configs[0], [1], [2] at their literal sizes and configs[3], [4] (here at reduced sizes), each
-    # with its own CPU leg and parity gate, and the PCIe-inclusive figure, all in the one line
+    raw = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(raw) == 1 and len(raw[0]) < 7000, len(raw[0])
+    d = json.loads(raw[0])
+    sub = d["sub"]
+    legend = json.load(open(os.path.join(ROOT, "bench_legend.json")))
+    for name, rec in sub.items():
+        assert name in legend["records"], name
+        assert set(rec) <= set(legend["sub_record_keys"]), (name, set(rec) - set(legend["sub_record_keys"]))
+    walks = ("dcf_points", "dpf_n16", "dpf_n64", "dcf_n16", "dcf_n64", "dpf_keys", "dcf_keys", "dpf_keys_n16", "dpf_keys_n64")
+    for key in walks + ("dpf_2e20", "dcf_2e20", "evalall_c4", "ht_c5", "grotto_c5"):
+        rec = sub[key]
+        assert rec["ok"] is True, key
+        assert rec["kms"] > 0 and 0 < rec["f"] < 1.2 and rec["v"] > 0, key
     for key in ("dpf_2e20", "dcf_2e20", "evalall_c4", "ht_c5", "grotto_c5", "c1_cpu"):
-        rec = d[key]
-        assert rec["gpu_matches_oracle_on_sample"] is True, key
-        cb = rec["cpu_baseline"]
-        assert cb["value"] > 0 and cb["single_thread_value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port", key
-    for key in ("dpf_2e20", "dcf_2e20", "evalall_c4", "ht_c5", "grotto_c5"):
-        assert d[key]["kernel_ms"] > 0 and 0 < d[key]["roofline"]["frac"] < 1.2, key
-        assert "traffic" in d[key]["roofline"] and "replay_matches_kernel_sources" in d[key]["roofline"], key
-    assert d["evalall_c4"]["cpu_baseline"]["timed_outputs_match_oracle_on_strided_sample"] is True
-    assert d["c1_cpu"]["cpu_baseline"]["oracle_matches_reference_sha256"] is True
-    assert d["e2e_pcie"]["outputs_identical_to_resident_run"] is True and d["e2e_pcie"]["serial_one_stream"]["value"] > 0
-    assert d["parity_gates"]["all_true"] is True and len(d["parity_gates"]["gates"]) >= 11
-    assert d["n_gpus"] == 1 and d["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
-    for key in ("dcf_points", "dpf_keys", "dpf_n16", "dpf_n64"):
-        rec = d[key]
-        assert rec["gpu_matches_oracle_on_sample"] is True, key
-        assert rec["kernel_ms"] > 0 and rec["roofline"]["bound"] == "lds"
-    assert d["dcf_points"]["aes_blocks_per_eval"] == 64 and d["dpf_n16"]["aes_blocks_per_eval"] == 16
-    assert d["shared_prefix"]["identical_to_plain_walk"] is True
-    assert "clock_ghz_in_pmc_run" not in json.dumps(d)
+        assert sub[key]["cpu"] > 0 and sub[key]["cpu1"] > 0, key
+    assert sub["dcf_points"]["a"] == 64 and sub["dpf_n16"]["a"] == 16 and sub["dcf_n64"]["a"] == 128 and sub["dcf_keys"]["a"] == 64
+    assert sub["grotto_c5"]["fx"] < sub["grotto_c5"]["f"]
+    assert sub["c1_cpu"]["kat"] is True and sub["c1_cpu"]["ok"] is True
+    assert sub["e2e_pcie"]["same"] is True and sub["e2e_pcie"]["serial"] > 0 and sub["e2e_pcie"]["pipe"] > 0
+    assert sub["shared_prefix"]["same"] is True
+    assert d["gates"]["all"] is True and d["gates"]["n"] >= 18
+    assert d["n_gpus"] == 1 and d["cpu_baseline"]["ok"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    # one GPU: the strong-scaled form of the metric is the headline launch itself
+    assert d["strong"]["v"] == d["value"] and d["strong"]["n"] == 1 << 18
+    assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
 
 
 def _digests(prefix, ranks):
@@ -198,11 +206,13 @@ def _digests(prefix, ranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload,size", [("evalall_c4", ["--log2-domain", "22"]), ("ht_c5", ["--log2-keys", "18"]),
+@pytest.mark.parametrize("workload,size", [("headline_strong", ["--log2-batch", "21"]),
+                                           ("evalall_c4", ["--log2-domain", "22"]), ("ht_c5", ["--log2-keys", "18"]),
                                            ("grotto_c5", ["--log2-keys", "18"]), ("grotto_evalall", ["--log2-domain", "20"])])
 def test_sharded_workloads_with_8_ranks_on_one_gpu(workload, size, tmp_path):
-    """BASELINE configs[3] / configs[4] as the driver's 8-GPU box would run them -- `bench.py --gpus 8 --workload ...`,
-    the domain cut by shard.domain_block, the key batch by shard.batch_slice -- with the eight ranks sharing this box's
+    """The metric's own batch split eight ways (headline_strong: 2^B / 8 points of the one key per rank) and
+    BASELINE configs[3] / configs[4] as the driver's 8-GPU box would run them -- `bench.py --gpus 8 --workload ...`,
+    the domain cut by shard.domain_block, the point and key batches by shard.batch_slice -- with the eight ranks sharing this box's
     one GPU (FSS_AMD_BENCH_SHARE_GPU: gloo instead of RCCL) at a reduced size.  Every rank writes the SHA-256 of its
     block of outputs; the eight digests must be the digests of the eight blocks of a single-rank run (for the Grotto
     full domain that includes the cross-block parity carry of shard.grotto_fix_shard)."""

@@ -36,3 +36,51 @@ def test_workload_pmc_summaries_are_found():
         assert 0.98 < r["traffic"] / bytes_ < (1.25 if name == "evalall_c4" else 1.05), (name, r["traffic"] / bytes_)
         assert 0.5 < r["lds_busy_pmc"] <= 1.0
         assert bench.replayed_counters(name, units[name] // 2)["traffic"] is None   # only the profiled launch size
+
+
+def test_committed_legend_is_what_bench_generates():
+    """bench_legend.json (where the line's prose lives) is generated from bench.py's own tables."""
+    import json
+    import bench
+    have = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_legend.json")))
+    assert have == json.loads(json.dumps(bench.legend()))
+    cells = [c[0] for c in bench.POINTS_CELLS + bench.KEYS_CELLS] + list(bench.SHARDED)
+    for name in cells + ["strong", "shared_prefix", "dpf_2e20", "dcf_2e20", "e2e_pcie", "c1_cpu"]:
+        assert name in have["records"], name
+    assert {s for _, s in bench.SHORT} | {"u"} == set(have["sub_record_keys"])
+
+
+def test_a_full_line_fits_the_drivers_record():
+    """The driver keeps about 8 KB of the line's tail: a line with every sub-record at full width (5 significant digits,
+    every optional key present) must stay under 7 000 bytes, and every number of it must be in it."""
+    import argparse
+    import json
+    import bench
+    walk = {"value": 3.5912e9, "unit": "evals/s", "ms_per_step": 4.6597, "kernel_ms": 4.6561, "units_per_launch": 1 << 24,
+            "aes_per_unit": 32, "frac": 0.93831, "lds_gbs": 73792.1, "hbm_gbs": 72.012, "hbm_frac": 0.0090015,
+            "kernel": "eval_points_kernel<Lds,0,true,2,1024,false>", "grid": 256, "block": 1024, "traffic_ratio": 1.0041,
+            "lds_busy_pmc": 0.95123, "replay_ok": True, "ok": True, "cpu": 2.0712e7, "cpu1": 1.3512e6}
+    subs = {c[0]: dict(walk) for c in bench.POINTS_CELLS + bench.KEYS_CELLS}
+    for name in ("dpf_2e20", "dcf_2e20", "ht_c5"):
+        subs[name] = dict(walk)
+    subs["evalall_c4"] = dict(walk, unit="leaves/s")
+    subs["grotto_c5"] = dict(walk, frac_executed=0.84123)
+    subs["shared_prefix"] = dict(walk, same=True)
+    subs["e2e_pcie"] = {"value": 2.7e9, "unit": "evals/s", "serial": 1.4475e9, "pipe": 2.7123e9, "gbs": 54.246, "same": True}
+    subs["c1_cpu"] = {"value": 2.1e7, "unit": "leaves/s", "us": 12.345, "cpu": 2.7e7, "cpu1": 2.75e7, "cpu_us": 9.4123, "cpu1_us": 9.3123,
+                      "kat": True, "ok": True}
+    cpu = {"value": 2.0712e7, "unit": "evals/s", "cores": 16, "kind": "port",
+           "sample": "first 16777216 points of the timed batch x 5 passes, 4.1 s; t1: 1048576 points", "t1": 1.3512e6, "ok": True,
+           "aesni": 2.9512e7}
+    args = argparse.Namespace(log2_batch=24, steps=20, warmup=5)
+    line, detail = bench.compose_line(args, 1, dict(walk), dict(walk, scaling="strong"), subs, cpu, "nccl")
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 7000, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["config"]["workload"] and back["roofline"]["bound"] == "lds" and back["cpu_baseline"]["sample"]
+    assert set(back["sub"]) == set(subs) and back["gates"]["all"] is True
+    assert back["sub"]["grotto_c5"]["fx"] == 0.84123 and back["sub"]["evalall_c4"]["u"] == "leaves/s"
+    assert back["strong"]["scaling"] == "strong" and back["strong"]["v"] == back["value"]

@@ -119,7 +119,13 @@ def test_python_layer_raises(raw):
                                  {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "0", "FSS_AMD_MIX_TAIL_UNITS": "1", "FSS_AMD_QUAD_POINTS_MAX": "0",
                                   "FSS_AMD_TAIL_MINWORK": "1"},
                                  {"FSS_AMD_ILP": "2", "FSS_AMD_MIX_MID_PCT": "0", "FSS_AMD_MIX_TAIL_UNITS": "0", "FSS_AMD_DYN": "1",
-                                  "FSS_AMD_QUAD_POINTS_MAX": "0"}])
+                                  "FSS_AMD_QUAD_POINTS_MAX": "0"},
+                                 # mid + tail share above 100 % of the batch: the one-per-lane region is the whole batch
+                                 # (the split must clamp, never start the body at a negative index)
+                                 {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_TAIL_PCT": "100", "FSS_AMD_QUAD_POINTS_MAX": "0",
+                                  "FSS_AMD_TAIL_MINWORK": "1"},
+                                 {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_TAIL_PCT": "100", "FSS_AMD_MIX_MID_PCT": "90",
+                                  "FSS_AMD_QUAD_POINTS_MAX": "0", "FSS_AMD_TAIL_MINWORK": "1"}])
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
     depths) pick by batch size, so the small oracle-checked cases would only ever see one of each; run the
