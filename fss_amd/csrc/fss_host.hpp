@@ -151,9 +151,7 @@ struct Tune {
   // "two, then one" (eval_points_kernel): what runs ONE evaluation per lane at the end of a two-per-lane launch --
   int mix_mid_pct = 6;   // FSS_AMD_MIX_MID_PCT: dynamic launches: % of the batch dealt per workgroup, before the tail_pct % launch-wide
   int mix_tail_units = 2;  // FSS_AMD_MIX_TAIL_UNITS: fixed shares: chunks of 64 per wave (0 with either: two per lane throughout)
-  int quad_tail = 0;       // FSS_AMD_QUAD_TAIL: fixed shares, shared key: granules of 16 evaluations per wave walked quad-wise at the end (0: none)
   Tune() {
-    if (const char* e = tune_env("FSS_AMD_QUAD_TAIL")) { quad_tail = atoi(e); if (quad_tail < 0 || quad_tail > 64) quad_tail = 0; }
     if (const char* e = tune_env("FSS_AMD_MIX_MID_PCT")) { mix_mid_pct = atoi(e); if (mix_mid_pct < 0 || mix_mid_pct > 90) mix_mid_pct = 6; }
     if (const char* e = tune_env("FSS_AMD_MIX_TAIL_UNITS")) { mix_tail_units = atoi(e); if (mix_tail_units < 0) mix_tail_units = 2; }
     if (const char* e = tune_env("FSS_AMD_TAIL_PCT")) { tail_pct = atoi(e); if (tail_pct < 0 || tail_pct > 100) tail_pct = 8; }
@@ -272,7 +270,7 @@ struct SharedKey {
 
 template <typename K>
 int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int bs, const SharedKey& k, EvalArgs a,
-                    hipStream_t st, bool tail_ok, bool mix_ok, int blocks_per_eval, bool quad_ok) {
+                    hipStream_t st, bool tail_ok, bool mix_ok, int blocks_per_eval) {
   int grid = 0;
   int rc = persistent_grid(ctx, kernel, bs, (a.n + ilp - 1) / ilp, &grid);
   if (rc != FSS_AMD_OK) return rc;
@@ -293,14 +291,6 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   a.static_chunks = 0;
   a.n_body = 0;
   a.tail_on_body = 0;
-  // the quad-walked end (shared key, fixed shares): quad_tail granules of 16 evaluations per resident wave
-  a.n_quad = 0;
-  if (quad_ok && !a.dyn && tune().quad_tail > 0) {
-    a.n_quad = (int64_t)tune().quad_tail * 16 * grid * (bs / 64);
-    if (a.n_quad > a.n / 2) a.n_quad = 0;  // a batch that small is not what the split is for
-  }
-  const int64_t n_all = a.n;
-  a.n -= a.n_quad;  // the per-lane regions below are laid out over [0, n - n_quad); restored before the launch
   if (ilp == 2 && !mix_ok) {
     // two per lane throughout (short walks: a one-evaluation chunk would be too short to end the launch on)
     a.n_body = a.n;
@@ -325,7 +315,6 @@ int launch_points_k(fss_amd_ctx* ctx, K kernel, const char* name, int ilp, int b
   } else if (tail_ok) {
     set_tail(ctx, st, a.dyn, a.n, 64, grid, &a.gq, &a.static_chunks);
   }
-  a.n = n_all;
 #if FSS_DIAG_STAMPS
   a.stamps = ctx->diag_stamps;
 #endif
@@ -364,7 +353,7 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   if (!tune().ilp_set && ctx->prg == FSS_AMD_PRG_CHACHA && walked >= 24) ilp = 1;
 #define FSS_L(I, B) \
   if (ilp == I && bs == B)                                                                                      \
-  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, mix_ok, blocks_per_eval, SHARED && !PREFIX)))
+  return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, mix_ok, blocks_per_eval)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
   if constexpr (PREFIX) return FSS_AMD_EINVAL;

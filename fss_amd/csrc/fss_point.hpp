@@ -56,8 +56,6 @@ struct EvalArgs {
   int64_t static_chunks;    // chunks (of the one-per-lane region) dealt out per workgroup before the launch-wide tail starts
   int64_t n_body;           // two-per-lane kernels: evaluations [0, n_body) run two per lane, the rest one (a multiple of 128, or == n: two per lane throughout)
   int tail_on_body;         // two-per-lane kernels without a one-per-lane region: the launch-wide tail deals two-per-lane chunks
-  int64_t n_quad;           // shared key only: the LAST n_quad evaluations are walked one per quad of lanes, 16 per wave-iteration,
-                            // handed out from the workgroup's LDS counter (walk_points_quad, fss_quad.hpp); 0: none
 };
 
 // Diagnostic build (-DFSS_DIAG_STAMPS=1, a separate library: in the product no stamp executes): lane 0 of every
@@ -284,12 +282,6 @@ struct HtWalk {
 // and the rest, [n_body, n), one per lane, so that the launch ends on chunks half as long (the idle tail of waves that
 // are done was 125-150 us of a 4.8 ms launch with two per lane throughout, 65-70 us with one).  Measured round 3:
 // profiles/r3/points_2e24_ilp_raw.txt (each alone), DESIGN.md 4.4 (combined).  n_body = n: two per lane throughout.
-// The last a.n_quad evaluations of a shared-key batch, one walk per quad of lanes (defined in fss_quad.hpp).
-template <class LT, int SCHEME>
-__device__ void walk_points_quad(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ k_seed,
-                                 const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw, const EvalArgs& a,
-                                 uint32_t* lds_ctr);
-
 template <class LT, int SCHEME, bool SHARED, int ILPT, int BS, bool PREFIX = false>
 __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                          const uint32_t* __restrict__ k_seed,  // uint32[4]
@@ -302,8 +294,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #endif
   FSS_PROGRESS_PROLOGUE();
   __shared__ uint32_t waveq_ctr2_;  // chunk counter of the one-per-lane region (zeroed before FSS_WAVEQ_PROLOGUE's barrier)
-  __shared__ uint32_t waveq_ctr3_;  // ... and of the quad-walked end of the batch
-  if (threadIdx.x == 0) { waveq_ctr2_ = 0; waveq_ctr3_ = 0; }
+  if (threadIdx.x == 0) waveq_ctr2_ = 0;
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
   uint32_t my_prog = 0;
@@ -311,8 +302,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   const int in_bits = a.in_bits, party = a.party;
   const Grp g = make_grp(a.group, c);
   const int lvl0 = PREFIX ? a.start_level : 0;
-  // the per-lane walks cover [0, n); a shared-key launch may leave its last n_quad evaluations to the quad walk below
-  const int64_t n = (SHARED && !PREFIX) ? a.n - a.n_quad : a.n;
+  const int64_t n = a.n;
   uint4* __restrict__ ys = reinterpret_cast<uint4*>(a.ys);
 
   constexpr int64_t SJ = 64;  // a lane's ILP evaluations are 64 apart: a chunk is 64 * ILP consecutive evaluations
@@ -474,9 +464,6 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   WaveQ q(a.dyn, ILPT == 2 ? &waveq_ctr2_ : &waveq_ctr_, n - n_body, 1, (ILPT == 2 && a.tail_on_body) ? nullptr : a.gq,
           a.static_chunks);
   for (int64_t base; q.next(base);) walk_chunk(std::integral_constant<int, 1>{}, n_body + base);
-  if constexpr (SHARED && !PREFIX) {
-    if (a.n_quad > 0) walk_points_quad<LT, SCHEME>(L, c, k_seed, k_cws, k_ocw, a, &waveq_ctr3_);
-  }
 #if FSS_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave, taken as the wave leaves its loop (before done()'s barrier)
     const int64_t rec = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);

@@ -263,48 +263,6 @@ __global__ __launch_bounds__(1024) void points_quad_kernel(const DevCtx K, const
   }
 }
 
-// The quad-walked END of a large shared-key batch (eval_points_kernel, EvalArgs::n_quad): evaluations
-// [a.n - a.n_quad, a.n) in granules of 16 (one wave-iteration: a walk per quad of lanes), workgroup b owns granules
-// b, b + G, ... and its waves take them one at a time from an LDS counter.  A granule's chain is a quarter as long as
-// a 64-evaluation chunk's, so the waves of a workgroup -- and the workgroups of a launch -- can end closer together;
-// whether that pays is a measurement (profiles/r4/points_2e20_quad_tail.txt).
-template <class LT, int SCHEME>
-__device__ void walk_points_quad(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ k_seed,
-                                 const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw, const EvalArgs& a,
-                                 uint32_t* lds_ctr) {
-  const int q = threadIdx.x & 3;
-  const uint32_t is3 = q == 3 ? ~0u : 0u;
-  QuadPrg<LT, SCHEME> P;
-  P.init(L, c, q);
-  const Grp g = make_grp(a.group, c);
-  const int n = a.in_bits, depth = SCHEME == S_HT ? n - 1 : n;
-  const int64_t first = a.n - a.n_quad, ngran = (a.n_quad + 15) >> 4;
-  uint32_t* __restrict__ ys = reinterpret_cast<uint32_t*>(a.ys);
-  __builtin_amdgcn_s_setprio(3);  // whoever is on its last granules goes first
-  for (int64_t gi = waveq_fetch(lds_ctr); gi < ngran; gi = waveq_fetch(lds_ctr)) {
-    int64_t j = first + gi * 16 + ((threadIdx.x & 63) >> 2);
-    const bool live = j < a.n;
-    if (!live) j = a.n - 1;  // clamp: the quad stays converged, its store is masked
-    const X128 x = load_x(a.xs, a.x_bytes, j);
-    uint32_t st = k_seed[q];
-    st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);
-    Acc v;
-#pragma unroll 1
-    for (int i = 0; i < depth; ++i) quad_level(P, g, k_cws, i, bit_mask(x, n - 1 - i), q, is3, st, v);
-    const uint32_t* p = k_cws + 8 * (SCHEME == S_HT ? n - 1 : n) + (SCHEME == S_DCF ? 4 : 0);
-    const uint32_t cwl[4] = {p[0], p[1], p[2], p[3]};
-    uint32_t y;
-    if constexpr (SCHEME == S_HT) {
-      const uint32_t oc[4] = {k_ocw[0], k_ocw[1], k_ocw[2], k_ocw[3]};
-      y = quad_finish<SCHEME>(L, c, g, a.party, q, st, v, x, cwl, p[4], oc);
-    } else {
-      y = quad_finish<SCHEME>(L, c, g, a.party, q, st, v, x, cwl, 0u, cwl);
-    }
-    if (live) ys[4 * j + q] = y;
-  }
-  __builtin_amdgcn_s_setprio(0);
-}
-
 // Small batches of independent level-major keys (fss::gpu::*EvalPointGpu's inputs): a quad per key.
 template <class LT, int SCHEME>
 __global__ __launch_bounds__(1024) void keys_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {

@@ -125,11 +125,6 @@ def test_python_layer_raises(raw):
                                  {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_TAIL_PCT": "100", "FSS_AMD_QUAD_POINTS_MAX": "0",
                                   "FSS_AMD_TAIL_MINWORK": "1"},
                                  {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_TAIL_PCT": "100", "FSS_AMD_MIX_MID_PCT": "90",
-                                  "FSS_AMD_QUAD_POINTS_MAX": "0", "FSS_AMD_TAIL_MINWORK": "1"},
-                                 # round 4: the end of a fixed-share launch walked one evaluation per quad of lanes
-                                 # (walk_points_quad), behind one-per-lane and behind two-then-one regions
-                                 {"FSS_AMD_QUAD_TAIL": "1", "FSS_AMD_DYN": "0", "FSS_AMD_QUAD_POINTS_MAX": "0"},
-                                 {"FSS_AMD_QUAD_TAIL": "2", "FSS_AMD_ILP": "2", "FSS_AMD_MIX_TAIL_UNITS": "1", "FSS_AMD_DYN": "0",
                                   "FSS_AMD_QUAD_POINTS_MAX": "0", "FSS_AMD_TAIL_MINWORK": "1"}])
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
