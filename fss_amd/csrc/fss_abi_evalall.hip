@@ -336,6 +336,9 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   if (fused_ok(ctx, SCHEME, pl, 1)) {
     FusedArgs f{};
     f.a = a;
+#if FSS_DIAG_STAMPS
+    f.a.stamps = ctx->diag_stamps;  // kFusedStampSlots x 4096 waves fit the context's stamp buffer
+#endif
     const int grid = fused_grid(ctx, (int64_t)1 << (pl.top - pl.tail));
     fused_slices(pl, 1, grid, bufn, bufv, &f);
     if (f.wg_cap[0] * grid <= pl.cap_a && f.wg_cap[1] * grid <= pl.cap_b) {

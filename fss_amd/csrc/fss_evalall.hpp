@@ -578,6 +578,7 @@ __global__ __launch_bounds__(BS) void expand_kernel(const DevCtx K, const uint32
 // no drain / ramp between the stages of a plan (2^25-leaf block: four launches of 25 + 12 + 42 + 585 us become one;
 // the thin stages were 12 % of the time for 6 % of the blocks).  The nodes a workgroup reads back were written by its
 // own CU, so they also come from its own XCD's L2.
+constexpr int kFusedStampSlots = 16;  // FSS_DIAG_STAMPS builds: stamps per wave of evalall_fused_kernel
 struct FusedArgs {
   ExpandArgs a;       // scheme, in_bits, party, group, prefix, ys; level0 / in / out are set per phase
   int p;              // depth of the block's root
@@ -625,9 +626,24 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
   constexpr int DM = SCHEME == S_DCF ? 1 : 2;  // levels a stage expands in registers
   const DevCtx* c = first_kernarg(K);
+#if FSS_DIAG_STAMPS
+  // per-wave phase stamps (s_memrealtime, 100 MHz): entry | tables filled | own walks done | then per stage {start
+  // (after the barrier), own chunks done}; tools/evalall_phases.py prints the table (kFusedStampSlots per wave)
+  uint64_t* const stamp_o = f.a.stamps ? f.a.stamps + (int64_t)kFusedStampSlots * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+  int stamp_k = 0;
+#define FSS_FUSED_STAMP()                                                                                          \
+  do {                                                                                                             \
+    if (stamp_o && (threadIdx.x & 63) == 0 && stamp_k < kFusedStampSlots) stamp_o[stamp_k] = __builtin_amdgcn_s_memrealtime(); \
+    ++stamp_k;                                                                                                     \
+  } while (0)
+#else
+#define FSS_FUSED_STAMP() do { } while (0)
+#endif
+  FSS_FUSED_STAMP();
   FSS_PROGRESS_PROLOGUE();
   FSS_WAVEQ_PROLOGUE();
   FSS_PRG_PROLOGUE(LT, te0);
+  FSS_FUSED_STAMP();
   const Grp g = make_grp(f.a.group, c);
   uint32_t* const prog = f.rank ? wave_prog_ : nullptr;
   // this workgroup's walks [w_lo, w_hi) of the 2^(top - tail) per key
@@ -645,12 +661,14 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     quad_frontier_walks<LT, WS, BATCH>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> 2), w_hi,
                                        blockDim.x >> 2);
   }
+  FSS_FUSED_STAMP();
   int cur = 0;
   for (int s = 0; s < f.nmid; ++s) {  // ---- intermediate stages: mine[cur] -> mine[cur ^ 1]
     __syncthreads();  // the nodes of the phase before are in place (same CU: same L1), the chunk counter is idle
     if (threadIdx.x == 0) waveq_ctr_ = 0;
     if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0;
     __syncthreads();
+    FSS_FUSED_STAMP();
     const int t = f.mid_t[s];
     a.level0 = level;
     a.in_nodes = mine[cur] - lo;
@@ -663,11 +681,13 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     else run_stage<LT, SCHEME, DM, false, 3 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
     lo <<= t; hi <<= t; level += t;
     cur ^= 1;
+    FSS_FUSED_STAMP();
   }
   __syncthreads();
   if (threadIdx.x == 0) waveq_ctr_ = 0;
   if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0;
   __syncthreads();
+  FSS_FUSED_STAMP();
   {  // ---- leaf stage: mine[cur] -> ys
     a.level0 = level;
     a.in_nodes = mine[cur] - lo;
@@ -675,6 +695,8 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     LocalQ q(&waveq_ctr_, lo, hi, f.rank != 0);
     run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
   }
+  FSS_FUSED_STAMP();
+#undef FSS_FUSED_STAMP
 }
 
 #ifndef FSS_EVALALL_TEMPLATES_ONLY  // the plain (non-template) kernels below belong to one unit: fss_abi_evalall.hip
