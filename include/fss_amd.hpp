@@ -393,7 +393,7 @@ template <int mul>
 class Aes128Mmo {
   static_assert(mul == 1 || mul == 2 || mul == 4);
   thread::AesSchedules<mul, false> ks_;  // raw keys + round keys (little-endian words), for Gen called on the device
-  mutable bool wave_tables_ready_ = false;  // device: has this thread's wave filled its LDS copy of the tables?
+  mutable bool wave_tables_ready_ = false;  // device: this thread has seen its wave's LDS copy of the tables filled (WaveTables)
 
   __host__ __device__ void SetKeys(const unsigned char* const* keys) {
     ks_.Set(keys, [](uint32_t b) { return static_cast<uint32_t>(thread::kAes.sbox[b]); });

@@ -175,14 +175,15 @@ struct AesKeySelect {
   __host__ __device__ uint32_t W(int r, int j) const { return a[4 * r + j] ^ (mask & d[4 * r + j]); }
 };
 
-// Key schedule in state word order from 16 key bytes (FIPS-197 5.2), S-box lookups through `S`.
+// Key schedule in state word order (FIPS-197 5.2) from the key as four little-endian words, S-box lookups through `S`.
+// Straight-line code (every index a constant): the 44 words stay in registers.
 template <bool BE, typename SboxFn>
-__host__ __device__ inline void AesExpandKeyWords(const unsigned char key[16], uint32_t rk[44], SboxFn S) {
+__host__ __device__ inline void AesExpandKeyFromWords(const uint32_t kw[4], uint32_t rk[44], SboxFn S) {
   uint32_t w[44];  // little-endian words while expanding
-  for (int i = 0; i < 4; ++i)
-    w[i] = static_cast<uint32_t>(key[4 * i]) | static_cast<uint32_t>(key[4 * i + 1]) << 8 |
-           static_cast<uint32_t>(key[4 * i + 2]) << 16 | static_cast<uint32_t>(key[4 * i + 3]) << 24;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = kw[i];
   uint32_t rcon = 1;
+#pragma unroll
   for (int i = 4; i < 44; ++i) {
     uint32_t t = w[i - 1];
     if (i % 4 == 0) {
@@ -193,7 +194,17 @@ __host__ __device__ inline void AesExpandKeyWords(const unsigned char key[16], u
     }
     w[i] = w[i - 4] ^ t;
   }
+#pragma unroll
   for (int i = 0; i < 44; ++i) rk[i] = BE ? ByteSwap(w[i]) : w[i];
+}
+// ... from 16 key bytes
+template <bool BE, typename SboxFn>
+__host__ __device__ inline void AesExpandKeyWords(const unsigned char key[16], uint32_t rk[44], SboxFn S) {
+  uint32_t kw[4];
+  for (int i = 0; i < 4; ++i)
+    kw[i] = static_cast<uint32_t>(key[4 * i]) | static_cast<uint32_t>(key[4 * i + 1]) << 8 |
+            static_cast<uint32_t>(key[4 * i + 2]) << 16 | static_cast<uint32_t>(key[4 * i + 3]) << 24;
+  AesExpandKeyFromWords<BE>(kw, rk, S);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -216,19 +227,38 @@ __device__ inline bool SameInAllLanes(const uint32_t* w, int n) {
   return __ballot(diff != 0) == 0;
 }
 
+// 64 bits that differ from launch to launch (the address of this launch's AQL packet, of its kernel arguments and its
+// completion signal, folded): LDS is not cleared between kernels, so a marker left behind by an earlier kernel must not
+// pass for this launch's.
+__device__ inline void LaunchNonce(uint32_t n[2]) {
+  const uint64_t* pkt = reinterpret_cast<const uint64_t*>(__builtin_amdgcn_dispatch_ptr());
+  const uint64_t v = reinterpret_cast<uint64_t>(pkt) * 0x9e3779b97f4a7c15ull ^ pkt[5] * 0xc2b2ae3d27d4eb4full ^ pkt[7];  // kernarg_address, completion_signal
+  n[0] = Uniform(static_cast<uint32_t>(v));
+  n[1] = Uniform(static_cast<uint32_t>(v >> 32));
+}
+
 // fss::prg::Aes128Mmo on the device has no table arguments (the reference's class is host-only, aes128_mmo.cuh:75-77):
-// every wave keeps a private copy of Te0 and the S-box in LDS -- 1 280 B per wave, 20 KiB for the largest workgroup --
+// every wave keeps a private copy of Te0 and the S-box in LDS -- 1 296 B per wave, 20 KiB for the largest workgroup --
 // filled by the lanes that make the wave's first call (no workgroup barrier: a kernel may call Gen from divergent
-// code, after some of its threads have returned).  `ready` is the caller's per-thread flag; lanes that arrive later
-// than their wave's first call fill the same values again, which is harmless.
+// code, after some of its threads have returned).  `ready` is the caller's per-thread flag: a thread's first call always
+// fills (nothing is assumed about what the LDS held before).  The copy also carries a 16-byte marker, written after the
+// tables and bound to this launch, and every call checks it: a PRG object that reaches a wave through memory with its
+// flag already set by another wave (a __shared__ or global scheme, a pointer handed between waves -- the object is
+// meant to be a per-thread value) still finds this wave's copy missing and fills it.
 struct WaveAesTables {
   uint32_t te0[256];
   uint8_t sbox[256];
+  uint32_t marker[4];
 };
 __device__ inline LdsTables WaveTables(bool& ready) {
-  __shared__ WaveAesTables tabs[16];
+  __shared__ __attribute__((aligned(16))) WaveAesTables tabs[16];
   WaveAesTables* mine = &tabs[(LinearTid() >> 6) & 15];
-  if (!ready) {
+  uint32_t nonce[2];
+  LaunchNonce(nonce);
+  const uint32_t want[4] = {0x66737361u, 0x6d645f74u, nonce[0], nonce[1]};
+  const bool missing = !ready || ((mine->marker[0] ^ want[0]) | (mine->marker[1] ^ want[1]) | (mine->marker[2] ^ want[2]) |
+                                  (mine->marker[3] ^ want[3])) != 0;
+  if (__ballot(missing) != 0) {
     const uint64_t act = __ballot(1);
     const int cnt = __popcll(act);
     const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(act >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(act), 0u));
@@ -236,12 +266,42 @@ __device__ inline LdsTables WaveTables(bool& ready) {
       mine->te0[i] = kAes.te0[i];
       mine->sbox[i] = kAes.sbox[i];
     }
+    WaveLdsSync();  // the tables first, then the marker that says they are there
+    mine->marker[0] = want[0]; mine->marker[1] = want[1]; mine->marker[2] = want[2]; mine->marker[3] = want[3];  // every active lane, the same values
     WaveLdsSync();
-    ready = true;
   }
+  ready = true;
   return LdsTables{(const __attribute__((address_space(3))) uint32_t*)(mine->te0),
                    (const __attribute__((address_space(3))) uint8_t*)(mine->sbox)};
 }
+
+// The LDS home of a four-key PRG's round keys (DCF: 4 x 44 words).  176 wave-uniform words do not fit the scalar
+// register file next to a walk's own state -- the compiler would park them in VGPR lanes and from there in scratch
+// (1 KiB per lane, round 3) -- so every wave keeps ONE copy in LDS and the cipher reads the eight words a round needs
+// from there: every lane reads the same address, which the LDS serves as a broadcast without bank conflicts.  The slot
+// is written when a thread constructs its PRG object on the device, or at the thread's first call for an object that
+// came from the host (`slot_ready` is the object's per-thread flag: nothing is assumed about what the LDS held before);
+// it carries a tag derived from the key bytes and this launch, checked by every call: a call that finds another tag
+// (the object reached this wave through memory with its flag set by another wave, or two key sets alternate in one
+// wave) re-derives the schedules from the object's key bytes and rewrites the slot.
+struct WaveKeySlot {
+  uint32_t tag[4];
+  uint32_t rk[4 * 44];  // the four schedules, key i at words 44 i .. 44 i + 43, state word order
+};
+__device__ inline WaveKeySlot* MyKeySlot() {
+  __shared__ __attribute__((aligned(16))) WaveKeySlot slots[16];
+  return &slots[(LinearTid() >> 6) & 15];
+}
+using LdsWords = const __attribute__((address_space(3))) uint32_t*;
+struct LdsKeyWords {
+  LdsWords rk;
+  __device__ uint32_t W(int r, int j) const { return rk[4 * r + j]; }
+};
+struct LdsKeySelect {  // per lane: schedule b where mask is ~0, schedule a where it is 0 (one v_bfi per word)
+  LdsWords a, b;
+  uint32_t mask;
+  __device__ uint32_t W(int r, int j) const { return (mask & b[4 * r + j]) | (~mask & a[4 * r + j]); }
+};
 #endif
 
 // The round keys of a PRG object with `mul` AES keys, as the per-thread cipher wants them.
@@ -256,9 +316,25 @@ struct AesSchedules {
   uint32_t keyw[mul][4];  // the raw keys, little-endian words (per lane)
   uint32_t rk[mul][44];   // A / D layout above, state word order
   bool uniform;
+  mutable bool slot_ready = false;  // mul = 4 on the device: this thread has seen its wave's LDS copy of the schedules filled
 
   template <typename SboxFn>
   __host__ __device__ void Set(const unsigned char* const* keys, SboxFn S) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (mul == 4) {
+      // four schedules: they live in the wave's LDS slot (WaveKeySlot), never in this object's registers
+      for (int i = 0; i < mul; ++i)
+        for (int j = 0; j < 4; ++j)
+          keyw[i][j] = static_cast<uint32_t>(keys[i][4 * j]) | static_cast<uint32_t>(keys[i][4 * j + 1]) << 8 |
+                       static_cast<uint32_t>(keys[i][4 * j + 2]) << 16 | static_cast<uint32_t>(keys[i][4 * j + 3]) << 24;
+      uniform = SameInAllLanes(&keyw[0][0], 4 * mul);
+      if (uniform) {
+        FillSlot(S);
+        slot_ready = true;
+      }
+      return;
+    }
+#endif
     uint32_t full[mul][44];
     for (int i = 0; i < mul; ++i) {
       for (int j = 0; j < 4; ++j)
@@ -282,6 +358,50 @@ struct AesSchedules {
       for (int w = 0; w < 44; ++w) rk[i][w] = Uniform(rk[i][w]);  // scalar registers (lane 0's when not uniform: unused then)
 #endif
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // ---- mul = 4 on the device: the wave's LDS copy of the schedules
+  __device__ void Tag(uint32_t t[4]) const {  // 128 bits of the key bytes (and the word order the slot is written in)
+    uint32_t nonce[2];
+    LaunchNonce(nonce);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      t[j] = keyw[0][j] ^ RotL(keyw[mul > 1 ? 1 : 0][j], 7) ^ RotL(keyw[mul > 2 ? 2 : 0][j], 13) ^ RotL(keyw[mul > 3 ? 3 : 0][j], 19) ^
+             (BE ? 0x9e3779b9u : 0u) ^ nonce[j & 1];
+  }
+  // Expand the four keys one after the other (44 words live at a time) into this wave's slot; every active lane
+  // writes the same values.  S: the S-box the expansion looks up through.
+  template <typename SboxFn>
+  __device__ void FillSlot(SboxFn S) const {
+    WaveKeySlot* s = MyKeySlot();
+    WaveLdsSync();  // the wave's earlier reads of the slot are done
+#pragma unroll 1  // one expansion at a time: 44 words live, not 176
+    for (int i = 0; i < 4; ++i) {
+      uint32_t kw[4], w[44];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)  // keyw[i] by selects, not by a runtime index (that would put the array on the stack)
+        kw[j] = i == 0 ? keyw[0][j] : (i == 1 ? keyw[1][j] : (i == 2 ? keyw[2][j] : keyw[3][j]));
+      AesExpandKeyFromWords<BE>(kw, w, S);
+#pragma unroll
+      for (int q = 0; q < 44; ++q) s->rk[44 * i + q] = w[q];
+    }
+    uint32_t t[4];
+    Tag(t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s->tag[j] = t[j];
+    WaveLdsSync();
+  }
+  // This wave's copy of the schedules, re-derived from the key bytes first if the slot holds something else.
+  template <typename Tab>
+  __device__ LdsWords SlotKeys(const Tab& tab) const {
+    WaveKeySlot* s = MyKeySlot();
+    uint32_t t[4];
+    Tag(t);
+    const bool stale = !slot_ready || ((s->tag[0] ^ t[0]) | (s->tag[1] ^ t[1]) | (s->tag[2] ^ t[2]) | (s->tag[3] ^ t[3])) != 0;
+    if (__ballot(stale) != 0) FillSlot([&tab](uint32_t b) { return tab.S(b); });
+    slot_ready = true;
+    return (LdsWords)(s->rk);
+  }
+#endif
   __host__ __device__ void KeyBytes(int i, unsigned char out[16]) const {
     for (int j = 0; j < 16; ++j) out[j] = static_cast<unsigned char>(keyw[i][j >> 2] >> (8 * (j & 3)));
   }
@@ -309,6 +429,17 @@ struct AesSchedules {
     uint32_t in[4], o[4];
     Words(seed, in);
     if (uniform) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (mul == 4) {
+        const LdsWords k = SlotKeys(tab);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          AesEncrypt<BE>(tab, LdsKeyWords{k + 44 * i}, in, o);
+          out[i] = Mmo(o, seed);
+        }
+        return out;
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < mul; ++i) {
         const bool direct = mul == 1 || i == 0 || (mul == 4 && i == 1);
@@ -317,8 +448,10 @@ struct AesSchedules {
         out[i] = Mmo(o, seed);
       }
     } else {
+#pragma unroll
       for (int i = 0; i < mul; ++i) {
-        AesEncrypt<BE>(tab, AesKeyWords{PerLane(tab, i).w}, in, o);
+        const Expanded e = PerLane(tab, keyw[i]);
+        AesEncrypt<BE>(tab, AesKeyWords{e.w}, in, o);
         out[i] = Mmo(o, seed);
       }
     }
@@ -334,14 +467,30 @@ struct AesSchedules {
     Words(seed, in);
     if (uniform) {
       const uint32_t mask = right ? ~0u : 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if constexpr (mul == 4) {
+        const LdsWords k = SlotKeys(tab);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          AesEncrypt<BE>(tab, LdsKeySelect{k + 44 * i, k + 44 * (2 + i), mask}, in, o);  // [sl, vl | sr, vr]: keys i and 2 + i
+          out[i] = Mmo(o, seed);
+        }
+        return out;
+      }
+#endif
 #pragma unroll
       for (int i = 0; i < half; ++i) {
         AesEncrypt<BE>(tab, AesKeySelect{rk[i], rk[half + i], mask}, in, o);
         out[i] = Mmo(o, seed);
       }
     } else {
+#pragma unroll
       for (int i = 0; i < half; ++i) {
-        AesEncrypt<BE>(tab, AesKeyWords{PerLane(tab, (right ? half : 0) + i).w}, in, o);
+        uint32_t kw[4];  // this lane's own key for output i of its side (constant indices: no stack array)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kw[j] = right ? keyw[half + i][j] : keyw[i][j];
+        const Expanded e = PerLane(tab, kw);
+        AesEncrypt<BE>(tab, AesKeyWords{e.w}, in, o);
         out[i] = Mmo(o, seed);
       }
     }
@@ -353,11 +502,9 @@ struct AesSchedules {
     uint32_t w[44];
   };
   template <typename Tab>
-  __host__ __device__ Expanded PerLane(const Tab& tab, int i) const {  // this lane's own key i, expanded for one call
-    unsigned char kb[16];
-    KeyBytes(i, kb);
+  __host__ __device__ static Expanded PerLane(const Tab& tab, const uint32_t kw[4]) {  // a lane's own key, expanded for one call
     Expanded e;
-    AesExpandKeyWords<BE>(kb, e.w, [&tab](uint32_t b) { return tab.S(b); });
+    AesExpandKeyFromWords<BE>(kw, e.w, [&tab](uint32_t b) { return tab.S(b); });
     return e;
   }
 };
@@ -510,25 +657,30 @@ __device__ inline void DcfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
   Group acc;  // zero
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
-    const std::array<int4, 4> g[2] = {prg.Gen(seed[0]), prg.Gen(seed[1])};
-    const int keep = BitAt(a, in_bits - 1 - i), lose = 1 - keep;
-    const int4 s_cw = X4(WithCtl(g[0][2 * lose], false), WithCtl(g[1][2 * lose], false));
-    auto val = [&g](int party, int side) { return Group::From(WithCtl(g[party][2 * side + 1], false)); };
+    const std::array<int4, 4> g0 = prg.Gen(seed[0]), g1 = prg.Gen(seed[1]);
+    const bool keep = BitAt(a, in_bits - 1 - i);  // the side ON the path; the other one is lost
+    // [sl, vl, sr, vr] of each party, sorted into the kept and the lost side by selects (a runtime index into the
+    // PRG's output array would put it on the stack)
+    const int4 ks[2] = {keep ? g0[2] : g0[0], keep ? g1[2] : g1[0]}, kv[2] = {keep ? g0[3] : g0[1], keep ? g1[3] : g1[1]};
+    const int4 ls[2] = {keep ? g0[0] : g0[2], keep ? g1[0] : g1[2]}, lv[2] = {keep ? g0[1] : g0[3], keep ? g1[1] : g1[3]};
+    const int4 s_cw = X4(WithCtl(ls[0], false), WithCtl(ls[1], false));
+    auto val = [](int4 v) { return Group::From(WithCtl(v, false)); };
     // the value word: everything accumulated so far is cancelled off the path, and beta is released there when the
     // off-path side is the side the predicate selects (x < alpha lies left of a 1 bit; x > alpha right of a 0 bit)
-    Group v_cw = -acc + val(1, lose) + (-val(0, lose));
-    if (gt ? lose == 1 : lose == 0) v_cw = v_cw + gbeta;
+    Group v_cw = -acc + val(lv[1]) + (-val(lv[0]));
+    if (gt ? !keep : keep) v_cw = v_cw + gbeta;
     if (t[1]) v_cw = -v_cw;
-    acc = acc + (-val(1, keep)) + val(0, keep);
+    acc = acc + (-val(kv[1])) + val(kv[0]);
     acc = t[1] ? acc + (-v_cw) : acc + v_cw;
-    const bool t_cw[2] = {static_cast<bool>(Ctl(g[0][0]) ^ Ctl(g[1][0]) ^ keep ^ 1),
-                          static_cast<bool>(Ctl(g[0][2]) ^ Ctl(g[1][2]) ^ keep)};
+    const bool t_cw[2] = {static_cast<bool>(Ctl(g0[0]) ^ Ctl(g1[0]) ^ keep ^ 1), static_cast<bool>(Ctl(g0[2]) ^ Ctl(g1[2]) ^ keep)};
+    const bool t_keep = keep ? t_cw[1] : t_cw[0];
+#pragma unroll
     for (int p = 0; p < 2; ++p) {
-      int4 s = WithCtl(g[p][2 * keep], false);
-      bool ct = Ctl(g[p][2 * keep]);
+      int4 s = WithCtl(ks[p], false);
+      bool ct = Ctl(ks[p]);
       if (t[p]) {
         s = X4(s, s_cw);
-        ct ^= t_cw[keep];
+        ct ^= t_keep;
       }
       seed[p] = s;
       t[p] = ct;

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "fss_amd.hpp"
@@ -401,6 +402,21 @@ __global__ void HtEvalKeysKernel(S sch, int4* ys, bool party, const int4* seeds,
   ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, ocws[tid], xs[tid]);
 }
 
+// the scheme reached through a pointer that all waves of the workgroup share (a __shared__ copy made by thread 0): the
+// per-wave LDS copies of the AES tables and of a four-key PRG's round keys must be found missing -- and filled -- by
+// every wave that arrives, whoever constructed or first used the object
+template <typename S, typename In>
+__global__ void EvalThroughSharedPointerKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws,
+                                               const In* xs, int n) {
+  __shared__ alignas(16) unsigned char raw[sizeof(S)];
+  if (threadIdx.x == 0) new (raw) S(sch);
+  __syncthreads();
+  const S* shared = reinterpret_cast<const S*>(raw);
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = shared->Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
+}
+
 static void Batches() {
   const int before = g_fail;
   constexpr int kN = 4096;
@@ -456,6 +472,14 @@ static void Batches() {
     fss::gpu::DcfEvalPointGpu<4>(false, d_seeds0, cw_s, cw_v, out_cw, d_xs, d_ye, kN, dcf);
     HIP_OK(hipDeviceSynchronize());
     auto ye = ToHost(d_ye, kN);
+    bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys0[i]);
+    EXPECT(bad == 0);
+    // the same evaluations with the scheme shared between the four waves of a workgroup through a pointer
+    HIP_OK(hipMemset(d_ye, 0xff, sizeof(int4) * kN));
+    EvalThroughSharedPointerKernel<Dcf, uint32_t><<<kN / 256, 256>>>(dcf, d_ye, false, d_seeds0, d_cws, d_xs, kN);
+    HIP_OK(hipDeviceSynchronize());
+    ye = ToHost(d_ye, kN);
     bad = 0;
     for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys0[i]);
     EXPECT(bad == 0);
@@ -637,6 +661,45 @@ static void Timing() {
   std::printf("     (DPF n=32, 2^18 keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
               "DpfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n",
               ms_thread, kN / ms_thread / 1e3, ms_engine, kN / ms_engine / 1e3, bad ? "NO" : "yes");
+  // the DPF scheme through a pointer shared by the waves of a workgroup (per-wave table copies found missing and filled)
+  HIP_OK(hipMemset(d_yt, 0xff, sizeof(int4) * kN));
+  EvalThroughSharedPointerKernel<Dpf, uint32_t><<<kN / 256, 256>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN);
+  HIP_OK(hipDeviceSynchronize());
+  yt = ToHost(d_yt, kN);
+  bad = 0;
+  for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+  EXPECT(bad == 0);
+  {  // DCF n=32 (four AES keys: the round keys live in the wave's LDS slot, no scratch), same batch size
+    using PrgD = fss::prg::Aes128Mmo<4>;
+    using Dcf = fss::Dcf<32, G, PrgD, uint32_t>;
+    const unsigned char* keys4[4] = {k0, k1, k2, k3};
+    Dcf dcf{PrgD(keys4)};
+    Dcf::Cw* d_dc = DeviceBuf<Dcf::Cw>(size_t(33) * kN);
+    int4* cw_v = DeviceBuf<int4>(size_t(32) * kN);
+    dcf.GenBatch(d_dc, d_seeds, d_alphas, d_betas, kN);
+    fss::gpu::DcfRelayoutGpu<32, G, PrgD, uint32_t>(d_dc, kN, cw_s, cw_v, out_cw);
+    float ms_t = 0, ms_e = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      HIP_OK(hipEventRecord(e0));
+      EvalKeysKernel<Dcf, uint32_t><<<kN / 256, 256>>>(dcf, d_yt, false, d_seeds0, d_dc, d_xs, kN);
+      HIP_OK(hipEventRecord(e1));
+      HIP_OK(hipEventSynchronize(e1));
+      HIP_OK(hipEventElapsedTime(&ms_t, e0, e1));
+      HIP_OK(hipEventRecord(e0));
+      fss::gpu::DcfEvalPointGpu<4>(false, d_seeds0, cw_s, cw_v, out_cw, d_xs, d_ye, kN, dcf);
+      HIP_OK(hipEventRecord(e1));
+      HIP_OK(hipEventSynchronize(e1));
+      HIP_OK(hipEventElapsedTime(&ms_e, e0, e1));
+    }
+    auto dt = ToHost(d_yt, kN), de = ToHost(d_ye, kN);
+    int badd = 0;
+    for (int i = 0; i < kN; ++i) badd += !Same(dt[i], de[i]);
+    EXPECT(badd == 0);
+    std::printf("     (DCF n=32, 2^18 keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+                "DcfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n",
+                ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, badd ? "NO" : "yes");
+    HIP_OK(hipFree(d_dc)); HIP_OK(hipFree(cw_v));
+  }
 }
 }  // namespace p2
 
