@@ -47,10 +47,13 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <span>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 
@@ -217,7 +220,18 @@ struct Registry {
   std::mutex mu;
   std::map<std::string, fss_amd_ctx*> ctxs;
   std::mutex stage_mu;  // the host-buffer methods share one staging area per context: one at a time
-  std::mutex launch_mu;  // the asynchronous launchers enqueue "small arguments, then the kernel" as one unit
+  // The asynchronous launchers enqueue "small arguments, then the kernel" as one unit PER (context, stream): launches on
+  // different streams (or contexts) never wait for each other -- not even while one of them grows its workspace, which
+  // waits for the device.  The per-thread streams behind hipStreamPerThread are different streams (keyed by thread).
+  std::mutex launch_map_mu;
+  std::map<std::tuple<fss_amd_ctx*, hipStream_t, std::thread::id>, std::unique_ptr<std::mutex>> launch_mus;
+  std::mutex& LaunchMutex(fss_amd_ctx* ctx, hipStream_t stream) {
+    const std::thread::id tid = stream == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id();
+    std::lock_guard<std::mutex> lk(launch_map_mu);
+    auto& m = launch_mus[std::make_tuple(ctx, stream, tid)];
+    if (!m) m = std::make_unique<std::mutex>();
+    return *m;
+  }
 };
 inline Registry& Reg() {
   static Registry* r = new Registry;  // never destroyed: contexts must not outlive the HIP runtime's own teardown
@@ -250,13 +264,20 @@ inline void ReleaseEngines() {
   std::lock_guard<std::mutex> lk(r.mu);
   for (auto& kv : r.ctxs) fss_amd_ctx_destroy(kv.second);
   r.ctxs.clear();
+  std::lock_guard<std::mutex> lm(r.launch_map_mu);
+  r.launch_mus.clear();  // no launcher may be running on a context that is being destroyed
 }
 // Free the scratch the asynchronous launchers keep for `stream` (every context); call before destroying the stream.
 // Waits for the device (hipFree).
 inline void ReleaseStreamScratch(hipStream_t stream) {
   Registry& r = Reg();
   std::lock_guard<std::mutex> lk(r.mu);
-  for (auto& kv : r.ctxs) Check(fss_amd_ctx_scratch_release(kv.second, stream), "fss_amd_ctx_scratch_release");
+  for (auto& kv : r.ctxs) {
+    // the (context, stream) launch lock: no launcher of another thread sits between "small arguments" and "kernel" on
+    // this stream while its buffer goes away
+    std::lock_guard<std::mutex> launch(r.LaunchMutex(kv.second, stream));
+    Check(fss_amd_ctx_scratch_release(kv.second, stream), "fss_amd_ctx_scratch_release");
+  }
 }
 
 template <typename In>
@@ -351,14 +372,14 @@ class Stage {
 };
 
 // Scratch of (ctx, stream) for the asynchronous launchers: [0, 256) small by-value arguments, then the workspace.
-// One buffer per stream (per thread for hipStreamPerThread).  A launcher holds launch_mu from taking the buffer until
-// its kernel is enqueued, so two host threads launching on the same stream (the default stream = 0 in particular)
+// One buffer per stream (per thread for hipStreamPerThread).  A launcher holds the (context, stream) launch lock from
+// taking the buffer until its kernel is enqueued, so two host threads launching on the same stream (the default stream = 0 in particular)
 // enqueue "upload, kernel" pairs whole: stream order then keeps one call's small arguments and workspace intact until
 // its kernel has read them.
 struct Scratch {
   std::lock_guard<std::mutex> lock_;
   char* base;
-  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) : lock_(Reg().launch_mu) {
+  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) : lock_(Reg().LaunchMutex(ctx, stream)) {
     void* p = nullptr;
     Check(fss_amd_ctx_scratch(ctx, stream, ws_bytes + 256, &p), "fss_amd_ctx_scratch");
     base = static_cast<char*>(p);

@@ -3,7 +3,7 @@
 # for its end) against the pure forms, diagnostic library with stamps, interleaved.
 export FSS_AMD_TUNE=1
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"
-O="$R/gpurun_out/exp_r3"; mkdir -p "$O"
+O="$R/gpurun_out/exp"; mkdir -p "$O"
 kc() {
   local out="$1" tag="$2"; shift 2
   local envs=()
