@@ -108,7 +108,8 @@ RECORDS = {
     "e2e_pcie": "the headline batch with x read from and y written to pinned host memory (4 B up + 16 B down per evaluation); "
                 "the PCIe-inclusive rate SURVEY 8(d) asks to state separately, never `value`",
     "c1_cpu": "BASELINE configs[0]: DPF kInBits=8, 1 key, 256-leaf EvalAll, Bytes (samples/dpf_dcf_cpu.cu constants); the CPU-runnable "
-              "case: v = GPU leaves/s, cpu* = the oracle, EVP contexts built once outside the repetitions",
+              "case: v = GPU leaves/s; cpu = the oracle's better shape (all threads in the reference's task recursion -- cpu_us -- or one "
+              "thread sequentially -- cpu1_us; a 16-thread team costs more than a 256-leaf tree), EVP contexts built once outside the repetitions",
 }
 TOP = {
     "roofline": "headline kernel against the LDS roof: achieved = 2^B x 32 AES x 640 B / kernel_ms; traffic = PMC HBM bytes per launch "
@@ -631,7 +632,8 @@ def c1_cpu_record(eng, threads):
     sd, cd = torch.from_numpy(seeds[0]).cuda(), torch.from_numpy(cws).cuda()
     yg = torch.empty((1 << n, 4), dtype=torch.int32, device="cuda")
     _, gms = time_steady(lambda: eng.eval_all(fss_amd.DPF, n, fss_amd.BYTES, 0, sd, cd, out=yg), steps=50, min_ms=50.0, warm_ms=20.0)
-    return {"value": 256 / (gms * 1e-3), "unit": "leaves/s", "us": gms * 1e3, "cpu": reps * 256 / dt, "cpu1": reps * 256 / dt1,
+    # `cpu` = the better of the two shapes: on a 256-leaf tree a 16-thread OpenMP team costs more than it computes
+    return {"value": 256 / (gms * 1e-3), "unit": "leaves/s", "us": gms * 1e3, "cpu": max(reps * 256 / dt, reps * 256 / dt1), "cpu1": reps * 256 / dt1,
             "cpu_us": dt / reps * 1e6, "cpu1_us": dt1 / reps * 1e6, "kat": bool(ok_kat), "ok": bool(ok_gpu and ok_kat)}
 
 

@@ -8,7 +8,7 @@
 # headline's, the format of rounds 1-2) and kernel_stats_by_workload.txt.  Copy the summaries to profiles/r<N>/.
 # usage: tools/profile_workloads.sh <tag>
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-TAG="${1:-r3}"
+TAG="${1:-r4}"
 OUT="$R/gpurun_out/prof_$TAG"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
