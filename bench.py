@@ -69,8 +69,9 @@ KEYS = {
     "cpu": "the oracle (OpenSSL EVP PRG in the reference's call pattern) on all usable host cores, units/s",
     "cpu1": "the same on one thread",
     "serial": "e2e_pcie: evals/s with H2D of x, the walk and D2H of y one after the other on one stream",
-    "pipe": "e2e_pcie: evals/s of the pipelined host-buffer path (fss_amd_dpf_eval_points_host)",
-    "gbs": "e2e_pcie: bytes over PCIe per second of the pipelined path (4 B up + 16 B down per evaluation), GB/s",
+    "pipe": "e2e_pcie: evals/s of the host-buffer entry point fss_amd_eval_points_host: ONE launch whose walk reads x from and "
+            "writes y to the pinned host buffers across PCIe (no staging copies)",
+    "gbs": "e2e_pcie: bytes over PCIe per second of `pipe` (4 B up + 16 B down per evaluation), GB/s",
     "same": "outputs bit-identical to the resident-input run of the same batch",
     "us": "c1_cpu: GPU microseconds per 256-leaf EvalAll",
     "cpu_us": "c1_cpu: oracle microseconds per EvalAll on all threads",
@@ -541,7 +542,8 @@ def _small_batch_record(eng, scheme, log2_points, with_cpu):
 
 def _e2e_pcie_record(eng, log2_batch):
     """The PCIe-inclusive rate SURVEY 8(d) asks to state separately (never `value`): x from and y back to pinned host
-    memory around the headline kernel -- serial on one stream, and through the library's pipelined host-buffer path."""
+    memory around the headline kernel -- copy, launch, copy on one stream (`serial`), and the library's host-buffer entry
+    point (`pipe`: fss_amd_eval_points_host, one zero-copy launch; profiles/r4/e2e_trace.txt)."""
     import fss_amd
     G, n, N = fss_amd.U64, 32, 1 << log2_batch
     sid, s0s, cws, _, _, _ = make_key(eng, "dpf", n, G, 0x5EED0002)
@@ -556,26 +558,8 @@ def _e2e_pcie_record(eng, log2_batch):
         eng.eval_points(sid, n, G, 0, sd, cd, xs_d, out=ys_d)
         ys_h.copy_(ys_d, non_blocking=True)
 
-    s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
-    chunks = 16
-
-    def pipelined():
-        if hasattr(eng, "eval_points_host"):
-            return eng.eval_points_host(sid, n, G, 0, sd, cd, xs_h, out=ys_h)
-        c_sz = N // chunks   # three in-order queues (H2D | walk | D2H) chained by events
-        for c in range(chunks):
-            sl = slice(c * c_sz, (c + 1) * c_sz)
-            e_in, e_k = torch.cuda.Event(), torch.cuda.Event()
-            with torch.cuda.stream(s_in):
-                xs_d[sl].copy_(xs_h[sl], non_blocking=True)
-                e_in.record()
-            with torch.cuda.stream(s_k):
-                s_k.wait_event(e_in)
-                eng.eval_points(sid, n, G, 0, sd, cd, xs_d[sl], out=ys_d[sl])
-                e_k.record()
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(e_k)
-                ys_h[sl].copy_(ys_d[sl], non_blocking=True)
+    def pipelined():  # one launch: the walk reads x from and writes y to the pinned buffers across PCIe itself
+        eng.eval_points_host(sid, n, G, 0, sd, cd, xs_h, out=ys_h)
 
     out = {"unit": "evals/s"}
     reps = 5

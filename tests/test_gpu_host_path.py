@@ -64,6 +64,27 @@ def test_host_batch_equals_resident_batch(engine, O, scheme, in_bits, n_points):
     assert (got0[:m].numpy() == ref).all()
 
 
+def test_views_into_pinned_buffers(engine):
+    """Interior pointers: a batch that starts in the middle of a pinned allocation (a slice of a larger pinned tensor, for
+    x and for y) is walked in place like one that starts at its base."""
+    import fss_amd
+    n, off = 70001, 12345
+    gen = torch.Generator().manual_seed(99)
+    s0s = torch.randint(-2**31, 2**31, (1, 2, 4), dtype=torch.int32, generator=gen)
+    cws, _ = engine.gen(fss_amd.DPF, 32, fss_amd.U64, s0s, torch.tensor([123456789], dtype=torch.int32),
+                        torch.randint(-2**31, 2**31, (1, 4), dtype=torch.int32, generator=gen))
+    big_x = torch.randint(-2**31, 2**31, (off + n + 77,), dtype=torch.int32, generator=gen).pin_memory()
+    big_y = torch.full((off + n + 5, 4), -1, dtype=torch.int32).pin_memory()
+    xs, out = big_x[off:off + n], big_y[off:off + n]
+    assert xs.is_pinned() and out.is_pinned() and xs.data_ptr() != big_x.data_ptr()
+    sd = s0s[0, 0].cuda()
+    engine.eval_points_host(fss_amd.DPF, 32, fss_amd.U64, 0, sd, cws[0], xs, out=out)
+    torch.cuda.synchronize()
+    want = engine.eval_points(fss_amd.DPF, 32, fss_amd.U64, 0, sd, cws[0], xs.cuda()).cpu()
+    assert bool((out == want).all())
+    assert bool((big_y[:off] == -1).all()) and bool((big_y[off + n:] == -1).all())   # nothing outside the view
+
+
 def test_pageable_memory_is_refused(engine):
     import fss_amd
     z = torch.zeros((64,), dtype=torch.int32)
