@@ -554,6 +554,13 @@ struct WaveQ {
     cur = dyn ? fetch() : cur + (int64_t)gridDim.x * (blockDim.x >> 6);
     return true;
   }
+  // The chunk the NEXT call of next() will hand out (already claimed: `cur` is requested a chunk ahead), without
+  // claiming another one: lets a walk request that chunk's inputs before it starts on the current chunk.
+  __device__ __forceinline__ bool peek(int64_t& unit0) const {
+    if (cur >= nchunks) return false;
+    unit0 = cur * per_chunk + (threadIdx.x & 63);
+    return true;
+  }
   // After the loop, every wave of the launch (a workgroup barrier inside): hand the launch-wide counter back zeroed.
   // One count per workgroup, not per wave: 4096 requests to one word at the end of a launch would take tens of
   // microseconds by themselves.

@@ -309,8 +309,17 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
 #if FSS_DIAG_STAMPS
   const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // one chunk: 64 * ILP consecutive evaluations from `base` on, ILP per lane
-  auto walk_chunk = [&](auto ilp_tag, const int64_t base) {
+  // the points of one chunk (64 * ILP consecutive evaluations from `base` on, ILP per lane)
+  auto load_chunk_x = [&](auto ilp_tag, const int64_t base, X128* xv) {
+    constexpr int ILP = decltype(ilp_tag)::value;
+#pragma unroll
+    for (int j = 0; j < ILP; ++j) {
+      const int64_t e = base + (int64_t)j * SJ;
+      xv[j] = load_x(a.xs, a.x_bytes, e < n ? e : n - 1);
+    }
+  };
+  // one chunk; its points arrive in xv (run_region)
+  auto walk_chunk = [&](auto ilp_tag, const int64_t base, const X128* xv) {
     constexpr int ILP = decltype(ilp_tag)::value;
     int64_t idx[ILP];
 #pragma unroll
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         uint32_t s0[4];
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
-        w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+        w[j].init(s0, party, xv[j]);
         if constexpr (PREFIX) {
           if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
         }
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         uint32_t s0[4];
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
-        w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+        w[j].init(s0, party, xv[j]);
         if constexpr (PREFIX) {
           if (lvl0 > 0) {
             const uint64_t q = (w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
         uint32_t s0[4];
         if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
         else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
-        w[j].init(s0, party, load_x(a.xs, a.x_bytes, idx[j]));
+        w[j].init(s0, party, xv[j]);
         if constexpr (PREFIX) {
           if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
         }
@@ -455,15 +464,42 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   };
   // two per lane over [0, n_body): this workgroup's chunks through its LDS counter (or the wave's fixed share) ...
   const int64_t n_body = ILPT == 2 ? a.n_body : 0;
+  // The chunks of one region.  The shared-key DPF walk requests each chunk's points a chunk ahead of their use
+  // (WaveQ::peek): +0.8-1.0 % at n = 16 / 32 / 64 x 2^24 points, +0.3 % at 2^20, three interleaved rounds on one box; the
+  // same form costs DCF, Half-Tree and every independent-key walk 0.2-0.4 % (their levels carry more live state), so
+  // those load their points when the chunk starts (profiles/r4/prefetch_x_ab.txt).
+  constexpr bool kAheadX = SCHEME == S_DPF && SHARED;
+  auto run_region = [&](auto ilp_tag, WaveQ& wq, const int64_t off) {
+    constexpr int ILP = decltype(ilp_tag)::value;
+    if constexpr (kAheadX) {
+      X128 xc[ILP], xn[ILP];
+      int64_t base, nb;
+      if (!wq.peek(base)) return;
+      load_chunk_x(ilp_tag, off + base, xc);
+      while (wq.next(base)) {
+        const bool more = wq.peek(nb);
+        if (more) load_chunk_x(ilp_tag, off + nb, xn);
+        walk_chunk(ilp_tag, off + base, xc);
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) xc[j] = xn[j];
+      }
+    } else {
+      for (int64_t base; wq.next(base);) {
+        X128 xc[ILP];
+        load_chunk_x(ilp_tag, off + base, xc);
+        walk_chunk(ilp_tag, off + base, xc);
+      }
+    }
+  };
   if constexpr (ILPT == 2) {
     WaveQ qb(a.dyn, &waveq_ctr_, n_body, 2, a.tail_on_body ? a.gq : nullptr, a.static_chunks);
-    for (int64_t base; qb.next(base);) walk_chunk(std::integral_constant<int, 2>{}, base);
+    run_region(std::integral_constant<int, 2>{}, qb, 0);
     qb.done();
   }
   // ... then one per lane over [n_body, n): the first static_chunks chunks per workgroup, the rest launch-wide
   WaveQ q(a.dyn, ILPT == 2 ? &waveq_ctr2_ : &waveq_ctr_, n - n_body, 1, (ILPT == 2 && a.tail_on_body) ? nullptr : a.gq,
           a.static_chunks);
-  for (int64_t base; q.next(base);) walk_chunk(std::integral_constant<int, 1>{}, n_body + base);
+  run_region(std::integral_constant<int, 1>{}, q, n_body);
 #if FSS_DIAG_STAMPS
   if ((threadIdx.x & 63) == 0 && a.stamps) {  // one record per wave, taken as the wave leaves its loop (before done()'s barrier)
     const int64_t rec = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
