@@ -14,7 +14,10 @@ from bench import (CLK_HZ, LDS_PEAK_GBS, LOOKUP_BYTES_PER_AES, N_CU, VALU_ISSUE_
                    hbm_bytes_per_eval, make_key, time_steady)
 
 CHACHA_VALU_PER_WAVE_BLOCK = 1003           # measured wave-instructions per 64 ChaCha20 blocks (960 in the rounds)
-CHACHA_CLK_PER_INSTR = 4.2                  # what the add-rotate-xor mix issues at on gfx950 (slow-class rotates)
+# Issue floor of the add-rotate-xor mix on gfx950: the rotates are slow-class instructions (4 clk) and drag the adds and
+# xors around them along; the lowest cost per instruction this mix has been measured at, in the
+# stand-alone permutation loop (tools/ubench/chacha_rate.hip) and in the best walk alike, is 3.75 clk at the nominal clock.
+CHACHA_CLK_PER_INSTR = 3.75
 
 
 def run_suite(args):
@@ -45,7 +48,7 @@ def run_suite(args):
                                    "algorithmic": f"{chacha_per_unit:g} ChaCha20 blocks per unit x {CHACHA_VALU_PER_WAVE_BLOCK} "
                                                   "wave-instructions per 64 blocks; peak = 256 CU x 4 SIMD x 2.4 GHz / 2 clk",
                                    "clk_per_instruction_and_simd": N_CU * 4 * CLK_HZ / wave_instr,
-                                   # against the issue floor of THIS instruction mix (one instruction per 4.2 clk and SIMD)
+                                   # against the issue floor of THIS instruction mix (one instruction per CHACHA_CLK_PER_INSTR clocks and SIMD)
                                    "frac_of_issue_floor": wave_instr / (N_CU * 4 * CLK_HZ / CHACHA_CLK_PER_INSTR)}
         print(json.dumps(res[-1]), file=sys.stderr, flush=True)
 
