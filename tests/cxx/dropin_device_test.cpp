@@ -417,6 +417,21 @@ __global__ void EvalThroughSharedPointerKernel(S sch, int4* ys, bool party, cons
   ys[tid] = shared->Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
 }
 
+// the first use of the scheme inside divergent code: the odd lanes of every wave evaluate (and fill their wave's LDS
+// copies of the tables and round keys) while the even ones wait, then the even lanes arrive at their own call site
+template <typename S, typename In>
+__global__ void EvalDivergentKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws, const In* xs,
+                                    int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  if (tid & 1) {
+    ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
+  } else {
+    if (tid % 6 == 0) return;  // some lanes never call at all
+    ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
+  }
+}
+
 static void Batches() {
   const int before = g_fail;
   constexpr int kN = 4096;
@@ -482,6 +497,18 @@ static void Batches() {
     ye = ToHost(d_ye, kN);
     bad = 0;
     for (int i = 0; i < kN; ++i) bad += !Same(ye[i], ys0[i]);
+    EXPECT(bad == 0);
+    // ... and with the first call made from divergent code (lanes that never call keep their 0xff fill)
+    HIP_OK(hipMemset(d_ye, 0xff, sizeof(int4) * kN));
+    EvalDivergentKernel<Dcf, uint32_t><<<kN / 192, 192>>>(dcf, d_ye, false, d_seeds0, d_cws, d_xs, kN - 64);
+    HIP_OK(hipDeviceSynchronize());
+    ye = ToHost(d_ye, kN);
+    bad = 0;
+    const int4 untouched = int4{-1, -1, -1, -1};
+    for (int i = 0; i < kN; ++i) {
+      const bool called = i < kN - 64 && ((i & 1) || i % 6 != 0);
+      bad += !Same(ye[i], called ? ys0[i] : untouched);
+    }
     EXPECT(bad == 0);
   }
   {  // Half-Tree n=64, Uint<u64>
