@@ -6,7 +6,7 @@ A "step" is one pass of the hot path over one batch: ONE launch of the shared-ke
 2^24 uniformly random points (configs[1]'s shape at the batch the metric is quoted on), party 0, Uint<uint64_t>
 outputs, inputs already resident in HBM.  With --gpus N every rank evaluates its own 2^24-point batch of the same key
 (`value`, weak scaling, no collective on the data path) and, beside it, the ONE 2^24-point batch cut into N slices
-(`strong`: SURVEY 8(e), "batch=2^24 on 1/2/4/8"); timed regions are bracketed by barrier + synchronize and the slowest
+(`headline_strong`: SURVEY 8(e), "batch=2^24 on 1/2/4/8"); timed regions are bracketed by barrier + synchronize and the slowest
 rank's time is used.
 
 `python bench.py --gpus N` with no launcher around it starts its own N ranks (one process per GPU, spawned before
@@ -49,7 +49,7 @@ VALU_ISSUE_PEAK_GINSTR = N_CU * 4 * CLK_HZ / 2.0 / 1e9   # 1 228.8 G wave64-inst
 METRIC = "DPF/DCF evals/sec at kInBits=32, batch=2^24"
 
 # ---------------------------------------------------------------------------------------------------------- legend
-# Short keys of the sub-records (and of `strong`); bench_legend.json is generated from these two tables.
+# Short keys of the sub-records (and of `headline_strong`); bench_legend.json is generated from these two tables.
 KEYS = {
     "v": "whole-job rate over all GPUs: units x steps / wall time of the timed region (max over ranks); evals/s unless `u` says otherwise",
     "u": "unit of `v` when it is not evals/s",
@@ -81,7 +81,7 @@ KEYS = {
 PTS = "party 0, Uint<uint64_t>, 2^B uniformly random points per GPU per step (B = --log2-batch, 24)"
 RECORDS = {
     "value": f"DPF (Boyle'16) kInBits=32, 1 key, {PTS}; configs[1]'s shape at the metric's batch. ok: the first --cpu-sample outputs",
-    "strong": "the headline's ONE 2^B-point batch cut by shard.batch_slice: 2^B / N points per rank, same key, max-over-ranks time "
+    "headline_strong": "the headline's ONE 2^B-point batch cut by shard.batch_slice: 2^B / N points per rank, same key, max-over-ranks time "
               "(SURVEY 8e); with one GPU it is the headline itself",
     "shared_prefix": "the headline batch through fss_amd_dpf_eval_points_shared: the top log2(batch) levels of the one key's tree are "
                      "expanded once per step, ~10 AES blocks executed per evaluation instead of 32 (work removed, never `value`); "
@@ -693,7 +693,7 @@ def run_headline(args, rank, world, dist):
     head = _walk_record(scheme, n, True, batch, wall, kernel_ms, world, args.steps, kname)
     head.update({"grid": grid, "block": block})
 
-    # `strong`: the ONE 2^B-point batch cut into `world` slices.  With one rank that is the launch above.
+    # `headline_strong`: the ONE 2^B-point batch cut into `world` slices.  With one rank that is the launch above.
     if world > 1:
         strong, _ = sharded_record(args, "headline_strong", rank, world, dist, eng, False)
     else:
@@ -788,7 +788,7 @@ def compose_line(args, world, head, strong, subs, cpu, process_group):
                                  "frac": valu_rate / 1.2288e12, "busy": pipes["valu_busy"]}
     if cpu is not None:
         line["cpu_baseline"] = cpu
-    line["strong"] = dict(compact(strong), scaling="strong")
+    line["headline_strong"] = dict(compact(strong), scaling="strong")
     line["sub"] = {k: compact(v) for k, v in subs.items()}
     gates = [v for rec in list(line["sub"].values()) + ([{"ok": cpu["ok"]}] if cpu else []) for k, v in rec.items() if k in ("ok", "same", "kat")]
     if gates:

@@ -129,7 +129,7 @@ def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
     for key in ("dcf_points", "dpf_keys", "dcf_keys", "dpf_n16", "dpf_n64", "dcf_n16", "dcf_n64", "dpf_keys_n16", "dpf_keys_n64"):
         assert d["sub"][key]["v"] > 0 and 0 < d["sub"][key]["f"] < 1.2, key
     # the one batch cut in two: half the points per rank, a rate of its own
-    assert d["strong"]["n"] == (1 << 19) and d["strong"]["v"] > 0 and d["strong"]["scaling"] == "strong"
+    assert d["headline_strong"]["n"] == (1 << 19) and d["headline_strong"]["v"] > 0 and d["headline_strong"]["scaling"] == "strong"
 
 
 @pytest.mark.gpu
@@ -193,7 +193,7 @@ def test_default_line_carries_the_whole_metric():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
     # one GPU: the strong-scaled form of the metric is the headline launch itself
-    assert d["strong"]["v"] == d["value"] and d["strong"]["n"] == 1 << 18
+    assert d["headline_strong"]["v"] == d["value"] and d["headline_strong"]["n"] == 1 << 18
     assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
 
 

@@ -45,7 +45,7 @@ def test_committed_legend_is_what_bench_generates():
     have = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_legend.json")))
     assert have == json.loads(json.dumps(bench.legend()))
     cells = [c[0] for c in bench.POINTS_CELLS + bench.KEYS_CELLS] + list(bench.SHARDED)
-    for name in cells + ["strong", "shared_prefix", "dpf_2e20", "dcf_2e20", "e2e_pcie", "c1_cpu"]:
+    for name in cells + ["headline_strong", "shared_prefix", "dpf_2e20", "dcf_2e20", "e2e_pcie", "c1_cpu"]:
         assert name in have["records"], name
     assert {s for _, s in bench.SHORT} | {"u"} == set(have["sub_record_keys"])
 
@@ -83,4 +83,4 @@ def test_a_full_line_fits_the_drivers_record():
     assert back["config"]["workload"] and back["roofline"]["bound"] == "lds" and back["cpu_baseline"]["sample"]
     assert set(back["sub"]) == set(subs) and back["gates"]["all"] is True
     assert back["sub"]["grotto_c5"]["fx"] == 0.84123 and back["sub"]["evalall_c4"]["u"] == "leaves/s"
-    assert back["strong"]["scaling"] == "strong" and back["strong"]["v"] == back["value"]
+    assert back["headline_strong"]["scaling"] == "strong" and back["headline_strong"]["v"] == back["value"]
