@@ -350,6 +350,14 @@ class Stage {
     if (T* v = DeviceView(dst)) return v;
     return static_cast<T*>(Take(count * sizeof(T)));
   }
+  // ... for an output that later kernels of the same call read back or update in place (Grotto's running XOR, its
+  // parity tree): only device memory is used in place; a pinned host buffer is staged like a pageable one (reads and
+  // read-modify-writes across PCIe would cost more than the one copy they save)
+  template <typename T>
+  T* OutReadBack(T* dst, size_t count) {
+    if (OnDevice(dst)) return dst;
+    return static_cast<T*>(Take(count * sizeof(T)));
+  }
   template <typename T>
   void Back(T* dst, const T* dev, size_t count) {
     if (static_cast<const void*>(DeviceView(dst)) == static_cast<const void*>(dev)) {
@@ -1160,12 +1168,12 @@ class GrottoDcf {
     static_assert(in_bits <= 40, "a parity table of 2^(in_bits + 1) bytes");
     fss_amd_ctx* ctx = handle();
     const size_t ws = PreprocessWorkspace();
-    const bool direct = detail::DeviceView(pt.p) != nullptr;
+    const bool direct = detail::OnDevice(pt.p);
     detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 64 + (direct ? 0 : ParityTreeBytes()));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     void* d_ws = st.Take(ws);
-    bool* d_pt = st.Out(pt.p, ParityTreeBytes());
+    bool* d_pt = st.OutReadBack(pt.p, ParityTreeBytes());
     PreprocessDevice(pt.b, reinterpret_cast<uint8_t*>(d_pt), d_s0, d_cws, d_ws, ws);
     st.Back(pt.p, static_cast<const bool*>(d_pt), ParityTreeBytes());
   }
@@ -1192,12 +1200,12 @@ class GrottoDcf {
     static_assert(in_bits <= 40, "a full-domain output of 2^in_bits bools");
     const size_t n = size_t(1) << in_bits, ws = EvalAllWorkspace();
     fss_amd_ctx* ctx = handle();
-    const bool direct = detail::DeviceView(ys) != nullptr;
+    const bool direct = detail::OnDevice(ys);
     detail::Stage st(ctx, 32 + sizeof(Cw) * kSlots + ws + 64 + (direct ? 0 : n));
     const int4* d_s0 = st.Value(s0);
     const Cw* d_cws = st.Load(cws, kSlots);
     void* d_ws = st.Take(ws);
-    bool* d_ys = st.Out(ys, n);
+    bool* d_ys = st.OutReadBack(ys, n);
     EvalAllBlock(b, d_s0, d_cws, reinterpret_cast<uint8_t*>(d_ys), d_ws, ws);
     st.Back(ys, static_cast<const bool*>(d_ys), n);
   }

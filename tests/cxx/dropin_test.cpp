@@ -599,7 +599,27 @@ static void PinnedHostBuffers() {
                                   pinned, nullptr) == FSS_AMD_EINVAL);
   HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_s0));
   HIP_OK(hipHostFree(xs)); HIP_OK(hipHostFree(pinned));
-  std::printf("pinned host buffers (EvalAll in place, EvalPointsHost): %s\n", g_fail == before ? "ok" : "FAILED");
+  {  // Grotto: EvalAll's bools and Preprocess's table are updated in place by later kernels of the call, so pinned
+     // buffers are staged like pageable ones -- same contents either way
+    using Gdcf = fss::GrottoDcf<12, DpfPrg, uint16_t>;
+    Gdcf gd{DpfPrg(keys)};
+    Gdcf::Cw gcws[13];
+    gd.Gen(gcws, seeds, (uint16_t)1234);
+    constexpr size_t N = size_t(1) << 12;
+    std::vector<uint8_t> ya(N), ta(2 * N - 1);
+    bool *yp = nullptr, *tp = nullptr;
+    HIP_OK(hipHostMalloc(&yp, N));
+    HIP_OK(hipHostMalloc(&tp, 2 * N - 1));
+    gd.EvalAll(true, seeds[1], gcws, reinterpret_cast<bool*>(ya.data()));
+    gd.EvalAll(true, seeds[1], gcws, yp);
+    EXPECT(std::memcmp(yp, ya.data(), N) == 0);
+    Gdcf::ParityTree pa{reinterpret_cast<bool*>(ta.data()), true}, pp{tp, true};
+    gd.Preprocess(pa, seeds[1], gcws);
+    gd.Preprocess(pp, seeds[1], gcws);
+    EXPECT(std::memcmp(tp, ta.data(), 2 * N - 1) == 0);
+    HIP_OK(hipHostFree(yp)); HIP_OK(hipHostFree(tp));
+  }
+  std::printf("pinned host buffers (EvalAll in place, EvalPointsHost, Grotto staged): %s\n", g_fail == before ? "ok" : "FAILED");
 }
 
 int main() {
