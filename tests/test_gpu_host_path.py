@@ -64,6 +64,70 @@ def test_host_batch_equals_resident_batch(engine, O, scheme, in_bits, n_points):
     assert (got0[:m].numpy() == ref).all()
 
 
+@pytest.mark.parametrize("in_bits,kind", [(8, "u8"), (16, "i16"), (100, "u128")])
+def test_host_batch_with_narrow_and_wide_points(engine, O, in_bits, kind):
+    """x arrays of 1-, 2- and 16-byte elements (In = uint8_t / uint16_t / __uint128_t) read from pinned host memory."""
+    rng = SplitMix64(7000 + in_bits)
+    g = G.U64
+    p = O.Prg(2)
+    s = [rng.i4(), rng.i4()]
+    alpha = rng.next() & ((1 << min(in_bits, 63)) - 1)
+    beta = rng.i4()
+    cws = O.dpf_gen(p, in_bits, g, s, alpha, beta)
+    n = 3001
+    vals = [alpha] + [rng.next() & ((1 << min(in_bits, 63)) - 1) for _ in range(n - 1)]
+    if kind == "u8":
+        xs = torch.tensor(vals, dtype=torch.int64).to(torch.uint8)
+        xo = np.array(vals, dtype=np.uint64)
+    elif kind == "i16":
+        xs = torch.from_numpy(np.array(vals, dtype=np.uint64).astype(np.uint16).view(np.int16).copy())
+        xo = np.array(vals, dtype=np.uint64)
+    else:
+        lo = np.array(vals, dtype=np.uint64)
+        hi = np.array([rng.next() & ((1 << (in_bits - 64)) - 1) for _ in range(n)], dtype=np.uint64)
+        hi[0] = 0
+        xs = torch.from_numpy(np.stack([lo, hi], axis=1).view(np.int64).copy())
+        xo = None
+    xs_h = xs.pin_memory()
+    cd = torch.from_numpy(np.ascontiguousarray(cws)).cuda()
+    for b in (0, 1):
+        sd = torch.from_numpy(s[b]).cuda()
+        want = engine.eval_points(0, in_bits, g, b, sd, cd, xs_h.cuda()).cpu()
+        got = engine.eval_points_host(0, in_bits, g, b, sd, cd, xs_h)
+        torch.cuda.synchronize()
+        assert bool((got == want).all()), b
+        if xo is not None:
+            assert (got.numpy() == O.eval_points(p, 0, in_bits, g, b, s[b], cws, xo)).all()
+
+
+def test_host_batch_in_a_hip_graph(engine):
+    """The host-resident call only enqueues a launch: it can be captured in a HIP graph and replayed on new points."""
+    import fss_amd
+    n = 1 << 18
+    gen = torch.Generator().manual_seed(5)
+    s0s = torch.randint(-2**31, 2**31, (1, 2, 4), dtype=torch.int32, generator=gen)
+    cws, _ = engine.gen(fss_amd.DPF, 32, fss_amd.U64, s0s, torch.tensor([77], dtype=torch.int32),
+                        torch.randint(-2**31, 2**31, (1, 4), dtype=torch.int32, generator=gen))
+    sd, cd = s0s[0, 0].cuda(), cws[0].contiguous()
+    xs_h = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, generator=gen).pin_memory()
+    out = torch.zeros((n, 4), dtype=torch.int32).pin_memory()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        engine.eval_points_host(fss_amd.DPF, 32, fss_amd.U64, 0, sd, cd, xs_h, out=out)   # warm: nothing allocates inside the capture
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            engine.eval_points_host(fss_amd.DPF, 32, fss_amd.U64, 0, sd, cd, xs_h, out=out)
+    for rep in range(2):
+        xs_h.copy_(torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, generator=gen))
+        xs_h[0] = 77
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = engine.eval_points(fss_amd.DPF, 32, fss_amd.U64, 0, sd, cd, xs_h.cuda()).cpu()
+        assert bool((out == want).all()), rep
+
+
 def test_views_into_pinned_buffers(engine):
     """Interior pointers: a batch that starts in the middle of a pinned allocation (a slice of a larger pinned tensor, for
     x and for y) is walked in place like one that starts at its base."""
