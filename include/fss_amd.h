@@ -16,7 +16,8 @@
  *    caller; nothing is allocated, freed or synchronised by the eval calls:
  *    they enqueue kernels on `stream` (a hipStream_t passed as void*, NULL =
  *    default stream) and return, like the reference launchers
- *    (include/fss/point_eval_gpu.cuh:448-460).
+ *    (include/fss/point_eval_gpu.cuh:448-460).  The one exception is named for it:
+ *    fss_amd_eval_points_host takes its points and outputs in PINNED HOST memory.
  *  - Alignment: every int4 / Cw array (seeds, cws, cw_s, cw_v, out_cw, ocws, cs, betas, ys, pi, workspaces)
  *    must be 16-byte aligned (the reference's int4 is; its Cw is alignas(32)), tr_bits 8-byte, extra 4-byte,
  *    xs / alphas sizeof(In)-aligned.  A misaligned pointer is FSS_AMD_EINVAL, never a device fault.
