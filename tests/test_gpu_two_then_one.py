@@ -90,31 +90,44 @@ def test_shared_key_ragged_large_batches(engine, O, scheme, in_bits, n_points):
 
 
 @pytest.mark.parametrize("nkeys", [(1 << 20) + 17, 3 * (1 << 19) + 640 + 5])
-@pytest.mark.parametrize("scheme,in_bits", [(DPF, 32), (HT, 64)])
+@pytest.mark.parametrize("scheme,in_bits", [(DPF, 32), (HT, 64), (DCF, 32), (DPF, 16), (DPF, 64)])
 def test_independent_keys_ragged_large_batches(engine, O, scheme, in_bits, nkeys):
+    """The cells of the metric's independent-keys grid (bench.py: dpf_keys, dcf_keys, dpf_keys_n16, dpf_keys_n64, ht_c5's
+    shape) at ragged sizes across the two-then-one region boundary: every output of both parties through the FSS
+    property, a sample across both regions against the oracle on the same keys brought back key-major."""
     g = G.U64
-    gen = torch.Generator(device="cuda").manual_seed(nkeys + scheme)
+    gen = torch.Generator(device="cuda").manual_seed(nkeys + scheme + in_bits)
     s0s = torch.randint(-2**31, 2**31, (nkeys, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
     betas = torch.randint(-2**31, 2**31, (nkeys, 4), dtype=torch.int32, device="cuda", generator=gen)
     if in_bits <= 32:
         alphas = torch.randint(-2**31, 2**31, (nkeys,), dtype=torch.int32, device="cuda", generator=gen)
         xs = torch.randint(-2**31, 2**31, (nkeys,), dtype=torch.int32, device="cuda", generator=gen)
+        if in_bits < 32:
+            alphas &= (1 << in_bits) - 1
+            xs &= (1 << in_bits) - 1
     else:
         alphas = torch.randint(-2**63, 2**63 - 1, (nkeys,), dtype=torch.int64, device="cuda", generator=gen)
         xs = torch.randint(-2**63, 2**63 - 1, (nkeys,), dtype=torch.int64, device="cuda", generator=gen)
     xs[::2] = alphas[::2]
     xs[-1] = alphas[-1]
+    if scheme == DCF:   # a third of the points just below their alpha, where a comparison share is beta
+        xs[1::3] = torch.where(alphas[1::3] != 0, alphas[1::3] - 1, alphas[1::3])
     keys, ocws = engine.gen_level_major(scheme, in_bits, g, s0s, alphas, betas)
     seeds = [s0s[:, b].contiguous() for b in (0, 1)]
     y = [engine.eval_keys(keys, g, b, seeds[b], xs, ocws=ocws) for b in (0, 1)]
     total = u64_of(y[0]) + u64_of(y[1])
     bl = (betas[:, 0].to(torch.int64) & 0xFFFFFFFF) | (betas[:, 1].to(torch.int64) << 32)
-    assert bool((total == torch.where(xs == alphas, bl, torch.zeros_like(bl))).all())
+    if scheme == DCF:   # x < alpha as unsigned in_bits-bit values (in_bits = 32: int32 bit patterns)
+        ux, ua = xs.to(torch.int64) & 0xFFFFFFFF, alphas.to(torch.int64) & 0xFFFFFFFF
+        hit = ux < ua
+    else:
+        hit = xs == alphas
+    assert bool((total == torch.where(hit, bl, torch.zeros_like(bl))).all())
     # a sample across both regions against the oracle, on the same keys brought back key-major
     from test_gpu_configs import _sub_keys
     idx = torch.from_numpy(_sample(nkeys)).cuda()
     km = engine.key_major(_sub_keys(keys, idx)).cpu().numpy()
-    p = O.Prg(2 if scheme == DPF else 1)
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
     xh = xs[idx].cpu().numpy()
     xh = (xh.view(np.uint32) if xh.dtype == np.int32 else xh.view(np.uint64)).astype(np.uint64)
     for b in (0, 1):
