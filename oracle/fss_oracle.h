@@ -6,7 +6,10 @@
  * the HIP path (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg); the
  * product (fss_amd/, libfss_amd.so) never links, imports or calls anything here.
  *
- * Parity pinning: the reference's own tests hold no golden vectors (every seed is
+ * PARITY UNPINNED against reference-produced outputs: this repository holds no vector the reference produced under its
+ * own control (the known answers below are a transcription of SURVEY.md 8(c), not regenerable here) and cannot run the
+ * reference.  What narrows the gap:
+ * the reference's own tests hold no golden vectors (every seed is
  * random per run), and the reference cannot be compiled in this
  * image without writing stand-ins for libcu++ <cuda/std/array|span|tuple> (prg.cuh:10,
  * util.cuh:10-11; no package here provides them), so no oracle/_ref build exists.  The oracle is pinned against
@@ -16,8 +19,8 @@
  *   (2) FIPS-197 appendix C.1 for the AES core, and OpenSSL EVP_aes_128_ecb (the
  *       reference's actual PRG dependency, libcrypto 3.0.2 in this image) block by block,
  *   (3) the reference's property tests (share reconstruction) restated in tests/.
- * That pins the AES-128-MMO path (the hot path).  The ChaCha PRG and the VDPF / BLAKE3 rows are PARITY UNPINNED
- * against reference outputs -- none are recorded and none can be produced here: they are pinned to the
+ * For the ChaCha PRG and the VDPF / BLAKE3 rows not even transcribed values exist -- none are recorded and none can be
+ * produced here: they are pinned to the
  * published algorithms only (RFC 7539 for the ChaCha permutation, the official BLAKE3 test vectors for the
  * compression function) and to the reference's source for the constructions around them.
  *
