@@ -39,221 +39,10 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-# MI355X constants (/opt/skills/guides/MI355X_MICROARCH.md): 256 CUs, 2.4 GHz max clock,
-# ds_read_b32 = 128 B/clk/CU, HBM3E 8 TB/s.
-N_CU, CLK_HZ = 256, 2.4e9
-LDS_PEAK_GBS = 128 * N_CU * CLK_HZ / 1e9   # 78 643 GB/s of 4-byte table lookups
-HBM_PEAK_GBS = 8000.0
-LOOKUP_BYTES_PER_AES = 160 * 4              # 144 Te0 + 16 S-box lookups, 4 B each
-VALU_ISSUE_PEAK_GINSTR = N_CU * 4 * CLK_HZ / 2.0 / 1e9   # 1 228.8 G wave64-instr/s: 32 lanes per SIMD and clock
-METRIC = "DPF/DCF evals/sec at kInBits=32, batch=2^24"
-
-# ---------------------------------------------------------------------------------------------------------- legend
-# Short keys of the sub-records (and of `headline_strong`); bench_legend.json is generated from these two tables.
-KEYS = {
-    "v": "whole-job rate over all GPUs: units x steps / wall time of the timed region (max over ranks); evals/s unless `u` says otherwise",
-    "u": "unit of `v` when it is not evals/s",
-    "ms": "wall milliseconds per step (barrier + synchronize either side, max over ranks)",
-    "kms": "rank 0's kernel milliseconds per launch, HIP events on the launch stream around the timed steps",
-    "n": "units (evaluations, keys or leaves) one launch of rank 0 processes",
-    "a": "algorithmic AES blocks per unit (taken child only; SURVEY 8d)",
-    "f": "LDS roofline fraction: n x a x 160 lookups x 4 B / kms / 78 643.2 GB/s (128 B/clk/CU x 256 CU x 2.4 GHz)",
-    "fx": "the same fraction counting only the lookups the kernel executes (Grotto: the 32 sibling blocks per walk are "
-          "control-bit-only, 133 of 160 lookups)",
-    "h": "algorithmic HBM bytes per second / 8 000 GB/s",
-    "tr": "HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) / "
-          "algorithmic bytes per launch; replayed from profiles/, only for the launch size profiled",
-    "lb": "SQ_LDS_IDX_ACTIVE / CU / kernel cycles of the committed PMC pass (LDS busy fraction)",
-    "rp": "true when the replayed counters were captured for exactly the sources this library's kernel is compiled from",
-    "ok": "parity gate: the GPU outputs of the timed launch equal the oracle's on the sample named in the legend",
-    "cpu": "the oracle (OpenSSL EVP PRG in the reference's call pattern) on all usable host cores, units/s",
-    "cpu1": "the same on one thread",
-    "serial": "e2e_pcie: evals/s with H2D of x, the walk and D2H of y one after the other on one stream",
-    "pipe": "e2e_pcie: evals/s of the host-buffer entry point fss_amd_eval_points_host: ONE launch whose walk reads x from and "
-            "writes y to the pinned host buffers across PCIe (no staging copies)",
-    "gbs": "e2e_pcie: bytes over PCIe per second of `pipe` (4 B up + 16 B down per evaluation), GB/s",
-    "same": "outputs bit-identical to the resident-input run of the same batch",
-    "us": "c1_cpu: GPU microseconds per 256-leaf EvalAll",
-    "cpu_us": "c1_cpu: oracle microseconds per EvalAll on all threads",
-    "cpu1_us": "c1_cpu: oracle microseconds per EvalAll on one thread",
-    "kat": "c1_cpu: the oracle's EvalAll reproduces the reference's recorded SHA-256 for both parties (SURVEY 8c)",
-}
-PTS = "party 0, Uint<uint64_t>, 2^B uniformly random points per GPU per step (B = --log2-batch, 24)"
-RECORDS = {
-    "value": f"DPF (Boyle'16) kInBits=32, 1 key, {PTS}; configs[1]'s shape at the metric's batch. ok: the first --cpu-sample outputs",
-    "headline_strong": "the headline's ONE 2^B-point batch cut by shard.batch_slice: 2^B / N points per rank, same key, max-over-ranks time "
-              "(SURVEY 8e); with one GPU it is the headline itself",
-    "shared_prefix": "the headline batch through fss_amd_dpf_eval_points_shared: the top log2(batch) levels of the one key's tree are "
-                     "expanded once per step, ~10 AES blocks executed per evaluation instead of 32 (work removed, never `value`); "
-                     "f counts the algorithmic 32. same: outputs identical to the plain walk",
-    "dcf_points": f"DCF (Boyle'21, mul=4 PRG, kLt) kInBits=32, 1 key, {PTS}. ok: 4096 strided outputs",
-    "dpf_n16": f"DPF kInBits=16, 1 key, {PTS}. ok: 4096 strided outputs",
-    "dpf_n64": f"DPF kInBits=64, 1 key, {PTS}. ok: 4096 strided outputs",
-    "dcf_n16": f"DCF kInBits=16, 1 key, {PTS}. ok: 4096 strided outputs",
-    "dcf_n64": f"DCF kInBits=64, 1 key, {PTS}. ok: 4096 strided outputs",
-    "dpf_keys": "DPF kInBits=32, 2^B independent level-major keys x 1 point each per GPU per step (SURVEY 8d M(ii); "
-                "src/bench_gpu.cu:604-633), keys generated on the device outside the timed region. ok: 4096 strided keys brought back key-major",
-    "dcf_keys": "DCF kInBits=32, 2^B independent level-major keys x 1 point (src/bench_gpu.cu:637-661). ok: 4096 strided keys",
-    "dpf_keys_n16": "DPF kInBits=16, 2^B independent level-major keys x 1 point. ok: 4096 strided keys",
-    "dpf_keys_n64": "DPF kInBits=64, 2^B independent level-major keys x 1 point. ok: 4096 strided keys",
-    "dpf_2e20": "BASELINE configs[1] at its literal size: DPF kInBits=32, 1 key, 2^20 points, 1 GPU; >= 150 ms of back-to-back "
-                "launches after 60 ms of warm-up. ok / cpu: all 2^20 points",
-    "dcf_2e20": "BASELINE configs[2] at its literal size: DCF kInBits=32, 1 key, 2^20 points, 1 GPU; timed like dpf_2e20",
-    "evalall_c4": "BASELINE configs[3]: DPF full-domain EvalAll kInBits=28 (--log2-domain), the domain cut into N aligned blocks "
-                  "(shard.domain_block), leaves/s, strong scaling. ok: a kInBits=22 domain leaf for leaf + 4097 strided leaves of "
-                  "the timed outputs. cpu: the oracle in the reference's task-recursion shape on 2^22 leaves",
-    "ht_c5": "BASELINE configs[4]: Half-Tree DPF kInBits=64, 2^24 (--log2-keys) independent keys x 1 point, key batch cut by "
-             "shard.batch_slice, strong scaling. ok / cpu: 2^18 strided keys",
-    "grotto_c5": "BASELINE configs[4]: Grotto DCF kInBits=64 path walk, 2^24 independent keys x 1 point, 1 B per output; a = 96 "
-                 "(64 taken children + 32 siblings on average); fx counts the siblings at the 133 lookups they execute. ok / cpu: 2^18 strided keys",
-    "e2e_pcie": "the headline batch with x read from and y written to pinned host memory (4 B up + 16 B down per evaluation); "
-                "the PCIe-inclusive rate SURVEY 8(d) asks to state separately, never `value`",
-    "c1_cpu": "BASELINE configs[0]: DPF kInBits=8, 1 key, 256-leaf EvalAll, Bytes (samples/dpf_dcf_cpu.cu constants); the CPU-runnable "
-              "case: v = GPU leaves/s; cpu = the oracle's better shape (all threads in the reference's task recursion -- cpu_us -- or one "
-              "thread sequentially -- cpu1_us; a 16-thread team costs more than a 256-leaf tree), EVP contexts built once outside the repetitions",
-}
-TOP = {
-    "roofline": "headline kernel against the LDS roof: achieved = 2^B x 32 AES x 640 B / kernel_ms; traffic = PMC HBM bytes per launch "
-                "(replayed from `replay`, valid when replay_ok); lds_busy / valu_busy = SQ_LDS_IDX_ACTIVE and SQ_ACTIVE_INST_VALU x 4 "
-                "per SIMD over the kernel's cycles in that PMC pass",
-    "roofline_hbm": "algorithmic 20 B per evaluation / kernel_ms against 8 TB/s",
-    "roofline_valu": "wave64 VALU instructions per launch (replayed SQ_INSTS_VALU) / kernel_ms against 256 CU x 4 SIMD x 2.4 GHz / 2 clk",
-    "cpu_baseline": "the oracle with the OpenSSL EVP PRG on the first --cpu-sample points of the timed batch: value = all usable cores, "
-                    "t1 = one thread, aesni = the AES-NI variant (the reference's Aes128MmoRaw), ok = GPU outputs equal",
-    "gates": "every `ok` / `same` / `kat` of the line and'ed, and how many there were",
-}
-
-
-def legend():
-    return {"line": "bench.py's one JSON line; numbers rounded to 5 significant digits", "top_level": TOP, "sub_record_keys": KEYS,
-            "records": RECORDS}
-
-
-def r5(x):
-    """5 significant digits (what the line prints; the detail file keeps full precision)."""
-    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
-        return x
-    if isinstance(x, float):
-        if x == 0 or not math.isfinite(x):
-            return x
-        return float(f"{x:.5g}")
-    if isinstance(x, dict):
-        return {k: r5(v) for k, v in x.items()}
-    if isinstance(x, (list, tuple)):
-        return [r5(v) for v in x]
-    return x
-
-
-SHORT = (("value", "v"), ("ms_per_step", "ms"), ("kernel_ms", "kms"), ("units_per_launch", "n"), ("aes_per_unit", "a"), ("frac", "f"),
-         ("frac_executed", "fx"), ("hbm_frac", "h"), ("traffic_ratio", "tr"), ("lds_busy_pmc", "lb"), ("replay_ok", "rp"), ("ok", "ok"),
-         ("cpu", "cpu"), ("cpu1", "cpu1"), ("serial", "serial"), ("pipe", "pipe"), ("gbs", "gbs"), ("same", "same"), ("us", "us"),
-         ("cpu_us", "cpu_us"), ("cpu1_us", "cpu1_us"), ("kat", "kat"))
-
-
-def compact(rec):
-    """A verbose record -> the short form of the line (KEYS)."""
-    out = {}
-    for long, short in SHORT:
-        if rec.get(long) is not None:
-            out[short] = r5(rec[long])
-    if rec.get("unit") not in (None, "evals/s"):
-        out["u"] = rec["unit"]
-    return out
-
-
-# ---------------------------------------------------------------------------------------------------------- work tables
-def aes_blocks_per_eval(scheme, n):
-    """Algorithmic minimum (taken child only), SURVEY.md 8(d)."""
-    return {"dpf": n, "dcf": 2 * n, "ht": n}[scheme]
-
-
-def hbm_bytes_per_eval(scheme, n, shared):
-    if shared:
-        return (4 if n <= 32 else 8) + 16
-    per_level = {"dpf": 16, "dcf": 32, "ht": 16}[scheme]
-    fixed = {"dpf": 16 + 8 + 16 + 16, "dcf": 16 + 16 + 16, "ht": 16 + 4 + 16 + 16}[scheme]
-    return fixed + per_level * n + (4 if n <= 32 else 8)
-
-
-def _headline_pmc(log2_batch):
-    """Counters of the headline kernel (plain DPF walk, shared key) REPLAYED from the committed rocprofv3 PMC passes
-    (profiles/r<N>/pmc_summary.json, highest N first): bench.py cannot read PMCs itself.  Only valid for the batch
-    profiled (2^24).  Returns (values, path relative to the repo) or (None, None)."""
-    import glob
-    import re
-    if log2_batch != 24:
-        return None, None
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json"))
-    rnd = lambda f: int(re.search(r"profiles[/\\]r(\d+)", f).group(1))
-    for f in sorted(files, key=rnd, reverse=True):
-        try:
-            d = json.load(open(f))
-            for k, v in d.items():
-                name = k.replace("fssamd::Lds, ", "")
-                if "eval_points_kernel<0, true" in name and name.rstrip().endswith("false>") and "FETCH_SIZE" in v:
-                    v = dict(v, _captured_for=d.get("_captured_for", {}).get("headline_sources_sha256"))
-                    return v, os.path.relpath(f, ROOT)
-        except Exception:
-            pass
-    return None, None
-
-
-def measured_hbm_traffic(log2_batch):
-    """HBM bytes per launch: FETCH_SIZE and WRITE_SIZE in KiB, collected in separate passes; FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950.  Replayed from profiles/ (see `roofline.replay`)."""
-    v, _ = _headline_pmc(log2_batch)
-    if not v or "WRITE_SIZE" not in v:
-        return None
-    return (2 * v["FETCH_SIZE"]["mean_per_launch"] + v["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-
-
-def measured_pipe_busy(log2_batch):
-    """LDS- and VALU-busy fractions of the profiled launch (north_star: "VALU-busy against the chip's peak"):
-    SQ_LDS_IDX_ACTIVE per CU, and SQ_ACTIVE_INST_VALU (counted in 4-cycle issue slots) per SIMD, over the
-    kernel's cycles (GRBM_GUI_ACTIVE / 8 XCDs).  Ratios of counters of one profiled launch -- not of this run."""
-    v, src = _headline_pmc(log2_batch)
-    need = ("GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU")
-    if not v or any(k not in v for k in need):
-        return None
-    cyc = v["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0
-    return {"lds_busy": v["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / cyc,
-            "valu_busy": v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] * 4.0 / 1024.0 / cyc,
-            "valu_wave_instructions_per_launch": v["SQ_INSTS_VALU"]["mean_per_launch"],
-            "replayed_from": src}
-
-
-def _workload_pmc(name):
-    """Counters of one workload's dominant kernel REPLAYED from profiles/r<N>/pmc_workloads.json (highest N first; written
-    by tools/profile_workloads.sh from separate rocprofv3 --pmc passes of `bench.py --workload <name>`)."""
-    import glob
-    import re
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_workloads.json"))
-    rnd = lambda f: int(re.search(r"profiles[/\\]r(\d+)", f).group(1))
-    for f in sorted(files, key=rnd, reverse=True):
-        try:
-            d = json.load(open(f))
-            if name in d:
-                return d[name], os.path.relpath(f, ROOT)
-        except Exception:
-            pass
-    return None, None
-
-
-def replayed_counters(name, units_per_launch):
-    """HBM traffic (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, MI355X_MICROARCH.md's gfx950 correction) and LDS busy
-    fraction per launch of the committed profile of this workload -- valid only for the launch size profiled and
-    labelled with whether the profile was captured for the sources this library's kernel is compiled from."""
-    rec, src = _workload_pmc(name)
-    out = {"traffic": None, "traffic_replayed_from": src, "replay_matches_kernel_sources": False}
-    if not rec or rec.get("units_per_launch") != units_per_launch:
-        return out
-    from fss_amd import _build
-    out["replay_matches_kernel_sources"] = rec.get("_captured_for") == _build.workload_digest(name)
-    if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
-        out["traffic"] = (2 * rec["FETCH_SIZE"]["mean_per_launch"] + rec["WRITE_SIZE"]["mean_per_launch"]) * 1024.0
-    if "GRBM_GUI_ACTIVE" in rec and "SQ_LDS_IDX_ACTIVE" in rec:
-        out["lds_busy_pmc"] = rec["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"] / 256.0 / (rec["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0)
-    return out
+from bench_meta import (CLK_HZ, HBM_PEAK_GBS, KEYS, LDS_PEAK_GBS, LOOKUP_BYTES_PER_AES, METRIC, N_CU, RECORDS, SHORT, TOP,  # noqa: E402,F401
+                        VALU_ISSUE_PEAK_GINSTR, _headline_pmc, _rand_xs, _u64, aes_blocks_per_eval, compact, hbm_bytes_per_eval, legend, make_key,
+                        measured_hbm_traffic, measured_pipe_busy, r5, replayed_counters)
+from bench_cpu import _timed_cpu, cpu_baseline, cpu_check_subrecords, cpu_evalall, cpu_keys, usable_cores  # noqa: E402,F401
 
 
 # ---------------------------------------------------------------------------------------------------------- timing
@@ -311,65 +100,60 @@ def pre_warm(fn, ms=100.0):
     torch.cuda.synchronize()
 
 
-def _timed_cpu(fn, min_s, max_reps=64):
-    """fn() repeated until min_s seconds have been spent: (repetitions, seconds)."""
-    reps, dt = 0, 0.0
-    while dt < min_s and reps < max_reps:
-        t0 = time.perf_counter()
-        fn()
-        dt += time.perf_counter() - t0
-        reps += 1
-    return reps, dt
-
-
-def usable_cores():
-    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box
-    shows 256 logical CPUs under a 16-CPU quota: 256 threads there run at 8.5 M evals/s, 16 threads at 19.7)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
-        if quota != "max":
-            n = min(n, max(1, int(quota) // int(period)))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
-# ---------------------------------------------------------------------------------------------------------- inputs
-def make_key(eng, scheme, n, group_id, seed_val):
-    """One valid key from fixed seeds, generated by the product's device Gen."""
+def bench_engine():
+    """The process-wide engine with FSS_AMD_POINTS_PLAIN: every cell of the metric measures the per-point tree walk
+    (in_bits PRG levels per point, north_star); the shared-prefix plan the library would pick by itself for batches this
+    size is reported in its own records (`shared_*`), through its explicit entry point."""
     import fss_amd
-    g = torch.Generator().manual_seed(seed_val)
-    s0s = torch.randint(-2**31, 2**31, (1, 2, 4), dtype=torch.int32, generator=g)
-    s0s[..., 3] &= ~1
-    beta = torch.randint(-2**31, 2**31, (1, 4), dtype=torch.int32, generator=g)
-    beta[..., 3] &= ~1
-    if n <= 32:
-        alpha = torch.randint(0, 2**31, (1,), dtype=torch.int32, generator=g) & ((1 << min(n, 31)) - 1)
-    else:
-        alpha = torch.randint(0, 2**62, (1,), dtype=torch.int64, generator=g)
-    sid = {"dpf": fss_amd.DPF, "dcf": fss_amd.DCF, "ht": fss_amd.HT}[scheme]
-    cws, ocws = eng.gen(sid, n, group_id, s0s, alpha, beta)
-    return sid, s0s[0].cpu(), cws[0].cpu(), (None if ocws is None else ocws[0].cpu()), alpha, beta
+    return fss_amd.default_engine(torch.cuda.current_device()).set_points_plan("plain")
 
 
-def _rand_xs(n, batch, seed):
-    gen = torch.Generator(device="cuda").manual_seed(seed)
-    if n <= 32:
-        xs = torch.randint(-2**31, 2**31, (batch,), dtype=torch.int32, device="cuda", generator=gen)
-        return xs & ((1 << n) - 1) if n < 32 else xs
-    return torch.randint(-2**63, 2**63 - 1, (batch,), dtype=torch.int64, device="cuda", generator=gen)
+_DIAG = {}
 
 
-def _u64(a):
-    """int32 / int64 bit patterns (numpy) -> uint64 values."""
-    return (a.view(np.uint32) if a.dtype == np.int32 else a.view(np.uint64)).astype(np.uint64)
+def diag_engine():
+    """A context of the diagnostic build (fss_amd/libfss_amd_diag.so, -DFSS_DIAG_STAMPS=1), or None without it."""
+    if "eng" not in _DIAG:
+        import fss_amd
+        from fss_amd import _lib
+        L = _lib.diag_lib()
+        _DIAG["eng"] = None if L is None else fss_amd.Engine(torch.cuda.current_device(), lib=L).set_points_plan("plain")
+    return _DIAG["eng"]
+
+
+def in_kernel_clock(mk_step, ms=50.0):
+    """Shader clock (GHz) the workload's kernel runs at, measured INSIDE the kernel: `ms` of back-to-back launches of
+    mk_step(engine) through the diagnostic build, whose waves record s_memtime (shader clock) and s_memrealtime
+    (100 MHz) at entry and exit; median over the waves of the last launch of d(memtime) / d(memrealtime) x 100 MHz.
+    Untimed (after the timed region of the record it annotates); None when the diagnostic library is not built."""
+    de = diag_engine()
+    if de is None:
+        return None
+    import ctypes as C
+    step = mk_step(de)
+    pre_warm(step, ms)
+    step()
+    torch.cuda.synchronize()
+    kname, grid, block = de.last_kernel()
+    nw = grid * (block // 64)
+    fused = kname == "evalall_fused"
+    buf = np.zeros((nw, 16 if fused else 4), dtype=np.uint64)
+    if de._L.fss_amd_diag_read_stamps(de._h, buf.ctypes.data_as(C.c_void_p), nw * (4 if fused else 1)) != 0:
+        return None
+    t = buf.astype(np.float64)
+    dcyc, dreal = (t[:, 15] - t[:, 14], t[:, 13] - t[:, 0]) if fused else (t[:, 2] - t[:, 0], t[:, 3] - t[:, 1])
+    ok = (dreal > 0) & (dcyc > 0)
+    return float(np.median(dcyc[ok] / dreal[ok] * 0.1)) if ok.any() else None
+
+
+def _attach_clock(rec, mk_step):
+    """`clk` and `fc` of a record: the in-kernel clock and the roofline fraction at THAT clock instead of the nominal
+    2.4 GHz the peak is computed for (what the kernel achieves per cycle, independent of the box's power-capped clock)."""
+    clk = in_kernel_clock(mk_step)
+    if clk:
+        rec["clk"] = clk
+        rec["frac_at_clock"] = rec.get("frac_executed", rec["frac"]) * CLK_HZ / (clk * 1e9)
+    return rec
 
 
 def _walk_record(scheme, n, shared, units, wall, kernel_ms, world, steps, kname):
@@ -394,119 +178,29 @@ def _attach_replay(rec, name, units, alg_bytes_per_unit):
         rec["lds_busy_pmc"] = rep["lds_busy_pmc"]
 
 
-# ---------------------------------------------------------------------------------------------------------- CPU legs
-def cpu_baseline(scheme, n, s0s, cws, ocw, xs_sample, gpu_sample, threads):
-    """Oracle = restatement of the reference CPU path with the OpenSSL EVP PRG, timed on a
-    bounded sample of the workload's own points; also the parity gate for this run."""
-    from oracle import oracle as O
-    mul = {"dpf": 2, "dcf": 4, "ht": 1}[scheme]
-    sid = {"dpf": O.DPF, "dcf": O.DCF, "ht": O.HT}[scheme]
-    p = O.Prg(mul, use_evp=True)
-    xs64 = xs_sample.astype(np.uint64)
-    oc = None if ocw is None else ocw.numpy()
-    O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64[:1024], ocw=oc, nthreads=1)  # warm
-    # the all-threads pass repeated until >= 4 s, a ~1 s single-thread sample, one AES-NI pass (the sub-records'
-    # CPU legs add about as much again: ~15 s of CPU work in the whole default run)
-    reps, dt = 0, 0.0
-    while dt < 4.0 and reps < 64:
-        t0 = time.perf_counter()
-        ys = O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64, ocw=oc, nthreads=threads)
-        dt += time.perf_counter() - t0
-        reps += 1
-    n1 = min(len(xs64), max(1024, 1 << 20))
-    t1 = time.perf_counter()
-    O.eval_points(p, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64[:n1], ocw=oc, nthreads=1)
-    dt1 = time.perf_counter() - t1
-    out = {"value": reps * len(xs64) / dt, "unit": "evals/s", "cores": threads, "kind": "port",
-           "sample": f"first {len(xs64)} points of the timed batch x {reps} passes, {dt:.1f} s; t1: {n1} points",
-           "t1": n1 / dt1, "ok": bool((ys == gpu_sample).all())}
-    if O.have_aesni():
-        # "best CPU" line: the same walk with AES-NI intrinsics, as the reference's Aes128MmoRaw (README.md:341)
-        pn = O.Prg(mul, aesni=True)
-        t2 = time.perf_counter()
-        ysn = O.eval_points(pn, sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), xs64, ocw=oc, nthreads=threads)
-        out["aesni"] = len(xs64) / (time.perf_counter() - t2)
-        out["ok"] = bool(out["ok"] and (ysn == ys).all())
-    return out
-
-
-def cpu_check_subrecords(checks):
-    """The sub-records' parity gates, run with the cpu_baseline leg: a strided sample of every sub-workload's GPU
-    outputs against the oracle (party 0, Uint<uint64_t>)."""
-    from oracle import oracle as O
-    res = {}
-    for key, (kind, sch, n, s0s, cws, xs, got) in checks.items():
-        sid, mul = {"dpf": (O.DPF, 2), "dcf": (O.DCF, 4)}[sch]
-        if kind == "keys":
-            want = O.eval_keys(O.Prg(mul), sid, n, O.U64, 0, s0s, cws, _u64(xs), nthreads=4)
-        else:
-            want = O.eval_points(O.Prg(mul), sid, n, O.U64, 0, s0s[0].numpy(), cws.numpy(), _u64(xs), nthreads=4)
-        res[key] = bool((want == got).all())
-    return res
-
-
-def cpu_evalall(eng, threads, n_cpu):
-    """CPU baseline of the full-domain workload: the oracle's EvalAll in the reference's own
-    execution shape -- depth-first, one OpenMP task per child above ceil(log2(threads)) levels (dpf.cuh:232-303,
-    util.cuh:40-45), OpenSSL EVP PRG -- on a 2^n_cpu-leaf domain, all threads and one thread; the GPU's EvalAll of
-    the same key is compared with it leaf for leaf."""
-    import fss_amd
-    from oracle import oracle as O
-    G = fss_amd.U64
-    sid, s0s, cws, _, _, _ = make_key(eng, "dpf", n_cpu, G, 0x5EED0400 + n_cpu)
-    got = eng.eval_all(sid, n_cpu, G, 0, s0s[0].cuda(), cws.cuda()).cpu().numpy()
-    p = O.Prg(2, use_evp=True)
-    out = np.zeros((1 << n_cpu, 4), dtype=np.int32)
-    s0, cw = s0s[0].numpy(), cws.numpy()
-    reps, dt = _timed_cpu(lambda: O.dpf_eval_all(p, n_cpu, O.U64, 0, s0, cw, task_threads=threads, out=out), 1.5)
-    parity = bool((out == got).all())
-    t1 = time.perf_counter()
-    O.dpf_eval_all(p, n_cpu, O.U64, 0, s0, cw, task_threads=1, out=out)
-    dt1 = time.perf_counter() - t1
-    return {"cpu": reps * (1 << n_cpu) / dt, "cpu1": (1 << n_cpu) / dt1, "ok": parity and bool((out == got).all()),
-            "cpu_sample": f"DPF EvalAll kInBits={n_cpu} x {reps} passes, {threads} threads, {dt:.1f} s; one thread: one pass, {dt1:.1f} s"}
-
-
-def cpu_keys(eng, scheme, n, keys, seeds0, xs, ocws, ys, threads, m):
-    """CPU baseline of the independent-keys workloads (C5): a strided subset of m keys brought back key-major, the
-    oracle's per-key Eval (Half-Tree: Aes128Mmo<1> hashes; Grotto: the path walk, both children per level as the
-    reference's ExpandTreeRec computes them) with the OpenSSL EVP PRG, all threads and one thread; the GPU's outputs
-    for those keys are compared with it."""
-    import fss_amd
-    from fss_amd.engine import LevelMajorKeys
-    from oracle import oracle as O
-    nk = keys.nkeys
-    m = min(m, nk)
-    pick = torch.arange(0, nk, max(1, nk // m), device="cuda")[:m]
-    m = int(pick.numel())
-    if scheme == "ht":
-        sub = LevelMajorKeys(fss_amd.HT, n, m, keys.cw_s[:, pick].contiguous(), extra=keys.extra[pick].contiguous())
-        osid, mul, oc = O.HT, 1, ocws[pick].cpu().numpy()
-    else:
-        sub = LevelMajorKeys(fss_amd.DPF, n, m, keys.cw_s[:, pick].contiguous(), tr_bits=keys.tr_bits[pick].contiguous(),
-                             out_cw=keys.out_cw[pick].contiguous())
-        osid, mul, oc = O.GROTTO, 2, None
-    km = eng.key_major(sub).cpu().numpy()
-    sd = seeds0[pick].cpu().numpy()
-    xh = xs[pick].cpu().numpy().view(np.uint64)
-    got = ys[pick].cpu().numpy()
-    p = O.Prg(mul, use_evp=True)
-    res = {}
-
-    def all_threads():
-        res["y"] = O.eval_keys(p, osid, n, O.U64 if scheme == "ht" else O.BYTES, 0, sd, km, xh, ocws=oc, nthreads=threads)
-    reps, dt = _timed_cpu(all_threads, 1.5)
-    m1 = min(m, 1 << 16)
-    t1 = time.perf_counter()
-    O.eval_keys(p, osid, n, O.U64 if scheme == "ht" else O.BYTES, 0, sd[:m1], km[:m1], xh[:m1],
-                ocws=None if oc is None else oc[:m1], nthreads=1)
-    dt1 = time.perf_counter() - t1
-    want = res["y"] if scheme == "ht" else res["y"][:, 0].astype(np.uint8)
-    return {"cpu": reps * m / dt, "cpu1": m1 / dt1, "ok": bool((want == got).all()),
-            "cpu_sample": f"{m} strided keys x {reps} passes, {threads} threads, {dt:.1f} s; one thread: {m1} keys"}
-
-
 # ---------------------------------------------------------------------------------------------------------- GPU legs
+def _shared_record(eng, scheme, sid, n, sd, cd, xs, ys_plain, plain_ms, timer=None, world=1, steps=1):
+    """The same batch through the shared-prefix plan (fss_amd_*_eval_points_shared with the library's own prefix_bits --
+    what fss_amd_*_eval_points picks by itself under FSS_AMD_POINTS_AUTO): the key's top k levels are expanded once per
+    call (2^(k+1) blocks), every point walks the remaining in_bits - k.  `a` = AES blocks EXECUTED per evaluation and `f`
+    the roofline fraction on those (never above 1); `x` = speed-up over the plain walk of the same batch; `same` =
+    outputs bit-identical to it.  Work removed, never `value`.  timer: step -> (wall seconds, kernel ms)."""
+    import fss_amd
+    G, N = fss_amd.U64, xs.numel()
+    k = eng._L.fss_amd_points_prefix_bits(sid, n, N) or max(1, N.bit_length() - 2)
+    ys2 = torch.empty_like(ys_plain)
+    mk = lambda e: (lambda: e.eval_points_shared(sid, n, G, 0, sd, cd, xs, out=ys2, prefix_bits=k))
+    step = mk(eng)
+    wall, kms = timer(step) if timer else time_steady(step)
+    aes = (2 if scheme == "dcf" else 1) * ((n - k) + (2 << k) / N)
+    rate = N / (kms * 1e-3)
+    rec = {"value": N * world * steps / wall if timer else rate, "unit": "evals/s", "ms_per_step": wall / steps * 1e3 if timer else kms,
+           "kernel_ms": kms, "units_per_launch": N, "aes_per_unit": aes, "k": k,
+           "frac": rate * aes * LOOKUP_BYTES_PER_AES / 1e9 / LDS_PEAK_GBS, "speedup": plain_ms / kms, "kernel": eng.last_kernel()[0],
+           "same": bool((ys2 == ys_plain).all())}
+    return _attach_clock(rec, mk)
+
+
 def _small_batch_record(eng, scheme, log2_points, with_cpu):
     """BASELINE configs[1] / configs[2] at their literal size (one key, kInBits=32, 2^20 random points, one GPU): a
     0.3 - 0.6 ms launch, timed at steady clocks (time_steady) like every short launch in this file."""
@@ -516,10 +210,13 @@ def _small_batch_record(eng, scheme, log2_points, with_cpu):
     xs = _rand_xs(n, batch, 0x5EED0700 + (7 if scheme == "dcf" else 0))
     sd, cd = s0s[0].cuda(), cws.cuda()
     ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
-    step = lambda: eng.eval_points(sid, n, G, 0, sd, cd, xs, out=ys)
+    mk = lambda e: (lambda: e.eval_points(sid, n, G, 0, sd, cd, xs, out=ys))
+    step = mk(eng)
     _, kms = time_steady(step)
     rec = _walk_record(scheme, n, True, batch, kms * 1e-3, kms, 1, 1, eng.last_kernel()[0])
     _attach_replay(rec, "dpf_2e20" if scheme == "dpf" else "dcf_2e20", batch, 20)
+    _attach_clock(rec, mk)
+    shared = _shared_record(eng, scheme, sid, n, sd, cd, xs, ys, kms)
     if with_cpu:
         from oracle import oracle as O
         p = O.Prg(2 if scheme == "dpf" else 4, use_evp=True)
@@ -537,7 +234,7 @@ def _small_batch_record(eng, scheme, log2_points, with_cpu):
         dt1 = time.perf_counter() - t1
         rec.update({"cpu": reps * batch / dt, "cpu1": m1 / dt1, "ok": bool((res["y"] == ys.cpu().numpy()).all()),
                     "cpu_sample": f"all 2^{log2_points} points x {reps} passes, {threads} threads, {dt:.1f} s; one thread: {m1} points"})
-    return rec
+    return rec, shared
 
 
 def _e2e_pcie_record(eng, log2_batch):
@@ -628,11 +325,15 @@ def _points_cell(args, rank, world, dist, eng, key, sch, nn, ys, pick, subs, che
     sid, s0s, cws, _, _, _ = make_key(eng, sch, nn, G, 0x5EED0100 + nn + (7 if sch == "dcf" else 0))
     xs = _rand_xs(nn, batch, 0x5EED0200 + nn + rank)
     sd, cd = s0s[0].cuda(), cws.cuda()
-    step = lambda: eng.eval_points(sid, nn, G, 0, sd, cd, xs, out=ys)
+    mk = lambda e: (lambda: e.eval_points(sid, nn, G, 0, sd, cd, xs, out=ys))
+    step = mk(eng)
     pre_warm(step, 40.0)
     w, k = time_steps(step, args.steps, args.warmup, dist)
-    subs[key] = _walk_record(sch, nn, True, batch, w, k, world, args.steps, eng.last_kernel()[0])
+    subs[key] = _attach_clock(_walk_record(sch, nn, True, batch, w, k, world, args.steps, eng.last_kernel()[0]), mk)
     checks[key] = ("points", sch, nn, s0s, cws, xs[pick].cpu().numpy(), ys[pick].cpu().numpy())
+    if key == "dcf_points":  # the DCF cell of the metric through the shared-prefix plan as well
+        subs["shared_dcf"] = _shared_record(eng, sch, sid, nn, sd, cd, xs, ys, k, timer=lambda f: time_steps(f, args.steps, args.warmup, dist),
+                                            world=world, steps=args.steps)
 
 
 def _keys_cell(args, rank, world, dist, eng, key, sch, nn, ys, pick, subs, checks):
@@ -651,10 +352,11 @@ def _keys_cell(args, rank, world, dist, eng, key, sch, nn, ys, pick, subs, check
     keys, _ = eng.gen_level_major(sid, nn, G, ks0s, kalphas, kbetas)
     kseeds = ks0s[:, 0].contiguous()
     del ks0s, kbetas, kalphas
-    step = lambda: eng.eval_keys(keys, G, 0, kseeds, kxs, out=ys)
+    mk = lambda e: (lambda: e.eval_keys(keys, G, 0, kseeds, kxs, out=ys))
+    step = mk(eng)
     pre_warm(step, 40.0)
     w, k = time_steps(step, args.steps, args.warmup, dist)
-    subs[key] = _walk_record(sch, nn, False, batch, w, k, world, args.steps, eng.last_kernel()[0])
+    subs[key] = _attach_clock(_walk_record(sch, nn, False, batch, w, k, world, args.steps, eng.last_kernel()[0]), mk)
     if rank == 0 and world == 1 and not args.no_cpu:
         m = int(pick.numel())
         if sch == "dpf":
@@ -676,7 +378,7 @@ SHARDED = ("evalall_c4", "ht_c5", "grotto_c5")
 
 def run_headline(args, rank, world, dist):
     import fss_amd
-    eng = fss_amd.default_engine(torch.cuda.current_device())
+    eng = bench_engine()
     n, scheme = 32, "dpf"
     batch = 1 << args.log2_batch
     G = fss_amd.U64
@@ -685,13 +387,13 @@ def run_headline(args, rank, world, dist):
     seed_d, cws_d = s0s[0].cuda(), cws.cuda()
     ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
 
-    def step():
-        eng.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys)
-
+    mk = lambda e: (lambda: e.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys))
+    step = mk(eng)
     wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
     kname, grid, block = eng.last_kernel()
     head = _walk_record(scheme, n, True, batch, wall, kernel_ms, world, args.steps, kname)
     head.update({"grid": grid, "block": block})
+    _attach_clock(head, mk)
 
     # `headline_strong`: the ONE 2^B-point batch cut into `world` slices.  With one rank that is the launch above.
     if world > 1:
@@ -699,18 +401,10 @@ def run_headline(args, rank, world, dist):
     else:
         strong = dict(head, scaling="strong")
 
-    # Same batch through the shared-prefix entry point (identical outputs; the top log2(batch) levels
-    # of the one key's tree are expanded once per step instead of once per point).  Reported beside
-    # the headline, never as `value`: it removes AES work rather than doing it faster.
-    ys2 = torch.empty_like(ys)
-
-    def step_shared():
-        eng.eval_points_shared(sid, n, G, 0, seed_d, cws_d, xs, out=ys2)
-
-    wall_sp, kernel_ms_sp = time_steps(step_shared, args.steps, args.warmup, dist)
-    shared = _walk_record(scheme, n, True, batch, wall_sp, kernel_ms_sp, world, args.steps, eng.last_kernel()[0])
-    shared["same"] = bool((ys == ys2).all())
-    del ys2
+    # Same batch through the shared-prefix plan (identical outputs; the key's top levels are expanded once per step
+    # instead of once per point).  Reported beside the headline, never as `value`: it removes AES work.
+    shared = _shared_record(eng, scheme, sid, n, seed_d, cws_d, xs, ys, kernel_ms, timer=lambda f: time_steps(f, args.steps, args.warmup, dist),
+                            world=world, steps=args.steps)
 
     # ---- the rest of the metric: DCF, independent keys, kInBits 16 / 64 (north_star), same protocol
     subs, checks = {"shared_prefix": shared}, {}
@@ -732,7 +426,7 @@ def run_headline(args, rank, world, dist):
         with_cpu = world == 1 and not args.no_cpu
         if world == 1:
             for key, sch in (("dpf_2e20", "dpf"), ("dcf_2e20", "dcf")):
-                subs[key] = _small_batch_record(eng, sch, 20, with_cpu)
+                subs[key], subs["shared_" + key] = _small_batch_record(eng, sch, 20, with_cpu)
         for name in SHARDED:
             rec, _ = sharded_record(args, name, rank, world, dist, eng, with_cpu)
             subs[name] = rec
@@ -774,7 +468,8 @@ def compose_line(args, world, head, strong, subs, cpu, process_group):
                    "kernel": head["kernel"], "grid": head.get("grid"), "block": head.get("block"),
                    "parallelism": f"batch-sharded x{world}, no collective", "process_group": process_group, "legend": "bench_legend.json"},
         "roofline": {"bound": "lds", "achieved": head["lds_gbs"], "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-                     "traffic": traffic, "kernel_ms": kernel_ms, "replay": replay_src, "replay_ok": replay_ok},
+                     "traffic": traffic, "kernel_ms": kernel_ms, "clk": head.get("clk"), "frac_at_clock": head.get("frac_at_clock"),
+                     "replay": replay_src, "replay_ok": replay_ok},
         "roofline_hbm": {"bound": "hbm", "achieved": head["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["hbm_frac"],
                          "traffic": traffic, "algorithmic_bytes": batch * 20},
     }
@@ -829,7 +524,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         torch.cuda.empty_cache()
         sd, cd = s0s[0].cuda(), cws.cuda()
         ys = torch.empty((hi - lo, 4), dtype=torch.int32, device="cuda")
-        step = lambda: eng.eval_points(sid, n, G, 0, sd, cd, xs, out=ys)
+        mk = lambda e: (lambda: e.eval_points(sid, n, G, 0, sd, cd, xs, out=ys))
+        step = mk(eng)
         units_total, units_rank, unit, aes_per_unit, hbm_unit = total, hi - lo, "evals/s", 32.0, 20
     elif name == "evalall_c4":
         n = args.log2_domain
@@ -837,7 +533,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         first, nleaves = shard.domain_block(n, rank, world)
         sd, cd = s0s[0].cuda(), cws.cuda()
         ys = torch.empty((nleaves, 4), dtype=torch.int32, device="cuda")
-        step = lambda: eng.eval_all(sid, n, G, 0, sd, cd, first_leaf=first, nleaves=nleaves, out=ys)
+        mk = lambda e: (lambda: e.eval_all(sid, n, G, 0, sd, cd, first_leaf=first, nleaves=nleaves, out=ys))
+        step = mk(eng)
         units_total, units_rank, unit, aes_per_unit, hbm_unit = 1 << n, nleaves, "leaves/s", 2.0, 16
     elif name == "grotto_evalall":
         # Grotto DCF full domain, domain-sharded: the one workload of the path with an exchange step -- the running XOR
@@ -859,6 +556,7 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         def step():
             warm_step()
             shard.grotto_fix_shard(ys, dist)
+        mk = None
         units_total, units_rank, unit, aes_per_unit, hbm_unit = 1 << n, nleaves, "leaves/s", 2.0, 1
     else:
         n, total = 64, 1 << args.log2_keys
@@ -884,7 +582,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         del s0s, betas, alphas
         ys = (torch.empty((nk, 4), dtype=torch.int32, device="cuda") if scheme == "ht"
               else torch.empty((nk,), dtype=torch.uint8, device="cuda"))
-        step = lambda: eng.eval_keys(keys, gg, 0, seeds0, xs, ocws=ocws, out=ys)
+        mk = lambda e: (lambda: e.eval_keys(keys, gg, 0, seeds0, xs, ocws=ocws, out=ys))
+        step = mk(eng)
         units_total, units_rank, unit = total, nk, "evals/s"
         aes_per_unit = 64.0 if scheme == "ht" else 96.0
         hbm_unit = 1084 if scheme == "ht" else 1057   # 16 seed + 8 x + 64 x 16 cw_s + (4 extra + 16 ocw + 16 y | 8 tr bits + 1 y)
@@ -917,6 +616,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         # SURVEY 8(d)'s algorithmic 96 whole blocks, `frac_executed` the lookups the kernel issues
         rec["frac_executed"] = rec["frac"] * (64 * 160 + 32 * 133) / (96 * 160.0)
     _attach_replay(rec, name, units_rank, hbm_unit)
+    if mk is not None:
+        _attach_clock(rec, mk)
     if cpu is not None:
         rec.update(cpu)
     return rec, ys
@@ -924,8 +625,7 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
 
 def run_sharded(args, rank, world, dist):
     """`--workload headline_strong | evalall_c4 | ht_c5 | grotto_c5 | grotto_evalall` as the whole run, one JSON line."""
-    import fss_amd
-    eng = fss_amd.default_engine(torch.cuda.current_device())
+    eng = bench_engine()
     rec, ys = sharded_record(args, args.workload, rank, world, dist, eng, with_cpu=not args.no_cpu)
     if args.hash_out:
         # tests/test_bench_launch.py: every rank leaves the SHA-256 of its outputs, cut into --hash-blocks equal blocks
@@ -1183,7 +883,7 @@ def main():
         if world != 1:
             raise SystemExit(f"--workload {args.workload} is a one-GPU workload")
         import fss_amd
-        rec = _small_batch_record(fss_amd.default_engine(torch.cuda.current_device()), args.workload[:3], 20, not args.no_cpu)
+        rec, _ = _small_batch_record(bench_engine(), args.workload[:3], 20, not args.no_cpu)
         print(json.dumps(r5(_workload_line(args, args.workload, rec, 1, "weak", None))), flush=True)
     else:
         run_sharded(args, rank, world, dist)

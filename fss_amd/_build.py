@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.path.join(_HERE, "libfss_amd.so")
 UNITS = ["fss_amd.hip", "fss_abi_evalall.hip", "fss_abi_gen.hip", "fss_abi_fused.hip", "fss_abi_fused_batch.hip",
-         "fss_abi_fused_chacha.hip"]  # compiled in parallel, linked into one .so
+         "fss_abi_fused_chacha.hip", "fss_abi_fused_nodes.hip"]  # compiled in parallel, linked into one .so
 HEADERS = ["fss_dev.hpp", "fss_point.hpp", "fss_quad.hpp", "fss_evalall.hpp", "fss_gen.hpp", "fss_vdpf.hpp", "fss_host.hpp",
            "fss_fused_launch.hpp"]
 OBJDIR = os.path.join(_HERE, "csrc", "build")
@@ -77,6 +77,23 @@ def build_variant(tag, defines, verbose=False):
     return build(force=True, verbose=verbose, so=os.path.join(_HERE, f"libfss_amd_{tag}.so"), defines=defines, tag=tag)
 
 
+DIAG_SO = os.path.join(_HERE, "libfss_amd_diag.so")
+
+
+def build_diag(force=False, verbose=False):
+    """The diagnostic build bench.py measures the in-kernel clock with (fss_amd._lib.diag_lib): the same sources with
+    -DFSS_DIAG_STAMPS=1 (every wave of the walks records s_memtime / s_memrealtime at entry and exit).  Stamped like the
+    product library, rebuilt only when the sources changed.  Never loaded by the product path."""
+    stamp = DIAG_SO + ".sources.sha256"
+    want = _sources_digest() + " FSS_DIAG_STAMPS=1"
+    if not force and os.path.exists(DIAG_SO) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return DIAG_SO
+    build_variant("diag", ["FSS_DIAG_STAMPS=1"], verbose=verbose)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
+    return DIAG_SO
+
+
 def build(force=False, verbose=False, so=None, defines=(), tag=""):
     """Compile fss_amd/csrc/*.hip for gfx950 (one hipcc per unit, in parallel) and link fss_amd/libfss_amd.so."""
     so = so or SO
@@ -114,7 +131,7 @@ SAMPLE_BIN = os.path.join(_HERE, "..", "samples", "dpf_dcf_gpu")
 def build_sample(force=False):
     """Compile the C++ sample (include/fss_amd.hpp over the C ABI) against libfss_amd.so."""
     build()
-    hdrs = [os.path.join(_HERE, "..", "include", h) for h in ("fss_amd.h", "fss_amd.hpp", "fss_amd_thread.hpp")]
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in PUBLIC_HEADERS]
     if (not force and os.path.exists(SAMPLE_BIN)
             and os.path.getmtime(SAMPLE_BIN) >= max(os.path.getmtime(f) for f in [SAMPLE_SRC, SO] + hdrs)):
         return SAMPLE_BIN
@@ -127,7 +144,7 @@ def build_sample(force=False):
 CXX_TESTS = os.path.join(_HERE, "..", "tests", "cxx")
 DROPIN_SRC = os.path.join(CXX_TESTS, "dropin_test.cpp")
 DROPIN_BIN = os.path.join(CXX_TESTS, "dropin_test")
-PUBLIC_HEADERS = ("fss_amd.h", "fss_amd.hpp", "fss_amd_thread.hpp")
+PUBLIC_HEADERS = ("fss_amd.h", "fss_amd.hpp", "fss_amd_thread.hpp", "fss_amd_multi.hpp")
 
 
 def _build_cxx_test(name, force=False):
@@ -150,3 +167,25 @@ def build_dropin_test(force=False):
 def build_dropin_device_test(force=False):
     """Compile tests/cxx/dropin_device_test.cpp: Gen / Eval called per thread inside the caller's own kernels."""
     return _build_cxx_test("dropin_device_test", force)
+
+
+def build_multi_gpu_test(force=False):
+    """Compile tests/cxx/multi_gpu_test.cpp: fss::gpu::DeviceSet, eight members on one GPU against one launch."""
+    return _build_cxx_test("multi_gpu_test", force)
+
+
+MULTI_SAMPLE_SRC = os.path.join(_HERE, "..", "samples", "multi_gpu.cpp")
+MULTI_SAMPLE_BIN = os.path.join(_HERE, "..", "samples", "multi_gpu")
+
+
+def build_multi_gpu_sample(force=False):
+    """Compile samples/multi_gpu.cpp (fss::gpu::DeviceSet over every visible device)."""
+    build()
+    hdrs = [os.path.join(_HERE, "..", "include", h) for h in PUBLIC_HEADERS]
+    if (not force and os.path.exists(MULTI_SAMPLE_BIN)
+            and os.path.getmtime(MULTI_SAMPLE_BIN) >= max(os.path.getmtime(f) for f in [MULTI_SAMPLE_SRC, SO] + hdrs)):
+        return MULTI_SAMPLE_BIN
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++20", "-I" + os.path.join(_HERE, "..", "include"),
+                           MULTI_SAMPLE_SRC, "-L" + _HERE, "-lfss_amd", "-Wl,-rpath,$ORIGIN/../fss_amd", "-o", MULTI_SAMPLE_BIN])
+    return MULTI_SAMPLE_BIN

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "fss_amd_ht_eval_points": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_eval_points_host": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "fss_amd_eval_points_workspace": (_sz, [_i, _i, _i]),
+    "fss_amd_ctx_set_points_plan": (_i, [_vp, _i]),
+    "fss_amd_points_prefix_bits": (_i, [_i, _i, _i64]),
     "fss_amd_dpf_eval_points_shared": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp, _sz, _vp]),
     "fss_amd_dcf_eval_points_shared": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp, _sz, _vp]),
     "fss_amd_ht_eval_points_shared": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _i, _vp, _sz, _vp]),
@@ -71,11 +73,24 @@ PROTOTYPES = {
     "fss_amd_last_kernel": (C.c_char_p, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "fss_amd_dpf_relayout_u32": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_dpf_eval_keys_u32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_batch_slice": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "fss_amd_domain_block": (_i, [_i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "fss_amd_grotto_carries": (_i, [_vp, _i, _vp]),
+    "fss_amd_grotto_apply_carry": (_i, [_vp, _vp, _i64, _i, _vp]),
     "fss_amd_ctx_scratch": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "fss_amd_ctx_scratch_release": (_i, [_vp, _vp]),
     "fss_amd_upload": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "fss_amd_ctx_read_te0": (_i, [_vp, _vp]),
 }
+
+
+def _bind(path):
+    L = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
 
 
 def lib():
@@ -86,13 +101,25 @@ def lib():
             raise ImportError(
                 f"{SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). fss_amd has no CPU fallback.")
-        L = C.CDLL(SO)
-        for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _bind(SO)
     return _lib
+
+
+DIAG_SO = os.path.join(_HERE, "libfss_amd_diag.so")
+_diag = None
+
+
+def diag_lib():
+    """The diagnostic build of the same sources (-DFSS_DIAG_STAMPS=1: every wave of the walks records s_memtime /
+    s_memrealtime; __graft_entry__.build() makes it), or None when it has not been built.  Measurement only
+    (bench.py's in-kernel clock): the product library executes no stamp."""
+    global _diag
+    if _diag is None and os.path.exists(DIAG_SO):
+        L = _bind(DIAG_SO)
+        L.fss_amd_diag_read_stamps.restype = _i
+        L.fss_amd_diag_read_stamps.argtypes = [_vp, _vp, _i]
+        _diag = L
+    return _diag
 
 
 class FssAmdError(RuntimeError):

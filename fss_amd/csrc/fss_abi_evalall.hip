@@ -10,6 +10,9 @@ int launch_fused_evalall_batch(fss_amd_ctx* ctx, int scheme, int leaf_t, const u
                                const fssamd::FusedArgs& f, int grid, hipStream_t st);
 int launch_fused_evalall_chacha(fss_amd_ctx* ctx, int scheme, int leaf_t, const uint32_t* seed, const uint32_t* cws,
                                 const uint32_t* ocw, const fssamd::FusedArgs& f, int grid, hipStream_t st, bool batch);
+// fss_abi_fused_nodes.hip
+int launch_fused_nodes(fss_amd_ctx* ctx, int scheme, int last_t, const uint32_t* seed, const uint32_t* cws,
+                       const fssamd::FusedArgs& f, int grid, hipStream_t st);
 
 namespace {
 
@@ -118,7 +121,9 @@ inline void fused_room(const Plan& pl, int64_t walks, int64_t* room_a, int64_t* 
   }
 }
 
-bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl) {
+// nodes: the plan of a node table (shared-prefix point walks): every one of the r levels is an expansion -- a Half-Tree
+// tree's last level too, which for leaves is the conversion (ConvertLastLevel) and not part of `top` / the stages.
+bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl, bool nodes = false) {
   if (in_bits < 1 || in_bits > 62 || nleaves < 1 || first_leaf < 0) return false;
   if (nleaves & (nleaves - 1)) return false;
   int r = 0;
@@ -126,10 +131,10 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
   if (r > in_bits) return false;
   if (first_leaf & (nleaves - 1)) return false;
   if (first_leaf + nleaves > ((int64_t)1 << in_bits)) return false;
-  if (scheme == S_HT && r < 1) return false;  // the last Half-Tree level always yields two leaves
+  if (scheme == S_HT && r < 1 && !nodes) return false;  // the last Half-Tree level always yields two leaves
   pl->r = r;
   pl->p = in_bits - r;
-  const int limit = r - (scheme == S_HT ? 1 : 0);
+  const int limit = r - ((scheme == S_HT && !nodes) ? 1 : 0);
   const int tmax = top_max(scheme, aes, true);
   int top = limit < tmax ? limit : tmax;
   pl->tail = frontier_tail(scheme, aes, top < limit, limit - top);
@@ -337,7 +342,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
     FusedArgs f{};
     f.a = a;
 #if FSS_DIAG_STAMPS
-    f.a.stamps = ctx->diag_stamps;  // kFusedStampSlots x 4096 waves fit the context's stamp buffer
+    f.a.stamps = ctx->diag_stamps;  // kFusedStampSlots x 4096 waves fit the context's stamp buffer (the kernel checks)
 #endif
     const int grid = fused_grid(ctx, (int64_t)1 << (pl.top - pl.tail));
     fused_slices(pl, 1, grid, bufn, bufv, &f);
@@ -553,9 +558,25 @@ bool make_prefix_plan(int scheme, bool aes, int in_bits, int k, PrefixPlan* pl) 
   return true;
 }
 
+// The node table as ONE launch (evalall_fused_kernel with OW = 0, fss_abi_fused_nodes.hip): the tree of the key's top
+// k levels under the one-launch EvalAll's plan, from kPrefixFusedMin levels on (below that a plan may end on a stage
+// that expands nothing; those tables are a few KiB and the chain of launches builds them).  Four launches of
+// 2^23 nodes: 0.219 ms as a chain (three of them thin: a table fill and a drain each), ~0.17 as one.
+constexpr int kPrefixFusedMin = 12;
+bool make_prefix_fused_plan(int scheme, int k, Plan* fp) {
+  if (k < kPrefixFusedMin || k > kPrefixMax) return false;
+  if (!make_plan(scheme, true, k, 0, (int64_t)1 << k, fp, /*nodes=*/true)) return false;
+  return fp->nstages >= 1 && fp->D[fp->nstages - 1] >= 1;
+}
 size_t prefix_workspace(int scheme, const PrefixPlan& pl, int k) {
   size_t per = (scheme == S_DCF) ? 32 : 16;
-  return align256(((size_t)1 << k) * per) + align256((size_t)pl.cap_a * per) + align256((size_t)pl.cap_b * per);
+  size_t chain = align256((size_t)pl.cap_a * per) + align256((size_t)pl.cap_b * per);
+  Plan fp;
+  if (make_prefix_fused_plan(scheme, k, &fp)) {
+    const size_t fused = align256((size_t)fp.cap_a * per) + align256((size_t)fp.cap_b * per);
+    if (fused > chain) chain = fused;
+  }
+  return align256(((size_t)1 << k) * per) + chain;
 }
 
 template <int SCHEME>
@@ -599,19 +620,38 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
   key.cws = reinterpret_cast<const uint32_t*>(cws);
   key.ocw = reinterpret_cast<const uint32_t*>(ocw);
 
-  // 1. the node table of level k: frontier walk to depth `top`, then expansion stages
+  // 1. the node table of level k: one launch (the one-launch EvalAll's plan, nodes instead of leaves) ...
   ExpandArgs e{};
   e.scheme = SCHEME; e.in_bits = in_bits; e.party = party; e.group = group;
   e.prefix = 0; e.level0 = pl.top;
+  bool fused = false;
+  static const bool fused_nodes_on = [] { const char* v = tune_env("FSS_AMD_PREFIX_FUSED"); return !(v && atoi(v) == 0); }();
+  Plan fp;
+  if (fused_nodes_on && ctx->prg != FSS_AMD_PRG_CHACHA && make_prefix_fused_plan(SCHEME, k, &fp) && fused_ok(ctx, SCHEME, fp, 1)) {
+    uint4* fbn[2] = {reinterpret_cast<uint4*>(w1), reinterpret_cast<uint4*>(w1 + align256((size_t)fp.cap_a * per))};
+    uint4* fbv[2] = {fbn[0] + fp.cap_a, fbn[1] + fp.cap_b};
+    FusedArgs fa{};
+    fa.a = e;
+    fa.a.out_nodes = tab_n;
+    fa.a.out_v = tab_v;
+    const int grid = fused_grid(ctx, (int64_t)1 << (fp.top - fp.tail));
+    fused_slices(fp, 1, grid, fbn, fbv, &fa);
+    if (fa.wg_cap[0] * grid <= fp.cap_a && fa.wg_cap[1] * grid <= fp.cap_b) {
+      int rc = launch_fused_nodes(ctx, SCHEME, fp.D[fp.nstages - 1], key.seed, key.cws, fa, grid, st);
+      if (rc != FSS_AMD_OK) return rc;
+      fused = true;
+    }
+  }
+  // ... or (ChaCha, small tables, FSS_AMD_PREFIX_FUSED=0) the frontier walk to depth `top`, then expansion stages
   e.out_nodes = pl.nstages ? bufn[0] : tab_n;
   e.out_v = pl.nstages ? bufv[0] : tab_v;
-  {
+  if (!fused) {
     int rc = launch_frontier<SCHEME, false>(ctx, st, (int64_t)1 << pl.top, key.seed, key.cws, e, pl.top, pl.tail);
     if (rc != FSS_AMD_OK) return rc;
   }
   int64_t f = (int64_t)1 << pl.top;
   int level = pl.top, cur = 0;
-  for (int s = 0; s < pl.nstages; ++s) {
+  for (int s = 0; s < pl.nstages && !fused; ++s) {
     const bool last = (s == pl.nstages - 1);
     e.level0 = level;
     e.n_in = f;
@@ -635,6 +675,27 @@ int points_shared_impl(fss_amd_ctx* ctx, const char* name, int in_bits, int grou
 }  // namespace
 
 extern "C" {
+
+// The plan FSS_AMD_POINTS_AUTO takes for `npoints` points of one key: prefix_bits, or 0 for the plain walk.
+// Blocks executed: npoints x (in_bits - k) walked + 2^(k+1) expanded, least at k ~ log2(npoints) - 0.5; with the
+// expansion a little less efficient than the walk the measured optimum is k = floor(log2 npoints) - 1
+// (profiles/r5/shared_prefix.txt), capped by the key (in_bits; Half-Tree in_bits - 1: its last level is the output
+// conversion) and by the table the plan may build (2^26 nodes).  Below kAutoPrefixMinPoints (2^18: 1.3 x there, 1.8 x at
+// 2^20, 2.9 x at 2^24) the plain walk is taken.
+constexpr int64_t kAutoPrefixMinPoints = (int64_t)1 << 18;
+int fss_amd_points_prefix_bits(int scheme, int in_bits, int64_t npoints) {
+  if ((scheme != S_DPF && scheme != S_DCF && scheme != S_HT) || in_bits < 1 || in_bits > 64) return 0;
+  static const int64_t min_points = [] { const char* e = tune_env("FSS_AMD_AUTO_PREFIX_MIN"); return e ? (int64_t)atoll(e) : kAutoPrefixMinPoints; }();
+  static const int back = [] { const char* e = tune_env("FSS_AMD_AUTO_PREFIX_BACK"); return e ? atoi(e) : 1; }();
+  if (npoints < min_points || npoints <= quad_points_max()) return 0;
+  int lg = 0;
+  while (((int64_t)2 << lg) <= npoints) ++lg;  // floor(log2 npoints)
+  int k = lg - (lg >= 19 ? back : back + 1);  // (2^18 points: every table up to 2^18 nodes costs the same ~60 us, a launch-latency chain)
+  const int cap = scheme == S_HT ? in_bits - 1 : in_bits;
+  if (k > cap) k = cap;
+  if (k > kPrefixMax) k = kPrefixMax;
+  return k < 1 ? 0 : k;
+}
 
 size_t fss_amd_eval_points_workspace(int scheme, int in_bits, int prefix_bits) {
   PrefixPlan pl;
@@ -783,6 +844,9 @@ int fss_amd_grotto_eval_keys(fss_amd_ctx* ctx, int in_bits, int party, const voi
         a.rot_prio = tune().rot_prio >= 0 ? tune().rot_prio : (a.dyn ? 0 : tune().static_prio);
         a.prio_every = tune().prio_every;
         if (in_bits >= 16) set_tail(ctx, S(stream), a.dyn, nkeys, 128, grid, &a.gq, &a.static_chunks);
+#if FSS_DIAG_STAMPS
+        a.stamps = ctx->diag_stamps;
+#endif
         return launch_grid(ctx, grotto_walk_defer_kernel<1024>, "grotto_eval_keys", grid, bs, S(stream), ctx->host, ctx->te0, a);
       }
     }

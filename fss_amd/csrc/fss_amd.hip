@@ -144,6 +144,8 @@ void fss_amd_ctx_destroy(fss_amd_ctx* ctx) {
   if (ctx->tail_pairs) (void)hipFree(ctx->tail_pairs);
   for (auto& kv : ctx->scratch)
     if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& kv : ctx->prefix_ws)
+    if (kv.second.p) (void)hipFree(kv.second.p);
   delete ctx;
 }
 
@@ -169,7 +171,7 @@ int fss_amd_ctx_scratch(fss_amd_ctx* ctx, void* stream, size_t bytes, void** out
 int fss_amd_ctx_scratch_release(fss_amd_ctx* ctx, void* stream) {
   if (!ctx) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
-  void* p = nullptr;
+  void *p = nullptr, *pw = nullptr;
   {
     std::lock_guard<std::mutex> lk(ctx->scratch_mu);
     auto it = ctx->scratch.find(stream_key(stream));
@@ -178,9 +180,21 @@ int fss_amd_ctx_scratch_release(fss_amd_ctx* ctx, void* stream) {
       ctx->scratch.erase(it);
     }
   }
-  // wait for the device either way: work still queued on the buffer (or using the stream's work-distribution
+  {  // the stream's shared-prefix buffer (FSS_AMD_POINTS_AUTO) goes with it
+    std::lock_guard<std::mutex> lk(ctx->auto_mu);
+    auto it = ctx->prefix_ws.find(stream_key(stream));
+    if (it != ctx->prefix_ws.end()) {
+      pw = it->second.p;
+      ctx->prefix_ws.erase(it);
+    }
+  }
+  // wait for the device either way: work still queued on the buffers (or using the stream's work-distribution
   // counters, which are handed on below) has finished
-  const hipError_t e = p ? hipFree(p) : hipDeviceSynchronize();
+  hipError_t e = p ? hipFree(p) : hipDeviceSynchronize();
+  if (pw) {
+    const hipError_t e2 = hipFree(pw);
+    if (e == hipSuccess) e = e2;
+  }
   // the counter pair goes back to the pool whatever the device said: the buffer is already forgotten, and a pair that
   // stayed with a dead stream would be lost for the life of the context
   ctx->tail_release(stream);
@@ -240,6 +254,12 @@ int fss_amd_ctx_set_prg(fss_amd_ctx* ctx, int prg, const int32_t nonce[2], int r
   return FSS_AMD_OK;
 }
 
+int fss_amd_ctx_set_points_plan(fss_amd_ctx* ctx, int plan) {
+  if (!ctx || (plan != FSS_AMD_POINTS_AUTO && plan != FSS_AMD_POINTS_PLAIN)) return FSS_AMD_EINVAL;
+  ctx->points_plan = plan;
+  return FSS_AMD_OK;
+}
+
 int fss_amd_ctx_set_uint_modulus(fss_amd_ctx* ctx, uint64_t mod) {
   if (!ctx) return FSS_AMD_EINVAL;
   ctx->host.uint_mod = mod;
@@ -265,6 +285,65 @@ const char* fss_amd_last_kernel(const fss_amd_ctx* ctx, int* grid, int* block) {
   return ctx->last_kernel;
 }
 
+// ------------------------------------------------------------------ one job across the GPUs of a node
+int fss_amd_batch_slice(int64_t n, int rank, int world, int64_t* lo, int64_t* hi) {
+  if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return FSS_AMD_EINVAL;
+  const int64_t base = n / world, rem = n % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+  return FSS_AMD_OK;
+}
+
+int fss_amd_domain_block(int in_bits, int rank, int world, int64_t* first_leaf, int64_t* nleaves) {
+  if (in_bits < 1 || in_bits > 62 || world < 1 || (world & (world - 1)) || rank < 0 || rank >= world || !first_leaf || !nleaves)
+    return FSS_AMD_EINVAL;
+  if ((int64_t)world > ((int64_t)1 << in_bits)) return FSS_AMD_EINVAL;  // more ranks than leaves
+  *nleaves = ((int64_t)1 << in_bits) / world;
+  *first_leaf = rank * *nleaves;
+  return FSS_AMD_OK;
+}
+
+int fss_amd_grotto_carries(const uint8_t* shard_last, int world, uint8_t* carry_in) {
+  if (!shard_last || !carry_in || world < 1) return FSS_AMD_EINVAL;
+  uint8_t acc = 0;
+  for (int r = 0; r < world; ++r) {
+    carry_in[r] = acc;
+    acc ^= shard_last[r] & 1u;
+  }
+  return FSS_AMD_OK;
+}
+
+}  // extern "C"
+namespace {
+__global__ void xor_bytes_kernel(uint8_t* p, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;  // bytes before the first 16-byte boundary
+  const int64_t h = head < n ? head : n, nv = (n - h) >> 4;
+  uint4* v = reinterpret_cast<uint4*>(p + h);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    uint4 t = v[i];
+    t.x ^= 0x01010101u; t.y ^= 0x01010101u; t.z ^= 0x01010101u; t.w ^= 0x01010101u;
+    v[i] = t;
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = threadIdx.x; i < h; i += blockDim.x) p[i] ^= 1u;
+    for (int64_t i = h + (nv << 4) + threadIdx.x; i < n; i += blockDim.x) p[i] ^= 1u;
+  }
+}
+}  // namespace
+extern "C" {
+
+int fss_amd_grotto_apply_carry(fss_amd_ctx* ctx, void* ys_bytes, int64_t nleaves, int carry, void* stream) {
+  if (!ctx || nleaves < 0 || (carry != 0 && carry != 1) || (nleaves > 0 && !ys_bytes)) return FSS_AMD_EINVAL;
+  if (carry == 0 || nleaves == 0) return FSS_AMD_OK;
+  FSS_ON_DEVICE(ctx);
+  const int64_t want = (nleaves / 16 + 255) / 256 + 1, cap = (int64_t)ctx->num_cu * 8;
+  hipLaunchKernelGGL(xor_bytes_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, S(stream),
+                     reinterpret_cast<uint8_t*>(ys_bytes), nleaves);
+  HIP_TRY(hipGetLastError());
+  return FSS_AMD_OK;
+}
+
 // ------------------------------------------------------------------ raw PRG
 int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, void* out, void* stream) {
   if (!ctx || !seeds || !out || n < 0 || (mul != 1 && mul != 2 && mul != 4)) return FSS_AMD_EINVAL;
@@ -288,13 +367,32 @@ int fss_amd_prg_gen(fss_amd_ctx* ctx, int mul, const void* seeds, int64_t n, voi
 // ------------------------------------------------------------------ point eval, shared key
 static int points_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int party, const void* seed,
                          const void* cws, const void* ocw, const void* xs, int x_bytes, int64_t n, void* ys,
-                         void* stream) {
+                         void* stream, bool resident = true) {
   if (!ctx || !seed || !cws || n < 0 || !group_ok(ctx, group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes))
     return FSS_AMD_EINVAL;
   if (n > 0 && (!xs || !ys)) return FSS_AMD_EINVAL;
   if (scheme == S_HT && !ocw) return FSS_AMD_EINVAL;
   if (!aligned16(seed, cws, ocw, ys) || !aligned_to(xs, x_bytes)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
+  // FSS_AMD_POINTS_AUTO (fss_amd.h): a batch large enough to pay for the key's top levels once takes the shared-prefix
+  // plan -- the same outputs, about a third of the AES blocks at 2^24 points.  Not for host-resident batches (they
+  // run at the PCIe rate either way), nor inside a stream capture (the plan's buffer may have to be allocated).
+  if (resident && ctx->points_plan == FSS_AMD_POINTS_AUTO && x_bytes <= 8) {
+    const int k = fss_amd_points_prefix_bits(scheme, in_bits, n);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (k > 0 && hipStreamIsCapturing(S(stream), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusActive; }
+    const size_t need = k > 0 ? fss_amd_eval_points_workspace(scheme, in_bits, k) : 0;
+    if (need > 0 && cap == hipStreamCaptureStatusNone) {
+      std::lock_guard<std::mutex> lk(ctx->auto_mu);
+      if (void* ws = ctx->prefix_buffer(stream, need)) {
+        switch (scheme) {
+          case S_DPF: return fss_amd_dpf_eval_points_shared(ctx, in_bits, group, party, seed, cws, xs, x_bytes, n, ys, k, ws, need, stream);
+          case S_DCF: return fss_amd_dcf_eval_points_shared(ctx, in_bits, group, party, seed, cws, xs, x_bytes, n, ys, k, ws, need, stream);
+          default: return fss_amd_ht_eval_points_shared(ctx, in_bits, group, party, seed, cws, ocw, xs, x_bytes, n, ys, k, ws, need, stream);
+        }
+      }
+    }
+  }
   EvalArgs a{};
   a.in_bits = in_bits; a.party = party; a.group = group; a.x_bytes = x_bytes; a.n = n;
   a.xs = xs; a.ys = ys;
@@ -357,7 +455,8 @@ int fss_amd_eval_points_host(fss_amd_ctx* ctx, int scheme, int in_bits, int grou
     if (!xs || !ys) return FSS_AMD_EINVAL;  // pageable memory: pin it (hipHostRegister) or stage it yourself
   }
   const int s = scheme == FSS_AMD_DPF ? S_DPF : (scheme == FSS_AMD_DCF ? S_DCF : S_HT);
-  return points_common(ctx, s, in_bits, group, party, seed, cws, s == S_HT ? ocw : nullptr, xs, x_bytes, npoints, ys, stream);
+  return points_common(ctx, s, in_bits, group, party, seed, cws, s == S_HT ? ocw : nullptr, xs, x_bytes, npoints, ys, stream,
+                       /*resident=*/false);
 }
 
 // ------------------------------------------------------------------ relayout

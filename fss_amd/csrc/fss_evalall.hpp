@@ -617,6 +617,9 @@ struct LocalQ {
 };
 
 // BATCH: nkeys trees side by side (a.nkeys, a.seeds, a.key_slots; walk j belongs to key j >> (top - tail)).
+// OW = 0: the last stage stores the NODES of its level (and the DCF running values) at their global index in
+// f.a.out_nodes / f.a.out_v instead of converting leaves -- the node table of the shared-prefix point walks
+// (fss_amd_*_eval_points_shared), whose top `prefix_bits` levels are this kernel's whole tree.
 template <class LT, int SCHEME, int LD, int LE, int OW, bool BATCH = false>
 __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
@@ -629,11 +632,17 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
 #if FSS_DIAG_STAMPS
   // per-wave phase stamps (s_memrealtime, 100 MHz): entry | tables filled | own walks done | then per stage {start
   // (after the barrier), own chunks done}; tools/evalall_phases.py prints the table (kFusedStampSlots per wave)
-  uint64_t* const stamp_o = f.a.stamps ? f.a.stamps + (int64_t)kFusedStampSlots * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) : nullptr;
+  // slots 0 .. 12: the phase stamps; 13 = s_memrealtime at the wave's end, 14 / 15 = s_memtime (shader clock) at its
+  // entry / end: in-kernel clock = (slot 15 - slot 14) / (slot 13 - slot 0) x 100 MHz (bench.py's `clk`).  A launch
+  // with more waves than the context's buffer has records for (FSS_AMD_FUSED_GRID above 320 workgroups) goes unstamped.
+  const int64_t stamp_rec = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  uint64_t* const stamp_o = (f.a.stamps && (stamp_rec + 1) * kFusedStampSlots <= (int64_t)kDiagStampRecords * 5)
+                                ? f.a.stamps + (int64_t)kFusedStampSlots * stamp_rec : nullptr;
   int stamp_k = 0;
+  if (stamp_o && (threadIdx.x & 63) == 0) stamp_o[14] = __builtin_amdgcn_s_memtime();
 #define FSS_FUSED_STAMP()                                                                                          \
   do {                                                                                                             \
-    if (stamp_o && (threadIdx.x & 63) == 0 && stamp_k < kFusedStampSlots) stamp_o[stamp_k] = __builtin_amdgcn_s_memrealtime(); \
+    if (stamp_o && (threadIdx.x & 63) == 0 && stamp_k < kFusedStampSlots - 3) stamp_o[stamp_k] = __builtin_amdgcn_s_memrealtime(); \
     ++stamp_k;                                                                                                     \
   } while (0)
 #else
@@ -688,14 +697,26 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
   if (threadIdx.x < 16) wave_prog_[threadIdx.x] = 0;
   __syncthreads();
   FSS_FUSED_STAMP();
-  {  // ---- leaf stage: mine[cur] -> ys
+  {  // ---- leaf stage: mine[cur] -> ys (OW = 0: -> the node table)
     a.level0 = level;
     a.in_nodes = mine[cur] - lo;
     a.in_v = minev[cur] - lo;
     LocalQ q(&waveq_ctr_, lo, hi, f.rank != 0);
-    run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    if constexpr (OW == 0) {
+      a.out_nodes = f.a.out_nodes;
+      a.out_v = f.a.out_v;
+      run_stage<LT, SCHEME, LD, false, LE, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    } else {
+      run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    }
   }
   FSS_FUSED_STAMP();
+#if FSS_DIAG_STAMPS
+  if (stamp_o && (threadIdx.x & 63) == 0) {
+    stamp_o[13] = __builtin_amdgcn_s_memrealtime();
+    stamp_o[15] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 #undef FSS_FUSED_STAMP
 }
 

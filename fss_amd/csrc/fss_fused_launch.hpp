@@ -24,7 +24,7 @@ int launch_one(fss_amd_ctx* ctx, const SharedKey& k, const FusedArgs& f, int gri
 template <int SCHEME, int OW, bool BATCH = false, class LT = Lds>
 int by_leaf(fss_amd_ctx* ctx, int leaf_t, const SharedKey& k, const FusedArgs& f, int grid, hipStream_t st) {
   constexpr int DM = SCHEME == S_DCF ? 1 : 2;
-  if constexpr (SCHEME != S_HT) {
+  if constexpr (SCHEME != S_HT && OW != 0) {  // (node tables, OW = 0, always end on a stage that expands)
     if (leaf_t == 0) return launch_one<SCHEME, 0, 0, 4, BATCH, LT>(ctx, k, f, grid, st);  // conversion only: no block to narrow
   }
   if (leaf_t == 1) return launch_one<SCHEME, 1, 0, OW, BATCH, LT>(ctx, k, f, grid, st);

@@ -46,6 +46,29 @@ struct fss_amd_ctx {
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   std::mutex scratch_mu;
   std::map<StreamKey, Scratch> scratch;
+  // fss_amd_*_eval_points under FSS_AMD_POINTS_AUTO: the node table + stage buffers of the shared-prefix plan, one
+  // grow-only buffer per stream, NOT the buffer fss_amd_ctx_scratch hands out (a caller may have parked the very seed it
+  // passes in that one).  auto_mu is held from taking the buffer until the plan's last kernel is enqueued: two host
+  // threads on one stream then enqueue "table, walk" pairs whole.
+  int points_plan = FSS_AMD_POINTS_AUTO;
+  std::mutex auto_mu;
+  std::map<StreamKey, Scratch> prefix_ws;
+  // (auto_mu held) the stream's buffer grown to `bytes`; nullptr when the device has no room (the caller walks plainly)
+  void* prefix_buffer(void* stream, size_t bytes) {
+    Scratch& s = prefix_ws[stream_key(stream)];
+    if (s.bytes < bytes || !s.p) {
+      if (s.p) (void)hipFree(s.p);  // waits for the device: work queued on the old buffer has finished
+      s.p = nullptr;
+      s.bytes = 0;
+      if (hipMalloc(&s.p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        s.p = nullptr;
+        return nullptr;
+      }
+      s.bytes = bytes;
+    }
+    return s.p;
+  }
   uint64_t* diag_stamps = nullptr;  // FSS_DIAG_STAMPS builds: 4 x uint64 per workgroup of the last point-walk launch
   // WaveQ's launch-wide tail counters: one {counter, waves done} pair per real stream that launched a dynamic walk
   // (launches on one stream run one after the other, and the kernel hands its pair back zeroed; StreamKey tells the
@@ -356,11 +379,12 @@ int launch_points(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const 
   return FSS_BY_PRG(ctx, (launch_points_k(ctx, eval_points_kernel<LT, SCHEME, SHARED, I, B, PREFIX>, name, I, B, k, a, st, tail_ok, mix_ok, blocks_per_eval)))
   FSS_L(1, 1024);
   FSS_L(2, 1024);
-  if constexpr (PREFIX) return FSS_AMD_EINVAL;
-  FSS_L(1, 512);
-  FSS_L(2, 512);
-  FSS_L(1, 256);
-  FSS_L(2, 256);
+  if constexpr (!PREFIX) {  // (discarded for PREFIX: those kernels exist for 1024 lanes only)
+    FSS_L(1, 512);
+    FSS_L(2, 512);
+    FSS_L(1, 256);
+    FSS_L(2, 256);
+  }
 #undef FSS_L
   return FSS_AMD_EINVAL;
 }

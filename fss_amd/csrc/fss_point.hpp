@@ -318,9 +318,14 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       xv[j] = load_x(a.xs, a.x_bytes, e < n ? e : n - 1);
     }
   };
-  // one chunk; its points arrive in xv (run_region)
-  auto walk_chunk = [&](auto ilp_tag, const int64_t base, const X128* xv) {
+  // Level at which a shared-prefix walk requests the NEXT chunk's start nodes (mid_hook): half way down, so the
+  // points those nodes are indexed by (requested before this chunk started) have had half a walk to arrive and the
+  // nodes have the other half.
+  const int mid_level = lvl0 + ((in_bits - lvl0) >> 1);
+  // one chunk; its points arrive in xv and, for the shared-prefix walks, its start nodes in pn / pv (run_region)
+  auto walk_chunk = [&](auto ilp_tag, const int64_t base, const X128* xv, const uint4* pn, const uint4* pv, auto&& mid_hook) {
     constexpr int ILP = decltype(ilp_tag)::value;
+    (void)pn; (void)pv; (void)mid_hook;
     int64_t idx[ILP];
 #pragma unroll
     for (int j = 0; j < ILP; ++j) {
@@ -332,12 +337,13 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       DpfWalk w[ILP];
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {
-        uint32_t s0[4];
-        if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
-        else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
-        w[j].init(s0, party, xv[j]);
         if constexpr (PREFIX) {
-          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
+          w[j].resume(pn[j], xv[j]);  // start_level >= 1 (make_prefix_plan): the root never starts a shared-prefix walk
+        } else {
+          uint32_t s0[4];
+          if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
+          else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+          w[j].init(s0, party, xv[j]);
         }
       }
       uint64_t trb[ILP], trbh[ILP];  // tr bits of levels 0..63 and 64..127 (second plane at + n)
@@ -348,10 +354,12 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
           trbh[j] = in_bits > 64 ? a.tr_bits[n + idx[j]] : 0ull;
         }
       }
+      if constexpr (PREFIX) { if (mid_level >= in_bits) mid_hook(); }  // no level left to walk: no iteration below
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
         else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack, (uint32_t)a.prio_every);
+        if constexpr (PREFIX) { if (i == mid_level) mid_hook(); }
         CwDpf cw[ILP];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
@@ -379,21 +387,21 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       DcfWalk w[ILP];
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {
-        uint32_t s0[4];
-        if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
-        else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
-        w[j].init(s0, party, xv[j]);
         if constexpr (PREFIX) {
-          if (lvl0 > 0) {
-            const uint64_t q = (w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
-            w[j].resume(a.pre_nodes[q], a.pre_v[q], w[j].x);
-          }
+          w[j].resume(pn[j], pv[j], xv[j]);
+        } else {
+          uint32_t s0[4];
+          if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
+          else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+          w[j].init(s0, party, xv[j]);
         }
       }
+      if constexpr (PREFIX) { if (mid_level >= in_bits) mid_hook(); }  // no level left to walk: no iteration below
 #pragma unroll 1
       for (int i = lvl0; i < in_bits; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
         else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack, (uint32_t)a.prio_every);
+        if constexpr (PREFIX) { if (i == mid_level) mid_hook(); }
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
           CwDcf cw;
@@ -422,18 +430,22 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       HtWalk w[ILP];
 #pragma unroll
       for (int j = 0; j < ILP; ++j) {
-        uint32_t s0[4];
-        if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
-        else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
-        w[j].init(s0, party, xv[j]);
         if constexpr (PREFIX) {
-          if (lvl0 > 0) w[j].resume(a.pre_nodes[(w[j].x.lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1)], w[j].x);
+          w[j].resume(pn[j], xv[j]);  // start_level >= 1 (make_prefix_plan): the root never starts a shared-prefix walk
+        } else {
+          uint32_t s0[4];
+          if constexpr (SHARED) { s0[0] = k_seed[0]; s0[1] = k_seed[1]; s0[2] = k_seed[2]; s0[3] = k_seed[3]; }
+          else { uint4 t = a.seeds[idx[j]]; s0[0] = t.x; s0[1] = t.y; s0[2] = t.z; s0[3] = t.w; }
+          w[j].init(s0, party, xv[j]);
         }
       }
+      // (a Half-Tree key with one walked level left has no loop iteration: its hook runs before the last level)
+      if constexpr (PREFIX) { if (mid_level >= in_bits - 1) mid_hook(); }
 #pragma unroll 1
       for (int i = lvl0; i < in_bits - 1; ++i) {
         if (a.rot_prio == 1) rotate_prio(i);
         else if (a.rot_prio == 2) rank_prio(wave_prog_, my_prog, (uint32_t)a.prio_slack, (uint32_t)a.prio_every);
+        if constexpr (PREFIX) { if (i == mid_level) mid_hook(); }
         uint32_t cw[ILP][4];
 #pragma unroll
         for (int j = 0; j < ILP; ++j) {
@@ -468,10 +480,41 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
   // (WaveQ::peek): +0.8-1.0 % at n = 16 / 32 / 64 x 2^24 points, +0.3 % at 2^20, three interleaved rounds on one box; the
   // same form costs DCF, Half-Tree and every independent-key walk 0.2-0.4 % (their levels carry more live state), so
   // those load their points when the chunk starts (profiles/r4/prefetch_x_ab.txt).
+  // The shared-prefix walks (PREFIX) go one step further: a chunk there is only in_bits - start_level levels long and
+  // starts with a dependent chain -- point, then a 16-byte gather from the node table at an address the point decides --
+  // so besides the points (a chunk ahead) the NEXT chunk's start nodes are requested half way down the current chunk
+  // (mid_hook) and the gather's latency runs under the second half of the walk.
   constexpr bool kAheadX = SCHEME == S_DPF && SHARED;
+  auto gather_nodes = [&](auto ilp_tag, const X128* xv, uint4* pn, uint4* pv) {
+    constexpr int ILP = decltype(ilp_tag)::value;
+    (void)pv;
+    if constexpr (PREFIX) {
+#pragma unroll
+      for (int j = 0; j < ILP; ++j) {
+        const uint64_t q = (xv[j].lo >> (in_bits - lvl0)) & ((1ull << lvl0) - 1);
+        pn[j] = a.pre_nodes[q];
+        if constexpr (SCHEME == S_DCF) pv[j] = a.pre_v[q];
+      }
+    }
+  };
   auto run_region = [&](auto ilp_tag, WaveQ& wq, const int64_t off) {
     constexpr int ILP = decltype(ilp_tag)::value;
-    if constexpr (kAheadX) {
+    auto no_hook = [] {};
+    if constexpr (PREFIX) {
+      X128 xc[ILP], xn[ILP];
+      uint4 nc[ILP], nn[ILP], vc[ILP], vn[ILP];
+      int64_t base, nb;
+      if (!wq.peek(base)) return;
+      load_chunk_x(ilp_tag, off + base, xc);
+      gather_nodes(ilp_tag, xc, nc, vc);
+      while (wq.next(base)) {
+        const bool more = wq.peek(nb);
+        if (more) load_chunk_x(ilp_tag, off + nb, xn);
+        walk_chunk(ilp_tag, off + base, xc, nc, vc, [&] { if (more) gather_nodes(ilp_tag, xn, nn, vn); });
+#pragma unroll
+        for (int j = 0; j < ILP; ++j) { xc[j] = xn[j]; nc[j] = nn[j]; vc[j] = vn[j]; }
+      }
+    } else if constexpr (kAheadX) {
       X128 xc[ILP], xn[ILP];
       int64_t base, nb;
       if (!wq.peek(base)) return;
@@ -479,7 +522,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       while (wq.next(base)) {
         const bool more = wq.peek(nb);
         if (more) load_chunk_x(ilp_tag, off + nb, xn);
-        walk_chunk(ilp_tag, off + base, xc);
+        walk_chunk(ilp_tag, off + base, xc, nullptr, nullptr, no_hook);
 #pragma unroll
         for (int j = 0; j < ILP; ++j) xc[j] = xn[j];
       }
@@ -487,7 +530,7 @@ __global__ __launch_bounds__(BS) void eval_points_kernel(const DevCtx K, const u
       for (int64_t base; wq.next(base);) {
         X128 xc[ILP];
         load_chunk_x(ilp_tag, off + base, xc);
-        walk_chunk(ilp_tag, off + base, xc);
+        walk_chunk(ilp_tag, off + base, xc, nullptr, nullptr, no_hook);
       }
     }
   };
@@ -557,11 +600,15 @@ __global__ __launch_bounds__(BS) void grotto_walk_kernel(const DevCtx K, const u
 // The same walk with the siblings deferred (AES tables only).  A level needs the taken child of every lane
 // but the left sibling -- and of it only the control bit -- just where e's bit is 1: computing both children
 // everywhere is 2n blocks for the 1.5n the walk needs.  So a level computes the taken child only (per-lane
-// key select, two keys per lane interleaved) and lanes whose bit is 1 append (parent seed, owner) to a
-// per-wave queue in LDS; whenever 64 jobs are queued the wave runs one dense AES over them (key 0, every
-// lane busy) and XORs each job's control bit into its owner's accumulator with an LDS atomic (XOR commutes,
-// so the order of delivery is free).  The correction of the sibling's bit (t & cw.tl) is the owner's own.
-// A short queue is flushed at the end of the chunk (one partly filled AES per 128 keys x n levels).
+// key select, two keys per lane interleaved) and lanes whose bit is 1 append the parent seed to a per-wave
+// queue in LDS; whenever 64 jobs are queued the wave runs one dense AES over them (key 0, every lane busy).
+// The 64 control bits go back to their owners without touching the LDS again: a lane remembers WHICH queue
+// positions it filled (a 64-bit mask per walk, `mine`), the dense block's bits are gathered into one wave-wide
+// ballot, and every owner XORs the parity of (ballot & mine) into its accumulator -- XOR commutes, so the order
+// of delivery is free.  (Round 4 delivered each bit with an LDS atomic XOR into a per-key word: 20.4 M bank-conflict
+// cycles per launch from jobs of one owner meeting in one word, profiles/r4/pmc_workloads.json.)  The correction of
+// the sibling's bit (t & cw.tl) is the owner's own.  A short queue is flushed at the end of the chunk (one partly
+// filled AES per 128 keys x n levels); the lanes past its end run the block on stale seeds whose bits nobody owns.
 template <int BS>
 __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
   const DevCtx* c = first_kernarg(K);
@@ -571,30 +618,29 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
   FSS_PRG_PROLOGUE(Lds, te0);
   constexpr int NW = BS / 64;
   __shared__ uint4 q_seed[NW][64];
-  __shared__ uint32_t q_own[NW][64];   // lane + 64 * j of the key that waits for the bit
-  __shared__ uint32_t q_acc[NW][128];  // per key of the chunk: XOR of the delivered bits
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  q_acc[wv][lane] = 0u;
-  q_acc[wv][lane + 64] = 0u;
+#if FSS_DIAG_STAMPS
+  const uint64_t stamp_t0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  q_seed[wv][lane] = make_uint4(0u, 0u, 0u, 0u);  // a short first flush reads every slot
   const int n = a.in_bits;
   uint8_t* __restrict__ ys = reinterpret_cast<uint8_t*>(a.ys);
-  // one dense AES over the first `count` queued jobs of this wave
-  auto flush = [&](int count) {
+  // one dense AES over the queued jobs of this wave: bit p of the result = control bit of the left child of job p
+  auto flush = [&]() -> uint64_t {
     wave_lds_sync();
-    if (lane < count) {
-      const uint4 s4 = q_seed[wv][lane];
-      const uint32_t own = q_own[wv][lane];
-      uint32_t in[4] = {s4.x, s4.y, s4.z, s4.w};
-      // key 0 = the left child (aes128_mmo.cuh:79-89); in[3]'s control bit is clear; control bit only
-      atomicXor(&q_acc[wv][own], prg_tbit_left(L, c, in) & 1u);
-    }
+    const uint4 s4 = q_seed[wv][lane];
+    uint32_t in[4] = {s4.x, s4.y, s4.z, s4.w};
+    // key 0 = the left child (aes128_mmo.cuh:79-89); in[3]'s control bit is clear; control bit only
+    const uint64_t bits = __ballot((prg_tbit_left(L, c, in) & 1u) != 0u);
     wave_lds_sync();
+    return bits;
   };
   WaveQ q(a.dyn, &waveq_ctr_, a.n, 2, a.gq, a.static_chunks);
   for (int64_t base; q.next(base);) {
     int64_t k[2];
     bool valid[2], whole[2];
     uint64_t e[2], trb[2];
+    uint64_t mine[2] = {0ull, 0ull};  // queue positions this lane filled for walk j since the last flush
     uint32_t st[2][4], pi[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -606,6 +652,13 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
       st[j][0] = s4.x; st[j][1] = s4.y; st[j][2] = s4.z; st[j][3] = (s4.w & ~1u) | (uint32_t)a.party;
       trb[j] = load_tr(a.tr_bits, a.tr32, k[j]);
     }
+    auto deliver = [&](uint64_t bits) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        pi[j] ^= (uint32_t)__popcll(bits & mine[j]) & 1u;
+        mine[j] = 0ull;
+      }
+    };
     int pending = 0;  // jobs queued by this wave (wave-uniform)
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
@@ -634,13 +687,13 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
         const int pos = pending + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (has && pos < 64) {
           q_seed[wv][pos] = make_uint4(in[j][0], in[j][1], in[j][2], in[j][3]);
-          q_own[wv][pos] = (uint32_t)(lane + 64 * j);
+          mine[j] |= 1ull << pos;
         }
         if (pending + cnt >= 64) {
-          flush(64);
+          deliver(flush());
           if (has && pos >= 64) {
             q_seed[wv][pos - 64] = make_uint4(in[j][0], in[j][1], in[j][2], in[j][3]);
-            q_own[wv][pos - 64] = (uint32_t)(lane + 64 * j);
+            mine[j] |= 1ull << (pos - 64);
           }
           pending += cnt - 64;
         } else {
@@ -648,16 +701,18 @@ __global__ __launch_bounds__(BS) void grotto_walk_defer_kernel(const DevCtx K, c
         }
       }
     }
-    if (pending > 0) flush(pending);
-    else wave_lds_sync();
+    if (pending > 0) deliver(flush());
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      pi[j] ^= q_acc[wv][lane + 64 * j];
-      q_acc[wv][lane + 64 * j] = 0u;
+    for (int j = 0; j < 2; ++j)
       if (valid[j]) ys[k[j]] = (uint8_t)(whole[j] ? (uint32_t)a.party : pi[j]);
-    }
-    wave_lds_sync();
   }
+#if FSS_DIAG_STAMPS
+  if (lane == 0 && a.stamps) {  // one record per wave, as eval_points_kernel's
+    const int64_t rec = (int64_t)blockIdx.x * NW + wv;
+    uint64_t* o = a.stamps + 4 * (rec < kDiagStampRecords ? rec : 0);
+    o[0] = stamp_t0; o[1] = stamp_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   q.done();
 }
 

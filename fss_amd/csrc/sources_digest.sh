@@ -4,7 +4,7 @@
 # tests/test_abi.py checks that the two agree.
 cd "$(dirname "$0")" || exit 1
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC"
-FILES="fss_amd.hip fss_abi_evalall.hip fss_abi_gen.hip fss_abi_fused.hip fss_abi_fused_batch.hip fss_abi_fused_chacha.hip \
+FILES="fss_amd.hip fss_abi_evalall.hip fss_abi_gen.hip fss_abi_fused.hip fss_abi_fused_batch.hip fss_abi_fused_chacha.hip fss_abi_fused_nodes.hip \
 fss_dev.hpp fss_point.hpp fss_quad.hpp fss_evalall.hpp fss_gen.hpp fss_vdpf.hpp fss_host.hpp fss_fused_launch.hpp \
 ../../include/fss_amd.h"
 {

@@ -53,8 +53,8 @@ class LevelMajorKeys:
 
 class Engine:
     def __init__(self, device=None, aes_keys=DEFAULT_AES_KEYS, hash_key=DEFAULT_HASH_KEY, prg="aes128_mmo",
-                 chacha_nonce=DEFAULT_CHACHA_NONCE, chacha_rounds=20):
-        L = _lib.lib()
+                 chacha_nonce=DEFAULT_CHACHA_NONCE, chacha_rounds=20, lib=None):
+        L = lib if lib is not None else _lib.lib()  # lib: another build of the library (bench.py: _lib.diag_lib())
         if not torch.cuda.is_available():
             raise RuntimeError("fss_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
         if device is None:
@@ -68,6 +68,7 @@ class Engine:
         _lib.check(L.fss_amd_ctx_create(C.byref(h), self.device.index, C.c_char_p(keys), hk), "fss_amd_ctx_create")
         self._h, self._L = h, L
         self.prg = prg
+        self.points_plan = "auto"
         if prg not in PRG_IDS:
             raise ValueError(f"prg must be one of {tuple(PRG_IDS)}, got {prg!r}")
         if prg == "chacha":
@@ -137,6 +138,16 @@ class Engine:
             return 8
         raise TypeError(f"xs must be uint8, int16, int32 or int64 bit patterns (or (n, 2) int64 pairs), got {xs.dtype}")
 
+    def set_points_plan(self, plan):
+        """'auto' (default): eval_points takes the shared-prefix plan for batches of >= 2^19 points of one key (same
+        outputs, about a third of the AES work at 2^24 points; the node table lives in a per-stream buffer of the
+        context).  'plain': every point walks from the root (what bench.py's `value` measures)."""
+        if plan not in ("auto", "plain"):
+            raise ValueError(f"plan must be 'auto' or 'plain', got {plan!r}")
+        _lib.check(self._L.fss_amd_ctx_set_points_plan(self._h, 0 if plan == "auto" else 1), "fss_amd_ctx_set_points_plan")
+        self.points_plan = plan
+        return self
+
     def last_kernel(self):
         g, b = C.c_int(0), C.c_int(0)
         name = self._L.fss_amd_last_kernel(self._h, C.byref(g), C.byref(b)).decode()
@@ -202,7 +213,8 @@ class Engine:
 
     def eval_points_shared(self, scheme, in_bits, group, party, seed, cws, xs, ocw=None, out=None, prefix_bits=None):
         """eval_points with the shared top of the tree expanded once per launch (same outputs).
-        prefix_bits=None picks ~log2(len(xs)), capped by in_bits and 26."""
+        prefix_bits=None: the library's own choice for this batch (fss_amd_points_prefix_bits: floor(log2 n) - 1, capped
+        by in_bits and 26), also for batches below the size from which eval_points would pick this plan by itself."""
         seed, cws, xs = self._dev(seed, torch.int32), self._dev(cws, torch.int32), self._dev(xs)
         xb = self._xbytes(xs, in_bits)
         if xb == 16:
@@ -210,7 +222,7 @@ class Engine:
         n = xs.numel()
         cap = min(in_bits - (1 if scheme == HT else 0), 26)
         if prefix_bits is None:
-            prefix_bits = min(cap, max(n, 2).bit_length() - 1)
+            prefix_bits = self._L.fss_amd_points_prefix_bits(scheme, in_bits, n) or min(cap, max(n, 4).bit_length() - 2)
         if prefix_bits < 1 or cap < 1:  # nothing to share (e.g. a 1-level Half-Tree key): plain walk
             return self.eval_points(scheme, in_bits, group, party, seed, cws, xs, ocw=ocw, out=out)
         L, st = self._L, self._stream()

@@ -5,37 +5,47 @@ has no collective: rank r evaluates its slice and keeps the outputs on its GPU. 
 only exchange on this path is Grotto's EvalAll, whose running XOR crosses shard
 boundaries: each rank needs the parity of all leaves before its block -- one byte per
 rank, all-gathered (torch.distributed; RCCL on GPUs, gloo in the CPU tests).
+
+The slice arithmetic is the library's (include/fss_amd.h: fss_amd_batch_slice,
+fss_amd_domain_block, fss_amd_grotto_carries): one definition for C, C++
+(fss::gpu::DeviceSet) and these wrappers.  Pure host functions: they need libfss_amd.so
+loaded, not a GPU.
 """
+import ctypes as C
+
+from . import _lib
 
 
 def batch_slice(n, rank, world):
     """Contiguous [lo, hi) of an n-element batch for `rank`; sizes differ by at most 1."""
-    if world < 1 or not (0 <= rank < world):
+    lo, hi = C.c_int64(), C.c_int64()
+    if _lib.lib().fss_amd_batch_slice(int(n), int(rank), int(world), C.byref(lo), C.byref(hi)) != 0:
         raise ValueError("bad rank/world")
-    base, rem = divmod(n, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    return lo.value, hi.value
 
 
 def domain_block(in_bits, rank, world):
     """(first_leaf, nleaves) of rank's EvalAll block: world must be a power of two no larger
     than the domain; rank owns the subtree whose path is its log2(world)-bit prefix."""
+    first, nleaves = C.c_int64(), C.c_int64()
     if world < 1 or world & (world - 1) or not (0 <= rank < world):
         raise ValueError("world must be a power of two")
-    if world > (1 << in_bits):
+    if in_bits <= 62 and world > (1 << in_bits):
         raise ValueError("more ranks than leaves")
-    nleaves = (1 << in_bits) // world
-    return rank * nleaves, nleaves
+    if _lib.lib().fss_amd_domain_block(int(in_bits), int(rank), int(world), C.byref(first), C.byref(nleaves)) != 0:
+        raise ValueError("bad in_bits/rank/world")
+    return first.value, nleaves.value
 
 
 def grotto_carries(last_bits):
     """Exclusive XOR scan of the per-shard parities (the last running-XOR byte of each
     shard computed with carry-in 0) -> carry-in of every shard."""
-    out, acc = [], 0
-    for b in last_bits:
-        out.append(acc)
-        acc ^= int(b) & 1
-    return out
+    world = len(last_bits)
+    src = (C.c_uint8 * world)(*[int(b) & 1 for b in last_bits])
+    dst = (C.c_uint8 * world)()
+    if _lib.lib().fss_amd_grotto_carries(src, world, dst) != 0:
+        raise ValueError("bad shard list")
+    return [int(v) for v in dst]
 
 
 def grotto_fix_shard(ys_local, dist=None):

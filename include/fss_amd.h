@@ -16,8 +16,9 @@
  *    caller; nothing is allocated, freed or synchronised by the eval calls:
  *    they enqueue kernels on `stream` (a hipStream_t passed as void*, NULL =
  *    default stream) and return, like the reference launchers
- *    (include/fss/point_eval_gpu.cuh:448-460).  The one exception is named for it:
- *    fss_amd_eval_points_host takes its points and outputs in PINNED HOST memory.
+ *    (include/fss/point_eval_gpu.cuh:448-460).  Two exceptions, both named where they are declared:
+ *    fss_amd_eval_points_host takes its points and outputs in PINNED HOST memory, and the one-key point
+ *    evaluations under FSS_AMD_POINTS_AUTO keep a per-stream node table in the context that grows on demand.
  *  - Alignment: every int4 / Cw array (seeds, cws, cw_s, cw_v, out_cw, ocws, cs, betas, ys, pi, workspaces)
  *    must be 16-byte aligned (the reference's int4 is; its Cw is alignas(32)), tr_bits 8-byte, extra 4-byte,
  *    xs / alphas sizeof(In)-aligned.  A misaligned pointer is FSS_AMD_EINVAL, never a device fault.
@@ -106,6 +107,20 @@ enum fss_amd_scheme { FSS_AMD_DPF = 0, FSS_AMD_DCF = 1, FSS_AMD_HT = 2, FSS_AMD_
  * dpf_eval / dcf_eval (fss_crypto/_csrc/dpf_binding_impl.cuh:58-101).
  * seed: device int4.  cws: device, in_bits+1 raw Cw slots (in_bits for Half-Tree).
  * ocw (Half-Tree): device int4.  ys: device int4[npoints]. */
+/* Plan of these three calls (context setting, default FSS_AMD_POINTS_AUTO):
+ *   FSS_AMD_POINTS_PLAIN  every point walks from the root: in_bits PRG levels per point, nothing allocated.
+ *   FSS_AMD_POINTS_AUTO   batches of at least 2^18 points (in_bits <= 64) take the shared-prefix plan below with
+ *                         prefix_bits = fss_amd_points_prefix_bits(): identical outputs, about in_bits - log2(npoints) + 3
+ *                         AES levels per point instead of in_bits (DPF kInBits=32, 2^24 points: 3.6 -> 10.8 G evals/s).
+ *                         Its node table lives in a buffer of the context, one per stream, grown on demand
+ *                         (hipMalloc / hipFree inside the call that needs more: about 2^prefix_bits x 16 B, DCF x 32 B;
+ *                         freed by fss_amd_ctx_scratch_release / _destroy).  Calls inside a stream capture, and calls
+ *                         the device has no room for, walk plainly.
+ * fss_amd_points_prefix_bits: the prefix_bits AUTO uses for that batch, 0 where it walks plainly. */
+#define FSS_AMD_POINTS_AUTO 0
+#define FSS_AMD_POINTS_PLAIN 1
+int fss_amd_ctx_set_points_plan(fss_amd_ctx *ctx, int plan);
+int fss_amd_points_prefix_bits(int scheme, int in_bits, int64_t npoints);
 int fss_amd_dpf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
                             const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
 int fss_amd_dcf_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seed, const void *cws,
@@ -322,6 +337,29 @@ int fss_amd_dpf_relayout_u32(fss_amd_ctx *ctx, int in_bits, const void *cws, int
 int fss_amd_dpf_eval_keys_u32(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
                               const void *extra, const void *out_cw, const void *xs, int x_bytes, int64_t nkeys,
                               void *ys, void *stream);
+
+/* ---- one job across the GPUs of a node --------------------------------------------------------
+ * The evaluation batch (points x keys) and the full domain split without any exchange (the
+ * reference's launchers, include/fss/point_eval_gpu.cuh:448-460 / eval_all_gpu.cuh:478-488, as
+ * src/bench_gpu.cu:604-627 calls them, are what each device runs on its share): device `rank` of `world`
+ * evaluates its slice with the calls above on a context of its own (fss_amd_ctx_create(.., device, ..)) and
+ * keeps the outputs.  These are the ONE definition of the split, for C, C++ (fss::gpu::DeviceSet,
+ * include/fss_amd_multi.hpp) and Python (fss_amd/shard.py):
+ *   batch_slice   [*lo, *hi) of an n-element batch (points of one key, or independent keys): contiguous,
+ *                 sizes differ by at most one, earlier ranks take the larger shares.
+ *   domain_block  rank's aligned block of a 2^in_bits domain for fss_amd_*_eval_all: world a power of two no
+ *                 larger than the domain; rank owns the subtree under its log2(world)-bit prefix.
+ *   grotto_carries  Grotto's EvalAll is a running XOR over the leaves, the one result that crosses block
+ *                 boundaries: every rank evaluates its block with carry-in 0, shard_last[r] = the last byte
+ *                 of rank r's block (the block's parity); carry_in[r] = XOR of shard_last[0 .. r-1] -- `world`
+ *                 bytes through the host, no collective.
+ *   grotto_apply_carry  ys_bytes[i] ^= 1 for the nleaves bytes of a block whose carry_in is 1 (device
+ *                 pointer, asynchronous on `stream`); carry = 0 does nothing.
+ * Pure host arithmetic apart from the last; FSS_AMD_EINVAL for rank / world out of range. */
+int fss_amd_batch_slice(int64_t n, int rank, int world, int64_t *lo, int64_t *hi);
+int fss_amd_domain_block(int in_bits, int rank, int world, int64_t *first_leaf, int64_t *nleaves);
+int fss_amd_grotto_carries(const uint8_t *shard_last, int world, uint8_t *carry_in);
+int fss_amd_grotto_apply_carry(fss_amd_ctx *ctx, void *ys_bytes, int64_t nleaves, int carry, void *stream);
 
 /* ---- host conveniences for layers that keep the reference's call signatures ------------------
  * The reference's launchers take the party seed BY VALUE and no workspace

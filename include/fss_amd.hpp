@@ -40,6 +40,7 @@
 // (static_assert).  Nothing in this header computes on the CPU.
 // Errors throw fss::Error (the reference asserts).
 #pragma once
+#define FSS_AMD_HPP_INCLUDED_ 1
 #include <hip/hip_runtime.h>
 
 #include <array>
@@ -56,6 +57,7 @@
 #include <tuple>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "fss_amd.h"
 #include "fss_amd_thread.hpp"
@@ -221,16 +223,28 @@ struct Registry {
   std::map<std::string, fss_amd_ctx*> ctxs;
   std::mutex stage_mu;  // the host-buffer methods share one staging area per context: one at a time
   // The asynchronous launchers enqueue "small arguments, then the kernel" as one unit PER (context, stream): launches on
-  // different streams (or contexts) never wait for each other -- not even while one of them grows its workspace, which
-  // waits for the device.  The per-thread streams behind hipStreamPerThread are different streams (keyed by thread).
+  // different streams (or contexts) do not take each other's launch lock.  (Inside ONE context a launcher whose
+  // workspace has to grow still holds the context's scratch lock across hipFree / hipMalloc -- a device-wide wait --
+  // and launchers of that context on other streams queue behind it for that long; steady-state launches never grow.)
+  // The per-thread streams behind hipStreamPerThread are different streams (keyed by thread).
+  // Lock order: `mu` and a launch lock are never held together (Engine() takes `mu` under a launch lock, so nothing may
+  // take a launch lock under `mu`); launch_map_mu is a leaf.
+  using LaunchKey = std::tuple<fss_amd_ctx*, hipStream_t, std::thread::id>;
   std::mutex launch_map_mu;
-  std::map<std::tuple<fss_amd_ctx*, hipStream_t, std::thread::id>, std::unique_ptr<std::mutex>> launch_mus;
-  std::mutex& LaunchMutex(fss_amd_ctx* ctx, hipStream_t stream) {
-    const std::thread::id tid = stream == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id();
+  std::map<LaunchKey, std::shared_ptr<std::mutex>> launch_mus;
+  static LaunchKey KeyFor(fss_amd_ctx* ctx, hipStream_t stream) {
+    return LaunchKey(ctx, stream, stream == hipStreamPerThread ? std::this_thread::get_id() : std::thread::id());
+  }
+  // shared ownership: an entry may be dropped (ForgetLaunchMutex) while a launcher still holds or waits for the mutex
+  std::shared_ptr<std::mutex> LaunchMutex(fss_amd_ctx* ctx, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(launch_map_mu);
-    auto& m = launch_mus[std::make_tuple(ctx, stream, tid)];
-    if (!m) m = std::make_unique<std::mutex>();
-    return *m;
+    auto& m = launch_mus[KeyFor(ctx, stream)];
+    if (!m) m = std::make_shared<std::mutex>();
+    return m;
+  }
+  void ForgetLaunchMutex(fss_amd_ctx* ctx, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(launch_map_mu);
+    launch_mus.erase(KeyFor(ctx, stream));
   }
 };
 inline Registry& Reg() {
@@ -271,12 +285,21 @@ inline void ReleaseEngines() {
 // Waits for the device (hipFree).
 inline void ReleaseStreamScratch(hipStream_t stream) {
   Registry& r = Reg();
-  std::lock_guard<std::mutex> lk(r.mu);
-  for (auto& kv : r.ctxs) {
-    // the (context, stream) launch lock: no launcher of another thread sits between "small arguments" and "kernel" on
-    // this stream while its buffer goes away
-    std::lock_guard<std::mutex> launch(r.LaunchMutex(kv.second, stream));
-    Check(fss_amd_ctx_scratch_release(kv.second, stream), "fss_amd_ctx_scratch_release");
+  std::vector<fss_amd_ctx*> ctxs;
+  {  // the contexts under `mu`, the launch locks after it is dropped: a launcher holds its launch lock while it resolves
+     // its context (Engine() takes `mu`), so taking them the other way round here could deadlock against it
+    std::lock_guard<std::mutex> lk(r.mu);
+    for (auto& kv : r.ctxs) ctxs.push_back(kv.second);
+  }
+  for (fss_amd_ctx* c : ctxs) {
+    {
+      // the (context, stream) launch lock: no launcher of another thread sits between "small arguments" and "kernel" on
+      // this stream while its buffer goes away
+      const std::shared_ptr<std::mutex> m = r.LaunchMutex(c, stream);
+      std::lock_guard<std::mutex> launch(*m);
+      Check(fss_amd_ctx_scratch_release(c, stream), "fss_amd_ctx_scratch_release");
+    }
+    r.ForgetLaunchMutex(c, stream);  // the stream is going away: its entry with it (a later launch starts a new one)
   }
 }
 
@@ -385,9 +408,10 @@ class Stage {
 // enqueue "upload, kernel" pairs whole: stream order then keeps one call's small arguments and workspace intact until
 // its kernel has read them.
 struct Scratch {
+  std::shared_ptr<std::mutex> mu_;
   std::lock_guard<std::mutex> lock_;
   char* base;
-  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) : lock_(Reg().LaunchMutex(ctx, stream)) {
+  Scratch(fss_amd_ctx* ctx, hipStream_t stream, size_t ws_bytes) : mu_(Reg().LaunchMutex(ctx, stream)), lock_(*mu_) {
     void* p = nullptr;
     Check(fss_amd_ctx_scratch(ctx, stream, ws_bytes + 256, &p), "fss_amd_ctx_scratch");
     base = static_cast<char*>(p);
@@ -811,6 +835,7 @@ template <int in_bits, typename Group, typename Prg, typename In = uint32_t, int
   requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 2>)
 class Dpf {
  public:
+  using GroupType = Group;
   Prg prg;
   struct alignas(32) Cw {  // dpf.cuh:76-81
     int4 s;
@@ -926,6 +951,7 @@ template <int in_bits, typename Group, typename Prg, typename In = uint32_t, Dcf
   requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 4>)
 class Dcf {
  public:
+  using GroupType = Group;
   Prg prg;
   struct alignas(32) Cw {  // dcf.cuh:91-96
     int4 s;
@@ -1029,6 +1055,7 @@ template <int in_bits, typename Group, typename Prg, typename In = uint32_t, int
   requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 1>)
 class HalfTreeDpf {
  public:
+  using GroupType = Group;
   Prg prg;
   int4 hash_key;           // half_tree_dpf.cuh:45
   struct alignas(32) Cw {  // half_tree_dpf.cuh:53-57
@@ -1519,3 +1546,5 @@ void DcfEvalAllGpu(bool b, int4 s0, const typename Dcf<in_bits, Group, Prg, In, 
 
 }  // namespace gpu
 }  // namespace fss
+
+#include "fss_amd_multi.hpp"  // fss::gpu::DeviceSet: one job across the GPUs of a node

@@ -227,12 +227,19 @@ __device__ inline bool SameInAllLanes(const uint32_t* w, int n) {
   return __ballot(diff != 0) == 0;
 }
 
-// 64 bits that differ from launch to launch (the address of this launch's AQL packet, of its kernel arguments and its
-// completion signal, folded): LDS is not cleared between kernels, so a marker left behind by an earlier kernel must not
-// pass for this launch's.
+// 64 bits that tell this launch (and this workgroup) from earlier ones: LDS is not cleared between kernels, so a marker
+// left behind by an earlier kernel must not pass for this launch's.  The queue's packet counter (dispatch id: monotonic
+// per queue, never reused) is folded with the AQL packet's address and its kernel-argument address (which tell queues
+// apart; by themselves they repeat -- the ring wraps, argument chunks are recycled) and with the workgroup id.  The
+// guarantee is probabilistic: two launches on different queues with equal counters would have to collide in the other
+// 64 bits as well.
+extern "C" __device__ uint64_t fss_amd_llvm_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");  // no clang builtin for it
 __device__ inline void LaunchNonce(uint32_t n[2]) {
   const uint64_t* pkt = reinterpret_cast<const uint64_t*>(__builtin_amdgcn_dispatch_ptr());
-  const uint64_t v = reinterpret_cast<uint64_t>(pkt) * 0x9e3779b97f4a7c15ull ^ pkt[5] * 0xc2b2ae3d27d4eb4full ^ pkt[7];  // kernarg_address, completion_signal
+  const uint64_t wg = blockIdx.x + gridDim.x * (blockIdx.y + static_cast<uint64_t>(gridDim.y) * blockIdx.z);
+  uint64_t v = fss_amd_llvm_dispatch_id() * 0x9e3779b97f4a7c15ull;
+  v ^= reinterpret_cast<uint64_t>(pkt) * 0xc2b2ae3d27d4eb4full ^ pkt[5];  // kernarg_address
+  v = (v ^ (v >> 29)) * 0xbf58476d1ce4e5b9ull + wg;
   n[0] = Uniform(static_cast<uint32_t>(v));
   n[1] = Uniform(static_cast<uint32_t>(v >> 32));
 }

@@ -32,6 +32,14 @@ def engine():
     return fss_amd.default_engine()
 
 
+@pytest.fixture(scope="session")
+def engine_plain(engine):
+    """A second context with the same keys whose one-key point evaluations always walk from the root
+    (FSS_AMD_POINTS_PLAIN): the reference the shared-prefix plan is compared with."""
+    import fss_amd
+    return fss_amd.Engine(engine.device.index).set_points_plan("plain")
+
+
 class SplitMix64:
     """Deterministic synthetic-input stream."""
 

@@ -11,10 +11,13 @@
 //           with uint32_t xs), :653-661 (Dcf), :688-697 (HalfTree), plus DpfEvalAllGpu<16> as
 //           check_evalall_gpu.cu:64-91 uses it, each compared with the host-signature methods and reconstructed.
 // Exit code 0 and a final "OK" line on success.
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "fss_amd.hpp"
@@ -622,6 +625,58 @@ static void PinnedHostBuffers() {
   std::printf("pinned host buffers (EvalAll in place, EvalPointsHost, Grotto staged): %s\n", g_fail == before ? "ok" : "FAILED");
 }
 
+// One thread launches on a stream while another releases that stream's scratch (round-4 advisor finding: the release
+// held the registry lock while taking the launch lock, the launchers the other way round -- a deadlock).  The run must
+// end, and a launch after the last release must still be right.
+static void LaunchVersusRelease() {
+  int before = g_fail;
+  using DpfPrg = fss::prg::Aes128Mmo<2>;
+  using DpfType = fss::Dpf<10, UintGroup, DpfPrg, uint>;
+  const unsigned char* keys[2] = {k0, k1};
+  DpfType dpf{DpfPrg(keys)};
+  int4 seeds[2] = {kSeeds[0], kSeeds[1]};
+  DpfType::Cw cws[11];
+  dpf.Gen(cws, seeds, 77u, int4{3, 0, 0, 0});
+  DpfType::Cw* d_cws = ToDevice(cws, 11);
+  hipStream_t st;
+  HIP_OK(hipStreamCreate(&st));
+  int4 *d_a, *d_b;
+  HIP_OK(hipMalloc(&d_a, sizeof(int4) << 10));
+  HIP_OK(hipMalloc(&d_b, sizeof(int4) << 10));
+  std::atomic<int> done{0};
+  std::thread launcher([&] {
+    for (int i = 0; i < 300; ++i) fss::gpu::DpfEvalAllGpu(false, seeds[0], d_cws, d_a, dpf, st);
+    ++done;
+  });
+  std::thread releaser([&] {
+    for (int i = 0; i < 60; ++i) fss::ReleaseStreamScratch(st);
+    ++done;
+  });
+  for (int waited = 0; done.load() < 2; ++waited) {
+    if (waited > 1200) {  // two minutes: the two threads are stuck on each other's locks
+      std::fprintf(stderr, "FAILED: launch loop and ReleaseStreamScratch deadlocked\n");
+      std::_Exit(4);
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+  }
+  launcher.join();
+  releaser.join();
+  fss::gpu::DpfEvalAllGpu(false, seeds[0], d_cws, d_a, dpf, st);
+  fss::gpu::DpfEvalAllGpu(true, seeds[1], d_cws, d_b, dpf, st);
+  HIP_OK(hipStreamSynchronize(st));
+  std::vector<int4> a(1024), b(1024);
+  ToHost(a.data(), d_a, 1024);
+  ToHost(b.data(), d_b, 1024);
+  int bad = 0;
+  for (int i = 0; i < 1024; ++i)
+    if (!Same(Recon<UintGroup>(a[i], b[i]), i == 77 ? int4{3, 0, 0, 0} : kZero)) ++bad;
+  EXPECT(bad == 0);
+  fss::ReleaseStreamScratch(st);
+  HIP_OK(hipStreamDestroy(st));
+  HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_a)); HIP_OK(hipFree(d_b));
+  std::printf("launch loop against ReleaseStreamScratch on one stream: %s\n", g_fail == before ? "ok" : "FAILED");
+}
+
 int main() {
   try {
     HostSignatureDpf();
@@ -640,6 +695,7 @@ int main() {
     HalfTreeLaunchers<12, UintGroup>(fss::prg::ChaCha<1>(kNonce), "ChaCha<1>   ");
     OnAStream();
     PinnedHostBuffers();
+    LaunchVersusRelease();
     fss::ReleaseEngines();
   } catch (const fss::Error& e) {
     std::fprintf(stderr, "fss::Error: %s\n", e.what());

@@ -89,6 +89,13 @@ def test_cxx_dropin_device_test_compiles():
     assert os.path.exists(_build.build_dropin_device_test())
 
 
+def test_cxx_multi_gpu_test_and_sample_compile():
+    """fss::gpu::DeviceSet (include/fss_amd_multi.hpp): tests/cxx/multi_gpu_test.cpp and samples/multi_gpu.cpp compile; they
+    run under -m gpu (tests/test_gpu_parity.py::test_cxx_multi_gpu_device_set)."""
+    from fss_amd import _build
+    assert os.path.exists(_build.build_multi_gpu_test()) and os.path.exists(_build.build_multi_gpu_sample())
+
+
 def test_makefile_stamp_equals_python_digest():
     """`make -C fss_amd/csrc` stamps the library with sources_digest.sh; fss_amd/_build.py must accept that stamp
     (same digest), or Python would rebuild a library make has just built."""

@@ -45,7 +45,8 @@ def test_committed_legend_is_what_bench_generates():
     have = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench_legend.json")))
     assert have == json.loads(json.dumps(bench.legend()))
     cells = [c[0] for c in bench.POINTS_CELLS + bench.KEYS_CELLS] + list(bench.SHARDED)
-    for name in cells + ["headline_strong", "shared_prefix", "dpf_2e20", "dcf_2e20", "e2e_pcie", "c1_cpu"]:
+    for name in cells + ["headline_strong", "shared_prefix", "shared_dcf", "shared_dpf_2e20", "shared_dcf_2e20", "dpf_2e20", "dcf_2e20",
+                         "e2e_pcie", "c1_cpu"]:
         assert name in have["records"], name
     assert {s for _, s in bench.SHORT} | {"u"} == set(have["sub_record_keys"])
 
@@ -59,13 +60,17 @@ def test_a_full_line_fits_the_drivers_record():
     walk = {"value": 3.5912e9, "unit": "evals/s", "ms_per_step": 4.6597, "kernel_ms": 4.6561, "units_per_launch": 1 << 24,
             "aes_per_unit": 32, "frac": 0.93831, "lds_gbs": 73792.1, "hbm_gbs": 72.012, "hbm_frac": 0.0090015,
             "kernel": "eval_points_kernel<Lds,0,true,2,1024,false>", "grid": 256, "block": 1024, "traffic_ratio": 1.0041,
-            "lds_busy_pmc": 0.95123, "replay_ok": True, "ok": True, "cpu": 2.0712e7, "cpu1": 1.3512e6}
+            "lds_busy_pmc": 0.95123, "replay_ok": True, "ok": True, "cpu": 2.0712e7, "cpu1": 1.3512e6, "clk": 2.3712, "frac_at_clock": 0.94971}
     subs = {c[0]: dict(walk) for c in bench.POINTS_CELLS + bench.KEYS_CELLS}
     for name in ("dpf_2e20", "dcf_2e20", "ht_c5"):
         subs[name] = dict(walk)
     subs["evalall_c4"] = dict(walk, unit="leaves/s")
     subs["grotto_c5"] = dict(walk, frac_executed=0.84123)
-    subs["shared_prefix"] = dict(walk, same=True)
+    shared = {"value": 1.0812e10, "unit": "evals/s", "ms_per_step": 1.5521, "kernel_ms": 1.5512, "units_per_launch": 1 << 24, "aes_per_unit": 10.0,
+              "k": 23, "frac": 0.88123, "speedup": 2.9712, "kernel": "eval_points_kernel<Lds,0,true,2,1024,true>", "same": True, "clk": 2.3512,
+              "frac_at_clock": 0.89951}
+    for name in ("shared_prefix", "shared_dcf", "shared_dpf_2e20", "shared_dcf_2e20"):
+        subs[name] = dict(shared)
     subs["e2e_pcie"] = {"value": 2.7e9, "unit": "evals/s", "serial": 1.4475e9, "pipe": 2.7123e9, "gbs": 54.246, "same": True}
     subs["c1_cpu"] = {"value": 2.1e7, "unit": "leaves/s", "us": 12.345, "cpu": 2.7e7, "cpu1": 2.75e7, "cpu_us": 9.4123, "cpu1_us": 9.3123,
                       "kat": True, "ok": True}
@@ -83,4 +88,6 @@ def test_a_full_line_fits_the_drivers_record():
     assert back["config"]["workload"] and back["roofline"]["bound"] == "lds" and back["cpu_baseline"]["sample"]
     assert set(back["sub"]) == set(subs) and back["gates"]["all"] is True
     assert back["sub"]["grotto_c5"]["fx"] == 0.84123 and back["sub"]["evalall_c4"]["u"] == "leaves/s"
+    assert back["sub"]["shared_prefix"]["f"] == 0.88123 and back["sub"]["shared_prefix"]["k"] == 23 and back["sub"]["shared_prefix"]["x"] == 2.9712
+    assert back["sub"]["dpf_keys"]["clk"] == 2.3712 and back["sub"]["dpf_keys"]["fc"] == 0.94971 and back["roofline"]["clk"] == 2.3712
     assert back["headline_strong"]["scaling"] == "strong" and back["headline_strong"]["v"] == back["value"]

@@ -41,7 +41,7 @@ def _release():
 
 
 @pytest.mark.parametrize("scheme", [DPF, DCF])
-def test_points_batch_past_2e31(engine, O, scheme):
+def test_points_batch_past_2e31(engine, engine_plain, O, scheme):
     n, g = 32, G.U64
     npts = (1 << 31) + 4099
     _need_free(npts * 20 + 4 * GiB)
@@ -62,8 +62,9 @@ def test_points_batch_past_2e31(engine, O, scheme):
         xs[m] = a32
     ys = torch.full((npts, 4), -1, dtype=torch.int32, device="cuda")
     party = 1
-    engine.eval_points(scheme, n, g, party, T(s[party]).cuda(), cd, xs, out=ys)
-    # slices of the batch through launches of their own, below 2^31 each
+    engine_plain.eval_points(scheme, n, g, party, T(s[party]).cuda(), cd, xs, out=ys)   # every point from the root
+    assert engine_plain.last_kernel()[0].endswith("_eval_points")
+    # slices of the batch through launches of their own, below 2^31 each (FSS_AMD_POINTS_AUTO: the shared-prefix plan)
     for lo, cnt in ((0, 1 << 20), ((1 << 31) - (1 << 19), 1 << 20), (npts - (1 << 20) - 3, (1 << 20) + 3)):
         part = engine.eval_points(scheme, n, g, party, T(s[party]).cuda(), cd, xs[lo:lo + cnt].clone())
         assert torch.equal(part, ys[lo:lo + cnt]), (lo, cnt)

@@ -36,10 +36,14 @@ def test_contexts_do_not_leak_device_memory():
 
     def once(prg):
         nonlocal first
-        e = Engine(prg=prg)
+        e = Engine(prg=prg).set_points_plan("plain")
         cws, _ = e.gen(DPF, 32, G.U64, s0s, al, be)
         e.eval_points(DPF, 32, G.U64, 0, s0s[0, 0].contiguous(), cws[0], xs, out=ys)
         assert e.last_kernel()[0] == "dpf_eval_points"
+        e.set_points_plan("auto")  # the shared-prefix plan's per-stream node table (64 MiB here) goes with the context too
+        e.eval_points(DPF, 32, G.U64, 0, s0s[0, 0].contiguous(), cws[0], xs, out=ys)
+        assert e.last_kernel()[0] == "dpf_eval_points_shared"
+        e.set_points_plan("plain")
         with torch.cuda.stream(side):  # a second stream: its own counter pair
             e.eval_points(DPF, 32, G.U64, 1, s0s[0, 1].contiguous(), cws[0], xs[:1 << 22], out=ys[:1 << 22])
         e.eval_all(DPF, 16, G.U64, 0, s0s[0, 0].contiguous(), e.gen(DPF, 16, G.U64, s0s, al & 0xFFFF, be)[0][0])

@@ -197,7 +197,7 @@ def test_eval_points_shared_prefix_vs_oracle(engine, O, scheme, n, g, k):
         assert (got == want).all(), (scheme, n, g, b, k)
 
 
-def test_eval_points_shared_prefix_full_size(engine):
+def test_eval_points_shared_prefix_full_size(engine, engine_plain):
     """2^22 points, automatic prefix: identical to the plain walk."""
     n, g = 32, G.U64
     import fss_amd
@@ -206,9 +206,79 @@ def test_eval_points_shared_prefix_full_size(engine):
     s0s = torch.randint(-2**31, 2**31, (2, 4), dtype=torch.int32, generator=gen)
     cws = d.gen(s0s, 0x1234567, torch.tensor([9, 8, 7, 6], dtype=torch.int32))
     xs = torch.randint(-2**31, 2**31, (1 << 22,), dtype=torch.int32, generator=gen).cuda()
-    a = engine.eval_points(DPF, n, g, 1, s0s[1], cws, xs)
+    a = engine_plain.eval_points(DPF, n, g, 1, s0s[1], cws, xs)
+    assert engine_plain.last_kernel()[0] == "dpf_eval_points"
     b = engine.eval_points_shared(DPF, n, g, 1, s0s[1], cws, xs)
+    assert engine.last_kernel()[0] == "dpf_eval_points_shared"
     assert bool((a == b).all())
+    # FSS_AMD_POINTS_AUTO (the default): the plain entry point picks the same plan for a batch this size ...
+    c = engine.eval_points(DPF, n, g, 1, s0s[1], cws, xs)
+    assert engine.last_kernel()[0] == "dpf_eval_points_shared"
+    assert engine._L.fss_amd_points_prefix_bits(DPF, n, 1 << 22) == 21
+    assert bool((a == c).all())
+    # ... not for a small one, and not inside a stream capture (its buffer may have to be allocated)
+    engine.eval_points(DPF, n, g, 1, s0s[1], cws, xs[: (1 << 18) - 1])
+    assert engine.last_kernel()[0] == "dpf_eval_points"
+    assert engine._L.fss_amd_points_prefix_bits(DPF, n, (1 << 18) - 1) == 0
+    assert engine._L.fss_amd_points_prefix_bits(DPF, n, 1 << 18) == 16 and engine._L.fss_amd_points_prefix_bits(DPF, 12, 1 << 24) == 12
+    assert engine._L.fss_amd_points_prefix_bits(HT, 12, 1 << 24) == 11 and engine._L.fss_amd_points_prefix_bits(DCF, 64, 1 << 40) == 26
+    side = torch.cuda.Stream()
+    out = torch.empty((1 << 22, 4), dtype=torch.int32, device="cuda")
+    s1, cw1 = s0s[1].cuda(), cws.cuda()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            engine.eval_points(DPF, n, g, 1, s1, cw1, xs, out=out)
+        assert engine.last_kernel()[0] == "dpf_eval_points"
+        graph.replay()
+    side.synchronize()
+    assert bool((a == out).all())
+
+
+@pytest.mark.parametrize("scheme,n,k", [(DPF, 20, 20), (DPF, 32, 22), (DPF, 64, 13), (DCF, 32, 18), (DCF, 18, 18), (DCF, 18, 17),
+                                        (HT, 21, 20), (HT, 21, 19), (HT, 64, 16)])
+def test_eval_points_shared_prefix_pipeline(engine, engine_plain, O, scheme, n, k):
+    """A batch large enough for the shared-prefix walk proper (past the quad-walk threshold, several chunks per wave):
+    every chunk's start nodes are requested half way down the chunk before it -- with zero, one, two and many walked
+    levels left (k = n: no level at all; Half-Tree k = n - 1: only the last level).  Ragged size, both parties,
+    the whole batch against the plain walk and a strided sample of it against the oracle."""
+    g = G.U64
+    rng = SplitMix64(9090 + 1000 * scheme + 10 * n + k)
+    p = O.Prg({DPF: 2, DCF: 4, HT: 1}[scheme])
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), beta_for(rng)
+    ocw = None
+    if scheme == DPF:
+        cws = O.dpf_gen(p, n, g, s, alpha, beta)
+    elif scheme == DCF:
+        cws = O.dcf_gen(p, n, g, 1, s, alpha, beta)
+    else:
+        cws, ocw = O.ht_gen(p, n, g, s, alpha, beta)
+    N = (1 << 20) + 77
+    gen = torch.Generator().manual_seed(n * 100 + k)
+    if n <= 32:
+        xs = torch.randint(-2**31, 2**31, (N,), dtype=torch.int32, generator=gen)
+        if n < 32:
+            xs &= (1 << n) - 1
+    else:
+        xs = torch.randint(-2**63, 2**63 - 1, (N,), dtype=torch.int64, generator=gen)
+    bits = 32 if n <= 32 else 64
+    xs[5] = alpha - (1 << bits) if alpha >= (1 << (bits - 1)) else alpha  # the key's alpha, as a bit pattern
+    xs = xs.cuda()
+    oc = None if ocw is None else T(ocw)
+    pick = torch.arange(0, N, 511)
+    xh = xs[pick.cuda()].cpu().numpy()
+    xu = (xh.view(np.uint32) if n <= 32 else xh.view(np.uint64)).astype(np.uint64)
+    for b in (0, 1):
+        plain = engine_plain.eval_points(scheme, n, g, b, T(s[b]), T(cws), xs, ocw=oc)
+        got = engine.eval_points_shared(scheme, n, g, b, T(s[b]), T(cws), xs, ocw=oc, prefix_bits=k)
+        assert bool((got == plain).all()), (scheme, n, k, b)
+        auto = engine.eval_points(scheme, n, g, b, T(s[b]), T(cws), xs, ocw=oc)  # FSS_AMD_POINTS_AUTO: its own prefix_bits
+        assert engine.last_kernel()[0].endswith("_eval_points_shared")
+        assert bool((auto == plain).all()), (scheme, n, k, b)
+        want = O.eval_points(p, scheme, n, g, b, s[b], cws, xu, ocw=ocw, nthreads=4)
+        assert (got[pick.cuda()].cpu().numpy() == want).all(), (scheme, n, k, b)
 
 
 def test_eval_points_empty(engine):
@@ -872,6 +942,20 @@ def test_cxx_dropin_device_side():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
+
+
+def test_cxx_multi_gpu_device_set():
+    """tests/cxx/multi_gpu_test.cpp: fss::gpu::DeviceSet (include/fss_amd_multi.hpp) with eight members sharing device 0
+    -- the headline batch, configs[3] in eight blocks, configs[4]'s schemes on independent keys, Grotto's carries -- gives
+    the bytes of one launch; then samples/multi_gpu.cpp over every visible device."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_multi_gpu_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
+    r = subprocess.run([_build.build_multi_gpu_sample(), "22"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("n,nkeys", [(1, 70), (20, 1000), (32, 5000), (31, 129)])

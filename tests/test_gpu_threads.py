@@ -13,10 +13,14 @@ pytestmark = pytest.mark.gpu
 HIP_STREAM_PER_THREAD = 2  # hipStreamPerThread = (hipStream_t)2, hip_runtime_api.h
 
 
-def test_two_threads_on_hip_stream_per_thread_large_batches():
+@pytest.mark.parametrize("plan", ["plain", "auto"])
+def test_two_threads_on_hip_stream_per_thread_large_batches(plan):
+    """plain: the dynamic walk with the launch-wide tail (its counters are per-stream state).  auto: the shared-prefix
+    plan FSS_AMD_POINTS_AUTO picks for a batch this size -- its node table is per-stream state too (one buffer per
+    (handle, thread)), and "table, then walk" must be enqueued whole by each thread."""
     import fss_amd
     from bench import make_key
-    eng = fss_amd.default_engine(0)
+    eng = fss_amd.Engine(0).set_points_plan(plan)
     L, h = eng._L, eng._h
     hip = C.CDLL("libamdhip64.so")
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -26,7 +30,7 @@ def test_two_threads_on_hip_stream_per_thread_large_batches():
     gen = torch.Generator(device="cuda").manual_seed(99)
     xs = [torch.randint(-2**31, 2**31, (N,), dtype=torch.int32, device="cuda", generator=gen) for _ in range(2)]
     want = [eng.eval_points(sid, n, G, 0, sd, cd, x).clone() for x in xs]
-    assert eng.last_kernel()[0] == "dpf_eval_points"
+    assert eng.last_kernel()[0] == ("dpf_eval_points" if plan == "plain" else "dpf_eval_points_shared")
     ys = [torch.full((N, 4), -1, dtype=torch.int32, device="cuda") for _ in range(2)]
     torch.cuda.synchronize()
     errs, rounds = [], 6
@@ -76,13 +80,16 @@ def test_scratch_is_per_thread_for_hip_stream_per_thread_and_can_be_released():
     assert L.fss_amd_ctx_scratch_release(h, C.c_void_p(HIP_STREAM_PER_THREAD)) == 0  # nothing left: still fine
 
 
-def test_many_short_lived_threads_release_their_per_thread_stream_state():
+@pytest.mark.parametrize("plan,nthreads", [("plain", 1100), ("auto", 48)])
+def test_many_short_lived_threads_release_their_per_thread_stream_state(plan, nthreads):
     """1 100 threads, one after the other, each launching a dynamic walk on its own hipStreamPerThread stream and
     releasing the stream's state when done: the context has 1 024 counter pairs, so the later threads run on pairs the
-    earlier ones handed back (fss_amd_ctx_scratch_release) -- every launch must still write every output."""
+    earlier ones handed back (fss_amd_ctx_scratch_release) -- every launch must still write every output.
+    auto: every thread's launch takes the shared-prefix plan, whose node table is a per-(stream, thread) buffer of the
+    context that the same release call frees (48 threads x 70 MiB would otherwise pile up)."""
     import fss_amd
     from bench import make_key
-    eng = fss_amd.default_engine(0)
+    eng = fss_amd.Engine(0).set_points_plan(plan)
     L, h = eng._L, eng._h
     hip = C.CDLL("libamdhip64.so")
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
@@ -109,8 +116,8 @@ def test_many_short_lived_threads_release_their_per_thread_stream_state():
         if not ok:
             bad.append(i)
 
-    for i in range(1100):
-        t = threading.Thread(target=once, args=(i, i % 100 == 0 or i >= 1020))
+    for i in range(nthreads):
+        t = threading.Thread(target=once, args=(i, i % 100 == 0 or i >= nthreads - 80 or plan == "auto"))
         t.start()
         t.join(120)
     assert not bad, bad[:10]
@@ -122,6 +129,7 @@ def test_four_streams_mixed_workloads_on_one_context():
     import fss_amd
     from fss_amd.engine import DPF, DCF, HT, GROTTO
     eng = fss_amd.default_engine(0)
+    engp = fss_amd.Engine(0).set_points_plan("plain")  # same keys; its large point batches walk from the root
     G64, GB = fss_amd.U64, fss_amd.BYTES
     gen = torch.Generator(device="cuda").manual_seed(0x57EA)
     ri = lambda *shape: torch.randint(-2**31, 2**31, shape, dtype=torch.int32, device="cuda", generator=gen)
@@ -141,7 +149,9 @@ def test_four_streams_mixed_workloads_on_one_context():
     bcw, _ = eng.gen(DPF, 10, G64, ks0[:bk].contiguous(), ri(bk) & 0x3FF, kbe[:bk].contiguous())
     bseeds = ks0[:bk, 0].contiguous()
     ops = [
-        lambda: eng.eval_points(DPF, 32, G64, 0, seed, cw_dpf[0], xs23),                     # dynamic + tail
+        lambda: engp.eval_points(DPF, 32, G64, 0, seed, cw_dpf[0], xs23),                    # dynamic + tail
+        lambda: engp.eval_points(DCF, 32, G64, 0, seed, cw_dcf[0], xs21),
+        lambda: eng.eval_points(DPF, 32, G64, 0, seed, cw_dpf[0], xs23),                     # FSS_AMD_POINTS_AUTO: shared prefix
         lambda: eng.eval_points(DCF, 32, G64, 0, seed, cw_dcf[0], xs21),
         lambda: eng.eval_keys(hkeys, G64, 0, kseeds, kx, ocws=hocw),
         lambda: eng.eval_keys(gkeys, GB, 0, kseeds, kx),                                    # Grotto walk (tail)
@@ -152,7 +162,7 @@ def test_four_streams_mixed_workloads_on_one_context():
     ]
     # the Gen op draws its alphas anew on every call: fix them
     al16 = ri(1 << 16)
-    ops[6] = lambda: eng.gen(DPF, 32, G64, ks0[:1 << 16].contiguous(), al16, kbe[:1 << 16].contiguous())[0]
+    ops[8] = lambda: eng.gen(DPF, 32, G64, ks0[:1 << 16].contiguous(), al16, kbe[:1 << 16].contiguous())[0]
     want = [op().clone() for op in ops]
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(4)]

@@ -42,9 +42,13 @@ def _sample(n):
 SIZES = [(1 << 20) + 1, (1 << 20) + 12345, 3 * (1 << 19) + 77, (1 << 21) - 1, (1 << 23) + 999]
 
 
+@pytest.mark.parametrize("plan", ["plain", "auto"])
 @pytest.mark.parametrize("n_points", SIZES)
 @pytest.mark.parametrize("scheme,in_bits", [(DPF, 32), (HT, 40), (DCF, 32)])
-def test_shared_key_ragged_large_batches(engine, O, scheme, in_bits, n_points):
+def test_shared_key_ragged_large_batches(engine, engine_plain, O, scheme, in_bits, n_points, plan):
+    """plain: the walk from the root (FSS_AMD_POINTS_PLAIN), whose "two, then one" regions these sizes cross.  auto: what
+    the same call does by default for batches this size -- the shared-prefix plan with the library's own prefix_bits."""
+    engine = engine if plan == "auto" else engine_plain
     rng = SplitMix64(0xBEEF00 + scheme * 1000 + n_points % 997)
     g = G.U64
     mul = {DPF: 2, DCF: 4, HT: 1}[scheme]
@@ -73,6 +77,7 @@ def test_shared_key_ragged_large_batches(engine, O, scheme, in_bits, n_points):
     cd = T(cws).cuda()
     od = None if ocw is None else T(ocw).cuda()
     ys = [engine.eval_points(scheme, in_bits, g, b, T(s[b]).cuda(), cd, xs, ocw=od) for b in (0, 1)]
+    assert engine.last_kernel()[0].endswith("_eval_points_shared") == (plan == "auto")
     assert ys[0].shape == (n_points, 4)
     total = u64_of(ys[0]) + u64_of(ys[1])
     bl = (int(np.uint32(beta[0])) | (int(np.uint32(beta[1])) << 32))
