@@ -109,10 +109,13 @@ def bench_engine():
 
 
 _DIAG = {}
+NO_CLK = False  # --no-clk: skip the in-kernel clock runs (the per-workload profiling passes: one kernel object per name)
 
 
 def diag_engine():
     """A context of the diagnostic build (fss_amd/libfss_amd_diag.so, -DFSS_DIAG_STAMPS=1), or None without it."""
+    if NO_CLK:
+        return None
     if "eng" not in _DIAG:
         import fss_amd
         from fss_amd import _lib
@@ -816,10 +819,15 @@ def main():
     ap.add_argument("--only-headline", action="store_true",
                     help="skip the sub-records (DCF, independent keys, kInBits 16 / 64): the PMC passes of tools/profile.sh "
                          "use this so that one kernel template means one workload")
+    ap.add_argument("--no-clk", action="store_true",
+                    help="skip the in-kernel clock measurements (clk / fc: ~50 ms of each record's kernel through the diagnostic build, "
+                         "after its timed region)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="self-launched multi-GPU runs: seconds before the ranks are stopped and the run fails")
     ap.add_argument("--write-legend", action="store_true", help="write bench_legend.json (the line's key and record descriptions) and exit")
     args = ap.parse_args()
+    global NO_CLK
+    NO_CLK = args.no_clk
     if args.write_legend:
         with open(os.path.join(ROOT, "bench_legend.json"), "w") as f:
             json.dump(legend(), f, indent=1)

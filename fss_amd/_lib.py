@@ -115,10 +115,17 @@ def diag_lib():
     (bench.py's in-kernel clock): the product library executes no stamp."""
     global _diag
     if _diag is None and os.path.exists(DIAG_SO):
-        L = _bind(DIAG_SO)
-        L.fss_amd_diag_read_stamps.restype = _i
-        L.fss_amd_diag_read_stamps.argtypes = [_vp, _vp, _i]
-        _diag = L
+        try:
+            from . import _build
+            stamp = DIAG_SO + ".sources.sha256"
+            if not os.path.exists(stamp) or open(stamp).read().strip() != _build._sources_digest() + " FSS_DIAG_STAMPS=1":
+                return None  # built from other sources than the product library: its clock would be another kernel's
+            L = _bind(DIAG_SO)
+            L.fss_amd_diag_read_stamps.restype = _i
+            L.fss_amd_diag_read_stamps.argtypes = [_vp, _vp, _i]
+            _diag = L
+        except (OSError, AttributeError):
+            return None
     return _diag
 
 

@@ -521,7 +521,7 @@ struct StageBody {
 
 // One stage over the input nodes [j_lo, j_hi) handed out 64 at a time by `next` (WaveQ / LocalQ): lane j loads
 // node j, walks E levels depth-first and expands the last D in registers.
-template <class LT, int SCHEME, int D, bool LEAF, int E, bool BATCH, int OW, class Queue>
+template <class LT, int SCHEME, int D, bool LEAF, int E, bool BATCH, int OW, bool UNI = false, class Queue>
 __device__ __forceinline__ void run_stage(const LT& L, const DevCtx* __restrict__ c, const Grp& g, const ExpandArgs& a,
                                           const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
                                           Queue& q, int64_t j_hi, uint32_t* prog = nullptr) {
@@ -538,11 +538,26 @@ __device__ __forceinline__ void run_stage(const LT& L, const DevCtx* __restrict_
         v0.v[0] = u.x; v0.v[1] = u.y; v0.v[2] = u.z; v0.v[3] = u.w;
       }
     }
-    // BATCH: node j belongs to key j >> level0; that key's slots (and Half-Tree ocw) are read per lane
-    const int64_t key = BATCH ? (j >> a.level0) : 0;
-    const uint32_t* kc = BATCH ? k_cws + 8 * key * a.key_slots : k_cws;
-    const uint32_t* koc = (BATCH && k_ocw) ? k_ocw + 4 * key : k_ocw;
-    OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
+    if constexpr (BATCH && UNI) {
+      // Node j belongs to key j >> level0.  UNI (the host's promise, launch_fused_evalall_batch): every stage has at least
+      // 64 nodes per key and every workgroup's node range starts on a multiple of 64, so the 64 nodes of a chunk share
+      // their key: its slots (and the Half-Tree ocw) are addressed from scalar registers and read with scalar loads, as
+      // for a single key.  Per-lane addresses (the form below) make every correction word of every level a vector load
+      // -- five per expansion, 5 % of a batch's time against a single tree of the same size (profiles/r5).
+      const int64_t key = j >> a.level0;
+      const int64_t key0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(key >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)key);
+      const uint32_t* kc = k_cws + 8 * key0 * a.key_slots;
+      const uint32_t* koc = k_ocw ? k_ocw + 4 * key0 : k_ocw;
+      OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
+    } else if constexpr (BATCH) {
+      const int64_t key = j >> a.level0;
+      const uint32_t* kc = k_cws + 8 * key * a.key_slots;
+      const uint32_t* koc = k_ocw ? k_ocw + 4 * key : k_ocw;
+      OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
+    } else {
+      OuterLevels<LT, SCHEME, E>::run(L, c, g, k_cws, k_ocw, a.level0, n0, v0, j << (E + D), E + D, body);
+    }
   }
 }
 
@@ -620,7 +635,7 @@ struct LocalQ {
 // OW = 0: the last stage stores the NODES of its level (and the DCF running values) at their global index in
 // f.a.out_nodes / f.a.out_v instead of converting leaves -- the node table of the shared-prefix point walks
 // (fss_amd_*_eval_points_shared), whose top `prefix_bits` levels are this kernel's whole tree.
-template <class LT, int SCHEME, int LD, int LE, int OW, bool BATCH = false>
+template <class LT, int SCHEME, int LD, int LE, int OW, bool BATCH = false, bool UNI = false>
 __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                             const uint32_t* __restrict__ k_seed,
                                                             const uint32_t* __restrict__ k_cws,
@@ -685,9 +700,9 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     a.out_nodes = mine[cur ^ 1] - (lo << t);
     a.out_v = minev[cur ^ 1] - (lo << t);
     LocalQ q(&waveq_ctr_, lo, hi, f.rank != 0);
-    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
-    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
-    else run_stage<LT, SCHEME, DM, false, 3 - DM, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    if (t == 1) run_stage<LT, SCHEME, 1, false, 0, BATCH, 4, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    else if (t == 2) run_stage<LT, SCHEME, DM, false, 2 - DM, BATCH, 4, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    else run_stage<LT, SCHEME, DM, false, 3 - DM, BATCH, 4, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
     lo <<= t; hi <<= t; level += t;
     cur ^= 1;
     FSS_FUSED_STAMP();
@@ -705,9 +720,9 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     if constexpr (OW == 0) {
       a.out_nodes = f.a.out_nodes;
       a.out_v = f.a.out_v;
-      run_stage<LT, SCHEME, LD, false, LE, BATCH, 4>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+      run_stage<LT, SCHEME, LD, false, LE, BATCH, 4, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
     } else {
-      run_stage<LT, SCHEME, LD, true, LE, BATCH, OW>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+      run_stage<LT, SCHEME, LD, true, LE, BATCH, OW, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
     }
   }
   FSS_FUSED_STAMP();

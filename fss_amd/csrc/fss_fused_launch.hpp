@@ -8,9 +8,9 @@
 
 namespace {
 
-template <int SCHEME, int LD, int LE, int OW, bool BATCH, class LT>
+template <int SCHEME, int LD, int LE, int OW, bool BATCH, class LT, bool UNI = false>
 int launch_one(fss_amd_ctx* ctx, const SharedKey& k, const FusedArgs& f, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((evalall_fused_kernel<LT, SCHEME, LD, LE, OW, BATCH>), dim3(grid), dim3(1024), 0, st, ctx->host, ctx->te0,
+  hipLaunchKernelGGL((evalall_fused_kernel<LT, SCHEME, LD, LE, OW, BATCH, UNI>), dim3(grid), dim3(1024), 0, st, ctx->host, ctx->te0,
                      k.seed, k.cws, k.ocw, f);
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = "evalall_fused";
@@ -21,18 +21,18 @@ int launch_one(fss_amd_ctx* ctx, const SharedKey& k, const FusedArgs& f, int gri
 
 // leaf_t levels in the leaf stage: up to DM in registers (DCF 1, the others 2; Half-Tree at least its conversion
 // level), then up to two rolled levels above them.
-template <int SCHEME, int OW, bool BATCH = false, class LT = Lds>
+template <int SCHEME, int OW, bool BATCH = false, class LT = Lds, bool UNI = false>
 int by_leaf(fss_amd_ctx* ctx, int leaf_t, const SharedKey& k, const FusedArgs& f, int grid, hipStream_t st) {
   constexpr int DM = SCHEME == S_DCF ? 1 : 2;
   if constexpr (SCHEME != S_HT && OW != 0) {  // (node tables, OW = 0, always end on a stage that expands)
-    if (leaf_t == 0) return launch_one<SCHEME, 0, 0, 4, BATCH, LT>(ctx, k, f, grid, st);  // conversion only: no block to narrow
+    if (leaf_t == 0) return launch_one<SCHEME, 0, 0, 4, BATCH, LT, UNI>(ctx, k, f, grid, st);  // conversion only: no block to narrow
   }
-  if (leaf_t == 1) return launch_one<SCHEME, 1, 0, OW, BATCH, LT>(ctx, k, f, grid, st);
+  if (leaf_t == 1) return launch_one<SCHEME, 1, 0, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
   if constexpr (DM == 2) {
-    if (leaf_t == 2) return launch_one<SCHEME, 2, 0, OW, BATCH, LT>(ctx, k, f, grid, st);
+    if (leaf_t == 2) return launch_one<SCHEME, 2, 0, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
   }
-  if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH, LT>(ctx, k, f, grid, st);
-  if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH, LT>(ctx, k, f, grid, st);
+  if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
+  if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
   return FSS_AMD_EINVAL;
 }
 

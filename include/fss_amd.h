@@ -129,16 +129,17 @@ int fss_amd_ht_eval_points(fss_amd_ctx *ctx, int in_bits, int group, int party, 
                            const void *ocw, const void *xs, int x_bytes, int64_t npoints, void *ys, void *stream);
 
 /* ---- the same on a batch that lives in HOST memory (the PCIe-inclusive path) -------------
- * What the reference's binding does around its kernel for host tensors -- copy in, evaluate, copy out
- * (fss_crypto/_csrc/dpf_binding_impl.cuh:58-101) -- without the copies and without staging buffers: xs_host and
- * ys_host are pinned host memory (hipHostMalloc, or hipHostRegister'ed) and the walk itself reads x from and
- * writes y to them across PCIe, 4 (8, 16) bytes up and 16 down per evaluation, in ONE launch.  The batch then runs at
+ * An entry point the reference has no counterpart for (its binding evaluates host tensors on the CPU and CUDA tensors in
+ * place, fss_crypto/_csrc/dpf_binding_impl.cuh:58-101; its launchers take device pointers only): it exists because
+ * SURVEY.md 8(d) asks for the PCIe-inclusive rate beside the kernel rate.  xs_host and ys_host are pinned host memory
+ * (hipHostMalloc, or hipHostRegister'ed) and the walk itself reads x from and writes y to them across PCIe, 4 (8, 16)
+ * bytes up and 16 down per evaluation, in ONE launch -- no staging buffers, no copies.  The batch then runs at
  * the PCIe rate (2^24 points of DPF kInBits=32: 6.1 ms = 55 GB/s both directions summed, against 4.7 ms resident and
  * 11.9 ms for copy, launch, copy on one stream; profiles/r4/e2e_trace.txt).  Outputs are those of
- * fss_amd_*_eval_points.  scheme: FSS_AMD_DPF / _DCF / _HT; seed, cws, ocw (Half-Tree) are DEVICE pointers as
- * above; y is complete when `stream` reaches the point after this call (hipStreamSynchronize / an event).
- * Pageable host memory is refused (FSS_AMD_EINVAL): no kernel can address it.  Device pointers are accepted and
- * make this the resident call. */
+ * fss_amd_*_eval_points (always the plain walk: the batch is PCIe-bound either way).  scheme: FSS_AMD_DPF / _DCF / _HT;
+ * seed, cws, ocw (Half-Tree) are DEVICE pointers as above; y is complete when `stream` reaches the point after this
+ * call (hipStreamSynchronize / an event).  Pageable host memory is refused (FSS_AMD_EINVAL): no kernel can address it.
+ * Device pointers are accepted and make this the resident plain walk. */
 int fss_amd_eval_points_host(fss_amd_ctx *ctx, int scheme, int in_bits, int group, int party, const void *seed,
                              const void *cws, const void *ocw, const void *xs_host, int x_bytes, int64_t npoints,
                              void *ys_host, void *stream);

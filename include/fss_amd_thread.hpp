@@ -5,7 +5,7 @@
 // Everything below is __device__ code written against the two hooks only -- Prgable (`prg.Gen(seed)`) and Groupable
 // (`From / + / - / Into`) -- so a caller's own PRG or group type works as well as the built-in ones, provided its
 // members are callable on the device.  It is the per-thread form: one thread walks one key.  With the AES PRGs the
-// tables are in LDS (the caller's for fss::prg::Aes128Soft, a per-wave copy for fss::prg::Aes128Mmo), the round keys in
+// tables are in LDS (the caller's for fss::prg::Aes128Soft, one bank-replicated copy per workgroup for fss::prg::Aes128Mmo), the round keys in
 // scalar registers, and a level computes only the child it takes (GenSide).  The engine's batched kernels behind
 // EvalPoints / fss::gpu::* (bank-conflict-free replicated tables, level-major keys) remain the fast forms; nothing here
 // is used by them.
@@ -72,7 +72,7 @@ __device__ inline uint32_t RotL(uint32_t v, int n) { return __builtin_rotateleft
 // The per-thread form of the cipher for calls from inside a caller's kernel (fss::prg::Aes128Soft, and the device
 // side of fss::prg::Aes128Mmo): the round table Te0 (1 KiB) and the S-box (256 B) are read from wherever the caller
 // keeps them -- LDS in every case that matters (include/fss/prg/aes128_mmo_soft.cuh:197-207 asks for __shared__
-// tables; Aes128Mmo fills a private copy per wave, WaveAesTables below) -- and the round keys are wave-uniform values
+// tables; Aes128Mmo keeps a bank-replicated copy per workgroup, WaveTables below) -- and the round keys are wave-uniform values
 // (scalar registers), never per-thread byte arrays.
 //
 // BE = the word order of the state and of the table.  The reference's software AES works on big-endian words
@@ -115,6 +115,14 @@ struct BankedLdsTables {
   const __attribute__((address_space(3))) uint8_t* sbox;
   __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
   __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
+};
+// ... the same layout with no separate S-box: S(x) is byte 1 of the little-endian round-table entry (2S, S, S, 3S), read
+// from this lane's own bank as well (a 256-byte S-box would put 64 random byte reads on 64 words of 32 banks).
+struct BankedLdsRoundTable {
+  static constexpr bool kUnrollRounds = true;
+  const __attribute__((address_space(3))) uint32_t* te0_lane;  // little-endian table base + this lane's bank
+  __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
+  __device__ uint32_t S(uint32_t i) const { return te0_lane[32 * i] >> 8 & 0xff; }
 };
 struct LdsTables {
   static constexpr bool kUnrollRounds = true;  // the fast path: nine straight-line rounds, keys by constant index
@@ -159,6 +167,54 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
   for (int j = 0; j < 4; ++j)
     out[j] = (u[j][0] << AesBytePos<BE>(0) | u[j][1] << AesBytePos<BE>(1) | u[j][2] << AesBytePos<BE>(2) |
               u[j][3] << AesBytePos<BE>(3)) ^ key.W(10, j);
+}
+
+// Two blocks of the same plaintext under two key schedules, round by round side by side: 32 lookups in flight per lane
+// instead of 16, one block's table latency under the other's arithmetic (the engine's aes_mmo2, fss_amd/csrc/fss_dev.hpp).
+// What a DCF level needs: the seed and the value block of the child it takes.
+template <bool BE, typename Tab, typename KeyA, typename KeyB>
+__host__ __device__ inline void AesEncrypt2(const Tab& tab, const KeyA& ka, const KeyB& kb, const uint32_t in[4], uint32_t oa[4],
+                                            uint32_t ob[4]) {
+  uint32_t a[4], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = in[j] ^ ka.W(0, j); b[j] = in[j] ^ kb.W(0, j); }
+  auto round = [&](int r) {
+    uint32_t ta[4][4], tb[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ta[j][k] = tab.T(a[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+        tb[j][k] = tab.T(b[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = ta[j][0] ^ AesRot<BE>(ta[j][1], 1) ^ AesRot<BE>(ta[j][2], 2) ^ AesRot<BE>(ta[j][3], 3) ^ ka.W(r, j);
+      b[j] = tb[j][0] ^ AesRot<BE>(tb[j][1], 1) ^ AesRot<BE>(tb[j][2], 2) ^ AesRot<BE>(tb[j][3], 3) ^ kb.W(r, j);
+    }
+  };
+  if constexpr (Tab::kUnrollRounds) {
+#pragma unroll
+    for (int r = 1; r < 10; ++r) round(r);
+  } else {
+#pragma unroll 1
+    for (int r = 1; r < 10; ++r) round(r);
+  }
+  uint32_t ua[4][4], ub[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ua[j][k] = tab.S(a[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+      ub[j][k] = tab.S(b[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    oa[j] = (ua[j][0] << AesBytePos<BE>(0) | ua[j][1] << AesBytePos<BE>(1) | ua[j][2] << AesBytePos<BE>(2) |
+             ua[j][3] << AesBytePos<BE>(3)) ^ ka.W(10, j);
+    ob[j] = (ub[j][0] << AesBytePos<BE>(0) | ub[j][1] << AesBytePos<BE>(1) | ub[j][2] << AesBytePos<BE>(2) |
+             ub[j][3] << AesBytePos<BE>(3)) ^ kb.W(10, j);
+  }
 }
 
 // Round keys as 44 words (one wave-uniform schedule), and the per-lane choice between two schedules A and B given as
@@ -245,41 +301,43 @@ __device__ inline void LaunchNonce(uint32_t n[2]) {
 }
 
 // fss::prg::Aes128Mmo on the device has no table arguments (the reference's class is host-only, aes128_mmo.cuh:75-77):
-// every wave keeps a private copy of Te0 and the S-box in LDS -- 1 296 B per wave, 20 KiB for the largest workgroup --
-// filled by the lanes that make the wave's first call (no workgroup barrier: a kernel may call Gen from divergent
-// code, after some of its threads have returned).  `ready` is the caller's per-thread flag: a thread's first call always
-// fills (nothing is assumed about what the LDS held before).  The copy also carries a 16-byte marker, written after the
-// tables and bound to this launch, and every call checks it: a PRG object that reaches a wave through memory with its
-// flag already set by another wave (a __shared__ or global scheme, a pointer handed between waves -- the object is
-// meant to be a per-thread value) still finds this wave's copy missing and fills it.
-struct WaveAesTables {
-  uint32_t te0[256];
-  uint8_t sbox[256];
-  uint32_t marker[4];
+// the workgroup keeps ONE bank-replicated copy of the round table in LDS (32 KiB: entry i at words 32 i .. 32 i + 31, lane
+// l reads copy l % 32 -- no bank conflicts whatever the 64 indices of a wave instruction are; a plain 1 KiB copy per
+// wave, round 4's form, served them in 4-5 turns), and the S-box is byte 1 of the same entries.  No workgroup barrier
+// may be used to fill it -- a kernel may call Gen from divergent code, after some of its threads have returned -- so
+// EVERY wave writes the whole table itself before its first use (32 16-byte stores per lane; all waves write the same
+// values, so a wave only ever needs its OWN stores to have landed, which a wave-level sync gives it; whatever another
+// wave stores at any time is what is there already).  `ready` is the caller's per-thread flag: a thread's first call
+// always fills (nothing is assumed about what the LDS held before).  Every wave also has a 16-byte marker, written after
+// its fill and bound to this launch, and every call checks it: a PRG object that reaches a wave through memory with
+// its flag already set by another wave (a __shared__ or global scheme, a pointer handed between waves -- the object is
+// meant to be a per-thread value) still finds this wave's marker missing and fills.
+struct WorkgroupAesTable {
+  uint32_t te0[256 * 32];
+  uint32_t marker[16][4];
 };
-__device__ inline LdsTables WaveTables(bool& ready) {
-  __shared__ __attribute__((aligned(16))) WaveAesTables tabs[16];
-  WaveAesTables* mine = &tabs[(LinearTid() >> 6) & 15];
+__device__ inline BankedLdsRoundTable WaveTables(bool& ready) {
+  __shared__ __attribute__((aligned(16))) WorkgroupAesTable tab;
+  uint32_t* mark = tab.marker[(LinearTid() >> 6) & 15];
   uint32_t nonce[2];
   LaunchNonce(nonce);
   const uint32_t want[4] = {0x66737361u, 0x6d645f74u, nonce[0], nonce[1]};
-  const bool missing = !ready || ((mine->marker[0] ^ want[0]) | (mine->marker[1] ^ want[1]) | (mine->marker[2] ^ want[2]) |
-                                  (mine->marker[3] ^ want[3])) != 0;
+  const bool missing = !ready || ((mark[0] ^ want[0]) | (mark[1] ^ want[1]) | (mark[2] ^ want[2]) | (mark[3] ^ want[3])) != 0;
   if (__ballot(missing) != 0) {
     const uint64_t act = __ballot(1);
     const int cnt = __popcll(act);
     const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(act >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(act), 0u));
-    for (int i = rank; i < 256; i += cnt) {
-      mine->te0[i] = kAes.te0[i];
-      mine->sbox[i] = kAes.sbox[i];
+    uint4* rows = reinterpret_cast<uint4*>(tab.te0);  // 2048 groups of four copies
+    for (int i = rank; i < 2048; i += cnt) {
+      const uint32_t v = kAes.te0[i >> 3];
+      rows[i] = make_uint4(v, v, v, v);
     }
-    WaveLdsSync();  // the tables first, then the marker that says they are there
-    mine->marker[0] = want[0]; mine->marker[1] = want[1]; mine->marker[2] = want[2]; mine->marker[3] = want[3];  // every active lane, the same values
+    WaveLdsSync();  // the table first, then the marker that says this wave has written it
+    mark[0] = want[0]; mark[1] = want[1]; mark[2] = want[2]; mark[3] = want[3];  // every active lane, the same values
     WaveLdsSync();
   }
   ready = true;
-  return LdsTables{(const __attribute__((address_space(3))) uint32_t*)(mine->te0),
-                   (const __attribute__((address_space(3))) uint8_t*)(mine->sbox)};
+  return BankedLdsRoundTable{(const __attribute__((address_space(3))) uint32_t*)(tab.te0) + (__lane_id() & 31)};
 }
 
 // The LDS home of a four-key PRG's round keys (DCF: 4 x 44 words).  176 wave-uniform words do not fit the scalar
@@ -308,6 +366,12 @@ struct LdsKeySelect {  // per lane: schedule b where mask is ~0, schedule a wher
   LdsWords a, b;
   uint32_t mask;
   __device__ uint32_t W(int r, int j) const { return (mask & b[4 * r + j]) | (~mask & a[4 * r + j]); }
+};
+// The same choice made in the ADDRESS: each lane reads its own schedule (two addresses per wave instruction, 88 words =
+// 24 banks apart: two broadcasts, no conflict) -- one LDS read per key word instead of two and a select.
+struct LdsKeyPerLane {
+  LdsWords rk;  // a or b, per lane
+  __device__ uint32_t W(int r, int j) const { return rk[4 * r + j]; }
 };
 #endif
 
@@ -440,13 +504,22 @@ struct AesSchedules {
       if constexpr (mul == 4) {
         const LdsWords k = SlotKeys(tab);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          AesEncrypt<BE>(tab, LdsKeyWords{k + 44 * i}, in, o);
+        for (int i = 0; i < 4; i += 2) {
+          uint32_t o2[4];
+          AesEncrypt2<BE>(tab, LdsKeyWords{k + 44 * i}, LdsKeyWords{k + 44 * (i + 1)}, in, o, o2);
           out[i] = Mmo(o, seed);
+          out[i + 1] = Mmo(o2, seed);
         }
         return out;
       }
 #endif
+      if constexpr (mul == 2) {  // both children side by side (Gen of a DPF level)
+        uint32_t o2[4];
+        AesEncrypt2<BE>(tab, AesKeyWords{rk[0]}, KeyXor{rk[0], rk[1]}, in, o, o2);
+        out[0] = Mmo(o, seed);
+        out[1] = Mmo(o2, seed);
+        return out;
+      }
 #pragma unroll
       for (int i = 0; i < mul; ++i) {
         const bool direct = mul == 1 || i == 0 || (mul == 4 && i == 1);
@@ -476,12 +549,12 @@ struct AesSchedules {
       const uint32_t mask = right ? ~0u : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (mul == 4) {
-        const LdsWords k = SlotKeys(tab);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          AesEncrypt<BE>(tab, LdsKeySelect{k + 44 * i, k + 44 * (2 + i), mask}, in, o);  // [sl, vl | sr, vr]: keys i and 2 + i
-          out[i] = Mmo(o, seed);
-        }
+        const LdsWords k = SlotKeys(tab) + (right ? 88 : 0);  // [sl, vl | sr, vr]: this lane's side, keys 0, 1 or 2, 3
+        uint32_t o2[4];
+        AesEncrypt2<BE>(tab, LdsKeyPerLane{k}, LdsKeyPerLane{k + 44}, in, o, o2);  // seed and value block side by side
+        out[0] = Mmo(o, seed);
+        out[1] = Mmo(o2, seed);
+        (void)mask;
         return out;
       }
 #endif

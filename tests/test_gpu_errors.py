@@ -125,7 +125,15 @@ def test_python_layer_raises(raw):
                                  {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_TAIL_PCT": "100", "FSS_AMD_QUAD_POINTS_MAX": "0",
                                   "FSS_AMD_TAIL_MINWORK": "1"},
                                  {"FSS_AMD_ILP": "2", "FSS_AMD_DYN": "1", "FSS_AMD_TAIL_PCT": "100", "FSS_AMD_MIX_MID_PCT": "90",
-                                  "FSS_AMD_QUAD_POINTS_MAX": "0", "FSS_AMD_TAIL_MINWORK": "1"}])
+                                  "FSS_AMD_QUAD_POINTS_MAX": "0", "FSS_AMD_TAIL_MINWORK": "1"},
+                                 # round 5: FSS_AMD_POINTS_AUTO from one point on -- every one-key point evaluation of the
+                                 # oracle-checked cases takes the shared-prefix plan (node table, then the walk that requests
+                                 # each chunk's start nodes half a chunk ahead) instead of the quad-lane / plain walk
+                                 {"FSS_AMD_AUTO_PREFIX_MIN": "1", "FSS_AMD_QUAD_POINTS_MAX": "0"},
+                                 {"FSS_AMD_AUTO_PREFIX_MIN": "1", "FSS_AMD_QUAD_POINTS_MAX": "0", "FSS_AMD_ILP": "1", "FSS_AMD_DYN": "1",
+                                  "FSS_AMD_AUTO_PREFIX_BACK": "0"},
+                                 # ... the node table as a chain of launches, batch EvalAll with per-lane key addressing
+                                 {"FSS_AMD_PREFIX_FUSED": "0", "FSS_AMD_BATCH_UNI": "0"}])
 def test_parity_under_forced_tunables(env):
     """The launch heuristics (dynamic vs static distribution, lanes per workgroup, evaluations per lane, stage
     depths) pick by batch size, so the small oracle-checked cases would only ever see one of each; run the
@@ -141,6 +149,28 @@ def test_parity_under_forced_tunables(env):
                         "-k", "vs_oracle or kats or subblocks or deep_prefix or chacha"],
                        env={**os.environ, "FSS_AMD_TUNE": "1", **env}, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_round5_entry_point_errors(raw):
+    """fss_amd_ctx_set_points_plan, fss_amd_points_prefix_bits and the slice functions refuse what they cannot do."""
+    L, h, _, _ = raw
+    assert L.fss_amd_ctx_set_points_plan(h, 2) == -1 and L.fss_amd_ctx_set_points_plan(None, 0) == -1
+    assert L.fss_amd_ctx_set_points_plan(h, 1) == 0 and L.fss_amd_ctx_set_points_plan(h, 0) == 0
+    assert L.fss_amd_points_prefix_bits(3, 32, 1 << 24) == 0      # Grotto keys have no one-key point walk
+    assert L.fss_amd_points_prefix_bits(0, 65, 1 << 24) == 0      # the node table is indexed by a 64-bit x
+    assert L.fss_amd_points_prefix_bits(0, 32, 1 << 24) == 23 and L.fss_amd_points_prefix_bits(1, 32, 1 << 20) == 19
+    lo, hi = C.c_int64(), C.c_int64()
+    assert L.fss_amd_batch_slice(10, 3, 3, C.byref(lo), C.byref(hi)) == -1 and L.fss_amd_batch_slice(-1, 0, 1, C.byref(lo), C.byref(hi)) == -1
+    assert L.fss_amd_batch_slice(10, 2, 3, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (7, 10)
+    assert L.fss_amd_domain_block(28, 0, 3, C.byref(lo), C.byref(hi)) == -1 and L.fss_amd_domain_block(2, 0, 8, C.byref(lo), C.byref(hi)) == -1
+    assert L.fss_amd_domain_block(63, 0, 1, C.byref(lo), C.byref(hi)) == -1
+    assert L.fss_amd_grotto_carries(None, 2, None) == -1
+    y = torch.zeros(1000, dtype=torch.uint8, device="cuda")
+    assert L.fss_amd_grotto_apply_carry(h, C.c_void_p(y.data_ptr()), 1000, 2, None) == -1
+    assert L.fss_amd_grotto_apply_carry(h, C.c_void_p(y.data_ptr() + 3), 997, 1, None) == 0   # unaligned start: byte-exact
+    torch.cuda.synchronize()
+    assert int(y.sum()) == 997 and int(y[:3].sum()) == 0
+    assert L.fss_amd_grotto_apply_carry(h, C.c_void_p(y.data_ptr()), 1000, 0, None) == 0 and int(y.sum()) == 997
 
 
 def test_engine_refuses_undersized_tensors():

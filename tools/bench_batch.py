@@ -21,4 +21,7 @@ for shape in a.shapes.split(","):
     seeds0 = s0s[:, 0].contiguous()
     yb = torch.empty((nk, 1 << n, 4), dtype=torch.int32, device="cuda")
     _, kms = time_steady(lambda: eng.eval_all_batch(sid, n, G, 0, seeds0, cws, ocws=ocws, out=yb))
-    print(f"{a.prg} {a.scheme} batch n={n} x {nk}: {kms*1e3:.1f} us  {(nk << n)/kms/1e6:.2f} G out/s")
+    aes = {"dpf": 2.0, "dcf": 4.0, "ht": 1.5}[a.scheme]
+    frac = (nk << n) * aes * 640 / (kms * 1e-3) / 1e9 / 78643.2
+    print(f"{a.prg} {a.scheme} batch n={n} x {nk}: {kms*1e3:.1f} us  {(nk << n)/kms/1e6:.2f} G out/s  lds_frac={frac:.3f}  "
+          f"uni={os.environ.get('FSS_AMD_BATCH_UNI', 'default')}  {eng.last_kernel()}")

@@ -21,10 +21,13 @@ def main():
     ap.add_argument("--in-bits", type=int, default=32)
     ap.add_argument("--kmin", type=int, default=16)
     ap.add_argument("--kmax", type=int, default=26)
+    ap.add_argument("--auto-k", action="store_true", help="only the prefix_bits the library picks by itself (fss_amd_points_prefix_bits)")
+    ap.add_argument("--sorted", action="store_true", help="evaluate the points in ascending order (the node gathers then walk the table in order: "
+                                                          "the locality upper bound of the walk)")
     args = ap.parse_args()
     eng = fss_amd.default_engine(0).set_points_plan("plain")  # eval_points = the plain walk; the plan only through _shared
     G, n = fss_amd.U64, args.in_bits
-    print(f"lib={os.environ.get('FSS_AMD_LIB', 'default')}")
+    print(f"lib={os.environ.get('FSS_AMD_LIB', 'default')} sorted={args.sorted}")
     for sch in args.schemes.split(","):
         sid, s0s, cws, ocw, _, _ = bench.make_key(eng, sch, n, G, 0x5EED0002)
         sd, cd = s0s[0].cuda(), cws.cuda()
@@ -32,6 +35,9 @@ def main():
         for lp in [int(v) for v in args.log2_points.split(",")]:
             N = 1 << lp
             xs = bench._rand_xs(n, N, 0x5EED0002)
+            if args.sorted:  # ascending as unsigned values (the int32 / int64 bit patterns sort with the sign bit flipped)
+                bias = (1 << 31) if n <= 32 else (1 << 63)
+                xs = ((xs ^ -bias).sort().values ^ -bias).contiguous()
             ys, ref = torch.empty((N, 4), dtype=torch.int32, device="cuda"), torch.empty((N, 4), dtype=torch.int32, device="cuda")
             eng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ref)
             _, plain = bench.time_steady(lambda: eng.eval_points(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys))
@@ -40,7 +46,8 @@ def main():
                   f"auto prefix_bits = {eng._L.fss_amd_points_prefix_bits(sid, n, N)}")
             small = xs[: (1 << 17) + 64].contiguous()
             ysm = torch.empty((small.numel(), 4), dtype=torch.int32, device="cuda")
-            for k in range(args.kmin, min(args.kmax, n - (1 if sch == "ht" else 0), 26) + 1):
+            auto = eng._L.fss_amd_points_prefix_bits(sid, n, N)
+            for k in ([auto] if args.auto_k and auto else range(args.kmin, min(args.kmax, n - (1 if sch == "ht" else 0), 26) + 1)):
                 ys.zero_()
                 step = lambda: eng.eval_points_shared(sid, n, G, 0, sd, cd, xs, ocw=od, out=ys, prefix_bits=k)
                 _, tot = bench.time_steady(step)
