@@ -194,6 +194,8 @@ def _shared_record(eng, scheme, sid, n, sd, cd, xs, ys_plain, plain_ms, timer=No
     ys2 = torch.empty_like(ys_plain)
     mk = lambda e: (lambda: e.eval_points_shared(sid, n, G, 0, sd, cd, xs, out=ys2, prefix_bits=k))
     step = mk(eng)
+    if timer:
+        pre_warm(step, 40.0)  # like every sub-record: the first calls size the per-call workspace, the clocks settle
     wall, kms = timer(step) if timer else time_steady(step)
     aes = (2 if scheme == "dcf" else 1) * ((n - k) + (2 << k) / N)
     rate = N / (kms * 1e-3)

@@ -10,7 +10,7 @@ for f in glob.glob(d + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"].split("(")[0].replace("void fssamd::", "").replace("fssamd::", "")
         if "eval_points_kernel" in n or "evalall_fused" in n or "expand_kernel" in n or "frontier" in n:
-            rows[(n, int(r["Grid_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            rows[(n, int(r.get("Grid_Size_X", r.get("Grid_Size", 0))))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("kernel trace of the same command (all dispatches of the run, by kernel and grid size):")
 for (n, g), v in sorted(rows.items()):
     print(f"  {n[:72]:72s} grid {g:8d}  calls {len(v):5d}  avg_us {sum(v) / len(v):9.2f}  min_us {min(v):9.2f}")
