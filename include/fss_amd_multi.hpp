@@ -85,6 +85,7 @@ class DeviceSet {
     } catch (...) {
       Destroy();
       (void)hipSetDevice(prev);
+      (void)hipGetLastError();  // e.g. a device that does not exist: do not leave the error for the caller's next launch check
       throw;
     }
     CheckHip(hipSetDevice(prev), "hipSetDevice");

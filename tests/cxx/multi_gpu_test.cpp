@@ -304,6 +304,34 @@ int main(int argc, char** argv) {
     int64_t lo, hi;
     EXPECT(fss_amd_batch_slice(10, 3, 3, &lo, &hi) == FSS_AMD_EINVAL && fss_amd_domain_block(28, 0, 3, &lo, &hi) == FSS_AMD_EINVAL);
 
+    {  // refusals: a domain cannot be cut into seven aligned blocks; a device that does not exist
+      using Prg = fss::prg::Aes128Mmo<2>;
+      using DpfT = fss::Dpf<12, U64, Prg, uint32_t>;
+      const unsigned char* keys[2] = {k0, k1};
+      DpfT dpf{Prg(keys)};
+      int4 seeds[2] = {kSeeds[0], kSeeds[1]};
+      std::vector<DpfT::Cw> cws(13);
+      dpf.Gen(cws.data(), seeds, 5u, int4{1, 0, 0, 0});
+      bool threw = false;
+      try {
+        DeviceSet seven(dpf, std::vector<int>(7, 0));
+        (void)seven.EvalAllSharded(dpf, false, seeds[0], cws.data());
+      } catch (const fss::Error&) { threw = true; }
+      EXPECT(threw);
+      threw = false;
+      try { DeviceSet bad(dpf, {4096}); } catch (const fss::Error&) { threw = true; }
+      EXPECT(threw);
+      DeviceSet one(dpf, {0});  // a set of one is the plain call
+      std::vector<uint32_t> xs = {0u, 5u, 4095u};
+      const auto r = one.EvalPointsSharded(dpf, false, seeds[0], cws.data(), xs.data(), 3);
+      std::vector<int4> y(3);
+      one.ToHost(r.shards[0], y.data());
+      EXPECT(r.shards.size() == 1 && r.shards[0].count == 3 && std::memcmp(&y[1], &y[1], 16) == 0);
+      const int4 want = dpf.Eval(false, seeds[0], cws.data(), 5u);
+      EXPECT(std::memcmp(&y[1], &want, sizeof want) == 0);
+      const auto none = one.EvalPointsSharded(dpf, false, seeds[0], cws.data(), xs.data(), 0);  // an empty batch
+      EXPECT(none.shards[0].count == 0);
+    }
     const std::vector<int> eight(8, 0);  // eight members sharing device 0
     Headline(eight, quick ? int64_t(1) << 20 : int64_t(1) << 24);
     if (quick) EvalAllBlocks<22>(eight);
