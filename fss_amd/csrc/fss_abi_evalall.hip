@@ -490,6 +490,9 @@ int eval_all_batch_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, con
   if ((SCHEME == S_DPF || SCHEME == S_HT) && ctx->prg != FSS_AMD_PRG_CHACHA && fused_ok(ctx, SCHEME, pl, nkeys)) {
     FusedArgs fa{};
     fa.a = a;
+#if FSS_DIAG_STAMPS
+    fa.a.stamps = ctx->diag_stamps;
+#endif
     const int grid = fused_grid(ctx, nkeys << (pl.top - pl.tail));
     fused_slices(pl, nkeys, grid, bufn, bufv, &fa);
     if (fa.wg_cap[0] * grid <= ca && fa.wg_cap[1] * grid <= cb)
