@@ -485,6 +485,14 @@ class Aes128Mmo {
   __host__ std::array<int4, mul> Gen(int4 seed) const {
     return detail::GenOne(*this, seed);
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device only: this PRG with its per-call checks made once, for a walk that calls it level after level
+  // (thread::PreparedAes; the per-thread Eval takes it by itself).
+  __device__ thread::PreparedAes<mul, false, thread::BankedLdsRoundTable> Prepared() const {
+    const thread::BankedLdsRoundTable tab = thread::WaveTables(wave_tables_ready_);
+    return thread::PreparedAes<mul, false, thread::BankedLdsRoundTable>{ks_, tab, ks_.ReadyKeys(tab)};
+  }
+#endif
   // Device only: the outputs a tree level takes for one side -- {Gen(seed)[right]} for mul = 2, {Gen(seed)[2 right],
   // Gen(seed)[2 right + 1]} for mul = 4 -- at one block per output instead of two (the per-thread Eval uses it).
   __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const

@@ -88,6 +88,29 @@ __host__ __device__ inline uint32_t AesRot(uint32_t v, int k) {  // the table en
   return BE ? (v >> (8 * k) | v << (32 - 8 * k)) : (v << (8 * k) | v >> (32 - 8 * k));
 }
 __host__ __device__ inline uint32_t ByteSwap(uint32_t v) { return __builtin_bswap32(v); }
+// Three-input logic in one instruction on the device (v_bitop3_b32; the compiler's own selection leaves chains of
+// two-input v_xor: 200 per block in round 4's per-thread cipher, profiles/r5/README.md).
+__host__ __device__ inline uint32_t Xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+__host__ __device__ inline uint32_t AndXor(uint32_t m, uint32_t d, uint32_t x) {  // (m & d) ^ x
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(m, d, x, 0x6a);
+#else
+  return (m & d) ^ x;
+#endif
+}
+// x ^ y ^ (round-key word j of round r): a key type may fold its own structure in (AesKeySelect: one more bitop3 for the
+// per-lane choice instead of a select and a move); the default is one three-input XOR.
+template <typename Key>
+__host__ __device__ inline uint32_t FoldKey(const Key& key, int r, int j, uint32_t x, uint32_t y) {
+  if constexpr (requires { key.Fold(r, j, x, y); }) return key.Fold(r, j, x, y);
+  else return Xor3(x, y, key.W(r, j));
+}
 
 // How a table is addressed: a plain pointer (host code, or tables somewhere else than LDS), or a 32-bit LDS address
 // (the form the device path converts the caller's pointers to: ds_read_b32 / ds_read_u8 instead of flat loads).
@@ -149,7 +172,7 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
       for (int k = 0; k < 4; ++k) t[j][k] = tab.T(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);  // 16 lookups in flight
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      c[j] = t[j][0] ^ AesRot<BE>(t[j][1], 1) ^ AesRot<BE>(t[j][2], 2) ^ AesRot<BE>(t[j][3], 3) ^ key.W(r, j);
+      c[j] = FoldKey(key, r, j, Xor3(t[j][0], AesRot<BE>(t[j][1], 1), AesRot<BE>(t[j][2], 2)), AesRot<BE>(t[j][3], 3));
   };
   if constexpr (Tab::kUnrollRounds) {
 #pragma unroll
@@ -165,8 +188,8 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
     for (int k = 0; k < 4; ++k) u[j][k] = tab.S(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    out[j] = (u[j][0] << AesBytePos<BE>(0) | u[j][1] << AesBytePos<BE>(1) | u[j][2] << AesBytePos<BE>(2) |
-              u[j][3] << AesBytePos<BE>(3)) ^ key.W(10, j);
+    out[j] = FoldKey(key, 10, j, u[j][0] << AesBytePos<BE>(0) | u[j][1] << AesBytePos<BE>(1),
+                     u[j][2] << AesBytePos<BE>(2) | u[j][3] << AesBytePos<BE>(3));
 }
 
 // Two blocks of the same plaintext under two key schedules, round by round side by side: 32 lookups in flight per lane
@@ -189,8 +212,8 @@ __host__ __device__ inline void AesEncrypt2(const Tab& tab, const KeyA& ka, cons
       }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      a[j] = ta[j][0] ^ AesRot<BE>(ta[j][1], 1) ^ AesRot<BE>(ta[j][2], 2) ^ AesRot<BE>(ta[j][3], 3) ^ ka.W(r, j);
-      b[j] = tb[j][0] ^ AesRot<BE>(tb[j][1], 1) ^ AesRot<BE>(tb[j][2], 2) ^ AesRot<BE>(tb[j][3], 3) ^ kb.W(r, j);
+      a[j] = FoldKey(ka, r, j, Xor3(ta[j][0], AesRot<BE>(ta[j][1], 1), AesRot<BE>(ta[j][2], 2)), AesRot<BE>(ta[j][3], 3));
+      b[j] = FoldKey(kb, r, j, Xor3(tb[j][0], AesRot<BE>(tb[j][1], 1), AesRot<BE>(tb[j][2], 2)), AesRot<BE>(tb[j][3], 3));
     }
   };
   if constexpr (Tab::kUnrollRounds) {
@@ -210,10 +233,10 @@ __host__ __device__ inline void AesEncrypt2(const Tab& tab, const KeyA& ka, cons
     }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    oa[j] = (ua[j][0] << AesBytePos<BE>(0) | ua[j][1] << AesBytePos<BE>(1) | ua[j][2] << AesBytePos<BE>(2) |
-             ua[j][3] << AesBytePos<BE>(3)) ^ ka.W(10, j);
-    ob[j] = (ub[j][0] << AesBytePos<BE>(0) | ub[j][1] << AesBytePos<BE>(1) | ub[j][2] << AesBytePos<BE>(2) |
-             ub[j][3] << AesBytePos<BE>(3)) ^ kb.W(10, j);
+    oa[j] = FoldKey(ka, 10, j, ua[j][0] << AesBytePos<BE>(0) | ua[j][1] << AesBytePos<BE>(1),
+                    ua[j][2] << AesBytePos<BE>(2) | ua[j][3] << AesBytePos<BE>(3));
+    ob[j] = FoldKey(kb, 10, j, ub[j][0] << AesBytePos<BE>(0) | ub[j][1] << AesBytePos<BE>(1),
+                    ub[j][2] << AesBytePos<BE>(2) | ub[j][3] << AesBytePos<BE>(3));
   }
 }
 
@@ -229,6 +252,9 @@ struct AesKeySelect {
   const uint32_t* d;
   uint32_t mask;
   __host__ __device__ uint32_t W(int r, int j) const { return a[4 * r + j] ^ (mask & d[4 * r + j]); }
+  __host__ __device__ uint32_t Fold(int r, int j, uint32_t x, uint32_t y) const {
+    return AndXor(mask, d[4 * r + j], Xor3(x, y, a[4 * r + j]));
+  }
 };
 
 // Key schedule in state word order (FIPS-197 5.2) from the key as four little-endian words, S-box lookups through `S`.
@@ -362,13 +388,9 @@ struct LdsKeyWords {
   LdsWords rk;
   __device__ uint32_t W(int r, int j) const { return rk[4 * r + j]; }
 };
-struct LdsKeySelect {  // per lane: schedule b where mask is ~0, schedule a where it is 0 (one v_bfi per word)
-  LdsWords a, b;
-  uint32_t mask;
-  __device__ uint32_t W(int r, int j) const { return (mask & b[4 * r + j]) | (~mask & a[4 * r + j]); }
-};
-// The same choice made in the ADDRESS: each lane reads its own schedule (two addresses per wave instruction, 88 words =
-// 24 banks apart: two broadcasts, no conflict) -- one LDS read per key word instead of two and a select.
+// A per-lane choice between two schedules of the slot, made in the ADDRESS: each lane reads its own schedule (two
+// addresses per wave instruction, 88 words = 24 banks apart: two broadcasts, no conflict) -- one LDS read per key word
+// (round 4 read both schedules and selected: two reads and a v_bfi per word).
 struct LdsKeyPerLane {
   LdsWords rk;  // a or b, per lane
   __device__ uint32_t W(int r, int j) const { return rk[4 * r + j]; }
@@ -473,6 +495,17 @@ struct AesSchedules {
     return (LdsWords)(s->rk);
   }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The key slot checked (and refilled if stale) once, for a walk that then passes it to every Gen / GenSide (mul = 4 with
+  // wave-uniform keys; nullptr otherwise: nothing to keep).
+  template <typename Tab>
+  __device__ const void* ReadyKeys(const Tab& tab) const {
+    if constexpr (mul == 4) {
+      if (uniform) return (const void*)(uintptr_t)SlotKeys(tab);
+    }
+    return nullptr;
+  }
+#endif
   __host__ __device__ void KeyBytes(int i, unsigned char out[16]) const {
     for (int j = 0; j < 16; ++j) out[j] = static_cast<unsigned char>(keyw[i][j >> 2] >> (8 * (j & 3)));
   }
@@ -493,16 +526,18 @@ struct AesSchedules {
                 static_cast<int>(c[3]) ^ seed.w};
   }
 
-  // out[i] = AES_{key i}(seed) ^ seed for every key
+  // out[i] = AES_{key i}(seed) ^ seed for every key.  ready (device, mul = 4): the wave's key slot as SlotKeys returned
+  // it earlier in the same walk (PreparedAes below) -- the slot's tag is then not checked again.
   template <typename Tab>
-  __host__ __device__ std::array<int4, mul> Gen(const Tab& tab, int4 seed) const {
+  __host__ __device__ std::array<int4, mul> Gen(const Tab& tab, int4 seed, const void* ready = nullptr) const {
     std::array<int4, mul> out;
     uint32_t in[4], o[4];
     Words(seed, in);
+    (void)ready;
     if (uniform) {
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (mul == 4) {
-        const LdsWords k = SlotKeys(tab);
+        const LdsWords k = ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab);
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
           uint32_t o2[4];
@@ -539,22 +574,22 @@ struct AesSchedules {
   }
   // The outputs of one side only: mul = 2: {right ? out[1] : out[0]};  mul = 4: {right ? out[2] : out[0], right ? out[3] : out[1]}
   template <typename Tab>
-  __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(const Tab& tab, int4 seed, bool right) const {
+  __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(const Tab& tab, int4 seed, bool right, const void* ready = nullptr) const {
     static_assert(mul == 2 || mul == 4);
     constexpr int half = mul / 2;
     std::array<int4, half> out;
     uint32_t in[4], o[4];
     Words(seed, in);
+    (void)ready;
     if (uniform) {
       const uint32_t mask = right ? ~0u : 0u;
 #if defined(__HIP_DEVICE_COMPILE__)
       if constexpr (mul == 4) {
-        const LdsWords k = SlotKeys(tab) + (right ? 88 : 0);  // [sl, vl | sr, vr]: this lane's side, keys 0, 1 or 2, 3
+        const LdsWords k = (ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab)) + (right ? 88 : 0);  // [sl, vl | sr, vr]: this lane's side, keys 0, 1 or 2, 3
         uint32_t o2[4];
         AesEncrypt2<BE>(tab, LdsKeyPerLane{k}, LdsKeyPerLane{k + 44}, in, o, o2);  // seed and value block side by side
         out[0] = Mmo(o, seed);
         out[1] = Mmo(o2, seed);
-        (void)mask;
         return out;
       }
 #endif
@@ -588,6 +623,31 @@ struct AesSchedules {
     return e;
   }
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// A PRG whose per-call checks were made ONCE: the workgroup table filled and this wave's marker seen (WaveTables), the
+// key slot's tag seen (mul = 4).  A walk takes one at its start (`prg.Prepared()`, PreparedPrg below) and calls it
+// level after level: nothing can invalidate either while the thread stays inside the walk -- LDS belongs to this
+// launch, and other waves only ever store the values that are there already.  Same Gen / GenSide as the PRG itself.
+template <int mul, bool BE, typename Tab>
+struct PreparedAes {
+  const AesSchedules<mul, BE>& ks;
+  Tab tab;
+  const void* keys;
+  __device__ std::array<int4, mul> Gen(int4 seed) const { return ks.Gen(tab, seed, keys); }
+  __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+    return ks.GenSide(tab, seed, right, keys);
+  }
+};
+#endif
+// The PRG a walk calls level after level: its prepared form where the type has one, the PRG itself otherwise.
+template <typename Prg>
+__device__ inline decltype(auto) PreparedPrg(const Prg& prg) {
+  if constexpr (requires { prg.Prepared(); }) return prg.Prepared();
+  else return (prg);
+}
 
 // ---------------------------------------------------------------- ChaCha (chacha.cuh:24-128)
 // State rows: [constant | seed | seed | 0, 0, nonce]; `rounds` rounds; every row XORed with its input row.
@@ -698,7 +758,8 @@ __device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
 }
 
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 DpfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
+__device__ inline int4 DpfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x) {
+  auto&& prg = PreparedPrg(prg_);
   int4 s = WithCtl(s0, false);
   bool t = b;
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
@@ -775,7 +836,8 @@ __device__ inline void DcfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
 }
 
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 DcfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
+__device__ inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x) {
+  auto&& prg = PreparedPrg(prg_);
   int4 s = WithCtl(s0, false);
   bool t = b;
   Group acc;
@@ -850,7 +912,8 @@ __device__ inline void HtGen(const Prg& prg, int4 hash_key, int4* slots, int4& o
 }
 
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 HtEvalOn(const Prg& prg, int4 hash_key, bool b, int4 s0, const Key& key, int4 ocw, In x) {
+__device__ inline int4 HtEvalOn(const Prg& prg_, int4 hash_key, bool b, int4 s0, const Key& key, int4 ocw, In x) {
+  auto&& prg = PreparedPrg(prg_);
   int4 node = WithCtl(s0, b);
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits - 1; ++i) {
