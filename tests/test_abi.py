@@ -96,6 +96,21 @@ def test_cxx_multi_gpu_test_and_sample_compile():
     assert os.path.exists(_build.build_multi_gpu_test()) and os.path.exists(_build.build_multi_gpu_sample())
 
 
+def test_header_is_c99_and_links_from_c(tmp_path):
+    """include/fss_amd.h is the drop-in boundary of a C FFI (cgo / JNI / ctypes): tests/c/abi_c99.c compiles as pedantic
+    C99 against it, links libfss_amd.so and runs the entry points that need no GPU (slice arithmetic, plan query)."""
+    import subprocess
+    from fss_amd import _build
+    _build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_c99")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_c99.c"), "-L" + os.path.join(root, "fss_amd"), "-lfss_amd",
+                           "-Wl,-rpath," + os.path.join(root, "fss_amd"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.returncode, r.stdout, r.stderr)
+
+
 def test_makefile_stamp_equals_python_digest():
     """`make -C fss_amd/csrc` stamps the library with sources_digest.sh; fss_amd/_build.py must accept that stamp
     (same digest), or Python would rebuild a library make has just built."""
