@@ -819,7 +819,7 @@ def main():
     ap.add_argument("--hash-out", default="", help="--workload runs: every rank writes the SHA-256 of its outputs to <this>.rank<r>")
     ap.add_argument("--hash-blocks", type=int, default=1, help="with --hash-out: digests of this many equal blocks of the rank's outputs")
     ap.add_argument("--only-headline", action="store_true",
-                    help="skip the sub-records (DCF, independent keys, kInBits 16 / 64): the PMC passes of tools/profile.sh "
+                    help="skip the sub-records (DCF, independent keys, kInBits 16 / 64): the PMC passes of tools/profile_workloads.sh "
                          "use this so that one kernel template means one workload")
     ap.add_argument("--no-clk", action="store_true",
                     help="skip the in-kernel clock measurements (clk / fc: ~50 ms of each record's kernel through the diagnostic build, "

@@ -69,7 +69,7 @@ inline int dmax_for(int scheme) { return scheme == S_DCF ? 1 : 2; }  // levels e
 // leaves were held back and stored as whole 128-byte lines (the loss had been half-written lines falling out of L2).
 // A deep leaf stage needs enough input nodes to give every wave of the chip a chunk (64 nodes x 4096 waves =
 // 2^18): below that the launch is a latency chain run by a fraction of the waves, and a shallower last stage
-// on more nodes is faster (DPF n = 20: 136 -> 94 us with E = 0, tools/sweep_evalall_small.sh).
+// on more nodes is faster (DPF n = 20: 136 -> 94 us with E = 0; round 2, profiles/r2).
 // log2_leaves = log2 of the leaves the stage produces in total (all keys of a batch).
 inline int leaf_extra(int scheme, int log2_leaves) {
   static int v = [] {

@@ -51,7 +51,7 @@ struct EvalArgs {
   int prio_every;           // rank_prio: exchange when (levels done & prio_every) == 0
   int rot_prio;             // wave priority per level: 1 = the waves of a SIMD take turns (rotate_prio), 2 = by progress (rank_prio)
   int tr32;                 // tr_bits is the reference's uint32_t `extra` array (point_eval_gpu.cuh:57-62; in_bits <= 32)
-  uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.sh): 4 x uint64 per workgroup; unused otherwise
+  uint64_t* stamps;         // FSS_DIAG_STAMPS builds only (tools/keys_clock.py, bench.py clk): 4 x uint64 per workgroup; unused otherwise
   uint32_t* gq;             // WaveQ's launch-wide tail: {counter, waves done} of this stream, or nullptr
   int64_t static_chunks;    // chunks (of the one-per-lane region) dealt out per workgroup before the launch-wide tail starts
   int64_t n_body;           // two-per-lane kernels: evaluations [0, n_body) run two per lane, the rest one (a multiple of 128, or == n: two per lane throughout)

@@ -148,6 +148,14 @@ class Engine:
         self.points_plan = plan
         return self
 
+    def release_stream(self, stream=None):
+        """Free what the context keeps for `stream` (default: the current stream): the node table of the shared-prefix
+        plan (up to 2^26 x 16 / 32 B, grown by eval_points under the 'auto' plan), its scratch buffer and its
+        work-distribution counters.  Waits for the device.  Call before dropping a side stream that evaluated large
+        batches; the context's destruction frees everything anyway."""
+        st = C.c_void_p((stream or torch.cuda.current_stream(self.device)).cuda_stream)
+        _lib.check(self._L.fss_amd_ctx_scratch_release(self._h, st), "fss_amd_ctx_scratch_release")
+
     def last_kernel(self):
         g, b = C.c_int(0), C.c_int(0)
         name = self._L.fss_amd_last_kernel(self._h, C.byref(g), C.byref(b)).decode()

@@ -59,3 +59,36 @@ def test_contexts_do_not_leak_device_memory():
         once("aes128_mmo" if i % 3 else "chacha")
     free1 = _free()
     assert free0 - free1 < 16 * MiB, (free0 - free1) / MiB
+
+
+def test_release_stream_frees_the_shared_prefix_table():
+    """FSS_AMD_POINTS_AUTO keeps a node table per stream in the context (64 MiB for 2^23 points); Engine.release_stream
+    gives it back without destroying the context, and a later call on that stream builds a new one."""
+    from fss_amd.engine import Engine
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    n = 1 << 23
+    xs = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda", generator=gen)
+    ys = torch.empty((n, 4), dtype=torch.int32, device="cuda")
+    s0s = torch.randint(-2**31, 2**31, (1, 2, 4), dtype=torch.int32, device="cuda", generator=gen)
+    al = torch.randint(-2**31, 2**31, (1,), dtype=torch.int32, device="cuda", generator=gen)
+    be = torch.randint(-2**31, 2**31, (1, 4), dtype=torch.int32, device="cuda", generator=gen)
+    e = Engine()
+    cws, _ = e.gen(DPF, 32, G.U64, s0s, al, be)
+    seed = s0s[0, 0].contiguous()
+    free0 = _free()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        e.eval_points(DPF, 32, G.U64, 0, seed, cws[0], xs, out=ys)
+        assert e.last_kernel()[0] == "dpf_eval_points_shared"
+        first = ys[:64].clone()
+    held = free0 - _free()
+    assert held >= 60 * MiB, held / MiB           # the 2^22-node table (64 MiB) + stage buffers
+    e.release_stream(side)
+    assert free0 - _free() < 8 * MiB
+    with torch.cuda.stream(side):
+        ys.zero_()
+        e.eval_points(DPF, 32, G.U64, 0, seed, cws[0], xs, out=ys)
+        side.synchronize()
+        assert torch.equal(ys[:64], first)
+    del e
+    assert free0 - _free() < 8 * MiB
