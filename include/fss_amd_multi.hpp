@@ -15,6 +15,11 @@
 // eight-GPU run -- tests/cxx/multi_gpu_test.cpp).  Keys, seeds and points come from HOST memory in the reference's own
 // formats (key-major Cw arrays as Gen writes them); each member's buffers are the DeviceSet's, grow on demand and stay
 // valid until the next call on the set.  One call at a time per DeviceSet.
+// The dealer side shards the same way: GenKeysSharded generates member r's slice of a key batch ON member r, straight
+// into the level-major layout (fss_amd_*_gen_level_major: no key-major intermediate, no relayout, no key upload -- 32 B
+// of seeds, alpha and beta per key go up instead of in_bits x 32 B of correction words), and keeps it resident;
+// EvalResidentKeysSharded then evaluates points on those keys for either party (what src/bench_gpu.cu:72-83 + :616-627
+// do on one device: Gen, relayout, EvalPoint).
 #pragma once
 #ifndef FSS_AMD_HPP_INCLUDED_
 #error "include fss_amd.hpp (it includes this header)"
@@ -153,6 +158,33 @@ class DeviceSet {
     return Keys(FSS_AMD_GROTTO, in_bits, group::Bytes::kId, in_bits + 1, b, seeds, cws, nullptr, xs, sizeof(In), nkeys);
   }
 
+  // ---- dealer and evaluator on the members: keys generated where they are evaluated --------------------------------
+  // s0s: both parties' seeds, two per key (as Gen takes them); alphas; betas (Grotto: none).  Member r generates keys
+  // [lo, hi) = BatchSlice(nkeys, r, size()) level-major on its device and keeps them (until the next GenKeysSharded).
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  void GenKeysSharded(const Dpf<in_bits, Group, Prg, In, pd>&, const int4* s0s, const In* alphas, const int4* betas, int64_t nkeys) {
+    GenKeys(FSS_AMD_DPF, in_bits, Group::kId, 0, s0s, alphas, sizeof(In), betas, nkeys);
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int pd>
+  void GenKeysSharded(const Dcf<in_bits, Group, Prg, In, pred, pd>&, const int4* s0s, const In* alphas, const int4* betas, int64_t nkeys) {
+    GenKeys(FSS_AMD_DCF, in_bits, Group::kId, static_cast<int>(pred), s0s, alphas, sizeof(In), betas, nkeys);
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  void GenKeysSharded(const HalfTreeDpf<in_bits, Group, Prg, In, pd>&, const int4* s0s, const In* alphas, const int4* betas, int64_t nkeys) {
+    GenKeys(FSS_AMD_HT, in_bits, Group::kId, 0, s0s, alphas, sizeof(In), betas, nkeys);
+  }
+  template <int in_bits, typename Prg, typename In, int pd>
+  void GenKeysSharded(const GrottoDcf<in_bits, Prg, In, pd>&, const int4* s0s, const In* alphas, int64_t nkeys) {
+    static_assert(in_bits <= 64);
+    GenKeys(FSS_AMD_GROTTO, in_bits, group::Bytes::kId, 0, s0s, alphas, sizeof(In), nullptr, nkeys);
+  }
+  // ys[k] = Eval(b, s0s[2k + b], key k, xs[k]) on the resident keys (xs: host, one point per key; Grotto: the path walk,
+  // one byte per key).  The scheme must be the one the keys were generated for.
+  template <typename Scheme, typename In>
+  Result EvalResidentKeysSharded(const Scheme&, bool b, const In* xs) {
+    return EvalResident(b, xs, sizeof(In));
+  }
+
   // ---- the full domain cut by DomainBlock (the set's size must be a power of two): member r holds leaves
   // [r 2^in_bits / world, (r + 1) 2^in_bits / world) --------------------------------------------------------------------
   template <int in_bits, typename Group, typename Prg, typename In, int pd>
@@ -209,6 +241,11 @@ class DeviceSet {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Buf in, aux, out;
+    // resident keys of GenKeysSharded: seeds (both parties) | cw_s | cw_v (DCF) | tr_bits / extra | out_cw / ocws
+    Buf keys;
+    int k_scheme = -1, k_in_bits = 0, k_group = 0;
+    int64_t k_lo = 0, k_n = 0;
+    size_t k_s = 0, k_v = 0, k_t = 0, k_o = 0;  // offsets of the arrays in `keys` (seeds at 0)
   };
   std::vector<std::unique_ptr<Member>> members_;
 
@@ -227,7 +264,7 @@ class DeviceSet {
       if (!m) continue;
       (void)hipSetDevice(m->device);
       if (m->stream) (void)hipStreamSynchronize(m->stream);
-      for (Buf* b : {&m->in, &m->aux, &m->out})
+      for (Buf* b : {&m->in, &m->aux, &m->out, &m->keys})
         if (b->p) (void)hipFree(b->p);
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -338,6 +375,69 @@ class DeviceSet {
       Check(rc, "fss_amd_*_eval_keys");
       CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
       return Shard{m.device, sl.lo, cnt, d_ys, 0.f};
+    });
+  }
+
+  void GenKeys(int scheme, int in_bits, int group, int pred, const int4* s0s, const void* alphas, size_t xb, const int4* betas,
+               int64_t nkeys) {
+    const int world = size();
+    (void)Run([=, this](Member& m, int r) {
+      const Slice sl = BatchSlice(nkeys, r, world);
+      const int64_t cnt = sl.hi - sl.lo;
+      const size_t nk = static_cast<size_t>(cnt), planes = in_bits > 64 ? 2 : 1;
+      m.k_scheme = scheme; m.k_in_bits = in_bits; m.k_group = group; m.k_lo = sl.lo; m.k_n = cnt;
+      m.k_s = Up(nk * 32);
+      m.k_v = m.k_s + Up(nk * 16 * in_bits);
+      m.k_t = m.k_v + (scheme == FSS_AMD_DCF ? Up(nk * 16 * in_bits) : 0);
+      m.k_o = m.k_t + Up(nk * 8 * planes);
+      char* keys = static_cast<char*>(m.keys.Need(m.k_o + Up(nk * 16)));
+      // uploads: alphas | betas (the seeds go straight into their resident place)
+      const size_t o_b = Up(nk * xb);
+      char* in = static_cast<char*>(m.in.Need(o_b + Up(nk * 16)));
+      CheckHip(hipEventRecord(m.ev0, m.stream), "hipEventRecord");
+      if (cnt > 0) {
+        H2D(keys, s0s + 2 * sl.lo, nk * 32, m.stream);
+        H2D(in, static_cast<const char*>(alphas) + static_cast<size_t>(sl.lo) * xb, nk * xb, m.stream);
+        if (betas) H2D(in + o_b, betas + sl.lo, nk * 16, m.stream);
+        const void* d_betas = betas ? in + o_b : nullptr;
+        const int xbi = static_cast<int>(xb);
+        int rc;
+        if (scheme == FSS_AMD_DPF || scheme == FSS_AMD_GROTTO)
+          rc = fss_amd_dpf_gen_level_major(m.ctx, in_bits, group, keys, in, xbi, d_betas, cnt, keys + m.k_s, keys + m.k_t, keys + m.k_o, m.stream);
+        else if (scheme == FSS_AMD_DCF)
+          rc = fss_amd_dcf_gen_level_major(m.ctx, in_bits, group, pred, keys, in, xbi, d_betas, cnt, keys + m.k_s, keys + m.k_v, keys + m.k_o, m.stream);
+        else
+          rc = fss_amd_ht_gen_level_major(m.ctx, in_bits, group, keys, in, xbi, d_betas, cnt, keys + m.k_s, keys + m.k_t, keys + m.k_o, m.stream);
+        Check(rc, "fss_amd_*_gen_level_major");
+      }
+      CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
+      return Shard{m.device, sl.lo, cnt, nullptr, 0.f};
+    });
+  }
+
+  Result EvalResident(bool b, const void* xs, size_t xb) {
+    return Run([=, this](Member& m, int) {
+      if (m.k_scheme < 0) throw Error("DeviceSet::EvalResidentKeysSharded before GenKeysSharded", FSS_AMD_EINVAL);
+      const int64_t cnt = m.k_n;
+      const size_t nk = static_cast<size_t>(cnt);
+      const bool grotto = m.k_scheme == FSS_AMD_GROTTO;
+      const size_t o_x = Up(nk * 16);
+      char* in = static_cast<char*>(m.in.Need(o_x + Up(nk * xb)));  // party b's seeds, contiguous | xs
+      char* keys = static_cast<char*>(m.keys.p);
+      void* d_ys = m.out.Need(grotto ? nk : nk * 16);
+      if (cnt == 0) return Shard{m.device, m.k_lo, 0, d_ys, 0.f};
+      CheckHip(hipMemcpy2DAsync(in, 16, keys + (b ? 16 : 0), 32, 16, nk, hipMemcpyDeviceToDevice, m.stream), "hipMemcpy2DAsync (seeds)");
+      H2D(in + o_x, static_cast<const char*>(xs) + static_cast<size_t>(m.k_lo) * xb, nk * xb, m.stream);
+      CheckHip(hipEventRecord(m.ev0, m.stream), "hipEventRecord");
+      const int xbi = static_cast<int>(xb), n = m.k_in_bits, g = m.k_group;
+      int rc;
+      if (m.k_scheme == FSS_AMD_DPF) rc = fss_amd_dpf_eval_keys(m.ctx, n, g, b, in, keys + m.k_s, keys + m.k_t, keys + m.k_o, in + o_x, xbi, cnt, d_ys, m.stream);
+      else if (m.k_scheme == FSS_AMD_DCF) rc = fss_amd_dcf_eval_keys(m.ctx, n, g, b, in, keys + m.k_s, keys + m.k_v, keys + m.k_o, in + o_x, xbi, cnt, d_ys, m.stream);
+      else if (m.k_scheme == FSS_AMD_HT) rc = fss_amd_ht_eval_keys(m.ctx, n, g, b, in, keys + m.k_s, keys + m.k_t, keys + m.k_o, in + o_x, xbi, cnt, d_ys, m.stream);
+      else rc = fss_amd_grotto_eval_keys(m.ctx, n, b, in, keys + m.k_s, keys + m.k_t, in + o_x, xbi, cnt, d_ys, m.stream);
+      Check(rc, "fss_amd_*_eval_keys");
+      CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
+      return Shard{m.device, m.k_lo, cnt, d_ys, 0.f};
     });
   }
 

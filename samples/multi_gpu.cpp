@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
     std::printf("%d device(s)\n", set.size());
     fss::gpu::DeviceSet::Result y[2];
     std::vector<int4> host[2];
+    (void)set.EvalPointsSharded(dpf, false, seeds[0], cws.data(), xs.data(), n);  // warm-up: buffers sized, clocks up
     for (int b = 0; b < 2; ++b) {
       y[b] = set.EvalPointsSharded(dpf, b != 0, seeds[b], cws.data(), xs.data(), n);
       host[b].resize(xs.size());
@@ -55,6 +56,7 @@ int main(int argc, char** argv) {
       DpfA dpa{Prg(keys)};
       std::vector<DpfA::Cw> acws(kAll + 1);
       dpa.Gen(acws.data(), seeds, alpha & ((1u << kAll) - 1), beta);
+      (void)set.EvalAllSharded(dpa, false, seeds[0], acws.data());  // warm-up
       const auto r = set.EvalAllSharded(dpa, false, seeds[0], acws.data());
       for (const auto& s : r.shards) std::printf("  device %d: leaves [%lld, +%lld)  %.3f ms\n", s.device, (long long)s.first, (long long)s.count, s.ms);
       std::printf("DPF EvalAll kInBits=%d: %.3f ms (slowest device) = %.2f G leaves/s\n", kAll, r.max_ms, (double)(int64_t(1) << kAll) / r.max_ms / 1e6);

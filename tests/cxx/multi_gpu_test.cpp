@@ -3,9 +3,9 @@
 // one stream each, one host thread each): what an 8-GPU node runs, minus the parallelism.
 //   headline    DPF kInBits=32, one key, 2^24 points (BASELINE metric)           -> EvalPointsSharded
 //   configs[3]  DPF EvalAll kInBits=28, the domain in 8 blocks of 2^25 leaves     -> EvalAllSharded
-//   configs[4]  Half-Tree DPF and Grotto DCF kInBits=64, independent keys x 1 pt  -> EvalKeysSharded (2^18 keys here: the
-//               keys come from host memory, key-major as Gen writes them; the full 2^24-key batch is covered by
-//               tests/test_bench_launch.py through the same fss_amd_batch_slice)
+//   configs[4]  Half-Tree DPF and Grotto DCF kInBits=64, 2^24 independent keys x 1 pt -> GenKeysSharded (the keys generated
+//               on the members, level-major) + EvalResidentKeysSharded; and EvalKeysSharded on 2^18 keys that come from host
+//               memory, key-major as Gen writes them
 //   + DCF points, DPF / DCF keys, Grotto EvalAll (the one result with a carry across blocks), uneven slices (7 members).
 // Every device on the box is used as well when there is more than one.  Exit code 0 and a final "OK" line on success.
 #include <cmath>
@@ -106,8 +106,8 @@ static void Headline(const std::vector<int>& devs, int64_t n) {
     const DeviceSet::Result res = set.EvalPointsSharded(dpf, false, seeds[0], cws.data(), xs.data(), n);
     EXPECT(res.shards.size() == devs.size() && res.max_ms > 0.f);
     EXPECT(SameBytes(Gather<int4>(set, res, xs.size()), one));
-    std::printf("  DPF n=32, 2^%d points over %zu members (%s): %.3f ms max over members = %.3f G evals/s\n", (int)std::log2((double)n),
-                devs.size(), plan == FSS_AMD_POINTS_PLAIN ? "plain" : "auto", res.max_ms, n / res.max_ms / 1e6);
+    std::printf("  DPF n=32, 2^%d points over %zu members (%s): %.3f ms max over members (a first call; members that share a GPU overlap)\n",
+                (int)std::log2((double)n), devs.size(), plan == FSS_AMD_POINTS_PLAIN ? "plain" : "auto", res.max_ms);
   }
   {  // DCF on the same points, uneven slices: seven members
     using Prg4 = fss::prg::Aes128Mmo<4>;
@@ -165,8 +165,7 @@ static void EvalAllBlocks(const std::vector<int>& devs) {
     EXPECT(SameBytes(a, b));
     EXPECT(s.first % s.count == 0 && s.count == static_cast<int64_t>(N / devs.size()));
   }
-  std::printf("  DPF EvalAll n=%d in %zu blocks: %.3f ms max over members = %.2f G leaves/s\n", in_bits, devs.size(), res.max_ms,
-              N / res.max_ms / 1e6);
+  std::printf("  DPF EvalAll n=%d in %zu blocks: %.3f ms max over members\n", in_bits, devs.size(), res.max_ms);
   HIP_OK(hipFree(d_s0)); HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_ys)); HIP_OK(hipFree(d_ws));
   {  // Grotto EvalAll n = 20: the running XOR crosses the blocks, the set applies the carries
     using Gr = fss::GrottoDcf<20, Prg, uint32_t>;
@@ -288,6 +287,94 @@ static void IndependentKeys(const std::vector<int>& devs, int64_t nkeys) {
   std::printf("independent keys across the set (Half-Tree, DPF, Grotto, DCF; n=64): %s\n", g_fail == before ? "ok" : "FAILED");
 }
 
+// configs[4] at its full size through the set: the keys are GENERATED on the members (GenKeysSharded: each member its
+// slice, level-major, from 32 B of seeds + alpha + beta per key) and evaluated where they are (EvalResidentKeysSharded),
+// against one Gen + one EvalPoint launch over the whole batch on device 0; both parties, and the FSS property on a sample.
+static void ResidentKeys(const std::vector<int>& devs, int64_t nkeys) {
+  const int before = g_fail;
+  const unsigned char* keys1[1] = {k0};
+  const unsigned char* keys2[2] = {k0, k1};
+  std::mt19937_64 rng(23);
+  const size_t nk = static_cast<size_t>(nkeys);
+  std::vector<int4> s0s(2 * nk), betas(nk);
+  std::vector<uint64_t> alphas(nk), xs(nk);
+  for (size_t k = 0; k < nk; ++k) {
+    const uint64_t a = rng(), b2 = rng(), c = rng(), d = rng();
+    s0s[2 * k] = int4{(int)a, (int)(a >> 32), (int)b2, (int)((b2 >> 32) & ~1ull)};
+    s0s[2 * k + 1] = int4{(int)c, (int)(c >> 32), (int)d, (int)((d >> 32) & ~1ull)};
+    const uint64_t e = rng();
+    betas[k] = int4{(int)e, (int)(e >> 32), 0, 0};
+    alphas[k] = rng();
+    xs[k] = (k & 1) ? rng() : alphas[k];
+  }
+  int4* d_s0s = ToDevice(s0s.data(), s0s.size());
+  uint64_t* d_al = ToDevice(alphas.data(), nk);
+  uint64_t* d_xs = ToDevice(xs.data(), nk);
+  int4* d_be = ToDevice(betas.data(), nk);
+  int4 *d_seeds = nullptr, *d_ys = nullptr, *d_cw_s = nullptr, *d_aux = nullptr;
+  HIP_OK(hipMalloc(&d_seeds, nk * sizeof(int4)));
+  HIP_OK(hipMalloc(&d_ys, nk * sizeof(int4)));
+  HIP_OK(hipMalloc(&d_cw_s, nk * 64 * sizeof(int4)));
+  HIP_OK(hipMalloc(&d_aux, nk * sizeof(int4)));  // ocws / out_cw
+  void* d_bits = nullptr;                        // extra (uint32) / tr_bits (uint64)
+  HIP_OK(hipMalloc(&d_bits, nk * sizeof(uint64_t)));
+  std::vector<int4> one[2], got[2];
+  {  // Half-Tree DPF n = 64
+    using Prg = fss::prg::Aes128Mmo<1>;
+    using HT = fss::HalfTreeDpf<64, U64, Prg, uint64_t>;
+    HT ht{Prg(keys1), int4{0x12345678, (int)0x9abcdef0u, 0x13572468, 0x2468ace0}};
+    ht.GenLevelMajor(d_cw_s, static_cast<uint32_t*>(d_bits), d_aux, d_s0s, d_al, d_be, nkeys);
+    DeviceSet set(ht, devs);
+    set.GenKeysSharded(ht, s0s.data(), alphas.data(), betas.data(), nkeys);
+    for (int b = 0; b < 2; ++b) {
+      HIP_OK(hipMemcpy2D(d_seeds, 16, reinterpret_cast<const char*>(d_s0s) + 16 * b, 32, 16, nk, hipMemcpyDeviceToDevice));
+      fss::gpu::HalfTreeDpfEvalPointGpu(b != 0, d_seeds, d_cw_s, static_cast<const uint32_t*>(d_bits), d_aux, d_xs, d_ys, nkeys, ht);
+      HIP_OK(hipDeviceSynchronize());
+      one[b] = FromDevice(d_ys, nk);
+      const DeviceSet::Result res = set.EvalResidentKeysSharded(ht, b != 0, xs.data());
+      got[b] = Gather<int4>(set, res, nk);
+      EXPECT(SameBytes(got[b], one[b]));
+      if (b == 0) std::printf("  Half-Tree n=64, %lld keys generated and evaluated on %zu members: %.3f ms max\n", (long long)nkeys, devs.size(), res.max_ms);
+    }
+    int64_t bad = 0;
+    for (size_t k = 0; k < nk; k += 997) {
+      const uint64_t y0 = (uint32_t)got[0][k].x | (uint64_t)(uint32_t)got[0][k].y << 32, y1 = (uint32_t)got[1][k].x | (uint64_t)(uint32_t)got[1][k].y << 32;
+      const uint64_t be = (uint32_t)betas[k].x | (uint64_t)(uint32_t)betas[k].y << 32;
+      bad += (y0 + y1) != (xs[k] == alphas[k] ? be : 0);
+    }
+    EXPECT(bad == 0);
+  }
+  {  // Grotto DCF n = 64, the path walk: one byte per key
+    using Prg = fss::prg::Aes128Mmo<2>;
+    using Gr = fss::GrottoDcf<64, Prg, uint64_t>;
+    Gr gd{Prg(keys2)};
+    uint8_t* d_yb = nullptr;
+    HIP_OK(hipMalloc(&d_yb, nk));
+    gd.GenLevelMajor(d_cw_s, static_cast<uint64_t*>(d_bits), d_aux, d_s0s, d_al, nkeys);
+    DeviceSet set(gd, devs);
+    set.GenKeysSharded(gd, s0s.data(), alphas.data(), nkeys);
+    std::vector<uint8_t> gb[2];
+    for (int b = 0; b < 2; ++b) {
+      HIP_OK(hipMemcpy2D(d_seeds, 16, reinterpret_cast<const char*>(d_s0s) + 16 * b, 32, 16, nk, hipMemcpyDeviceToDevice));
+      gd.EvalKeysWalk(b != 0, d_seeds, d_cw_s, static_cast<const uint64_t*>(d_bits), d_xs, d_yb, nkeys);
+      HIP_OK(hipDeviceSynchronize());
+      const std::vector<uint8_t> oneb = FromDevice(d_yb, nk);
+      const DeviceSet::Result res = set.EvalResidentKeysSharded(gd, b != 0, xs.data());
+      gb[b] = Gather<uint8_t>(set, res, nk);
+      EXPECT(SameBytes(gb[b], oneb));
+      if (b == 0) std::printf("  Grotto n=64, %lld keys generated and evaluated on %zu members: %.3f ms max\n", (long long)nkeys, devs.size(), res.max_ms);
+    }
+    int64_t bad = 0;
+    for (size_t k = 0; k < nk; k += 997) bad += ((gb[0][k] ^ gb[1][k]) & 1) != (alphas[k] <= xs[k] ? 1 : 0);
+    EXPECT(bad == 0);
+    HIP_OK(hipFree(d_yb));
+  }
+  HIP_OK(hipFree(d_s0s)); HIP_OK(hipFree(d_al)); HIP_OK(hipFree(d_xs)); HIP_OK(hipFree(d_be)); HIP_OK(hipFree(d_seeds));
+  HIP_OK(hipFree(d_ys)); HIP_OK(hipFree(d_cw_s)); HIP_OK(hipFree(d_aux)); HIP_OK(hipFree(d_bits));
+  std::printf("configs[4] with the keys generated on the members (Half-Tree, Grotto; n=64, 2^%d keys): %s\n", (int)std::log2((double)nkeys),
+              g_fail == before ? "ok" : "FAILED");
+}
+
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && std::strcmp(argv[1], "--quick") == 0;  // smaller sizes (development)
   try {
@@ -337,6 +424,7 @@ int main(int argc, char** argv) {
     if (quick) EvalAllBlocks<22>(eight);
     else EvalAllBlocks<28>(eight);
     IndependentKeys(eight, quick ? int64_t(1) << 14 : int64_t(1) << 18);
+    ResidentKeys(eight, quick ? int64_t(1) << 16 : int64_t(1) << 24);
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (ndev > 1) {  // and every GPU of the box, once each (a power of two of them for the domain blocks)
@@ -346,6 +434,7 @@ int main(int argc, char** argv) {
       while (all.size() & (all.size() - 1)) all.pop_back();
       EvalAllBlocks<28>(all);
       IndependentKeys(all, int64_t(1) << 18);
+      ResidentKeys(all, int64_t(1) << 24);
     }
     fss::ReleaseEngines();
   } catch (const fss::Error& e) {
