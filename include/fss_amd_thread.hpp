@@ -757,30 +757,32 @@ __device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
   slots[2 * in_bits + 1] = int4{0, 0, 0, 0};
 }
 
+// The walks below ask for the NEXT level's correction word before they start this level's cipher and apply it without a
+// branch: a thread's key is its own cache lines (key-major: 32 bytes per level), and a load issued where it is used
+// -- inside `if (t)` -- stalls the wave for a memory round trip per level with nothing of its own left to issue.
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
 __device__ inline int4 DpfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x) {
   auto&& prg = PreparedPrg(prg_);
   int4 s = WithCtl(s0, false);
   bool t = b;
+  int4 cw = key.S(0);
+  bool flag = key.Flag(0);
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
+    const int4 cw_next = key.S(i + 1);  // slot in_bits: the output correction word
+    const bool flag_next = key.Flag(i + 1 < in_bits ? i + 1 : i);  // (no branch around the load: it would be waited for at once)
     const int side = BitAt(x, in_bits - 1 - i);
     int4 taken;  // Gen(s)[side]; a PRG that can compute one side alone is asked for just that
     if constexpr (requires { prg.GenSide(s, true); }) taken = prg.GenSide(s, side != 0)[0];
     else taken = prg.Gen(s)[side];
-    const int4 cw = key.S(i);
-    const bool side_cw = side ? key.Flag(i) : Ctl(cw);
-    int4 child = WithCtl(taken, false);
-    bool ct = Ctl(taken);
-    if (t) {
-      child = X4(child, WithCtl(cw, false));
-      ct ^= side_cw;
-    }
-    s = child;
-    t = ct;
+    const bool side_cw = side ? flag : Ctl(cw);
+    s = X4(WithCtl(taken, false), If(t, WithCtl(cw, false)));
+    t = Ctl(taken) ^ (t && side_cw);
+    cw = cw_next;
+    flag = flag_next;
   }
   Group y = Group::From(s);
-  if (t) y = y + Group::From(key.S(in_bits));
+  if (t) y = y + Group::From(cw);
   if (b) y = -y;
   return y.Into();
 }
@@ -842,6 +844,8 @@ __device__ inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& ke
   bool t = b;
   Group acc;
   auto add = [b](Group sum, Group term) { return b ? sum + (-term) : sum + term; };  // party 1 subtracts
+  // (no request-ahead of the correction words here: a level is two ciphers side by side, the loads measured as hidden,
+  // and eight more live registers put a caller's kernel without launch bounds over its 128)
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
     const int side = BitAt(x, in_bits - 1 - i);
@@ -915,13 +919,16 @@ template <int in_bits, typename Group, typename In, typename Prg, typename Key>
 __device__ inline int4 HtEvalOn(const Prg& prg_, int4 hash_key, bool b, int4 s0, const Key& key, int4 ocw, In x) {
   auto&& prg = PreparedPrg(prg_);
   int4 node = WithCtl(s0, b);
+  int4 cw = key.S(0);
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits - 1; ++i) {
+    const int4 cw_next = key.S(i + 1);  // (see DpfEvalOn)
     const int4 h = HtHash(prg, hash_key, node);
-    node = X4(X4(h, If(BitAt(x, in_bits - 1 - i), node)), If(Ctl(node), key.S(i)));
+    node = X4(X4(h, If(BitAt(x, in_bits - 1 - i), node)), If(Ctl(node), cw));
+    cw = cw_next;
   }
   const bool sigma = BitAt(x, 0), t = Ctl(node);
-  const int4 last = key.S(in_bits - 1);
+  const int4 last = cw;  // key.S(in_bits - 1)
   const bool lcw = sigma ? key.Flag(in_bits - 1) : Ctl(last);
   const int4 h = HtHash(prg, hash_key, WithCtl(node, sigma));
   const int4 high = X4(WithCtl(h, false), If(t, WithCtl(last, false)));
