@@ -445,7 +445,8 @@ struct AesKeyCtx {
 template <int mul>
 class Aes128Mmo {
   static_assert(mul == 1 || mul == 2 || mul == 4);
-  thread::AesSchedules<mul, false> ks_;  // raw keys + round keys (little-endian words), for Gen called on the device
+  using Schedules = thread::AesSchedules<mul, false, true>;
+  Schedules ks_;  // raw keys + round keys (little-endian words), for Gen called on the device
   mutable bool wave_tables_ready_ = false;  // device: this thread has seen its wave's LDS copy of the tables filled (WaveTables)
 
   __host__ __device__ void SetKeys(const unsigned char* const* keys) {
@@ -474,8 +475,11 @@ class Aes128Mmo {
   }
   // Host: one seed through the engine (a batch of one on the GPU; fss_amd_prg_gen is the batched form).
   // Device: computed by the calling thread (the reference's OpenSSL-backed Gen traps there, aes128_mmo.cuh:75-77)
-  // on its wave's LDS copy of the tables, round keys in scalar registers (fss_amd_thread.hpp).
-  __device__ std::array<int4, mul> Gen(int4 seed) const {
+  // on its workgroup's LDS copy of the round table, round keys in scalar registers (one key) or in the wave's LDS slot
+  // (two, four) (fss_amd_thread.hpp).
+  // (always inlined: out of line the call takes `this`, and the whole scheme object moves from the kernel's arguments to
+  // the stack -- 784 bytes of scratch per lane in a DCF Gen kernel)
+  __device__ __attribute__((always_inline)) std::array<int4, mul> Gen(int4 seed) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     return ks_.Gen(thread::WaveTables(wave_tables_ready_), seed);
 #else
@@ -488,14 +492,14 @@ class Aes128Mmo {
 #if defined(__HIP_DEVICE_COMPILE__)
   // Device only: this PRG with its per-call checks made once, for a walk that calls it level after level
   // (thread::PreparedAes; the per-thread Eval takes it by itself).
-  __device__ thread::PreparedAes<mul, false, thread::BankedLdsRoundTable> Prepared() const {
+  __device__ thread::PreparedAes<mul, Schedules, thread::BankedLdsRoundTable> Prepared() const {
     const thread::BankedLdsRoundTable tab = thread::WaveTables(wave_tables_ready_);
-    return thread::PreparedAes<mul, false, thread::BankedLdsRoundTable>{ks_, tab, ks_.ReadyKeys(tab)};
+    return thread::PreparedAes<mul, Schedules, thread::BankedLdsRoundTable>{ks_, tab, ks_.ReadyKeys(tab)};
   }
 #endif
   // Device only: the outputs a tree level takes for one side -- {Gen(seed)[right]} for mul = 2, {Gen(seed)[2 right],
   // Gen(seed)[2 right + 1]} for mul = 4 -- at one block per output instead of two (the per-thread Eval uses it).
-  __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+  __device__ __attribute__((always_inline)) std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
     requires(mul >= 2)
   {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -146,6 +146,31 @@ struct BankedLdsRoundTable {
   const __attribute__((address_space(3))) uint32_t* te0_lane;  // little-endian table base + this lane's bank
   __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
   __device__ uint32_t S(uint32_t i) const { return te0_lane[32 * i] >> 8 & 0xff; }
+  // Addresses for the four bytes of a state word in six instructions instead of eight (v_bfe + v_lshl_add each): the
+  // word is split once into its even and its odd bytes, one per 16-bit half (v_and, v_perm), and every lookup address
+  // is then ONE v_mad_u32_u16 -- half x 128 + this lane's base -- with op_sel picking the half (the compiler has no
+  // pattern for it; 80 of a block's 580 VALU instructions, and the VALU is what bounds a per-thread walk).
+  struct Halves {
+    uint32_t even, odd;  // bytes (2, 0) and (3, 1) of the word, zero-extended to 16 bits each
+  };
+  // (the row size and the v_perm selector sit in vector registers: a walk's scalar registers hold its round keys, and two
+  // more scalar constants made the compiler park keys in VGPR lanes)
+  uint32_t row_bytes, odd_sel;
+  __device__ static BankedLdsRoundTable At(const __attribute__((address_space(3))) uint32_t* lane_base) {
+    BankedLdsRoundTable t{lane_base, 0, 0};
+    asm("v_mov_b32 %0, 0x80" : "=v"(t.row_bytes));
+    asm("v_mov_b32 %0, 0x0c030c01" : "=v"(t.odd_sel));
+    return t;
+  }
+  __device__ Halves Split(uint32_t w) const { return Halves{w & 0x00ff00ffu, __builtin_amdgcn_perm(0u, w, odd_sel)}; }
+  template <int pos>  // pos: the byte's bit position in the word, 0 / 8 / 16 / 24
+  __device__ uint32_t TAt(const Halves& h) const {
+    const uint32_t base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(te0_lane)), src = (pos & 8) ? h.odd : h.even;
+    uint32_t addr;
+    if constexpr (pos & 16) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr) : "v"(src), "v"(row_bytes), "v"(base));
+    else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(addr) : "v"(src), "v"(row_bytes), "v"(base));
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(addr));
+  }
 };
 struct LdsTables {
   static constexpr bool kUnrollRounds = true;  // the fast path: nine straight-line rounds, keys by constant index
@@ -155,6 +180,58 @@ struct LdsTables {
   __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
 };
 #endif
+
+// The sixteen table entries of a round: t[j][k] = T(byte k of state word (j + k) % 4) (ShiftRows in the indices).
+template <bool BE, typename Tab>
+__host__ __device__ inline void AesLookups(const Tab& tab, const uint32_t c[4], uint32_t t[4][4]) {
+  if constexpr (requires { tab.Split(0u); }) {
+    const typename Tab::Halves h[4] = {tab.Split(c[0]), tab.Split(c[1]), tab.Split(c[2]), tab.Split(c[3])};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[j][0] = tab.template TAt<AesBytePos<BE>(0)>(h[j]);
+      t[j][1] = tab.template TAt<AesBytePos<BE>(1)>(h[(j + 1) & 3]);
+      t[j][2] = tab.template TAt<AesBytePos<BE>(2)>(h[(j + 2) & 3]);
+      t[j][3] = tab.template TAt<AesBytePos<BE>(3)>(h[(j + 3) & 3]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[j][k] = tab.T(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+  }
+}
+
+// The last round: SubBytes, ShiftRows and the key, no MixColumns.  A table with split addressing has no S-box of its
+// own: S(x) is byte 1 of the entry, and two v_perm put the four of them in their places (three instructions a word
+// instead of four extractions and three merges).
+template <bool BE, typename Tab, typename Key>
+__host__ __device__ inline void AesLastRound(const Tab& tab, const Key& key, const uint32_t c[4], uint32_t out[4]) {
+  if constexpr (requires { tab.Split(0u); }) {
+    uint32_t t[4][4];
+    AesLookups<BE>(tab, c, t);
+    // byte 1 of t[j][k] goes to byte AesBytePos(k) / 8 of the word: selector 1 = byte 1 of the second operand, 5 = byte 1
+    // of the first, 0x0c = zero
+    constexpr auto sel = [](int ka, int kb) {
+      uint32_t v = 0x0c0c0c0cu;
+      v = (v & ~(0xffu << AesBytePos<BE>(ka))) | 0x01u << AesBytePos<BE>(ka);
+      v = (v & ~(0xffu << AesBytePos<BE>(kb))) | 0x05u << AesBytePos<BE>(kb);
+      return v;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      out[j] = FoldKey(key, 10, j, __builtin_amdgcn_perm(t[j][1], t[j][0], sel(0, 1)), __builtin_amdgcn_perm(t[j][3], t[j][2], sel(2, 3)));
+  } else {
+    uint32_t u[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) u[j][k] = tab.S(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      out[j] = FoldKey(key, 10, j, u[j][0] << AesBytePos<BE>(0) | u[j][1] << AesBytePos<BE>(1),
+                       u[j][2] << AesBytePos<BE>(2) | u[j][3] << AesBytePos<BE>(3));
+  }
+}
 
 // One block: out = AES_k(in).  `Key` supplies the round-key words: key.W(r, j) = word j of round r's key, in the word
 // order of the state.  The nine table rounds are unrolled (the reference's loop is `#pragma unroll 1`,
@@ -166,10 +243,7 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
   for (int j = 0; j < 4; ++j) c[j] = in[j] ^ key.W(0, j);
   auto round = [&](int r) {
     uint32_t t[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) t[j][k] = tab.T(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);  // 16 lookups in flight
+    AesLookups<BE>(tab, c, t);  // 16 lookups in flight
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       c[j] = FoldKey(key, r, j, Xor3(t[j][0], AesRot<BE>(t[j][1], 1), AesRot<BE>(t[j][2], 2)), AesRot<BE>(t[j][3], 3));
@@ -181,15 +255,7 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
 #pragma unroll 1
     for (int r = 1; r < 10; ++r) round(r);
   }
-  uint32_t u[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) u[j][k] = tab.S(c[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-    out[j] = FoldKey(key, 10, j, u[j][0] << AesBytePos<BE>(0) | u[j][1] << AesBytePos<BE>(1),
-                     u[j][2] << AesBytePos<BE>(2) | u[j][3] << AesBytePos<BE>(3));
+  AesLastRound<BE>(tab, key, c, out);
 }
 
 // Two blocks of the same plaintext under two key schedules, round by round side by side: 32 lookups in flight per lane
@@ -203,13 +269,8 @@ __host__ __device__ inline void AesEncrypt2(const Tab& tab, const KeyA& ka, cons
   for (int j = 0; j < 4; ++j) { a[j] = in[j] ^ ka.W(0, j); b[j] = in[j] ^ kb.W(0, j); }
   auto round = [&](int r) {
     uint32_t ta[4][4], tb[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        ta[j][k] = tab.T(a[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
-        tb[j][k] = tab.T(b[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
-      }
+    AesLookups<BE>(tab, a, ta);
+    AesLookups<BE>(tab, b, tb);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       a[j] = FoldKey(ka, r, j, Xor3(ta[j][0], AesRot<BE>(ta[j][1], 1), AesRot<BE>(ta[j][2], 2)), AesRot<BE>(ta[j][3], 3));
@@ -223,21 +284,8 @@ __host__ __device__ inline void AesEncrypt2(const Tab& tab, const KeyA& ka, cons
 #pragma unroll 1
     for (int r = 1; r < 10; ++r) round(r);
   }
-  uint32_t ua[4][4], ub[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      ua[j][k] = tab.S(a[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
-      ub[j][k] = tab.S(b[(j + k) & 3] >> AesBytePos<BE>(k) & 0xff);
-    }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    oa[j] = FoldKey(ka, 10, j, ua[j][0] << AesBytePos<BE>(0) | ua[j][1] << AesBytePos<BE>(1),
-                    ua[j][2] << AesBytePos<BE>(2) | ua[j][3] << AesBytePos<BE>(3));
-    ob[j] = FoldKey(kb, 10, j, ub[j][0] << AesBytePos<BE>(0) | ub[j][1] << AesBytePos<BE>(1),
-                    ub[j][2] << AesBytePos<BE>(2) | ub[j][3] << AesBytePos<BE>(3));
-  }
+  AesLastRound<BE>(tab, ka, a, oa);  // (its lookups are independent of the other block's: the scheduler interleaves them)
+  AesLastRound<BE>(tab, kb, b, ob);
 }
 
 // Round keys as 44 words (one wave-uniform schedule), and the per-lane choice between two schedules A and B given as
@@ -363,24 +411,28 @@ __device__ inline BankedLdsRoundTable WaveTables(bool& ready) {
     WaveLdsSync();
   }
   ready = true;
-  return BankedLdsRoundTable{(const __attribute__((address_space(3))) uint32_t*)(tab.te0) + (__lane_id() & 31)};
+  return BankedLdsRoundTable::At((const __attribute__((address_space(3))) uint32_t*)(tab.te0) + (__lane_id() & 31));
 }
 
-// The LDS home of a four-key PRG's round keys (DCF: 4 x 44 words).  176 wave-uniform words do not fit the scalar
-// register file next to a walk's own state -- the compiler would park them in VGPR lanes and from there in scratch
-// (1 KiB per lane, round 3) -- so every wave keeps ONE copy in LDS and the cipher reads the eight words a round needs
-// from there: every lane reads the same address, which the LDS serves as a broadcast without bank conflicts.  The slot
+// The LDS home of a two- or four-key PRG's round keys (DPF: 2 x 44 words, DCF: 4 x 44).  176 wave-uniform words do not
+// fit the scalar register file next to a walk's own state -- the compiler would park them in VGPR lanes and from there
+// in scratch (1 KiB per lane, round 3) -- and 88 fill it: the compiler reloads or spills some every level, and the
+// per-lane choice between two scalar schedules costs an instruction per key word.  So every wave keeps ONE copy in LDS
+// and the cipher reads the words a round needs from there: every lane reads the same address (Gen) or one of two (the
+// taken child's schedule, chosen in the address), which the LDS serves as broadcasts without bank conflicts.  The slot
 // is written when a thread constructs its PRG object on the device, or at the thread's first call for an object that
 // came from the host (`slot_ready` is the object's per-thread flag: nothing is assumed about what the LDS held before);
 // it carries a tag derived from the key bytes and this launch, checked by every call: a call that finds another tag
 // (the object reached this wave through memory with its flag set by another wave, or two key sets alternate in one
 // wave) re-derives the schedules from the object's key bytes and rewrites the slot.
+template <int mul>
 struct WaveKeySlot {
   uint32_t tag[4];
-  uint32_t rk[4 * 44];  // the four schedules, key i at words 44 i .. 44 i + 43, state word order
+  uint32_t rk[mul * 44];  // the schedules, key i at words 44 i .. 44 i + 43, state word order
 };
-__device__ inline WaveKeySlot* MyKeySlot() {
-  __shared__ __attribute__((aligned(16))) WaveKeySlot slots[16];
+template <int mul>
+__device__ inline WaveKeySlot<mul>* MyKeySlot() {
+  __shared__ __attribute__((aligned(16))) WaveKeySlot<mul> slots[16];
   return &slots[(LinearTid() >> 6) & 15];
 }
 using LdsWords = const __attribute__((address_space(3))) uint32_t*;
@@ -389,7 +441,7 @@ struct LdsKeyWords {
   __device__ uint32_t W(int r, int j) const { return rk[4 * r + j]; }
 };
 // A per-lane choice between two schedules of the slot, made in the ADDRESS: each lane reads its own schedule (two
-// addresses per wave instruction, 88 words = 24 banks apart: two broadcasts, no conflict) -- one LDS read per key word
+// addresses per wave instruction, 88 words = 24 banks apart (DPF: 44 = 12): two broadcasts, no conflict) -- one LDS read per key word
 // (round 4 read both schedules and selected: two reads and a v_bfi per word).
 struct LdsKeyPerLane {
   LdsWords rk;  // a or b, per lane
@@ -401,21 +453,25 @@ struct LdsKeyPerLane {
 //  * Layout: schedules that a tree level chooses between per lane are stored as A and D = A ^ B, so the taken child
 //    costs one block (AesKeySelect) and the other child's key is A ^ D:
 //      mul = 1: [k0]      mul = 2: [k0, k0 ^ k1]      mul = 4 (DCF, outputs sl, vl, sr, vr): [k0, k1, k0 ^ k2, k1 ^ k3]
-//  * On the device the words are wave-uniform values in scalar registers when every lane of the wave was constructed
-//    from the same keys (`uniform`; the normal case: one key set per kernel).  Lanes with keys of their own fall back
-//    to expanding their key per call.
-template <int mul, bool BE>
+//  * On the device a single schedule (mul = 1) is wave-uniform values in scalar registers, two or four live in the wave's
+//    LDS slot (WaveKeySlot) in plain form -- when every lane of the wave was constructed from the same keys (`uniform`;
+//    the normal case: one key set per kernel).  Lanes with keys of their own fall back to expanding their key per call.
+//  * lds2: two schedules in the LDS slot as well (four always are).  What pays with the bank-replicated table, whose
+//    lookups leave the LDS pipe half idle; the reference-shaped Aes128Soft, bound by its 1 KiB table's bank conflicts,
+//    keeps its two schedules in scalar registers (1.93 G evals/s against 1.77 with them in LDS).
+template <int mul, bool BE, bool lds2 = false>
 struct AesSchedules {
   uint32_t keyw[mul][4];  // the raw keys, little-endian words (per lane)
   uint32_t rk[mul][44];   // A / D layout above, state word order
   bool uniform;
-  mutable bool slot_ready = false;  // mul = 4 on the device: this thread has seen its wave's LDS copy of the schedules filled
+  mutable bool slot_ready = false;  // mul >= 2 on the device: this thread has seen its wave's LDS copy of the schedules filled
+  static constexpr bool kSlotted = mul == 4 || (mul == 2 && lds2);  // (device) the schedules live in the wave's LDS slot
 
   template <typename SboxFn>
   __host__ __device__ void Set(const unsigned char* const* keys, SboxFn S) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (mul == 4) {
-      // four schedules: they live in the wave's LDS slot (WaveKeySlot), never in this object's registers
+    if constexpr (kSlotted) {
+      // two or four schedules: they live in the wave's LDS slot (WaveKeySlot), never in this object's registers
       for (int i = 0; i < mul; ++i)
         for (int j = 0; j < 4; ++j)
           keyw[i][j] = static_cast<uint32_t>(keys[i][4 * j]) | static_cast<uint32_t>(keys[i][4 * j + 1]) << 8 |
@@ -452,7 +508,7 @@ struct AesSchedules {
 #endif
   }
 #if defined(__HIP_DEVICE_COMPILE__)
-  // ---- mul = 4 on the device: the wave's LDS copy of the schedules
+  // ---- mul >= 2 on the device: the wave's LDS copy of the schedules
   __device__ void Tag(uint32_t t[4]) const {  // 128 bits of the key bytes (and the word order the slot is written in)
     uint32_t nonce[2];
     LaunchNonce(nonce);
@@ -461,18 +517,21 @@ struct AesSchedules {
       t[j] = keyw[0][j] ^ RotL(keyw[mul > 1 ? 1 : 0][j], 7) ^ RotL(keyw[mul > 2 ? 2 : 0][j], 13) ^ RotL(keyw[mul > 3 ? 3 : 0][j], 19) ^
              (BE ? 0x9e3779b9u : 0u) ^ nonce[j & 1];
   }
-  // Expand the four keys one after the other (44 words live at a time) into this wave's slot; every active lane
+  // Expand the keys one after the other (44 words live at a time) into this wave's slot; every active lane
   // writes the same values.  S: the S-box the expansion looks up through.
   template <typename SboxFn>
   __device__ void FillSlot(SboxFn S) const {
-    WaveKeySlot* s = MyKeySlot();
+    WaveKeySlot<mul>* s = MyKeySlot<mul>();
     WaveLdsSync();  // the wave's earlier reads of the slot are done
 #pragma unroll 1  // one expansion at a time: 44 words live, not 176
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < mul; ++i) {
       uint32_t kw[4], w[44];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)  // keyw[i] by selects, not by a runtime index (that would put the array on the stack)
-        kw[j] = i == 0 ? keyw[0][j] : (i == 1 ? keyw[1][j] : (i == 2 ? keyw[2][j] : keyw[3][j]));
+      for (int j = 0; j < 4; ++j) {  // keyw[i] by selects, not by a runtime index (that would put the array on the stack)
+        kw[j] = keyw[0][j];
+#pragma unroll
+        for (int q = 1; q < mul; ++q) kw[j] = i == q ? keyw[q][j] : kw[j];
+      }
       AesExpandKeyFromWords<BE>(kw, w, S);
 #pragma unroll
       for (int q = 0; q < 44; ++q) s->rk[44 * i + q] = w[q];
@@ -486,7 +545,7 @@ struct AesSchedules {
   // This wave's copy of the schedules, re-derived from the key bytes first if the slot holds something else.
   template <typename Tab>
   __device__ LdsWords SlotKeys(const Tab& tab) const {
-    WaveKeySlot* s = MyKeySlot();
+    WaveKeySlot<mul>* s = MyKeySlot<mul>();
     uint32_t t[4];
     Tag(t);
     const bool stale = !slot_ready || ((s->tag[0] ^ t[0]) | (s->tag[1] ^ t[1]) | (s->tag[2] ^ t[2]) | (s->tag[3] ^ t[3])) != 0;
@@ -496,11 +555,11 @@ struct AesSchedules {
   }
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-  // The key slot checked (and refilled if stale) once, for a walk that then passes it to every Gen / GenSide (mul = 4 with
+  // The key slot checked (and refilled if stale) once, for a walk that then passes it to every Gen / GenSide (mul >= 2 with
   // wave-uniform keys; nullptr otherwise: nothing to keep).
   template <typename Tab>
   __device__ const void* ReadyKeys(const Tab& tab) const {
-    if constexpr (mul == 4) {
+    if constexpr (kSlotted) {
       if (uniform) return (const void*)(uintptr_t)SlotKeys(tab);
     }
     return nullptr;
@@ -529,17 +588,17 @@ struct AesSchedules {
   // out[i] = AES_{key i}(seed) ^ seed for every key.  ready (device, mul = 4): the wave's key slot as SlotKeys returned
   // it earlier in the same walk (PreparedAes below) -- the slot's tag is then not checked again.
   template <typename Tab>
-  __host__ __device__ std::array<int4, mul> Gen(const Tab& tab, int4 seed, const void* ready = nullptr) const {
+  __host__ __device__ __attribute__((always_inline)) std::array<int4, mul> Gen(const Tab& tab, int4 seed, const void* ready = nullptr) const {
     std::array<int4, mul> out;
     uint32_t in[4], o[4];
     Words(seed, in);
     (void)ready;
     if (uniform) {
 #if defined(__HIP_DEVICE_COMPILE__)
-      if constexpr (mul == 4) {
+      if constexpr (kSlotted) {
         const LdsWords k = ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab);
 #pragma unroll
-        for (int i = 0; i < 4; i += 2) {
+        for (int i = 0; i < mul; i += 2) {
           uint32_t o2[4];
           AesEncrypt2<BE>(tab, LdsKeyWords{k + 44 * i}, LdsKeyWords{k + 44 * (i + 1)}, in, o, o2);
           out[i] = Mmo(o, seed);
@@ -574,7 +633,7 @@ struct AesSchedules {
   }
   // The outputs of one side only: mul = 2: {right ? out[1] : out[0]};  mul = 4: {right ? out[2] : out[0], right ? out[3] : out[1]}
   template <typename Tab>
-  __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(const Tab& tab, int4 seed, bool right, const void* ready = nullptr) const {
+  __host__ __device__ __attribute__((always_inline)) std::array<int4, (mul + 1) / 2> GenSide(const Tab& tab, int4 seed, bool right, const void* ready = nullptr) const {
     static_assert(mul == 2 || mul == 4);
     constexpr int half = mul / 2;
     std::array<int4, half> out;
@@ -590,6 +649,11 @@ struct AesSchedules {
         AesEncrypt2<BE>(tab, LdsKeyPerLane{k}, LdsKeyPerLane{k + 44}, in, o, o2);  // seed and value block side by side
         out[0] = Mmo(o, seed);
         out[1] = Mmo(o2, seed);
+        return out;
+      } else if constexpr (kSlotted) {
+        const LdsWords k = (ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab)) + (right ? 44 : 0);  // [left | right]: this lane's child
+        AesEncrypt<BE>(tab, LdsKeyPerLane{k}, in, o);
+        out[0] = Mmo(o, seed);
         return out;
       }
 #endif
@@ -629,9 +693,9 @@ struct AesSchedules {
 // key slot's tag seen (mul = 4).  A walk takes one at its start (`prg.Prepared()`, PreparedPrg below) and calls it
 // level after level: nothing can invalidate either while the thread stays inside the walk -- LDS belongs to this
 // launch, and other waves only ever store the values that are there already.  Same Gen / GenSide as the PRG itself.
-template <int mul, bool BE, typename Tab>
+template <int mul, typename Ks, typename Tab>
 struct PreparedAes {
-  const AesSchedules<mul, BE>& ks;
+  const Ks& ks;
   Tab tab;
   const void* keys;
   __device__ std::array<int4, mul> Gen(int4 seed) const { return ks.Gen(tab, seed, keys); }

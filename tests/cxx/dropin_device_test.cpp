@@ -634,9 +634,11 @@ static void Groups() {
   GroupCase<fss::group::Uint<uint64_t, 18446744073709551557ull>>("Uint<u64, 2^64 - 59>");
 }
 
-// what the compatibility form costs next to the engine: DPF n=32, 2^18 independent keys, one evaluation each
+// what the compatibility form costs next to the engine: DPF / DCF n=32, 2^kLog independent keys, one evaluation each
+// (2^18: 1024 workgroups, ONE residency of the chip -- start-up and the ragged end are in the figure; 2^21: eight)
+template <int kLog>
 static void Timing() {
-  constexpr int kN = 1 << 18;
+  constexpr int kN = 1 << kLog;
   using G = fss::group::Uint<uint64_t>;
   using Prg = fss::prg::Aes128Mmo<2>;
   using Dpf = fss::Dpf<32, G, Prg, uint32_t>;
@@ -685,9 +687,9 @@ static void Timing() {
   int bad = 0;
   for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
   EXPECT(bad == 0);
-  std::printf("     (DPF n=32, 2^18 keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+  std::printf("     (DPF n=32, 2^%d keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
               "DpfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n",
-              ms_thread, kN / ms_thread / 1e3, ms_engine, kN / ms_engine / 1e3, bad ? "NO" : "yes");
+              kLog, ms_thread, kN / ms_thread / 1e3, ms_engine, kN / ms_engine / 1e3, bad ? "NO" : "yes");
   // the DPF scheme through a pointer shared by the waves of a workgroup (per-wave table copies found missing and filled)
   HIP_OK(hipMemset(d_yt, 0xff, sizeof(int4) * kN));
   EvalThroughSharedPointerKernel<Dpf, uint32_t><<<kN / 256, 256>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN);
@@ -722,11 +724,14 @@ static void Timing() {
     int badd = 0;
     for (int i = 0; i < kN; ++i) badd += !Same(dt[i], de[i]);
     EXPECT(badd == 0);
-    std::printf("     (DCF n=32, 2^18 keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+    std::printf("     (DCF n=32, 2^%d keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
                 "DcfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n",
-                ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, badd ? "NO" : "yes");
+                kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, badd ? "NO" : "yes");
     HIP_OK(hipFree(d_dc)); HIP_OK(hipFree(cw_v));
   }
+  for (void* q : {(void*)d_seeds, (void*)d_seeds0, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_cws, (void*)d_yt, (void*)d_ye,
+                  (void*)cw_s, (void*)extra, (void*)out_cw})
+    HIP_OK(hipFree(q));
 }
 }  // namespace p2
 
@@ -1314,7 +1319,8 @@ int main() {
     p2::Kats();
     p2::Batches();
     p2::Groups();
-    p2::Timing();
+    p2::Timing<18>();
+    p2::Timing<21>();
     p3::Run();
     p4::Run();
     fss::ReleaseEngines();

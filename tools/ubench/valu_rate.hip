@@ -53,6 +53,13 @@
 #define S_XORE64(i) "v_xor_b32_e64 %" #i ", %8, %" #i "\n"
 #define S_XORE64S(i) "v_xor_b32_e64 %" #i ", %9, %" #i "\n"
 #define S_PKADD(i) "v_pk_add_u16 %" #i ", %" #i ", %8\n"
+#define S_MADU16(i) "v_mad_u32_u16 %" #i ", %" #i ", %8, %8 op_sel:[1,0,0,0]\n"
+#define S_MADU24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %8\n"
+#define S_MADU16LO(i) "v_mad_u32_u16 %" #i ", %" #i ", %8, %8\n"
+#define S_MULU24(i) "v_mul_u32_u24 %" #i ", %" #i ", %8\n"
+#define S_LSHLSDWA(i) "v_lshlrev_b32_sdwa %" #i ", %8, %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n"
+#define S_ADDSDWA(i) "v_add_u32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD\n"
+#define S_PKMAD(i) "v_pk_mad_u16 %" #i ", %" #i ", %8, %8\n"
 
 KERNEL(k_xor, OP8(S_XOR))
 KERNEL(k_bitop3, OP8(S_BITOP))
@@ -84,6 +91,13 @@ KERNEL(k_or3, OP8(S_OR3))
 KERNEL(k_xore64, OP8(S_XORE64))
 KERNEL(k_xore64s, OP8(S_XORE64S))
 KERNEL(k_pkadd, OP8(S_PKADD))
+KERNEL(k_madu16, OP8(S_MADU16))
+KERNEL(k_madu16lo, OP8(S_MADU16LO))
+KERNEL(k_madu24, OP8(S_MADU24))
+KERNEL(k_mulu24, OP8(S_MULU24))
+KERNEL(k_lshlsdwa, OP8(S_LSHLSDWA))
+KERNEL(k_addsdwa, OP8(S_ADDSDWA))
+KERNEL(k_pkmad, OP8(S_PKMAD))
 #ifdef HAVE_XOR3
 KERNEL(k_xor3, OP8(S_XOR3))
 #endif
@@ -138,6 +152,13 @@ int main() {
     run("v_lshl_add vvv", k_lshladd, out, blocks, threads);
     run("v_add3 vvv", k_add3, out, blocks, threads);
     run("v_or3 vvv", k_or3, out, blocks, threads);
+    run("v_mad_u32_u16 hi", k_madu16, out, blocks, threads);
+    run("v_mad_u32_u16 lo", k_madu16lo, out, blocks, threads);
+    run("v_mad_u32_u24", k_madu24, out, blocks, threads);
+    run("v_mul_u32_u24", k_mulu24, out, blocks, threads);
+    run("v_lshl sdwa b1", k_lshlsdwa, out, blocks, threads);
+    run("v_add sdwa w1", k_addsdwa, out, blocks, threads);
+    run("v_pk_mad_u16", k_pkmad, out, blocks, threads);
     run("v_xor e64", k_xore64, out, blocks, threads);
     run("v_xor e64 sgpr", k_xore64s, out, blocks, threads);
     run("v_pk_add_u16", k_pkadd, out, blocks, threads);
