@@ -132,36 +132,22 @@ struct BankedPlainTables {  // host code / tables outside LDS: copy 0
   __host__ __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
 };
 #if defined(__HIP_DEVICE_COMPILE__)
-struct BankedLdsTables {
-  static constexpr bool kUnrollRounds = true;
+// Addresses into a bank-replicated table (128-byte rows) for the four bytes of a state word in six instructions
+// instead of eight (v_bfe + v_lshl_add each): the word is split once into its even and its odd bytes, one per 16-bit
+// half (v_and, v_perm), and every lookup address is then ONE v_mad_u32_u16 -- half x 128 + this lane's base -- with
+// op_sel picking the half (the compiler has no pattern for it; 80 of a block's 580 VALU instructions, and the VALU is
+// what bounds a per-thread walk).  The row size and the v_perm selector sit in vector registers: a walk's scalar
+// registers hold round keys, and two more scalar constants made the compiler park keys in VGPR lanes.
+struct BankedRows {
   const __attribute__((address_space(3))) uint32_t* te0_lane;  // table base + this lane's bank
-  const __attribute__((address_space(3))) uint8_t* sbox;
-  __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
-  __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
-};
-// ... the same layout with no separate S-box: S(x) is byte 1 of the little-endian round-table entry (2S, S, S, 3S), read
-// from this lane's own bank as well (a 256-byte S-box would put 64 random byte reads on 64 words of 32 banks).
-struct BankedLdsRoundTable {
-  static constexpr bool kUnrollRounds = true;
-  const __attribute__((address_space(3))) uint32_t* te0_lane;  // little-endian table base + this lane's bank
-  __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
-  __device__ uint32_t S(uint32_t i) const { return te0_lane[32 * i] >> 8 & 0xff; }
-  // Addresses for the four bytes of a state word in six instructions instead of eight (v_bfe + v_lshl_add each): the
-  // word is split once into its even and its odd bytes, one per 16-bit half (v_and, v_perm), and every lookup address
-  // is then ONE v_mad_u32_u16 -- half x 128 + this lane's base -- with op_sel picking the half (the compiler has no
-  // pattern for it; 80 of a block's 580 VALU instructions, and the VALU is what bounds a per-thread walk).
+  uint32_t row_bytes, odd_sel;
+  __device__ explicit BankedRows(const __attribute__((address_space(3))) uint32_t* lane_base) : te0_lane(lane_base) {
+    asm("v_mov_b32 %0, 0x80" : "=v"(row_bytes));
+    asm("v_mov_b32 %0, 0x0c030c01" : "=v"(odd_sel));
+  }
   struct Halves {
     uint32_t even, odd;  // bytes (2, 0) and (3, 1) of the word, zero-extended to 16 bits each
   };
-  // (the row size and the v_perm selector sit in vector registers: a walk's scalar registers hold its round keys, and two
-  // more scalar constants made the compiler park keys in VGPR lanes)
-  uint32_t row_bytes, odd_sel;
-  __device__ static BankedLdsRoundTable At(const __attribute__((address_space(3))) uint32_t* lane_base) {
-    BankedLdsRoundTable t{lane_base, 0, 0};
-    asm("v_mov_b32 %0, 0x80" : "=v"(t.row_bytes));
-    asm("v_mov_b32 %0, 0x0c030c01" : "=v"(t.odd_sel));
-    return t;
-  }
   __device__ Halves Split(uint32_t w) const { return Halves{w & 0x00ff00ffu, __builtin_amdgcn_perm(0u, w, odd_sel)}; }
   template <int pos>  // pos: the byte's bit position in the word, 0 / 8 / 16 / 24
   __device__ uint32_t TAt(const Halves& h) const {
@@ -171,6 +157,22 @@ struct BankedLdsRoundTable {
     else asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[0,0,0,0]" : "=v"(addr) : "v"(src), "v"(row_bytes), "v"(base));
     return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(addr));
   }
+  __device__ uint32_t T(uint32_t i) const { return te0_lane[32 * i]; }
+};
+struct BankedLdsTables : BankedRows {
+  static constexpr bool kUnrollRounds = true;
+  const __attribute__((address_space(3))) uint8_t* sbox;
+  __device__ BankedLdsTables(const __attribute__((address_space(3))) uint32_t* lane_base, const __attribute__((address_space(3))) uint8_t* sbox_)
+      : BankedRows(lane_base), sbox(sbox_) {}
+  __device__ uint32_t S(uint32_t i) const { return sbox[i]; }
+};
+// ... the same layout with no separate S-box: S(x) is byte 1 of the little-endian round-table entry (2S, S, S, 3S), read
+// from this lane's own bank as well (a 256-byte S-box would put 64 random byte reads on 64 words of 32 banks).
+struct BankedLdsRoundTable : BankedRows {
+  static constexpr bool kUnrollRounds = true;
+  static constexpr bool kSboxInTable = true;
+  using BankedRows::BankedRows;
+  __device__ uint32_t S(uint32_t i) const { return te0_lane[32 * i] >> 8 & 0xff; }
 };
 struct LdsTables {
   static constexpr bool kUnrollRounds = true;  // the fast path: nine straight-line rounds, keys by constant index
@@ -201,12 +203,12 @@ __host__ __device__ inline void AesLookups(const Tab& tab, const uint32_t c[4], 
   }
 }
 
-// The last round: SubBytes, ShiftRows and the key, no MixColumns.  A table with split addressing has no S-box of its
+// The last round: SubBytes, ShiftRows and the key, no MixColumns.  BankedLdsRoundTable has no S-box of its
 // own: S(x) is byte 1 of the entry, and two v_perm put the four of them in their places (three instructions a word
 // instead of four extractions and three merges).
 template <bool BE, typename Tab, typename Key>
 __host__ __device__ inline void AesLastRound(const Tab& tab, const Key& key, const uint32_t c[4], uint32_t out[4]) {
-  if constexpr (requires { tab.Split(0u); }) {
+  if constexpr (requires { Tab::kSboxInTable; }) {
     uint32_t t[4][4];
     AesLookups<BE>(tab, c, t);
     // byte 1 of t[j][k] goes to byte AesBytePos(k) / 8 of the word: selector 1 = byte 1 of the second operand, 5 = byte 1
@@ -411,7 +413,7 @@ __device__ inline BankedLdsRoundTable WaveTables(bool& ready) {
     WaveLdsSync();
   }
   ready = true;
-  return BankedLdsRoundTable::At((const __attribute__((address_space(3))) uint32_t*)(tab.te0) + (__lane_id() & 31));
+  return BankedLdsRoundTable((const __attribute__((address_space(3))) uint32_t*)(tab.te0) + (__lane_id() & 31));
 }
 
 // The LDS home of a two- or four-key PRG's round keys (DPF: 2 x 44 words, DCF: 4 x 44).  176 wave-uniform words do not
