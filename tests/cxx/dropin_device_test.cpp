@@ -432,6 +432,94 @@ __global__ void EvalDivergentKernel(S sch, int4* ys, bool party, const int4* see
   }
 }
 
+// two key sets inside one wave, the cases the wave's LDS key slot (two / four schedules, fss_amd_thread.hpp) has to get
+// right: (a) lanes that construct their PRG from DIFFERENT keys (odd lanes set B, even lanes set A: no wave-uniform
+// schedule exists, every lane expands its own), (b) one thread using two PRG objects in turn (A, B, A: the slot's tag
+// names the other set each time and the schedules are re-derived).
+__constant__ unsigned char kSetA[4][16] = {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16},
+                                           {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1},
+                                           {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+                                           {8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1}};
+__constant__ unsigned char kSetB[4][16] = {{8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1},
+                                           {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+                                           {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1},
+                                           {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16}};
+template <typename S, typename Prg, typename In>
+__global__ void PerLaneKeySetKernel(int4* ys, bool party, const int4* seeds, const typename S::Cw* cws_a,
+                                    const typename S::Cw* cws_b, const In* xs, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  const bool odd = tid & 1;
+  const unsigned char* keys[Prg::kMul];
+  for (int i = 0; i < Prg::kMul; ++i) keys[i] = odd ? kSetB[i] : kSetA[i];
+  S sch{Prg(keys)};
+  ys[tid] = sch.Eval(party, seeds[tid], (odd ? cws_b : cws_a) + size_t(tid) * S::kSlots, xs[tid]);
+}
+template <typename S, typename In>
+__global__ void AlternatingKeySetKernel(S sch_a, S sch_b, int4* ys /* [3][n] */, bool party, const int4* seeds,
+                                        const typename S::Cw* cws_a, const typename S::Cw* cws_b, const In* xs, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = sch_a.Eval(party, seeds[tid], cws_a + size_t(tid) * S::kSlots, xs[tid]);
+  ys[n + tid] = sch_b.Eval(party, seeds[tid], cws_b + size_t(tid) * S::kSlots, xs[tid]);
+  ys[2 * n + tid] = sch_a.Eval(party, seeds[tid], cws_a + size_t(tid) * S::kSlots, xs[tid]);
+}
+template <typename S, typename Prg>
+static void KeySetCase(const char* name) {
+  const int before = g_fail;
+  constexpr int kN = 1024;
+  const unsigned char* ka[4] = {k0, k1, k2, k3};
+  const unsigned char* kb[4] = {k3, k2, k1, k0};
+  S sch_a{Prg(ka)}, sch_b{Prg(kb)};
+  std::vector<int4> seeds(2 * kN), seeds0(kN), betas(kN);
+  std::vector<uint16_t> alphas(kN), xs(kN);
+  for (int i = 0; i < kN; ++i) {
+    seeds0[i] = seeds[2 * i] = RandSeed();
+    seeds[2 * i + 1] = RandSeed();
+    betas[i] = RandSeed();
+    alphas[i] = static_cast<uint16_t>(Next());
+    xs[i] = i % 3 == 0 ? alphas[i] : static_cast<uint16_t>(Next());
+  }
+  int4* d_seeds = ToDevice(seeds.data(), 2 * kN);
+  int4* d_seeds0 = ToDevice(seeds0.data(), kN);
+  int4* d_betas = ToDevice(betas.data(), kN);
+  uint16_t* d_alphas = ToDevice(alphas.data(), kN);
+  uint16_t* d_xs = ToDevice(xs.data(), kN);
+  typename S::Cw* d_ca = DeviceBuf<typename S::Cw>(size_t(S::kSlots) * kN);
+  typename S::Cw* d_cb = DeviceBuf<typename S::Cw>(size_t(S::kSlots) * kN);
+  int4* d_ya = DeviceBuf<int4>(kN);
+  int4* d_yb = DeviceBuf<int4>(kN);
+  int4* d_mixed = DeviceBuf<int4>(kN);
+  int4* d_turns = DeviceBuf<int4>(3 * kN);
+  sch_a.GenBatch(d_ca, d_seeds, d_alphas, d_betas, kN);  // the engine's keys and (uniform-key kernels) reference shares
+  sch_b.GenBatch(d_cb, d_seeds, d_alphas, d_betas, kN);
+  EvalKeysKernel<S, uint16_t><<<kN / 128, 128>>>(sch_a, d_ya, false, d_seeds0, d_ca, d_xs, kN);
+  EvalKeysKernel<S, uint16_t><<<kN / 128, 128>>>(sch_b, d_yb, false, d_seeds0, d_cb, d_xs, kN);
+  PerLaneKeySetKernel<S, Prg, uint16_t><<<kN / 128, 128>>>(d_mixed, false, d_seeds0, d_ca, d_cb, d_xs, kN);
+  AlternatingKeySetKernel<S, uint16_t><<<kN / 128, 128>>>(sch_a, sch_b, d_turns, false, d_seeds0, d_ca, d_cb, d_xs, kN);
+  HIP_OK(hipDeviceSynchronize());
+  auto ya = ToHost(d_ya, kN), yb = ToHost(d_yb, kN), mixed = ToHost(d_mixed, kN), turns = ToHost(d_turns, 3 * kN);
+  int differ = 0, bad_mixed = 0, bad_turns = 0;
+  for (int i = 0; i < kN; ++i) {
+    differ += !Same(ya[i], yb[i]);
+    bad_mixed += !Same(mixed[i], i & 1 ? yb[i] : ya[i]);
+    bad_turns += !Same(turns[i], ya[i]) || !Same(turns[kN + i], yb[i]) || !Same(turns[2 * kN + i], ya[i]);
+  }
+  EXPECT(differ > kN / 2);  // the two key sets really give different shares
+  EXPECT(bad_mixed == 0);
+  EXPECT(bad_turns == 0);
+  for (void* q : {(void*)d_seeds, (void*)d_seeds0, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_ca, (void*)d_cb, (void*)d_ya,
+                  (void*)d_yb, (void*)d_mixed, (void*)d_turns})
+    HIP_OK(hipFree(q));
+  std::printf("AES-128-MMO  %s: key sets differing per lane, and alternating in one thread == the uniform-key kernels: %s\n", name,
+              g_fail == before ? "ok" : "FAILED");
+}
+static void KeySets() {
+  using G = fss::group::Uint<uint64_t>;
+  KeySetCase<fss::Dpf<16, G, fss::prg::Aes128Mmo<2>, uint16_t>, fss::prg::Aes128Mmo<2>>("DPF n=16 (two schedules)");
+  KeySetCase<fss::Dcf<16, G, fss::prg::Aes128Mmo<4>, uint16_t>, fss::prg::Aes128Mmo<4>>("DCF n=16 (four schedules)");
+}
+
 static void Batches() {
   const int before = g_fail;
   constexpr int kN = 4096;
@@ -1319,6 +1407,7 @@ int main() {
     p2::Kats();
     p2::Batches();
     p2::Groups();
+    p2::KeySets();
     p2::Timing<18>();
     p2::Timing<21>();
     p3::Run();
