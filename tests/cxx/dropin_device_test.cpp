@@ -817,6 +817,45 @@ static void Timing() {
                 kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, badd ? "NO" : "yes");
     HIP_OK(hipFree(d_dc)); HIP_OK(hipFree(cw_v));
   }
+  if constexpr (kLog <= 18) {  // Half-Tree n=64 (one AES key: the schedule in scalar registers), 2^18 keys
+    using PrgH = fss::prg::Aes128Mmo<1>;
+    using Ht = fss::HalfTreeDpf<64, G, PrgH, uint64_t>;
+    const unsigned char* keys1[1] = {k0};
+    Ht ht{PrgH(keys1), int4{0x12345678, static_cast<int>(0x9abcdef0u), 0x13572468, 0x2468ace0}};
+    std::vector<uint64_t> ha(kN), hx(kN);
+    for (int i = 0; i < kN; ++i) {
+      ha[i] = Next();
+      hx[i] = i % 2 ? ha[i] : Next();
+    }
+    uint64_t* d_ha = ToDevice(ha.data(), kN);
+    uint64_t* d_hx = ToDevice(hx.data(), kN);
+    typename Ht::Cw* d_hc = DeviceBuf<typename Ht::Cw>(size_t(64) * kN);
+    int4* d_ho = DeviceBuf<int4>(kN);
+    int4* h_s = DeviceBuf<int4>(size_t(64) * kN);
+    ht.GenBatch(d_hc, d_ho, d_seeds, d_ha, d_betas, kN);
+    fss::gpu::HalfTreeDpfRelayoutGpu<64, G, PrgH, uint64_t>(d_hc, kN, h_s, extra);
+    float ms_t = 0, ms_e = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      HIP_OK(hipEventRecord(e0));
+      HtEvalKeysKernel<Ht, uint64_t><<<kN / 256, 256>>>(ht, d_yt, false, d_seeds0, d_hc, d_ho, d_hx, kN);
+      HIP_OK(hipEventRecord(e1));
+      HIP_OK(hipEventSynchronize(e1));
+      HIP_OK(hipEventElapsedTime(&ms_t, e0, e1));
+      HIP_OK(hipEventRecord(e0));
+      fss::gpu::HalfTreeDpfEvalPointGpu<4>(false, d_seeds0, h_s, extra, d_ho, d_hx, d_ye, kN, ht);
+      HIP_OK(hipEventRecord(e1));
+      HIP_OK(hipEventSynchronize(e1));
+      HIP_OK(hipEventElapsedTime(&ms_e, e0, e1));
+    }
+    auto ht_t = ToHost(d_yt, kN), ht_e = ToHost(d_ye, kN);
+    int badh = 0;
+    for (int i = 0; i < kN; ++i) badh += !Same(ht_t[i], ht_e[i]);
+    EXPECT(badh == 0);
+    std::printf("     (Half-Tree n=64, 2^%d keys: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+                "HalfTreeDpfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n",
+                kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, badh ? "NO" : "yes");
+    for (void* q : {(void*)d_ha, (void*)d_hx, (void*)d_hc, (void*)d_ho, (void*)h_s}) HIP_OK(hipFree(q));
+  }
   for (void* q : {(void*)d_seeds, (void*)d_seeds0, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_cws, (void*)d_yt, (void*)d_ye,
                   (void*)cw_s, (void*)extra, (void*)out_cw})
     HIP_OK(hipFree(q));
