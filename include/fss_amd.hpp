@@ -483,6 +483,7 @@ class Aes128Mmo {
 #if defined(__HIP_DEVICE_COMPILE__)
     return ks_.Gen(thread::WaveTables(wave_tables_ready_), seed);
 #else
+    (void)seed;
     return {};
 #endif
   }
@@ -505,6 +506,8 @@ class Aes128Mmo {
 #if defined(__HIP_DEVICE_COMPILE__)
     return ks_.GenSide(thread::WaveTables(wave_tables_ready_), seed, right);
 #else
+    (void)seed;
+    (void)right;
     return {};
 #endif
   }

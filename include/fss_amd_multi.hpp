@@ -314,7 +314,7 @@ class DeviceSet {
   Result Points(int scheme, int in_bits, int group, int slots, bool b, int4 s0, const void* cws, const int4* ocw,
                 const void* xs, size_t xb, int64_t n) {
     const int world = size();
-    return Run([=, this](Member& m, int r) {
+    return Run([=](Member& m, int r) {
       const Slice sl = BatchSlice(n, r, world);
       const int64_t cnt = sl.hi - sl.lo;
       const size_t key_bytes = 32 + size_t(32) * slots + 32;
@@ -343,7 +343,7 @@ class DeviceSet {
   Result Keys(int scheme, int in_bits, int group, int slots, bool b, const int4* seeds, const void* cws, const int4* ocws,
               const void* xs, size_t xb, int64_t nkeys) {
     const int world = size();
-    return Run([=, this](Member& m, int r) {
+    return Run([=](Member& m, int r) {
       const Slice sl = BatchSlice(nkeys, r, world);
       const int64_t cnt = sl.hi - sl.lo;
       const size_t nk = static_cast<size_t>(cnt), key_bytes = size_t(32) * slots;
@@ -381,7 +381,7 @@ class DeviceSet {
   void GenKeys(int scheme, int in_bits, int group, int pred, const int4* s0s, const void* alphas, size_t xb, const int4* betas,
                int64_t nkeys) {
     const int world = size();
-    (void)Run([=, this](Member& m, int r) {
+    (void)Run([=](Member& m, int r) {
       const Slice sl = BatchSlice(nkeys, r, world);
       const int64_t cnt = sl.hi - sl.lo;
       const size_t nk = static_cast<size_t>(cnt), planes = in_bits > 64 ? 2 : 1;
@@ -416,7 +416,7 @@ class DeviceSet {
   }
 
   Result EvalResident(bool b, const void* xs, size_t xb) {
-    return Run([=, this](Member& m, int) {
+    return Run([=](Member& m, int) {
       if (m.k_scheme < 0) throw Error("DeviceSet::EvalResidentKeysSharded before GenKeysSharded", FSS_AMD_EINVAL);
       const int64_t cnt = m.k_n;
       const size_t nk = static_cast<size_t>(cnt);
@@ -444,7 +444,7 @@ class DeviceSet {
   Result All(int scheme, int in_bits, int group, int slots, bool b, int4 s0, const void* cws, const int4* ocw) {
     const int world = size();
     const bool grotto = scheme == FSS_AMD_GROTTO;
-    Result res = Run([=, this](Member& m, int r) {
+    Result res = Run([=](Member& m, int r) {
       const Block bl = DomainBlock(in_bits, r, world);
       const size_t key_bytes = 32 + size_t(32) * slots + 32;
       char* in = static_cast<char*>(m.in.Need(Up(key_bytes)));
