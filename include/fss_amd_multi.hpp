@@ -20,6 +20,8 @@
 // of seeds, alpha and beta per key go up instead of in_bits x 32 B of correction words), and keeps it resident;
 // EvalResidentKeysSharded then evaluates points on those keys for either party (what src/bench_gpu.cu:72-83 + :616-627
 // do on one device: Gen, relayout, EvalPoint).
+// A point batch can stay resident the same way: UploadPointsSharded cuts it once, EvalResidentPointsSharded evaluates
+// key after key on the members' slices.
 #pragma once
 #ifndef FSS_AMD_HPP_INCLUDED_
 #error "include fss_amd.hpp (it includes this header)"
@@ -129,6 +131,29 @@ class DeviceSet {
   Result EvalPointsSharded(const HalfTreeDpf<in_bits, Group, Prg, In, pd>&, bool b, int4 s0,
                            const typename HalfTreeDpf<in_bits, Group, Prg, In, pd>::Cw* cws, int4 ocw, const In* xs, int64_t n) {
     return Points(FSS_AMD_HT, in_bits, Group::kId, in_bits, b, s0, cws, &ocw, xs, sizeof(In), n);
+  }
+
+  // ---- the same with the points resident: UploadPointsSharded cuts a batch by BatchSlice and leaves member r's slice on
+  // its device (until the next upload); EvalResidentPointsSharded then evaluates a key on it -- only the key (about a
+  // KiB) crosses PCIe per call: many keys over one set of points.
+  template <typename In>
+  void UploadPointsSharded(const In* xs, int64_t n) {
+    UploadPoints(xs, sizeof(In), n);
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  Result EvalResidentPointsSharded(const Dpf<in_bits, Group, Prg, In, pd>&, bool b, int4 s0,
+                                   const typename Dpf<in_bits, Group, Prg, In, pd>::Cw* cws) {
+    return Points(FSS_AMD_DPF, in_bits, Group::kId, in_bits + 1, b, s0, cws, nullptr, nullptr, sizeof(In), 0);
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int pd>
+  Result EvalResidentPointsSharded(const Dcf<in_bits, Group, Prg, In, pred, pd>&, bool b, int4 s0,
+                                   const typename Dcf<in_bits, Group, Prg, In, pred, pd>::Cw* cws) {
+    return Points(FSS_AMD_DCF, in_bits, Group::kId, in_bits + 1, b, s0, cws, nullptr, nullptr, sizeof(In), 0);
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  Result EvalResidentPointsSharded(const HalfTreeDpf<in_bits, Group, Prg, In, pd>&, bool b, int4 s0,
+                                   const typename HalfTreeDpf<in_bits, Group, Prg, In, pd>::Cw* cws, int4 ocw) {
+    return Points(FSS_AMD_HT, in_bits, Group::kId, in_bits, b, s0, cws, &ocw, nullptr, sizeof(In), 0);
   }
 
   // ---- independent keys cut by BatchSlice: ys[k] = Eval(b, seeds[k], key k, xs[k]) ---------------------------------
@@ -246,6 +271,10 @@ class DeviceSet {
     int k_scheme = -1, k_in_bits = 0, k_group = 0;
     int64_t k_lo = 0, k_n = 0;
     size_t k_s = 0, k_v = 0, k_t = 0, k_o = 0;  // offsets of the arrays in `keys` (seeds at 0)
+    // resident points of UploadPointsSharded
+    Buf pts;
+    int64_t p_lo = 0, p_n = -1;
+    size_t p_xb = 0;
   };
   std::vector<std::unique_ptr<Member>> members_;
 
@@ -264,7 +293,7 @@ class DeviceSet {
       if (!m) continue;
       (void)hipSetDevice(m->device);
       if (m->stream) (void)hipStreamSynchronize(m->stream);
-      for (Buf* b : {&m->in, &m->aux, &m->out, &m->keys})
+      for (Buf* b : {&m->in, &m->aux, &m->out, &m->keys, &m->pts})
         if (b->p) (void)hipFree(b->p);
       if (m->ev0) (void)hipEventDestroy(m->ev0);
       if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -311,23 +340,41 @@ class DeviceSet {
     if (bytes) CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync (slice to device)");
   }
 
+  void UploadPoints(const void* xs, size_t xb, int64_t n) {
+    if (n < 0 || (n > 0 && !xs)) throw Error("DeviceSet::UploadPointsSharded: bad arguments", FSS_AMD_EINVAL);
+    const int world = size();
+    (void)Run([=](Member& m, int r) {
+      const Slice sl = BatchSlice(n, r, world);
+      const int64_t cnt = sl.hi - sl.lo;
+      void* d = m.pts.Need(static_cast<size_t>(cnt) * xb);
+      CheckHip(hipEventRecord(m.ev0, m.stream), "hipEventRecord");
+      H2D(d, static_cast<const char*>(xs) + static_cast<size_t>(sl.lo) * xb, static_cast<size_t>(cnt) * xb, m.stream);
+      CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
+      m.p_lo = sl.lo; m.p_n = cnt; m.p_xb = xb;
+      return Shard{m.device, sl.lo, cnt, nullptr, 0.f};
+    });
+  }
+
+  // xs == nullptr: the members' resident points (UploadPointsSharded; `n` is then theirs)
   Result Points(int scheme, int in_bits, int group, int slots, bool b, int4 s0, const void* cws, const int4* ocw,
                 const void* xs, size_t xb, int64_t n) {
     const int world = size();
     return Run([=](Member& m, int r) {
-      const Slice sl = BatchSlice(n, r, world);
+      if (!xs && (m.p_n < 0 || m.p_xb != xb))
+        throw Error("DeviceSet::EvalResidentPointsSharded before UploadPointsSharded (or with another point type)", FSS_AMD_EINVAL);
+      const Slice sl = xs ? BatchSlice(n, r, world) : Slice{m.p_lo, m.p_lo + m.p_n};
       const int64_t cnt = sl.hi - sl.lo;
       const size_t key_bytes = 32 + size_t(32) * slots + 32;
-      char* in = static_cast<char*>(m.in.Need(Up(key_bytes) + static_cast<size_t>(cnt) * xb));
+      char* in = static_cast<char*>(m.in.Need(Up(key_bytes) + (xs ? static_cast<size_t>(cnt) * xb : 0)));
       int4* d_s0 = reinterpret_cast<int4*>(in);
       void* d_cws = in + 32;
       int4* d_ocw = reinterpret_cast<int4*>(in + 32 + 32 * slots);
-      void* d_xs = in + Up(key_bytes);
+      void* d_xs = xs ? static_cast<void*>(in + Up(key_bytes)) : m.pts.p;
       void* d_ys = m.out.Need(static_cast<size_t>(cnt) * 16);
       H2D(d_s0, &s0, 16, m.stream);
       H2D(d_cws, cws, size_t(32) * slots, m.stream);
       if (ocw) H2D(d_ocw, ocw, 16, m.stream);
-      H2D(d_xs, static_cast<const char*>(xs) + static_cast<size_t>(sl.lo) * xb, static_cast<size_t>(cnt) * xb, m.stream);
+      if (xs) H2D(d_xs, static_cast<const char*>(xs) + static_cast<size_t>(sl.lo) * xb, static_cast<size_t>(cnt) * xb, m.stream);
       CheckHip(hipStreamSynchronize(m.stream), "hipStreamSynchronize");  // s0 / ocw are stack values of this call
       CheckHip(hipEventRecord(m.ev0, m.stream), "hipEventRecord");
       int rc;

@@ -109,6 +109,33 @@ static void Headline(const std::vector<int>& devs, int64_t n) {
     std::printf("  DPF n=32, 2^%d points over %zu members (%s): %.3f ms max over members (a first call; members that share a GPU overlap)\n",
                 (int)std::log2((double)n), devs.size(), plan == FSS_AMD_POINTS_PLAIN ? "plain" : "auto", res.max_ms);
   }
+  {  // the points resident on the members: two keys over one upload, and the refusals
+    set.SetPointsPlan(FSS_AMD_POINTS_AUTO);
+    bool refused = false;
+    try { (void)set.EvalResidentPointsSharded(dpf, false, seeds[0], cws.data()); } catch (const fss::Error&) { refused = true; }
+    EXPECT(refused);  // nothing uploaded yet
+    set.UploadPointsSharded(xs.data(), n);
+    const DeviceSet::Result r0 = set.EvalResidentPointsSharded(dpf, false, seeds[0], cws.data());
+    EXPECT(SameBytes(Gather<int4>(set, r0, xs.size()), one));
+    std::vector<DpfT::Cw> cws2(33);
+    int4 seeds2[2] = {kSeeds[1], kSeeds[0]};
+    dpf.Gen(cws2.data(), seeds2, 0x0badcafeu, int4{9, 0, 0, 0});
+    const DeviceSet::Result want2 = set.EvalPointsSharded(dpf, true, seeds2[1], cws2.data(), xs.data(), n);
+    const std::vector<int4> w2 = Gather<int4>(set, want2, xs.size());
+    const DeviceSet::Result r2 = set.EvalResidentPointsSharded(dpf, true, seeds2[1], cws2.data());
+    EXPECT(SameBytes(Gather<int4>(set, r2, xs.size()), w2));
+    EXPECT(!SameBytes(w2, one));
+    refused = false;
+    try {  // a resident batch of 4-byte points under a scheme that takes 8-byte ones
+      using Dpf64 = fss::Dpf<64, U64, Prg, uint64_t>;
+      Dpf64 d64{Prg(keys)};
+      std::vector<Dpf64::Cw> c64(65);
+      (void)set.EvalResidentPointsSharded(d64, false, seeds[0], c64.data());
+    } catch (const fss::Error&) { refused = true; }
+    EXPECT(refused);
+    std::printf("  DPF n=32, 2^%d resident points over %zu members: %.3f ms max over members; a second key on the same upload: %.3f\n",
+                (int)std::log2((double)n), devs.size(), r0.max_ms, r2.max_ms);
+  }
   {  // DCF on the same points, uneven slices: seven members
     using Prg4 = fss::prg::Aes128Mmo<4>;
     using DcfT = fss::Dcf<32, U64, Prg4, uint32_t>;
