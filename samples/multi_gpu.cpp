@@ -4,6 +4,7 @@
 //   ./multi_gpu [log2_points=24] [eval_all_in_bits=28]
 // Prints per-device kernel times and the job's rate (total units / slowest device); checks the FSS property on a sample.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 #include <vector>
@@ -45,6 +46,15 @@ int main(int argc, char** argv) {
       }
     }
     std::printf("DPF kInBits=32, 1 key, 2^%d points: %.3f ms (slowest device) = %.2f G evals/s\n", lg, y[0].max_ms, n / y[0].max_ms / 1e6);
+    {  // the same points left on the devices: only the key crosses PCIe per call
+      set.UploadPointsSharded(xs.data(), n);
+      const fss::gpu::DeviceSet::Result r = set.EvalResidentPointsSharded(dpf, false, seeds[0], cws.data());
+      std::vector<int4> again(xs.size());
+      for (const auto& s : r.shards) set.ToHost(s, again.data() + s.first);
+      const bool same = std::memcmp(again.data(), host[0].data(), again.size() * sizeof(int4)) == 0;
+      std::printf("  ... on resident points: %.3f ms (slowest device), %s\n", r.max_ms, same ? "same shares" : "DIFFERENT SHARES");
+      if (!same) return 1;
+    }
     int64_t bad = 0;
     for (int64_t i = 0; i < n; i += (i == n / 2 - 1 ? 1 : 97)) {
       const uint64_t a = (uint32_t)host[0][i].x | (uint64_t)(uint32_t)host[0][i].y << 32, c = (uint32_t)host[1][i].x | (uint64_t)(uint32_t)host[1][i].y << 32;
