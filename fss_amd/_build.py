@@ -164,6 +164,11 @@ def build_dropin_test(force=False):
     return _build_cxx_test("dropin_test", force)
 
 
+def build_host_kat_test(force=False):
+    """Compile tests/cxx/host_kat_test.cpp: the software AES of include/fss_amd.hpp called on the host (runs without a GPU)."""
+    return _build_cxx_test("host_kat_test", force)
+
+
 def build_dropin_device_test(force=False):
     """Compile tests/cxx/dropin_device_test.cpp: Gen / Eval called per thread inside the caller's own kernels."""
     return _build_cxx_test("dropin_device_test", force)

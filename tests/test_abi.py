@@ -89,6 +89,17 @@ def test_cxx_dropin_device_test_compiles():
     assert os.path.exists(_build.build_dropin_device_test())
 
 
+def test_cxx_host_side_aes_known_answers():
+    """The software AES of include/fss_amd.hpp on the HOST (tests/cxx/host_kat_test.cpp: aes_detail helpers, FIPS-197 C.1,
+    the reference's PRG known answers through Aes128Soft / Aes128SoftBanked Gen and GenSide) -- the cipher code the per-thread
+    device path instantiates with its LDS tables, run here without a GPU."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_host_kat_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_cxx_multi_gpu_test_and_sample_compile():
     """fss::gpu::DeviceSet (include/fss_amd_multi.hpp): tests/cxx/multi_gpu_test.cpp and samples/multi_gpu.cpp compile; they
     run under -m gpu (tests/test_gpu_parity.py::test_cxx_multi_gpu_device_set)."""
