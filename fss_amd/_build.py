@@ -94,9 +94,28 @@ def build_diag(force=False, verbose=False):
     return DIAG_SO
 
 
+def remove_stale_variants():
+    """Delete tuning builds (fss_amd/libfss_amd_<tag>.so, tag != diag) left by an earlier session: nothing loads them,
+    and every .so in the tree is pushed to the GPU box with each gpurun call."""
+    import glob
+    gone = []
+    if os.environ.get("FSS_AMD_KEEP_VARIANTS"):  # an A/B session that builds variants and the library in turn
+        return gone
+    for f in glob.glob(os.path.join(_HERE, "libfss_amd_*.so")) + glob.glob(os.path.join(_HERE, "libfss_amd_*.so.sources.sha256")):
+        if os.path.basename(f).startswith("libfss_amd_diag.so"):
+            continue
+        os.remove(f)
+        gone.append(f)
+    return gone
+
+
 def build(force=False, verbose=False, so=None, defines=(), tag=""):
     """Compile fss_amd/csrc/*.hip for gfx950 (one hipcc per unit, in parallel) and link fss_amd/libfss_amd.so."""
     so = so or SO
+    if so == SO:
+        for f in remove_stale_variants():
+            if verbose:
+                print("removed stale variant", f)
     if so == SO and not force and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
