@@ -4,10 +4,12 @@
 Metric (BASELINE.json): DPF/DCF evals/sec at kInBits=32, batch=2^24.
 A "step" is one pass of the hot path over one batch: ONE launch of the shared-key DPF point-evaluation kernel over
 2^24 uniformly random points (configs[1]'s shape at the batch the metric is quoted on), party 0, Uint<uint64_t>
-outputs, inputs already resident in HBM.  With --gpus N every rank evaluates its own 2^24-point batch of the same key
-(`value`, weak scaling, no collective on the data path) and, beside it, the ONE 2^24-point batch cut into N slices
-(`headline_strong`: SURVEY 8(e), "batch=2^24 on 1/2/4/8"); timed regions are bracketed by barrier + synchronize and the slowest
-rank's time is used.
+outputs, inputs already resident in HBM.  With --gpus N the metric's ONE 2^24-point batch is cut into N slices, one per
+rank, no collective on the data path (`value`, "scaling": "strong": SURVEY 8(e), "batch=2^24 on 1/2/4/8"; the same record is
+printed as `headline_strong`); what every rank does with a 2^24-point batch of its own is the side record `weak`.  With
+one GPU the two are the same launch.  Timed regions are bracketed by barrier + synchronize and the slowest rank's time is
+used; `config.ranks` lists what every rank ran on (device UUID / PCI address, process-group backend and size as that rank
+sees them) and `config.distinct_devices` how many different GPUs that is.
 
 `python bench.py --gpus N` with no launcher around it starts its own N ranks (one process per GPU, spawned before
 anything touches the GPU; a failed or hung rank ends the run non-zero); under `python -m torch.distributed.run` (RANK /
@@ -47,32 +49,50 @@ from bench_launch import launch_ranks, run_dry, visible_gpus_without_hip  # noqa
 
 
 # ---------------------------------------------------------------------------------------------------------- timing
-def time_steps(fn, steps, warmup, dist):
+class Timing(tuple):
+    """(wall seconds, mean kernel ms) of a timed region, with `.median`: the median of the K per-launch kernel times (ms)
+    when the region recorded an event between its steps, else None."""
+    median = None
+
+
+PER_STEP_EVENTS_MAX = 256  # regions of at most this many steps record one event per step (the median); longer ones two
+
+
+def time_steps(fn, steps, warmup, dist, per_step=False):
     """W warm-up steps, then exactly K timed steps between barrier+synchronize pairs.
-    Returns (wall seconds max over ranks, mean kernel ms from HIP events on the launch stream)."""
+    Returns Timing(wall seconds max over ranks, mean kernel ms from HIP events on the launch stream); with per_step the K
+    launches are separated by events on the same stream and `.median` is the median launch ("median of >= 10
+    launches", as src/bench_gpu.cu:48-68 times; the mean stays what ms_per_step and every rate are computed from)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per_step = per_step and 0 < steps <= PER_STEP_EVENTS_MAX
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1 if per_step else 2)]
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         fn()
-    ev1.record()
+        if per_step:
+            evs[i + 1].record()
+    if not per_step:
+        evs[1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / steps
+    kernel_ms = evs[0].elapsed_time(evs[-1]) / max(steps, 1)
     if dist is not None:
         t = torch.tensor([wall], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    return wall, kernel_ms
+    out = Timing((wall, kernel_ms))
+    if per_step:
+        out.median = float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]))
+    return out
 
 
 def time_steady(fn, steps=10, min_ms=150.0, warm_ms=60.0):
@@ -101,12 +121,18 @@ def pre_warm(fn, ms=100.0):
     torch.cuda.synchronize()
 
 
+_BENCH_ENGINE = {}
+
+
 def bench_engine():
-    """The process-wide engine with FSS_AMD_POINTS_PLAIN: every cell of the metric measures the per-point tree walk
-    (in_bits PRG levels per point, north_star); the shared-prefix plan the library would pick by itself for batches this
-    size is reported in its own records (`shared_*`), through its explicit entry point."""
+    """bench.py's own engine (not the process-wide default one) with FSS_AMD_POINTS_PLAIN: every cell of the metric
+    measures the per-point tree walk (in_bits PRG levels per point, north_star); the shared-prefix plan is reported in
+    its own records (`shared_*`), through its explicit entry point."""
     import fss_amd
-    return fss_amd.default_engine(torch.cuda.current_device()).set_points_plan("plain")
+    dev = torch.cuda.current_device()
+    if dev not in _BENCH_ENGINE:
+        _BENCH_ENGINE[dev] = fss_amd.Engine(dev).set_points_plan("plain")
+    return _BENCH_ENGINE[dev]
 
 
 _DIAG = {}
@@ -158,6 +184,35 @@ def _attach_clock(rec, mk_step):
         rec["clk"] = clk
         rec["frac_at_clock"] = rec.get("frac_executed", rec["frac"]) * CLK_HZ / (clk * 1e9)
     return rec
+
+
+def rank_identities(rank, world, dist):
+    """`config.ranks`: what every rank ran on, all-gathered -- (rank, local device index, the device's UUID / PCI address as
+    the runtime reports them, the process group's backend and size as THIS rank sees them) -- so that a reader of the one
+    line can see N distinct GPUs and a process group of N ranks behind an `n_gpus: N` line.  Not timed."""
+    i = torch.cuda.current_device()
+    pr = torch.cuda.get_device_properties(i)
+    ident = {"rank": rank, "pid": os.getpid(), "dev": i, "name": pr.name}
+    if getattr(pr, "uuid", None) is not None:
+        ident["uuid"] = str(pr.uuid)
+    pci = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(v is not None for v in pci):
+        ident["pci"] = "%04x:%02x:%02x" % tuple(int(v) for v in pci)
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    if vis:
+        ident["visible"] = vis
+    ident["pg"] = None if dist is None else [dist.get_backend(), dist.get_world_size()]
+    if dist is None:
+        return [ident]
+    out = [None] * world
+    dist.all_gather_object(out, ident)
+    return out
+
+
+def distinct_devices(ranks):
+    """How many different physical devices `config.ranks` names (by UUID when the runtime gives one, else by PCI address)."""
+    key = lambda r: r.get("uuid") or (r.get("pci"), r.get("visible"), r["dev"])
+    return len({key(r) for r in ranks})
 
 
 def _walk_record(scheme, n, shared, units, wall, kernel_ms, world, steps, kname):
@@ -393,12 +448,14 @@ def run_headline(args, rank, world, dist):
     seed_d, cws_d = s0s[0].cuda(), cws.cuda()
     ys = torch.empty((batch, 4), dtype=torch.int32, device="cuda")
 
+    ranks = rank_identities(rank, world, dist)
     mk = lambda e: (lambda: e.eval_points(sid, n, G, 0, seed_d, cws_d, xs, out=ys))
     step = mk(eng)
-    wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
+    tm = time_steps(step, args.steps, args.warmup, dist, per_step=True)
+    wall, kernel_ms = tm
     kname, grid, block = eng.last_kernel()
     head = _walk_record(scheme, n, True, batch, wall, kernel_ms, world, args.steps, kname)
-    head.update({"grid": grid, "block": block})
+    head.update({"grid": grid, "block": block, "ms_median": tm.median})
     _attach_clock(head, mk)
 
     # `headline_strong`: the ONE 2^B-point batch cut into `world` slices.  With one rank that is the launch above.
@@ -449,36 +506,54 @@ def run_headline(args, rank, world, dist):
         cpu = cpu_baseline(scheme, n, s0s, cws, ocw, head_xs, head_ys, usable_cores())
         for key, ok in cpu_check_subrecords(checks).items():  # part of the cpu_baseline leg: the oracle as checker
             subs[key]["ok"] = ok
-    line, detail = compose_line(args, world, head, strong, subs, cpu, dist.get_backend() if dist is not None else None)
+    line, detail = compose_line(args, world, head, strong, subs, cpu, dist.get_backend() if dist is not None else None, ranks)
     print(json.dumps(line, separators=(",", ":")), flush=True)
     _write_detail(detail)
 
 
-def compose_line(args, world, head, strong, subs, cpu, process_group):
-    """The one JSON line (short; KEYS / RECORDS / TOP describe it) and the unabridged detail record."""
+def compose_line(args, world, head, strong, subs, cpu, process_group, ranks=None):
+    """The one JSON line (short; KEYS / RECORDS / TOP describe it) and the unabridged detail record.
+    The metric is "batch=2^24 on 1/2/4/8": with more than one rank `value` is the ONE 2^B-point batch cut into `world`
+    slices (`strong`, the record also printed as headline_strong) and the line says "scaling": "strong"; what every rank
+    does with a 2^B batch of its own is the side record `weak`.  With one rank the two are the same launch."""
     from fss_amd import _build
     B = args.log2_batch
     batch = 1 << B
-    kernel_ms = head["kernel_ms"]
-    pipes = measured_pipe_busy(B)
-    replay_v, replay_src = _headline_pmc(B)
+    prim = strong if world > 1 else head   # the record `value`, `ms_per_step` and the roofs describe
+    kernel_ms = prim["kernel_ms"]
+    at_profiled_size = prim["units_per_launch"] == (1 << 24)
+    pipes = measured_pipe_busy(B) if at_profiled_size else None
+    replay_v, replay_src = _headline_pmc(B) if at_profiled_size else (None, None)
     # True only when the profile was captured for exactly the sources this library's point walk is compiled from
     replay_ok = bool(replay_v) and replay_v.get("_captured_for") == _build.headline_digest()
-    traffic = measured_hbm_traffic(B)
+    traffic = measured_hbm_traffic(B) if at_profiled_size else None
+    per_rank = f"2^{B} / {world} points of ONE 2^{B}-point batch per GPU per step (shard.batch_slice)" if world > 1 else f"2^{B} random points per step"
     line = {
-        "metric": METRIC, "value": head["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "metric": METRIC, "value": prim["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": prim["ms_per_step"], "ms_median": prim.get("ms_median"), "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": f"DPF kInBits=32, 1 key, 2^{B} random points per GPU per step (configs[1] shape at the metric's batch), "
+        "config": {"workload": f"DPF kInBits=32, 1 key, {per_rank} (configs[1] shape at the metric's batch), "
                                "party 0, Uint<uint64_t>",
-                   "kernel": head["kernel"], "grid": head.get("grid"), "block": head.get("block"),
+                   "kernel": prim["kernel"], "grid": prim.get("grid"), "block": prim.get("block"),
                    "parallelism": f"batch-sharded x{world}, no collective", "process_group": process_group, "legend": "bench_legend.json"},
-        "roofline": {"bound": "lds", "achieved": head["lds_gbs"], "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-                     "traffic": traffic, "kernel_ms": kernel_ms, "clk": head.get("clk"), "frac_at_clock": head.get("frac_at_clock"),
+        "roofline": {"bound": "lds", "achieved": prim["lds_gbs"], "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": prim["frac"],
+                     "traffic": traffic, "kernel_ms": kernel_ms, "clk": prim.get("clk"), "frac_at_clock": prim.get("frac_at_clock"),
                      "replay": replay_src, "replay_ok": replay_ok},
-        "roofline_hbm": {"bound": "hbm", "achieved": head["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["hbm_frac"],
-                         "traffic": traffic, "algorithmic_bytes": batch * 20},
+        "roofline_hbm": {"bound": "hbm", "achieved": prim["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": prim["hbm_frac"],
+                         "traffic": traffic, "algorithmic_bytes": prim["units_per_launch"] * 20},
     }
+    if line["ms_median"] is None:
+        del line["ms_median"]
+    if ranks is not None:
+        names = {r.get("name") for r in ranks}
+        if len(names) == 1:  # the usual case: say it once
+            line["config"]["device_name"] = names.pop()
+            ranks = [{k: v for k, v in r.items() if k != "name"} for r in ranks]
+        line["config"]["ranks"] = ranks
+        line["config"]["distinct_devices"] = distinct_devices(ranks)
+    if world > 1:
+        line["weak"] = dict(compact(head), scaling="weak")
     if pipes:
         line["roofline"].update({"lds_busy": pipes["lds_busy"], "valu_busy": pipes["valu_busy"]})
         # third roof SURVEY 8(d) asks for: VALU issue.  Peak = 256 CU x 4 SIMD x one wave64 instruction per 2 clk x
@@ -594,7 +669,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
         aes_per_unit = 64.0 if scheme == "ht" else 96.0
         hbm_unit = 1084 if scheme == "ht" else 1057   # 16 seed + 8 x + 64 x 16 cw_s + (4 extra + 16 ocw + 16 y | 8 tr bits + 1 y)
     pre_warm(warm_step if name == "grotto_evalall" else step)
-    wall, kernel_ms = time_steps(step, args.steps, args.warmup, dist)
+    tm = time_steps(step, args.steps, args.warmup, dist, per_step=True)
+    wall, kernel_ms = tm
     kname, grid, block = eng.last_kernel()
     if with_cpu and rank == 0 and world == 1:
         threads = usable_cores()
@@ -616,7 +692,8 @@ def sharded_record(args, name, rank, world, dist, eng, with_cpu):
     rec = {"value": units_total * args.steps / wall, "unit": unit, "ms_per_step": wall / args.steps * 1e3, "kernel_ms": kernel_ms,
            "units_per_launch": units_rank, "scaling": "strong", "kernel": kname, "grid": grid, "block": block,
            "aes_per_unit": aes_per_unit, "frac": lds_gbs / LDS_PEAK_GBS, "lds_gbs": lds_gbs, "hbm_gbs": rate * hbm_unit / 1e9,
-           "hbm_frac": rate * hbm_unit / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": units_rank * hbm_unit}
+           "hbm_frac": rate * hbm_unit / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": units_rank * hbm_unit,
+           "ms_median": tm.median}
     if name == "grotto_c5":
         # the 32 sibling blocks of a walk are control-bit-only (aes_mmo<.., LSB3>: 133 of 160 lookups); `frac` charges
         # SURVEY 8(d)'s algorithmic 96 whole blocks, `frac_executed` the lookups the kernel issues
@@ -651,8 +728,8 @@ def run_sharded(args, rank, world, dist):
 def _workload_line(args, name, rec, world, scaling, dist):
     """The line of a `--workload` run (what tools/profile_workloads.sh profiles): one workload, the contract keys."""
     line = {"metric": f"{name}: {rec['unit'][:-2]} per second", "value": rec["value"], "unit": rec["unit"], "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "ms_median": rec.get("ms_median"),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": RECORDS.get(name, name), "kernel": rec["kernel"], "grid": rec.get("grid"), "block": rec.get("block"),
                        "units_per_launch": rec["units_per_launch"], "parallelism": f"sharded x{world}, no collective",
                        "process_group": dist.get_backend() if dist is not None else None},
@@ -708,7 +785,9 @@ def main():
 
     # Not under a launcher but asked for several GPUs: become the launcher.  This must stay ahead of anything that
     # initialises the GPU (torch.cuda.is_available() does): the ranks are fresh child processes.
-    if args.gpus > 1 and "RANK" not in os.environ:
+    # FSS_AMD_BENCH_SELF_LAUNCH=1: the launcher also for --gpus 1, so that its RCCL branch (rank spawned by launch_ranks,
+    # process group "nccl") can run on a one-GPU box (tests/test_bench_launch.py).
+    if "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("FSS_AMD_BENCH_SELF_LAUNCH") == "1"):
         sys.exit(launch_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -141,9 +141,17 @@ def run_dry(args, rank, world, dist):
         t = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    # config.ranks as the real run gathers it (bench.rank_identities), minus the device: one entry per rank, each with the
+    # process group as THAT rank sees it
+    ident = {"rank": rank, "dev": None, "pid": os.getpid(), "pg": None if dist is None else [dist.get_backend(), dist.get_world_size()]}
+    ranks = [ident]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, ident)
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "evals/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / max(args.steps, 1) * 1e3,
-                          "dry_run": True, "config": {"workload": "none (control-flow test hook, no GPU work)"}}), flush=True)
+                          "scaling": "strong" if world > 1 else "weak", "dry_run": True,
+                          "config": {"workload": "none (control-flow test hook, no GPU work)", "ranks": ranks}}), flush=True)
 
 

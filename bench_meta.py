@@ -27,6 +27,7 @@ KEYS = {
     "u": "unit of `v` when it is not evals/s",
     "ms": "wall milliseconds per step (barrier + synchronize either side, max over ranks)",
     "kms": "rank 0's kernel milliseconds per launch, HIP events on the launch stream around the timed steps",
+    "med": "rank 0's MEDIAN launch of the K timed steps, ms (an event between the steps; SURVEY 8(d) asks for the median, `kms` is the mean)",
     "n": "units (evaluations, keys or leaves) one launch of rank 0 processes",
     "a": "algorithmic AES blocks per unit (taken child only; SURVEY 8d)",
     "f": "LDS roofline fraction: n x a x 160 lookups x 4 B / kms / 78 643.2 GB/s (128 B/clk/CU x 256 CU x 2.4 GHz)",
@@ -59,7 +60,10 @@ KEYS = {
 }
 PTS = "party 0, Uint<uint64_t>, 2^B uniformly random points per GPU per step (B = --log2-batch, 24)"
 RECORDS = {
-    "value": f"DPF (Boyle'16) kInBits=32, 1 key, {PTS}; configs[1]'s shape at the metric's batch. ok: the first --cpu-sample outputs",
+    "value": f"DPF (Boyle'16) kInBits=32, 1 key, {PTS}; configs[1]'s shape at the metric's batch. ok: the first --cpu-sample outputs. "
+             "With N > 1 ranks `value` is headline_strong (the metric's ONE batch cut N ways, \"scaling\": \"strong\") and the per-rank-batch "
+             "number is the side record `weak`",
+    "weak": "N > 1 only: every rank its own 2^B-point batch of the headline key (weak scaling), whole-job rate",
     "headline_strong": "the headline's ONE 2^B-point batch cut by shard.batch_slice: 2^B / N points per rank, same key, max-over-ranks time "
               "(SURVEY 8e); with one GPU it is the headline itself",
     "shared_prefix": "the headline batch through the shared-prefix plan (fss_amd_dpf_eval_points_shared with the library's own prefix_bits k = "
@@ -105,6 +109,11 @@ TOP = {
     "cpu_baseline": "the oracle with the OpenSSL EVP PRG on the first --cpu-sample points of the timed batch: value = all usable cores, "
                     "t1 = one thread, aesni = the AES-NI variant (the reference's Aes128MmoRaw), ok = GPU outputs equal",
     "gates": "every `ok` / `same` / `kat` of the line and'ed, and how many there were",
+    "ms_median": "median of the K timed launches of `value`'s kernel on rank 0, ms, from an event between the steps (SURVEY 8(d); "
+                 "src/bench_gpu.cu:48-68); ms_per_step stays the wall mean the rate is computed from",
+    "config.ranks": "one entry per rank, all-gathered: rank, local device index, device name, UUID and PCI address as the runtime reports "
+                    "them, visible-devices variable if set, pg = [process-group backend, its size as that rank sees it]; "
+                    "config.distinct_devices = how many different GPUs the entries name",
 }
 
 
@@ -128,7 +137,7 @@ def r5(x):
     return x
 
 
-SHORT = (("value", "v"), ("ms_per_step", "ms"), ("kernel_ms", "kms"), ("units_per_launch", "n"), ("aes_per_unit", "a"), ("k", "k"),
+SHORT = (("value", "v"), ("ms_per_step", "ms"), ("kernel_ms", "kms"), ("ms_median", "med"), ("units_per_launch", "n"), ("aes_per_unit", "a"), ("k", "k"),
          ("frac", "f"), ("frac_executed", "fx"), ("clk", "clk"), ("frac_at_clock", "fc"), ("speedup", "x"), ("hbm_frac", "h"), ("traffic_ratio", "tr"), ("lds_busy_pmc", "lb"), ("replay_ok", "rp"), ("ok", "ok"),
          ("cpu", "cpu"), ("cpu1", "cpu1"), ("serial", "serial"), ("pipe", "pipe"), ("gbs", "gbs"), ("same", "same"), ("us", "us"),
          ("cpu_us", "cpu_us"), ("cpu1_us", "cpu1_us"), ("kat", "kat"))

@@ -183,6 +183,66 @@ class DeviceSet {
     return Keys(FSS_AMD_GROTTO, in_bits, group::Bytes::kId, in_bits + 1, b, seeds, cws, nullptr, xs, sizeof(In), nkeys);
   }
 
+  // ---- inputs that already live on the members' devices -------------------------------------------------------------
+  // The reference's launchers take device pointers (include/fss/point_eval_gpu.cuh:448-460: seeds, cw_s, extra, out_cw,
+  // xs, ys all in device memory): a caller whose own kernels produced the points -- or the level-major keys -- ON the
+  // GPUs hands every member its part in place.  Entry r of `per_member` belongs to member r and must point into memory
+  // of THAT member's device (checked: FSS_AMD_EINVAL otherwise); nothing is uploaded but the kilobyte of a shared key.
+  // `ys` null: the member's own output buffer (valid until the set's next call), else the caller's, written in place.
+  // Shard.first is the running sum of the members' counts.
+  template <typename In>
+  struct PointsOn {
+    const In* xs = nullptr;  // device: n points
+    int64_t n = 0;
+    int4* ys = nullptr;      // device: n outputs, or null
+  };
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  Result EvalPointsShardedOn(const Dpf<in_bits, Group, Prg, In, pd>&, bool b, int4 s0,
+                             const typename Dpf<in_bits, Group, Prg, In, pd>::Cw* cws, std::span<const PointsOn<In>> per_member) {
+    return PointsOnMembers(FSS_AMD_DPF, in_bits, Group::kId, in_bits + 1, b, s0, cws, nullptr, Erase(per_member), sizeof(In));
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int pd>
+  Result EvalPointsShardedOn(const Dcf<in_bits, Group, Prg, In, pred, pd>&, bool b, int4 s0,
+                             const typename Dcf<in_bits, Group, Prg, In, pred, pd>::Cw* cws, std::span<const PointsOn<In>> per_member) {
+    return PointsOnMembers(FSS_AMD_DCF, in_bits, Group::kId, in_bits + 1, b, s0, cws, nullptr, Erase(per_member), sizeof(In));
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  Result EvalPointsShardedOn(const HalfTreeDpf<in_bits, Group, Prg, In, pd>&, bool b, int4 s0,
+                             const typename HalfTreeDpf<in_bits, Group, Prg, In, pd>::Cw* cws, int4 ocw,
+                             std::span<const PointsOn<In>> per_member) {
+    return PointsOnMembers(FSS_AMD_HT, in_bits, Group::kId, in_bits, b, s0, cws, &ocw, Erase(per_member), sizeof(In));
+  }
+  // Independent keys, level-major as *RelayoutGpu / fss_amd_*_gen_level_major leave them (the arrays the reference's
+  // {Dpf,Dcf,HalfTreeDpf}EvalPointGpu take, point_eval_gpu.cuh:416-491), one point per key.
+  template <typename In>
+  struct KeysOn {
+    const int4* seeds = nullptr;  // the evaluating party's seed of every key
+    const int4* cw_s = nullptr;   // [in_bits][nkeys]
+    const int4* cw_v = nullptr;   // DCF: [in_bits][nkeys]; otherwise unused
+    const void* tr_bits = nullptr;  // DPF / Grotto: uint64_t tr bits per key (two planes when in_bits > 64); Half-Tree: uint32_t extra
+    const int4* out_cw = nullptr;   // DPF / DCF: cws[in_bits].s (.v); Half-Tree: ocws; Grotto: unused
+    const In* xs = nullptr;
+    int64_t nkeys = 0;
+    void* ys = nullptr;  // int4[nkeys] (Grotto: uint8_t[nkeys]), or null
+  };
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  Result EvalKeysShardedOn(const Dpf<in_bits, Group, Prg, In, pd>&, bool b, std::span<const KeysOn<In>> per_member) {
+    return KeysOnMembers(FSS_AMD_DPF, in_bits, Group::kId, b, EraseKeys(per_member), sizeof(In));
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, DcfPred pred, int pd>
+  Result EvalKeysShardedOn(const Dcf<in_bits, Group, Prg, In, pred, pd>&, bool b, std::span<const KeysOn<In>> per_member) {
+    return KeysOnMembers(FSS_AMD_DCF, in_bits, Group::kId, b, EraseKeys(per_member), sizeof(In));
+  }
+  template <int in_bits, typename Group, typename Prg, typename In, int pd>
+  Result EvalKeysShardedOn(const HalfTreeDpf<in_bits, Group, Prg, In, pd>&, bool b, std::span<const KeysOn<In>> per_member) {
+    return KeysOnMembers(FSS_AMD_HT, in_bits, Group::kId, b, EraseKeys(per_member), sizeof(In));
+  }
+  template <int in_bits, typename Prg, typename In, int pd>
+  Result EvalKeysShardedOn(const GrottoDcf<in_bits, Prg, In, pd>&, bool b, std::span<const KeysOn<In>> per_member) {
+    static_assert(in_bits <= 64);
+    return KeysOnMembers(FSS_AMD_GROTTO, in_bits, group::Bytes::kId, b, EraseKeys(per_member), sizeof(In));
+  }
+
   // ---- dealer and evaluator on the members: keys generated where they are evaluated --------------------------------
   // s0s: both parties' seeds, two per key (as Gen takes them); alphas; betas (Grotto: none).  Member r generates keys
   // [lo, hi) = BatchSlice(nkeys, r, size()) level-major on its device and keeps them (until the next GenKeysSharded).
@@ -313,6 +373,7 @@ class DeviceSet {
     Result res;
     res.shards.resize(static_cast<size_t>(world));
     std::vector<std::string> errs(static_cast<size_t>(world));
+    std::vector<int> codes(static_cast<size_t>(world), FSS_AMD_OK);
     std::vector<std::thread> th;
     for (int r = 0; r < world; ++r) {
       th.emplace_back([&, r] {
@@ -325,16 +386,26 @@ class DeviceSet {
           s.ms = 0.f;
           if (s.count > 0) CheckHip(hipEventElapsedTime(&s.ms, m.ev0, m.ev1), "hipEventElapsedTime");
           res.shards[static_cast<size_t>(r)] = s;
+        } catch (const Error& e) {  // the member's own code (an EINVAL refusal stays an EINVAL)
+          errs[static_cast<size_t>(r)] = e.what()[0] ? e.what() : "error";
+          codes[static_cast<size_t>(r)] = e.code;
         } catch (const std::exception& e) {
           errs[static_cast<size_t>(r)] = e.what()[0] ? e.what() : "error";
+          codes[static_cast<size_t>(r)] = FSS_AMD_EHIP;
         }
       });
     }
     for (auto& t : th) t.join();
     for (int r = 0; r < world; ++r)
-      if (!errs[static_cast<size_t>(r)].empty()) throw Error(("DeviceSet member " + std::to_string(r) + ": " + errs[static_cast<size_t>(r)]).c_str(), FSS_AMD_EHIP);
+      if (!errs[static_cast<size_t>(r)].empty()) throw MemberError(r, errs[static_cast<size_t>(r)], codes[static_cast<size_t>(r)]);
     for (const Shard& s : res.shards) res.max_ms = s.ms > res.max_ms ? s.ms : res.max_ms;
     return res;
+  }
+  // the first failing member's message and CODE (Error's constructor would append the code's text a second time)
+  static Error MemberError(int r, const std::string& what, int code) {
+    Error e("", code);
+    static_cast<std::runtime_error&>(e) = std::runtime_error("DeviceSet member " + std::to_string(r) + ": " + what);
+    return e;
   }
   static void H2D(void* dst, const void* src, size_t bytes, hipStream_t st) {
     if (bytes) CheckHip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync (slice to device)");
@@ -422,6 +493,99 @@ class DeviceSet {
       Check(rc, "fss_amd_*_eval_keys");
       CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
       return Shard{m.device, sl.lo, cnt, d_ys, 0.f};
+    });
+  }
+
+  struct RawPoints { const void* xs; int64_t n; void* ys; };
+  struct RawKeys { const void *seeds, *cw_s, *cw_v, *tr_bits, *out_cw, *xs; int64_t nkeys; void* ys; };
+  template <typename In>
+  static std::vector<RawPoints> Erase(std::span<const PointsOn<In>> v) {
+    std::vector<RawPoints> o;
+    for (const auto& p : v) o.push_back(RawPoints{p.xs, p.n, p.ys});
+    return o;
+  }
+  template <typename In>
+  static std::vector<RawKeys> EraseKeys(std::span<const KeysOn<In>> v) {
+    std::vector<RawKeys> o;
+    for (const auto& k : v) o.push_back(RawKeys{k.seeds, k.cw_s, k.cw_v, k.tr_bits, k.out_cw, k.xs, k.nkeys, k.ys});
+    return o;
+  }
+  // `p` (null allowed) is device memory of the member's device -- a pointer into another GPU's memory would be read
+  // across xGMI at a fraction of the rate, or fault: refused instead
+  static void OnDevice(const Member& m, const void* p, const char* what) {
+    if (!p) return;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+      (void)hipGetLastError();
+      throw Error((std::string(what) + ": not a device pointer").c_str(), FSS_AMD_EINVAL);
+    }
+    if (at.type == hipMemoryTypeHost) throw Error((std::string(what) + ": host memory (use the host-input calls)").c_str(), FSS_AMD_EINVAL);
+    if (at.device != m.device) throw Error((std::string(what) + ": memory of device " + std::to_string(at.device) + ", member runs on " + std::to_string(m.device)).c_str(), FSS_AMD_EINVAL);
+  }
+
+  Result PointsOnMembers(int scheme, int in_bits, int group, int slots, bool b, int4 s0, const void* cws, const int4* ocw,
+                         std::vector<RawPoints> pm, size_t xb) {
+    if (static_cast<int>(pm.size()) != size()) throw Error("DeviceSet::EvalPointsShardedOn: one entry per member", FSS_AMD_EINVAL);
+    std::vector<int64_t> first(pm.size() + 1, 0);
+    for (size_t r = 0; r < pm.size(); ++r) {
+      if (pm[r].n < 0 || (pm[r].n > 0 && !pm[r].xs)) throw Error("DeviceSet::EvalPointsShardedOn: bad entry", FSS_AMD_EINVAL);
+      first[r + 1] = first[r] + pm[r].n;
+    }
+    const int4 ocw_v = ocw ? *ocw : int4{0, 0, 0, 0};
+    const bool has_ocw = ocw != nullptr;
+    return Run([=, &pm, &first](Member& m, int r) {
+      const RawPoints& p = pm[static_cast<size_t>(r)];
+      OnDevice(m, p.xs, "EvalPointsShardedOn xs");
+      OnDevice(m, p.ys, "EvalPointsShardedOn ys");
+      const size_t key_bytes = 32 + size_t(32) * slots + 32;
+      char* in = static_cast<char*>(m.in.Need(Up(key_bytes)));
+      int4* d_s0 = reinterpret_cast<int4*>(in);
+      void* d_cws = in + 32;
+      int4* d_ocw = reinterpret_cast<int4*>(in + 32 + 32 * slots);
+      void* d_ys = p.ys ? p.ys : m.out.Need(static_cast<size_t>(p.n) * 16);
+      H2D(d_s0, &s0, 16, m.stream);
+      H2D(d_cws, cws, size_t(32) * slots, m.stream);
+      if (has_ocw) H2D(d_ocw, &ocw_v, 16, m.stream);
+      CheckHip(hipStreamSynchronize(m.stream), "hipStreamSynchronize");  // s0 / ocw are values of this call
+      CheckHip(hipEventRecord(m.ev0, m.stream), "hipEventRecord");
+      int rc;
+      const int xbi = static_cast<int>(xb);
+      if (scheme == FSS_AMD_DPF) rc = fss_amd_dpf_eval_points(m.ctx, in_bits, group, b, d_s0, d_cws, p.xs, xbi, p.n, d_ys, m.stream);
+      else if (scheme == FSS_AMD_DCF) rc = fss_amd_dcf_eval_points(m.ctx, in_bits, group, b, d_s0, d_cws, p.xs, xbi, p.n, d_ys, m.stream);
+      else rc = fss_amd_ht_eval_points(m.ctx, in_bits, group, b, d_s0, d_cws, d_ocw, p.xs, xbi, p.n, d_ys, m.stream);
+      Check(rc, "fss_amd_*_eval_points");
+      CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
+      return Shard{m.device, first[static_cast<size_t>(r)], p.n, d_ys, 0.f};
+    });
+  }
+
+  Result KeysOnMembers(int scheme, int in_bits, int group, bool b, std::vector<RawKeys> km, size_t xb) {
+    if (static_cast<int>(km.size()) != size()) throw Error("DeviceSet::EvalKeysShardedOn: one entry per member", FSS_AMD_EINVAL);
+    std::vector<int64_t> first(km.size() + 1, 0);
+    const bool grotto = scheme == FSS_AMD_GROTTO;
+    for (size_t r = 0; r < km.size(); ++r) {
+      const RawKeys& k = km[r];
+      const bool need_v = scheme == FSS_AMD_DCF, need_t = scheme != FSS_AMD_DCF, need_o = !grotto;
+      if (k.nkeys < 0 || (k.nkeys > 0 && (!k.seeds || !k.cw_s || !k.xs || (need_v && !k.cw_v) || (need_t && !k.tr_bits) || (need_o && !k.out_cw))))
+        throw Error("DeviceSet::EvalKeysShardedOn: bad entry", FSS_AMD_EINVAL);
+      first[r + 1] = first[r] + k.nkeys;
+    }
+    return Run([=, &km, &first](Member& m, int r) {
+      const RawKeys& k = km[static_cast<size_t>(r)];
+      for (const void* p : {k.seeds, k.cw_s, k.cw_v, k.tr_bits, k.out_cw, k.xs, static_cast<const void*>(k.ys)}) OnDevice(m, p, "EvalKeysShardedOn");
+      const size_t nk = static_cast<size_t>(k.nkeys);
+      void* d_ys = k.ys ? k.ys : m.out.Need(grotto ? nk : nk * 16);
+      if (k.nkeys == 0) return Shard{m.device, first[static_cast<size_t>(r)], 0, d_ys, 0.f};
+      CheckHip(hipEventRecord(m.ev0, m.stream), "hipEventRecord");
+      const int xbi = static_cast<int>(xb);
+      int rc;
+      if (scheme == FSS_AMD_DPF) rc = fss_amd_dpf_eval_keys(m.ctx, in_bits, group, b, k.seeds, k.cw_s, k.tr_bits, k.out_cw, k.xs, xbi, k.nkeys, d_ys, m.stream);
+      else if (scheme == FSS_AMD_DCF) rc = fss_amd_dcf_eval_keys(m.ctx, in_bits, group, b, k.seeds, k.cw_s, k.cw_v, k.out_cw, k.xs, xbi, k.nkeys, d_ys, m.stream);
+      else if (scheme == FSS_AMD_HT) rc = fss_amd_ht_eval_keys(m.ctx, in_bits, group, b, k.seeds, k.cw_s, k.tr_bits, k.out_cw, k.xs, xbi, k.nkeys, d_ys, m.stream);
+      else rc = fss_amd_grotto_eval_keys(m.ctx, in_bits, b, k.seeds, k.cw_s, k.tr_bits, k.xs, xbi, k.nkeys, d_ys, m.stream);
+      Check(rc, "fss_amd_*_eval_keys");
+      CheckHip(hipEventRecord(m.ev1, m.stream), "hipEventRecord");
+      return Shard{m.device, first[static_cast<size_t>(r)], k.nkeys, d_ys, 0.f};
     });
   }
 

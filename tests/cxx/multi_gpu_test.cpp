@@ -75,6 +75,33 @@ static bool SameBytes(const std::vector<T>& a, const std::vector<T>& b) {
   return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0;
 }
 
+// rows [0, rows) x columns [lo, lo + cnt) of a host [rows][n] array, as a [rows][cnt] array in the memory of device `dev`
+// (what a caller's own kernels on that GPU would have produced there); the current device is restored
+template <typename T>
+static T* SliceOn(int dev, const std::vector<T>& full, size_t rows, size_t n, size_t lo, size_t cnt) {
+  std::vector<T> part(rows * cnt);
+  for (size_t r = 0; r < rows; ++r) std::memcpy(part.data() + r * cnt, full.data() + r * n + lo, cnt * sizeof(T));
+  int prev = 0;
+  HIP_OK(hipGetDevice(&prev));
+  HIP_OK(hipSetDevice(dev));
+  T* d = nullptr;
+  HIP_OK(hipMalloc(&d, (part.size() ? part.size() : 1) * sizeof(T)));
+  if (!part.empty()) HIP_OK(hipMemcpy(d, part.data(), part.size() * sizeof(T), hipMemcpyHostToDevice));
+  HIP_OK(hipSetDevice(prev));
+  return d;
+}
+struct OnDeviceArrays {  // frees what SliceOn handed out
+  std::vector<std::pair<int, void*>> v;
+  template <typename T>
+  T* Keep(int dev, T* p) { v.emplace_back(dev, (void*)p); return p; }
+  ~OnDeviceArrays() {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (auto& e : v) { (void)hipSetDevice(e.first); (void)hipFree(e.second); }
+    (void)hipSetDevice(prev);
+  }
+};
+
 static void Headline(const std::vector<int>& devs, int64_t n) {
   const int before = g_fail;
   using Prg = fss::prg::Aes128Mmo<2>;
@@ -108,6 +135,48 @@ static void Headline(const std::vector<int>& devs, int64_t n) {
     EXPECT(SameBytes(Gather<int4>(set, res, xs.size()), one));
     std::printf("  DPF n=32, 2^%d points over %zu members (%s): %.3f ms max over members (a first call; members that share a GPU overlap)\n",
                 (int)std::log2((double)n), devs.size(), plan == FSS_AMD_POINTS_PLAIN ? "plain" : "auto", res.max_ms);
+  }
+  {  // the points already ON the members' devices (EvalPointsShardedOn: device pointers in, as the reference's launchers
+     // take them): uneven parts, an empty one, the last member writing into the caller's own buffer
+    OnDeviceArrays keep;
+    const int world = static_cast<int>(devs.size());
+    std::vector<DeviceSet::PointsOn<uint32_t>> per(devs.size());
+    std::vector<int64_t> cut(devs.size() + 1, 0);
+    for (int r = 0; r < world; ++r) cut[r + 1] = r + 1 == world ? n : std::min<int64_t>(n, cut[r] + (r == 1 ? 0 : n / world + 17 * r));
+    for (int r = 0; r < world; ++r) {
+      const size_t lo = static_cast<size_t>(cut[r]), cnt = static_cast<size_t>(cut[r + 1] - cut[r]);
+      per[r].xs = keep.Keep(devs[r], SliceOn(devs[r], xs, 1, xs.size(), lo, cnt));
+      per[r].n = static_cast<int64_t>(cnt);
+    }
+    int prev = 0;
+    HIP_OK(hipGetDevice(&prev));
+    HIP_OK(hipSetDevice(devs.back()));
+    int4* own = nullptr;
+    HIP_OK(hipMalloc(&own, (per.back().n ? per.back().n : 1) * sizeof(int4)));
+    HIP_OK(hipSetDevice(prev));
+    per.back().ys = keep.Keep(devs.back(), own);
+    for (int plan : {FSS_AMD_POINTS_PLAIN, FSS_AMD_POINTS_AUTO}) {
+      set.SetPointsPlan(plan);
+      const DeviceSet::Result res = set.EvalPointsShardedOn(dpf, false, seeds[0], cws.data(), std::span<const DeviceSet::PointsOn<uint32_t>>(per));
+      EXPECT(res.shards.size() == devs.size() && res.shards.back().ys == own);
+      EXPECT(SameBytes(Gather<int4>(set, res, xs.size()), one));
+    }
+    if (world > 1) {
+      EXPECT(per[1].n == 0);
+      bool refused = false;  // one entry per member
+      try { (void)set.EvalPointsShardedOn(dpf, false, seeds[0], cws.data(), std::span<const DeviceSet::PointsOn<uint32_t>>(per.data(), 1)); }
+      catch (const fss::Error& e) { refused = e.code == FSS_AMD_EINVAL; }
+      EXPECT(refused);
+    }
+    {  // host memory where device memory is expected: refused with the member's own code (EINVAL, not a generic HIP error)
+      auto bad = per;
+      bad[0].xs = xs.data();
+      bool refused = false;
+      try { (void)set.EvalPointsShardedOn(dpf, false, seeds[0], cws.data(), std::span<const DeviceSet::PointsOn<uint32_t>>(bad)); }
+      catch (const fss::Error& e) { refused = e.code == FSS_AMD_EINVAL; }
+      EXPECT(refused);
+    }
+    std::printf("  DPF n=32, 2^%d points already on the members' devices (uneven parts, caller-owned output): same bytes\n", (int)std::log2((double)n));
   }
   {  // the points resident on the members: two keys over one upload, and the refusals
     set.SetPointsPlan(FSS_AMD_POINTS_AUTO);
@@ -254,6 +323,25 @@ static void IndependentKeys(const std::vector<int>& devs, int64_t nkeys) {
     const DeviceSet::Result res = set.EvalKeysSharded(ht, false, seeds0.data(), h_cws.data(), h_ocws.data(), xs.data(), nkeys);
     EXPECT(SameBytes(Gather<int4>(set, res, nk), one));
     std::printf("  Half-Tree n=64, %lld keys over %zu members: %.3f ms max\n", (long long)nkeys, devs.size(), res.max_ms);
+    {  // the same keys level-major ON the members (EvalKeysShardedOn)
+      OnDeviceArrays keep;
+      const auto h_cw_s = FromDevice(d_cw_s, nk * 64);
+      const auto h_extra = FromDevice(d_extra, nk);
+      std::vector<DeviceSet::KeysOn<uint64_t>> per(devs.size());
+      for (size_t r = 0; r < devs.size(); ++r) {
+        const fss::gpu::Slice sl = fss::gpu::BatchSlice(nkeys, (int)r, (int)devs.size());
+        const size_t lo = (size_t)sl.lo, cnt = (size_t)(sl.hi - sl.lo);
+        const int d = devs[r];
+        per[r].seeds = keep.Keep(d, SliceOn(d, seeds0, 1, nk, lo, cnt));
+        per[r].cw_s = keep.Keep(d, SliceOn(d, h_cw_s, 64, nk, lo, cnt));
+        per[r].tr_bits = keep.Keep(d, SliceOn(d, h_extra, 1, nk, lo, cnt));
+        per[r].out_cw = keep.Keep(d, SliceOn(d, h_ocws, 1, nk, lo, cnt));
+        per[r].xs = keep.Keep(d, SliceOn(d, xs, 1, nk, lo, cnt));
+        per[r].nkeys = (int64_t)cnt;
+      }
+      const DeviceSet::Result on = set.EvalKeysShardedOn(ht, false, std::span<const DeviceSet::KeysOn<uint64_t>>(per));
+      EXPECT(SameBytes(Gather<int4>(set, on, nk), one));
+    }
     HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_ocws)); HIP_OK(hipFree(d_cw_s)); HIP_OK(hipFree(d_extra));
   }
   {  // Grotto DCF n = 64 path walk (configs[4]) and DPF n = 64 on the same DPF-format keys
@@ -287,6 +375,34 @@ static void IndependentKeys(const std::vector<int>& devs, int64_t nkeys) {
     EXPECT(SameBytes(Gather<uint8_t>(set, gres, nk), oneb));
     std::printf("  DPF / Grotto n=64, %lld keys over %zu members: %.3f / %.3f ms max\n", (long long)nkeys, devs.size(), res.max_ms,
                 gres.max_ms);
+    {  // level-major ON the members: DPF and the Grotto walk on the same arrays
+      OnDeviceArrays keep;
+      const auto h_cw_s = FromDevice(d_cw_s, nk * 64);
+      const auto h_tr = FromDevice(d_tr, nk);
+      const auto h_out = FromDevice(d_out_cw, nk);
+      std::vector<DeviceSet::KeysOn<uint64_t>> per(devs.size());
+      for (size_t r = 0; r < devs.size(); ++r) {
+        const fss::gpu::Slice sl = fss::gpu::BatchSlice(nkeys, (int)r, (int)devs.size());
+        const size_t lo = (size_t)sl.lo, cnt = (size_t)(sl.hi - sl.lo);
+        const int d = devs[r];
+        per[r].seeds = keep.Keep(d, SliceOn(d, seeds0, 1, nk, lo, cnt));
+        per[r].cw_s = keep.Keep(d, SliceOn(d, h_cw_s, 64, nk, lo, cnt));
+        per[r].tr_bits = keep.Keep(d, SliceOn(d, h_tr, 1, nk, lo, cnt));
+        per[r].out_cw = keep.Keep(d, SliceOn(d, h_out, 1, nk, lo, cnt));
+        per[r].xs = keep.Keep(d, SliceOn(d, xs, 1, nk, lo, cnt));
+        per[r].nkeys = (int64_t)cnt;
+      }
+      const DeviceSet::Result on = set.EvalKeysShardedOn(dpf, false, std::span<const DeviceSet::KeysOn<uint64_t>>(per));
+      EXPECT(SameBytes(Gather<int4>(set, on, nk), one));
+      const DeviceSet::Result gon = set.EvalKeysShardedOn(gd, false, std::span<const DeviceSet::KeysOn<uint64_t>>(per));
+      EXPECT(SameBytes(Gather<uint8_t>(set, gon, nk), oneb));
+      auto bad = per;  // a DPF entry without its tr bits
+      bad[0].tr_bits = nullptr;
+      bool refused = false;
+      try { (void)set.EvalKeysShardedOn(dpf, false, std::span<const DeviceSet::KeysOn<uint64_t>>(bad)); }
+      catch (const fss::Error& e) { refused = e.code == FSS_AMD_EINVAL; }
+      EXPECT(refused);
+    }
     HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_cw_s)); HIP_OK(hipFree(d_out_cw)); HIP_OK(hipFree(d_tr)); HIP_OK(hipFree(d_yb));
   }
   {  // DCF n = 64
@@ -308,6 +424,26 @@ static void IndependentKeys(const std::vector<int>& devs, int64_t nkeys) {
     DeviceSet set(dcf, devs);
     const DeviceSet::Result res = set.EvalKeysSharded(dcf, false, seeds0.data(), h_cws.data(), xs.data(), nkeys);
     EXPECT(SameBytes(Gather<int4>(set, res, nk), one));
+    {  // level-major ON the members
+      OnDeviceArrays keep;
+      const auto h_cw_s = FromDevice(d_cw_s, nk * 64);
+      const auto h_cw_v = FromDevice(d_cw_v, nk * 64);
+      const auto h_out = FromDevice(d_out_cw, nk);
+      std::vector<DeviceSet::KeysOn<uint64_t>> per(devs.size());
+      for (size_t r = 0; r < devs.size(); ++r) {
+        const fss::gpu::Slice sl = fss::gpu::BatchSlice(nkeys, (int)r, (int)devs.size());
+        const size_t lo = (size_t)sl.lo, cnt = (size_t)(sl.hi - sl.lo);
+        const int d = devs[r];
+        per[r].seeds = keep.Keep(d, SliceOn(d, seeds0, 1, nk, lo, cnt));
+        per[r].cw_s = keep.Keep(d, SliceOn(d, h_cw_s, 64, nk, lo, cnt));
+        per[r].cw_v = keep.Keep(d, SliceOn(d, h_cw_v, 64, nk, lo, cnt));
+        per[r].out_cw = keep.Keep(d, SliceOn(d, h_out, 1, nk, lo, cnt));
+        per[r].xs = keep.Keep(d, SliceOn(d, xs, 1, nk, lo, cnt));
+        per[r].nkeys = (int64_t)cnt;
+      }
+      const DeviceSet::Result on = set.EvalKeysShardedOn(dcf, false, std::span<const DeviceSet::KeysOn<uint64_t>>(per));
+      EXPECT(SameBytes(Gather<int4>(set, on, nk), one));
+    }
     HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_cw_s)); HIP_OK(hipFree(d_cw_v)); HIP_OK(hipFree(d_out_cw));
   }
   HIP_OK(hipFree(d_s0s)); HIP_OK(hipFree(d_seeds0)); HIP_OK(hipFree(d_al)); HIP_OK(hipFree(d_xs)); HIP_OK(hipFree(d_be)); HIP_OK(hipFree(d_ys));

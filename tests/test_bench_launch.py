@@ -65,6 +65,11 @@ def test_bare_gpus_8_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["dry_run"] is True
+    # config.ranks: eight entries, one per rank, eight different processes, each of which saw a process group of eight
+    ranks = lines[0]["config"]["ranks"]
+    assert sorted(r["rank"] for r in ranks) == list(range(8)) and len({r["pid"] for r in ranks}) == 8
+    assert all(r["pg"] == ["gloo", 8] for r in ranks)
+    assert lines[0]["scaling"] == "strong"
 
 
 def test_sigterm_to_the_launcher_takes_the_ranks_down():
@@ -125,7 +130,18 @@ def test_bare_gpus_2_on_one_gpu_with_the_share_hook():
     lines = json_lines(r.stdout)
     assert len(lines) == 1
     d = lines[0]
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    # the metric's ONE batch cut in two is `value`; every rank's own batch is the side record
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["value"] == d["headline_strong"]["v"] and d["ms_per_step"] == d["headline_strong"]["ms"]
+    assert d["weak"]["v"] > 0 and d["weak"]["n"] == (1 << 20) and d["weak"]["scaling"] == "weak"
+    assert d["config"]["kernel"] and "ONE 2^20-point batch" in d["config"]["workload"]
+    assert d["roofline"]["kernel_ms"] == d["headline_strong"]["kms"]
+    # what the ranks ran on: two entries, two ranks, a process group of two each (gloo under the share hook) -- and ONE GPU
+    ranks = d["config"]["ranks"]
+    assert len(ranks) == 2 and sorted(r["rank"] for r in ranks) == [0, 1]
+    assert len({json.dumps(r, sort_keys=True) for r in ranks}) == 2
+    assert all(r["pg"] == ["gloo", 2] for r in ranks) and all(r["dev"] == 0 for r in ranks)
+    assert d["config"]["distinct_devices"] == 1
     for key in ("dcf_points", "dpf_keys", "dcf_keys", "dpf_n16", "dpf_n64", "dcf_n16", "dcf_n64", "dpf_keys_n16", "dpf_keys_n64"):
         assert d["sub"][key]["v"] > 0 and 0 < d["sub"][key]["f"] < 1.2, key
     # the one batch cut in two: half the points per rank, a rate of its own
@@ -156,6 +172,23 @@ def test_one_rank_under_torch_distributed_run_goes_through_rccl(extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["config"]["process_group"] == "nccl"
+
+
+@pytest.mark.gpu
+def test_self_launcher_rccl_branch_with_one_rank():
+    """bench.py's OWN launcher (bench_launch.launch_ranks, not torch.distributed.run) with one rank: the rank it spawns
+    forms its process group over RCCL (backend "nccl"), gathers config.ranks through it, passes the barriers and the
+    device-tensor reduction -- the branch an 8-GPU `python bench.py --gpus 8` takes, on the one GPU of this box."""
+    r, _ = run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--log2-batch", "20", "--only-headline"],
+               {"FSS_AMD_BENCH_SELF_LAUNCH": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["process_group"] == "nccl"
+    assert d["config"]["ranks"][0]["pg"] == ["nccl", 1] and d["config"]["ranks"][0]["dev"] == 0
+    assert d["config"]["distinct_devices"] == 1 and d["ms_median"] > 0
+    assert d["headline_strong"]["v"] == d["value"] and d["scaling"] == "weak" and "weak" not in d
 
 
 @pytest.mark.gpu
@@ -194,6 +227,8 @@ def test_default_line_carries_the_whole_metric():
         assert k in d["roofline"], k
     # one GPU: the strong-scaled form of the metric is the headline launch itself
     assert d["headline_strong"]["v"] == d["value"] and d["headline_strong"]["n"] == 1 << 18
+    assert d["scaling"] == "weak" and d["ms_median"] > 0 and abs(d["ms_median"] - d["roofline"]["kernel_ms"]) < 0.5 * d["ms_median"]
+    assert d["config"]["ranks"][0]["rank"] == 0 and d["config"]["ranks"][0]["pg"] is None and d["config"]["distinct_devices"] == 1
     assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
 
 

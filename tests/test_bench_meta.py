@@ -91,3 +91,43 @@ def test_a_full_line_fits_the_drivers_record():
     assert back["sub"]["shared_prefix"]["f"] == 0.88123 and back["sub"]["shared_prefix"]["k"] == 23 and back["sub"]["shared_prefix"]["x"] == 2.9712
     assert back["sub"]["dpf_keys"]["clk"] == 2.3712 and back["sub"]["dpf_keys"]["fc"] == 0.94971 and back["roofline"]["clk"] == 2.3712
     assert back["headline_strong"]["scaling"] == "strong" and back["headline_strong"]["v"] == back["value"]
+
+
+def test_an_eight_rank_line_is_the_metrics_one_batch_and_names_its_devices():
+    """With N > 1 ranks `value` is headline_strong (the ONE 2^24-point batch cut N ways), the line says "strong", the
+    per-rank-batch number moves to `weak`, the roofs describe the strong launch (no PMC replay: another launch size),
+    config.ranks names eight devices -- and the line still fits the driver's record."""
+    import argparse
+    import json
+    import bench
+    walk = {"value": 2.8712e10, "unit": "evals/s", "ms_per_step": 4.6597, "kernel_ms": 4.6561, "units_per_launch": 1 << 24,
+            "aes_per_unit": 32, "frac": 0.93831, "lds_gbs": 73792.1, "hbm_gbs": 72.012, "hbm_frac": 0.0090015,
+            "kernel": "eval_points_kernel<Lds,0,true,2,1024,false>", "grid": 256, "block": 1024, "clk": 2.3712, "frac_at_clock": 0.94971,
+            "ms_median": 4.6512}
+    strong = dict(walk, value=2.7512e10, ms_per_step=0.60981, kernel_ms=0.60012, units_per_launch=1 << 21, frac=0.90123, scaling="strong",
+                  ms_median=0.59871)
+    subs = {c[0]: dict(walk) for c in bench.POINTS_CELLS + bench.KEYS_CELLS}
+    for name in ("ht_c5", "grotto_c5"):
+        subs[name] = dict(walk, ms_median=1.2345)
+    subs["evalall_c4"] = dict(walk, unit="leaves/s")
+    for name in ("shared_prefix", "shared_dcf"):
+        subs[name] = dict(walk, k=23, speedup=2.9712, same=True)
+    ranks = [{"rank": r, "pid": 100000 + r, "dev": r, "name": "AMD Instinct MI355X", "uuid": "GPU-%032x" % (0xabcdef0123456789 * (r + 1)),
+              "pci": "0000:%02x:00" % (5 + 16 * r), "pg": ["nccl", 8]} for r in range(8)]
+    args = argparse.Namespace(log2_batch=24, steps=20, warmup=5)
+    line, _ = bench.compose_line(args, 8, dict(walk), strong, subs, None, "nccl", ranks)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < 7000, len(text)
+    back = json.loads(text)
+    assert back["n_gpus"] == 8 and back["scaling"] == "strong"
+    assert back["value"] == back["headline_strong"]["v"] == 2.7512e10 and back["ms_per_step"] == back["headline_strong"]["ms"]
+    assert back["ms_median"] == 0.59871 and back["roofline"]["kernel_ms"] == 0.60012 and back["roofline"]["frac"] == 0.90123
+    assert back["roofline"]["traffic"] is None and back["roofline"]["replay_ok"] is False
+    assert back["roofline_hbm"]["algorithmic_bytes"] == (1 << 21) * 20
+    assert back["weak"]["v"] == 2.8712e10 and back["weak"]["scaling"] == "weak" and back["weak"]["n"] == 1 << 24
+    assert len(back["config"]["ranks"]) == 8 and back["config"]["distinct_devices"] == 8 and back["config"]["device_name"] == "AMD Instinct MI355X"
+    assert all(r["pg"] == ["nccl", 8] for r in back["config"]["ranks"]) and "name" not in back["config"]["ranks"][0]
+    assert bench.distinct_devices([dict(r, uuid=ranks[0]["uuid"]) for r in ranks]) == 1   # eight ranks sharing one GPU
+    # one rank: the same launch under both names, "weak", no side record
+    one, _ = bench.compose_line(args, 1, dict(walk), dict(walk, scaling="strong"), subs, None, None, ranks[:1])
+    assert one["scaling"] == "weak" and "weak" not in one and one["value"] == one["headline_strong"]["v"] and one["ms_median"] == 4.6512
