@@ -826,6 +826,11 @@ def main():
             dist_mod.barrier()
         finally:
             sys.stdout.flush()
+            try:  # RCCL's banner goes through C stdio, which buffers when stdout is a pipe: flush it while fd 1 still is stderr
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
             os.dup2(saved, 1)
             os.close(saved)
         dist = dist_mod

@@ -73,6 +73,8 @@ PROTOTYPES = {
     "fss_amd_last_kernel": (C.c_char_p, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "fss_amd_dpf_relayout_u32": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "fss_amd_dpf_eval_keys_u32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "fss_amd_vdpf_relayout_u32": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp]),
+    "fss_amd_vdpf_eval_keys_u32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp]),
     "fss_amd_batch_slice": (_i, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "fss_amd_domain_block": (_i, [_i, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "fss_amd_grotto_carries": (_i, [_vp, _i, _vp]),

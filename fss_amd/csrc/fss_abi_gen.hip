@@ -180,21 +180,29 @@ int fss_amd_vdpf_gen_level_major(fss_amd_ctx* ctx, int in_bits, int group, const
                                retry, stream);
 }
 
-int fss_amd_vdpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
-                          void* stream) {
-  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > 128) return FSS_AMD_EINVAL;
+static int vdpf_relayout_common(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
+                                int tr32, void* stream) {
+  if (!ctx || nkeys < 0 || in_bits < 1 || in_bits > (tr32 ? 32 : 128)) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!cws || !cw_s || !tr_bits) return FSS_AMD_EINVAL;
-  if (!aligned16(cws, cw_s) || !aligned_to(tr_bits, 8)) return FSS_AMD_EINVAL;
+  if (!aligned16(cws, cw_s) || !aligned_to(tr_bits, tr32 ? 4 : 8)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   launch_relayout<S_DPF>(ctx, S(stream), in_bits,
                      in_bits, reinterpret_cast<const uint4*>(cws), nkeys, reinterpret_cast<uint4*>(cw_s), (uint4*)nullptr,
-                     reinterpret_cast<uint64_t*>(tr_bits), (uint4*)nullptr, (uint32_t*)nullptr);
+                     reinterpret_cast<uint64_t*>(tr_bits), (uint4*)nullptr, (uint32_t*)nullptr, tr32);
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = "relayout";
   ctx->last_grid = (int)((nkeys + 63) / 64);
   ctx->last_block = 256;
   return FSS_AMD_OK;
+}
+int fss_amd_vdpf_relayout(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* tr_bits,
+                          void* stream) {
+  return vdpf_relayout_common(ctx, in_bits, cws, nkeys, cw_s, tr_bits, 0, stream);
+}
+int fss_amd_vdpf_relayout_u32(fss_amd_ctx* ctx, int in_bits, const void* cws, int64_t nkeys, void* cw_s, void* extra,
+                              void* stream) {
+  return vdpf_relayout_common(ctx, in_bits, cws, nkeys, cw_s, extra, 1, stream);
 }
 
 int fss_amd_vdpf_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seed, const void* cws,
@@ -214,13 +222,14 @@ int fss_amd_vdpf_eval_points(fss_amd_ctx* ctx, int in_bits, int group, int party
                            reinterpret_cast<const uint32_t*>(ocw), a, S(stream));
 }
 
-int fss_amd_vdpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
-                           const void* tr_bits, const void* cs, const void* ocws, const void* xs, int x_bytes,
-                           int64_t nkeys, void* ys, void* pi_tildes, void* stream) {
+static int vdpf_eval_keys_common(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                                 const void* tr_bits, const void* cs, const void* ocws, const void* xs, int x_bytes,
+                                 int64_t nkeys, void* ys, void* pi_tildes, int tr32, void* stream) {
   if (!ctx || nkeys < 0 || !group_ok(ctx, group) || (party != 0 && party != 1) || !x_ok(in_bits, x_bytes)) return FSS_AMD_EINVAL;
+  if (tr32 && in_bits > 32) return FSS_AMD_EINVAL;
   if (nkeys == 0) return FSS_AMD_OK;
   if (!seeds || !cw_s || !tr_bits || !cs || !ocws || !xs || !ys || !pi_tildes) return FSS_AMD_EINVAL;
-  if (!aligned16(seeds, cw_s, cs, ocws, ys, pi_tildes) || !aligned_to(tr_bits, 8) || !aligned_to(xs, x_bytes))
+  if (!aligned16(seeds, cw_s, cs, ocws, ys, pi_tildes) || !aligned_to(tr_bits, tr32 ? 4 : 8) || !aligned_to(xs, x_bytes))
     return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
   VdpfArgs a{};
@@ -229,9 +238,20 @@ int fss_amd_vdpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, 
   a.seeds = reinterpret_cast<const uint4*>(seeds);
   a.cw_s = reinterpret_cast<const uint4*>(cw_s);
   a.tr_bits = reinterpret_cast<const uint64_t*>(tr_bits);
+  a.tr32 = tr32;
   a.cs = reinterpret_cast<const uint4*>(cs);
   a.ocws = reinterpret_cast<const uint4*>(ocws);
   return vdpf_launch<false>(ctx, "vdpf_eval_keys", nullptr, nullptr, nullptr, nullptr, a, S(stream));
+}
+int fss_amd_vdpf_eval_keys(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                           const void* tr_bits, const void* cs, const void* ocws, const void* xs, int x_bytes,
+                           int64_t nkeys, void* ys, void* pi_tildes, void* stream) {
+  return vdpf_eval_keys_common(ctx, in_bits, group, party, seeds, cw_s, tr_bits, cs, ocws, xs, x_bytes, nkeys, ys, pi_tildes, 0, stream);
+}
+int fss_amd_vdpf_eval_keys_u32(fss_amd_ctx* ctx, int in_bits, int group, int party, const void* seeds, const void* cw_s,
+                               const void* extra, const void* cs, const void* ocws, const void* xs, int x_bytes,
+                               int64_t nkeys, void* ys, void* pi_tildes, void* stream) {
+  return vdpf_eval_keys_common(ctx, in_bits, group, party, seeds, cw_s, extra, cs, ocws, xs, x_bytes, nkeys, ys, pi_tildes, 1, stream);
 }
 
 int fss_amd_vdpf_prove(fss_amd_ctx* ctx, const void* pi_tildes, int64_t npoints, const void* cs, void* pi, void* stream) {

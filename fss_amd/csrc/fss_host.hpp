@@ -46,21 +46,26 @@ struct fss_amd_ctx {
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   std::mutex scratch_mu;
   std::map<StreamKey, Scratch> scratch;
-  // fss_amd_*_eval_points under FSS_AMD_POINTS_AUTO: the node table + stage buffers of the shared-prefix plan, one
+  // fss_amd_*_eval_points under FSS_AMD_POINTS_AUTO (opt-in: fss_amd_ctx_set_points_plan; a fresh context walks
+  // plainly and its eval calls allocate nothing): the node table + stage buffers of the shared-prefix plan, one
   // grow-only buffer per stream, NOT the buffer fss_amd_ctx_scratch hands out (a caller may have parked the very seed it
   // passes in that one).  auto_mu is held from taking the buffer until the plan's last kernel is enqueued: two host
   // threads on one stream then enqueue "table, walk" pairs whole.
-  int points_plan = FSS_AMD_POINTS_AUTO;
+  int points_plan = FSS_AMD_POINTS_PLAIN;
   std::mutex auto_mu;
   std::map<StreamKey, Scratch> prefix_ws;
-  // (auto_mu held) the stream's buffer grown to `bytes`; nullptr when the device has no room (the caller walks plainly)
+  // (auto_mu held) the stream's buffer grown to `bytes`; nullptr when the device has no room (the caller walks plainly).
+  // Stream-ordered (hipMallocAsync / hipFreeAsync on the caller's stream): the old buffer goes away after the work already
+  // queued on it, the new one exists before the kernels enqueued next -- no device-wide wait inside an eval call, and
+  // nothing a capture another thread has open in global mode would be invalidated by (hipMalloc / hipFree are).
   void* prefix_buffer(void* stream, size_t bytes) {
     Scratch& s = prefix_ws[stream_key(stream)];
     if (s.bytes < bytes || !s.p) {
-      if (s.p) (void)hipFree(s.p);  // waits for the device: work queued on the old buffer has finished
+      hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+      if (s.p && hipFreeAsync(s.p, st) != hipSuccess) (void)hipGetLastError();
       s.p = nullptr;
       s.bytes = 0;
-      if (hipMalloc(&s.p, bytes) != hipSuccess) {
+      if (hipMallocAsync(&s.p, bytes, st) != hipSuccess) {
         (void)hipGetLastError();
         s.p = nullptr;
         return nullptr;

@@ -68,6 +68,9 @@ class Engine:
         _lib.check(L.fss_amd_ctx_create(C.byref(h), self.device.index, C.c_char_p(keys), hk), "fss_amd_ctx_create")
         self._h, self._L = h, L
         self.prg = prg
+        # The C ABI's contexts start FSS_AMD_POINTS_PLAIN (nothing allocated inside an eval call, as the reference's
+        # launchers); this layer allocates its outputs per call anyway and opts in to the shared-prefix plan.
+        _lib.check(L.fss_amd_ctx_set_points_plan(h, 0), "fss_amd_ctx_set_points_plan")
         self.points_plan = "auto"
         if prg not in PRG_IDS:
             raise ValueError(f"prg must be one of {tuple(PRG_IDS)}, got {prg!r}")
@@ -139,9 +142,10 @@ class Engine:
         raise TypeError(f"xs must be uint8, int16, int32 or int64 bit patterns (or (n, 2) int64 pairs), got {xs.dtype}")
 
     def set_points_plan(self, plan):
-        """'auto' (default): eval_points takes the shared-prefix plan for batches of >= 2^19 points of one key (same
-        outputs, about a third of the AES work at 2^24 points; the node table lives in a per-stream buffer of the
-        context).  'plain': every point walks from the root (what bench.py's `value` measures)."""
+        """'auto' (this class's default; the C ABI's own default is 'plain'): eval_points takes the shared-prefix plan for
+        batches of >= 2^18 points of one key (same outputs, about a third of the AES work at 2^24 points; the node table
+        lives in a per-stream buffer of the context, allocated stream-ordered; release_stream() before dropping a side
+        stream).  'plain': every point walks from the root, nothing is allocated -- bench.py's own engine is set to it."""
         if plan not in ("auto", "plain"):
             raise ValueError(f"plan must be 'auto' or 'plain', got {plan!r}")
         _lib.check(self._L.fss_amd_ctx_set_points_plan(self._h, 0 if plan == "auto" else 1), "fss_amd_ctx_set_points_plan")

@@ -17,8 +17,9 @@
  *    they enqueue kernels on `stream` (a hipStream_t passed as void*, NULL =
  *    default stream) and return, like the reference launchers
  *    (include/fss/point_eval_gpu.cuh:448-460).  Two exceptions, both named where they are declared:
- *    fss_amd_eval_points_host takes its points and outputs in PINNED HOST memory, and the one-key point
- *    evaluations under FSS_AMD_POINTS_AUTO keep a per-stream node table in the context that grows on demand.
+ *    fss_amd_eval_points_host takes its points and outputs in PINNED HOST memory, and a context that has been
+ *    switched to FSS_AMD_POINTS_AUTO (opt-in; a fresh context is FSS_AMD_POINTS_PLAIN) keeps a per-stream node
+ *    table for its one-key point evaluations that grows on demand, stream-ordered.
  *  - Alignment: every int4 / Cw array (seeds, cws, cw_s, cw_v, out_cw, ocws, cs, betas, ys, pi, workspaces)
  *    must be 16-byte aligned (the reference's int4 is; its Cw is alignas(32)), tr_bits 8-byte, extra 4-byte,
  *    xs / alphas sizeof(In)-aligned.  A misaligned pointer is FSS_AMD_EINVAL, never a device fault.
@@ -107,15 +108,21 @@ enum fss_amd_scheme { FSS_AMD_DPF = 0, FSS_AMD_DCF = 1, FSS_AMD_HT = 2, FSS_AMD_
  * dpf_eval / dcf_eval (fss_crypto/_csrc/dpf_binding_impl.cuh:58-101).
  * seed: device int4.  cws: device, in_bits+1 raw Cw slots (in_bits for Half-Tree).
  * ocw (Half-Tree): device int4.  ys: device int4[npoints]. */
-/* Plan of these three calls (context setting, default FSS_AMD_POINTS_AUTO):
- *   FSS_AMD_POINTS_PLAIN  every point walks from the root: in_bits PRG levels per point, nothing allocated.
- *   FSS_AMD_POINTS_AUTO   batches of at least 2^18 points (in_bits <= 64) take the shared-prefix plan below with
+/* Plan of these three calls (context setting; a fresh context is FSS_AMD_POINTS_PLAIN):
+ *   FSS_AMD_POINTS_PLAIN  every point walks from the root: in_bits PRG levels per point; nothing is allocated, freed or
+ *                         waited for -- the contract of the reference's launchers.  The default.
+ *   FSS_AMD_POINTS_AUTO   opt-in (fss_amd_ctx_set_points_plan; the Python Engine and the C++ value types, which stage
+ *                         and allocate for their callers anyway, opt in at creation): batches of at least 2^18 points
+ *                         (in_bits <= 64) take the shared-prefix plan below with
  *                         prefix_bits = fss_amd_points_prefix_bits(): identical outputs, about in_bits - log2(npoints) + 3
  *                         AES levels per point instead of in_bits (DPF kInBits=32, 2^24 points: 3.6 -> 10.8 G evals/s).
- *                         Its node table lives in a buffer of the context, one per stream, grown on demand
- *                         (hipMalloc / hipFree inside the call that needs more: about 2^prefix_bits x 16 B, DCF x 32 B;
- *                         freed by fss_amd_ctx_scratch_release / _destroy).  Calls inside a stream capture, and calls
- *                         the device has no room for, walk plainly.
+ *                         Its node table lives in a buffer of the context, one per stream, grown on demand by the call
+ *                         that needs more -- hipMallocAsync / hipFreeAsync on the CALLER'S stream (stream-ordered: no
+ *                         device-wide wait, nothing that breaks a capture another thread has open): 2^prefix_bits x 16 B,
+ *                         DCF x 32 B, prefix_bits <= 26, i.e. at most 1 / 2 GiB per stream.  The buffer is keyed by the
+ *                         stream HANDLE: call fss_amd_ctx_scratch_release(ctx, stream) before destroying a stream that
+ *                         evaluated large batches (fss_amd_ctx_destroy frees whatever is left).  Calls inside a capture
+ *                         of their own stream, host-resident batches, and calls the device has no room for, walk plainly.
  * fss_amd_points_prefix_bits: the prefix_bits AUTO uses for that batch, 0 where it walks plainly. */
 #define FSS_AMD_POINTS_AUTO 0
 #define FSS_AMD_POINTS_PLAIN 1
@@ -338,6 +345,14 @@ int fss_amd_dpf_relayout_u32(fss_amd_ctx *ctx, int in_bits, const void *cws, int
 int fss_amd_dpf_eval_keys_u32(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
                               const void *extra, const void *out_cw, const void *xs, int x_bytes, int64_t nkeys,
                               void *ys, void *stream);
+/* ... and the VDPF launchers on it: fss::gpu::VdpfRelayoutGpu(cws, int nkeys, cw_s, uint32_t* extra, stream) and
+ * VdpfEvalPointGpu(b, seeds, cw_s, const uint32_t* extra, const array<int4,4>* cs, ocws, const uint32_t* xs, ys, pi,
+ * int nkeys, vdpf, stream) as the reference declares them (point_eval_gpu.cuh:389-396, :514-526); in_bits <= 32. */
+int fss_amd_vdpf_relayout_u32(fss_amd_ctx *ctx, int in_bits, const void *cws, int64_t nkeys, void *cw_s, void *extra,
+                              void *stream);
+int fss_amd_vdpf_eval_keys_u32(fss_amd_ctx *ctx, int in_bits, int group, int party, const void *seeds, const void *cw_s,
+                               const void *extra, const void *cs, const void *ocws, const void *xs, int x_bytes,
+                               int64_t nkeys, void *ys, void *pi_tildes, void *stream);
 
 /* ---- one job across the GPUs of a node --------------------------------------------------------
  * The evaluation batch (points x keys) and the full domain split without any exchange (the

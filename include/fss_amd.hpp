@@ -43,6 +43,7 @@
 #define FSS_AMD_HPP_INCLUDED_ 1
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <concepts>
 #include <cstdint>
@@ -67,6 +68,17 @@ template <typename Prg, int mul>
 concept Prgable = requires(Prg prg, int4 seed) {
   { prg.Gen(seed) } -> std::same_as<std::array<int4, mul>>;
 };
+
+// include/fss/hash.cuh:15-30
+template <typename Hash>
+concept Hashable = requires(Hash hash, std::span<const int4, 4> msg) {
+  { hash.Hash(msg) } -> std::same_as<std::array<int4, 2>>;
+};
+template <typename Hash>
+concept XorHashable = requires(Hash hash, std::tuple<int4, const int4> msg) {
+  { hash.Hash(msg) } -> std::same_as<std::array<int4, 4>>;
+};
+static_assert(Hashable<fss::hash::Blake3> && XorHashable<fss::hash::Blake3> && Hashable<fss::hash::Sha256> && XorHashable<fss::hash::Sha256>);
 
 // include/fss/group.cuh:39-45
 template <typename Group>
@@ -105,6 +117,15 @@ __host__ __device__ inline int4 SetLsb(int4 v, bool bit) {
   return v;
 }
 __host__ __device__ inline bool GetLsb(int4 v) { return v.w & 1; }
+// util.cuh:40-45: par_depth as given, or ceil(log2(host threads)) for -1.  The reference asks OpenMP for the thread count;
+// nothing here runs on OpenMP (EvalAll is one GPU launch), so the value only matters to callers that use it themselves.
+inline int ResolveParDepth(int par_depth) {
+  if (par_depth >= 0) return par_depth;
+  const unsigned threads = std::max(1u, std::thread::hardware_concurrency());
+  int d = 0;
+  while ((1u << d) < threads) ++d;
+  return d;
+}
 template <typename In>
 __host__ __device__ inline int4 Pack(In val) {
   const unsigned __int128 v = static_cast<unsigned __int128>(val);
@@ -207,7 +228,7 @@ struct Spec {
   int32_t nonce[2] = {};
   int rounds = 20;
   uint64_t mod = 0;
-  int has_iv = 0;
+  int has_iv = 0;   // 1: keyed BLAKE3 with iv[0..7] (fss::hash::Blake3); 2: SHA-256 keyed with iv[0..3] (fss::hash::Sha256)
   int32_t iv[8] = {};
 };
 inline std::string KeyOf(const Spec& s) {
@@ -262,7 +283,11 @@ inline fss_amd_ctx* Engine(Spec s) {
   Check(fss_amd_ctx_create(&c, s.device, s.aes, s.hash_key), "fss_amd_ctx_create");
   int rc = s.prg == FSS_AMD_PRG_CHACHA ? fss_amd_ctx_set_prg(c, s.prg, s.nonce, s.rounds) : FSS_AMD_OK;
   if (rc == FSS_AMD_OK && s.mod) rc = fss_amd_ctx_set_uint_modulus(c, s.mod);
-  if (rc == FSS_AMD_OK && s.has_iv) rc = fss_amd_ctx_set_hash_iv(c, s.iv);
+  if (rc == FSS_AMD_OK && s.has_iv == 1) rc = fss_amd_ctx_set_hash_iv(c, s.iv);
+  if (rc == FSS_AMD_OK && s.has_iv == 2) rc = fss_amd_ctx_set_hash_sha256(c, s.iv);
+  // the value types stage and allocate for their callers already: their contexts opt in to the shared-prefix plan for
+  // large one-key batches (the C ABI's own default is FSS_AMD_POINTS_PLAIN: nothing allocated inside an eval call)
+  if (rc == FSS_AMD_OK) rc = fss_amd_ctx_set_points_plan(c, FSS_AMD_POINTS_AUTO);
   if (rc != FSS_AMD_OK) {
     fss_amd_ctx_destroy(c);
     Check(rc, "fss_amd_ctx setup");
@@ -731,7 +756,7 @@ concept EngineGroup = Groupable<G> && requires {
 };
 
 template <typename Prg>
-fss_amd_ctx* CtxOf(const Prg& prg, uint64_t mod = 0, const int4* hash_key = nullptr, const int32_t* iv = nullptr) {
+fss_amd_ctx* CtxOf(const Prg& prg, uint64_t mod = 0, const int4* hash_key = nullptr, const int32_t* iv = nullptr, int hash_kind = 0) {
   static_assert(EnginePrg<Prg>, "the engine runs fss::prg::Aes128Mmo and fss::prg::ChaCha; other Prgable types cannot "
                                 "be executed by its prebuilt kernels");
   Spec s;
@@ -739,8 +764,8 @@ fss_amd_ctx* CtxOf(const Prg& prg, uint64_t mod = 0, const int4* hash_key = null
   s.mod = mod;
   if (hash_key) std::memcpy(s.hash_key, hash_key, sizeof s.hash_key);
   if (iv) {
-    s.has_iv = 1;
-    std::memcpy(s.iv, iv, sizeof s.iv);
+    s.has_iv = hash_kind == 1 ? 2 : 1;
+    std::memcpy(s.iv, iv, hash_kind == 1 ? 16 : 32);
   }
   return Engine(s);
 }
@@ -1295,34 +1320,190 @@ class GrottoDcf {
   }
 };
 
-// ---------------------------------------------------------------- verifiable DPF
-namespace hash {
-// fss::hash::Blake3 (include/fss/hash/blake3.cuh:13-172): the 8-word key of the keyed BLAKE3 hashes.
-// A tag carrying the IV; the hashing runs in the kernels.
-struct Blake3 {
-  int32_t iv[8];
-  explicit Blake3(std::span<const int4, 2> iv2) { std::memcpy(iv, iv2.data(), sizeof(iv)); }
-  explicit Blake3(const int4 iv2[2]) { std::memcpy(iv, iv2, sizeof(iv)); }
+// ---------------------------------------------------------------- verifiable DPF (include/fss/vdpf.cuh:57-404)
+// (fss::hash::Blake3 / Sha256: include/fss_amd_thread.hpp)
+namespace detail {
+// hash types the engine's kernels implement: keyed BLAKE3 / keyed SHA-256, one key for H and H' per context
+template <typename H>
+concept EngineHash = requires(const H& h) {
+  { H::kEngineHashKind } -> std::convertible_to<int>;
+  { h.SameKey(h) } -> std::convertible_to<bool>;
 };
-}  // namespace hash
+inline const int32_t* HashKeyWords(const hash::Blake3& h) { return h.iv; }
+inline const int32_t* HashKeyWords(const hash::Sha256& h) { return &h.key.x; }
 
-// include/fss/vdpf.cuh:57-404 with XorHash = Hash = hash::Blake3 (one IV for both, as the reference's tests and
-// benches use them).  A key = kSlots Cw slots + cs (4 int4) + ocw.  Batched device forms only.
-template <int in_bits, typename Group, typename Prg, typename In = uint32_t>
-  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 2>)
+// generic per-thread kernels for caller-defined PRG / group / hash types (one key, or one point, per thread)
+template <typename S, typename In>
+__global__ void ThreadVdpfGenKernel(S sch, typename S::Cw* cws, std::array<int4, 4>* cs, int4* ocws, const int4* s0s, const In* alphas,
+                                    const int4* betas, int64_t nkeys, int32_t* retry) {
+  const int64_t k = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (k >= nkeys) return;
+  const int r = sch.Gen(cws + k * S::kSlots, cs[k], ocws[k], std::span<const int4, 2>(s0s + 2 * k, 2), alphas[k], betas[k]);
+  if (retry) retry[k] = r;
+}
+template <typename S, typename In>
+__global__ void ThreadVdpfEvalKernel(S sch, bool b, const int4* s0, const typename S::Cw* cws, const int4* cs, const int4* ocw,
+                                     const In* xs, int4* ys, std::array<int4, 4>* pis, int64_t n) {
+  const int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  int4 y;
+  pis[i] = sch.Eval(b, *s0, std::span<const typename S::Cw>(cws, S::kSlots), std::span<const int4, 4>(cs, 4), *ocw,
+                    xs ? xs[i] : static_cast<In>(i), y);
+  ys[i] = y;
+}
+}  // namespace detail
+
+// The reference's class, parameter for parameter: `fss::Vdpf<in_bits, Group, Prg, XorHash, Hash, In, par_depth> v{prg,
+// xor_hash, hash}` with public members and Gen / Eval / Prove / Verify / EvalAll in its signatures (cuda::std::array /
+// span / tuple spelled std::).  A key = in_bits Cw slots + cs (4 int4) + ocw.
+//  * Host forms stage onto the engine (fss_amd_vdpf_*) when Prg, Group and both hashes are engine types and the two hash
+//    objects hold the same key (a context has one hash pair; the reference's tests and benches construct both from one
+//    IV); other types run the per-thread code in a generic kernel.  Prove folds on the host (a sequential hash chain:
+//    nothing for a GPU to do) unless the hashes it is given already live in device memory.
+//  * Device forms: the calling thread walks the key itself (include/fss_amd_thread.hpp), as src/bench_gpu.cu:172-205.
+//  * GenBatch / GenLevelMajor / EvalPoints / ProveChain / ProveKeys: the batched device forms.
+template <int in_bits, typename Group, typename Prg, typename XorHash = hash::Blake3, typename Hash = XorHash, typename In = uint32_t,
+          int par_depth = -1>
+  requires(detail::InType<In> && in_bits >= 1 && in_bits <= (int)sizeof(In) * 8 && Groupable<Group> && Prgable<Prg, 2> &&
+           XorHashable<XorHash> && Hashable<Hash>)
 class Vdpf {
  public:
+  using GroupType = Group;
   Prg prg;
-  hash::Blake3 xor_hash;
-  using Cw = typename Dpf<in_bits, Group, Prg, In>::Cw;  // vdpf.cuh:77-82
+  XorHash xor_hash;
+  Hash hash;
+  struct alignas(32) Cw {  // vdpf.cuh:77-82
+    int4 s;
+    bool tr;
+  };
+  static_assert(sizeof(Cw) == 32);
   static constexpr int kSlots = in_bits;
-  fss_amd_ctx* handle() const { return detail::CtxOf(prg, Group::kMod, nullptr, xor_hash.iv); }
+  static constexpr bool kEngine = detail::EnginePrg<Prg> && detail::EngineGroup<Group> && detail::EngineHash<XorHash> && std::is_same_v<XorHash, Hash>;
+  fss_amd_ctx* handle() const {
+    static_assert(kEngine, "this form needs fss::prg::Aes128Mmo / ChaCha, fss::group::Bytes / Uint<T, mod> and fss::hash::Blake3 / Sha256 for both hashes");
+    if (!xor_hash.SameKey(hash))
+      throw Error("fss::Vdpf: xor_hash and hash hold different keys (an engine context has one hash key for H and H')", FSS_AMD_EINVAL);
+    return detail::CtxOf(prg, Group::kMod, nullptr, detail::HashKeyWords(xor_hash), XorHash::kEngineHashKind);
+  }
+  fss_amd_ctx* StageCtx() const {
+    if constexpr (kEngine) return handle();
+    else return detail::AnyCtx();
+  }
 
-  // Vdpf::Gen (vdpf.cuh:103-189) for nkeys keys; d_retry[k] = its return value (may be null).
-  void Gen(Cw* d_cws, int4* d_cs /* 4 per key */, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
-           const int4* d_betas, int64_t nkeys, int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws,
-                           d_cs, d_ocws, d_retry, stream), "fss_amd_vdpf_gen");
+  // ---- the reference's signatures ----------------------------------------------------------------------------------------
+  // vdpf.cuh:103: cws[in_bits], cs and ocw out; returns 1 when the leaf control bits agree (resample the seeds, retry)
+  __device__ int Gen(Cw cws[], std::array<int4, 4>& cs, int4& ocw, std::span<const int4, 2> s0s, In a, int4 b_buf) const {
+    const int4 seeds[2] = {s0s[0], s0s[1]};
+    return thread::VdpfGen<in_bits, Group, In>(prg, xor_hash, reinterpret_cast<int4*>(cws), cs, ocw, seeds, a, b_buf);
+  }
+  __host__ int Gen(Cw cws[], std::array<int4, 4>& cs, int4& ocw, std::span<const int4, 2> s0s, In a, int4 b_buf) const {
+    detail::Stage st(StageCtx(), 32 + 32 + 32 + sizeof(Cw) * kSlots + 64 + 32 + 32);
+    const int4* d_s0s = st.Load(s0s.data(), 2);
+    const In* d_a = st.Value(a);
+    const int4* d_b = st.Value(b_buf);
+    Cw* d_cws = st.Out(cws, kSlots);
+    int4* d_cs = static_cast<int4*>(st.Take(64));
+    int4* d_ocw = static_cast<int4*>(st.Take(16));
+    int32_t* d_retry = static_cast<int32_t*>(st.Take(4));
+    GenBatch(d_cws, d_cs, d_ocw, d_s0s, d_a, d_b, 1, d_retry);
+    st.Back(cws, static_cast<const Cw*>(d_cws), kSlots);
+    int32_t retry = 0;
+    int4 new_ocw;
+    st.Back(cs.data(), static_cast<const int4*>(d_cs), 4);
+    st.Back(&new_ocw, static_cast<const int4*>(d_ocw), 1);
+    st.Back(&retry, static_cast<const int32_t*>(d_retry), 1);
+    if (retry == 0) ocw = new_ocw;  // (the reference leaves ocw untouched when it asks for a retry, vdpf.cuh:171-178)
+    return retry;
+  }
+  // vdpf.cuh:204: y = party b's share of f(x); returns the corrected per-point hash for Prove
+  __device__ std::array<int4, 4> Eval(bool b, int4 s0, std::span<const Cw> cws, std::span<const int4, 4> cs, int4 ocw, In x, int4& y) const {
+    return thread::VdpfEval<in_bits, Group, In>(prg, xor_hash, b, s0, reinterpret_cast<const int4*>(cws.data()), cs.data(), ocw, x, y);
+  }
+  __host__ std::array<int4, 4> Eval(bool b, int4 s0, std::span<const Cw> cws, std::span<const int4, 4> cs, int4 ocw, In x, int4& y) const {
+    if (cws.size() < static_cast<size_t>(kSlots)) throw Error("fss::Vdpf::Eval: cws must hold in_bits correction words", FSS_AMD_EINVAL);
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 64 + 32 + 32 + 32 + 64);
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws.data(), kSlots);
+    const int4* d_cs = st.Load(cs.data(), 4);
+    const int4* d_ocw = st.Value(ocw);
+    const In* d_x = st.Value(x);
+    int4* d_y = static_cast<int4*>(st.Take(16));
+    int4* d_pi = static_cast<int4*>(st.Take(64));
+    EvalPoints(b, d_s0, d_cws, d_cs, d_ocw, d_x, d_y, d_pi, 1);
+    std::array<int4, 4> pi;
+    st.Back(&y, static_cast<const int4*>(d_y), 1);
+    st.Back(pi.data(), static_cast<const int4*>(d_pi), 4);
+    return pi;
+  }
+  // vdpf.cuh:268: pi = cs; for every per-point hash: pi[0..1] ^= H'(pi ^ pi_tilde)
+  void Prove(std::span<const std::array<int4, 4>> pi_tildes, std::span<const int4, 4> cs, std::array<int4, 4>& pi) const {
+    if constexpr (kEngine) {
+      if (!pi_tildes.empty() && detail::OnDevice(pi_tildes.data())) {  // the hashes are where EvalPoints left them: fold there
+        fss_amd_ctx* ctx = handle();
+        detail::Stage st(ctx, 64 + 64 + 64);
+        const int4* d_cs = st.Load(cs.data(), 4);
+        int4* d_pi = static_cast<int4*>(st.Take(64));
+        ProveChain(reinterpret_cast<const int4*>(pi_tildes.data()), static_cast<int64_t>(pi_tildes.size()), d_cs, d_pi);
+        st.Back(pi.data(), static_cast<const int4*>(d_pi), 4);
+        return;
+      }
+    }
+    Hash h = hash;
+    pi = {cs[0], cs[1], cs[2], cs[3]};
+    for (const std::array<int4, 4>& pt : pi_tildes) {
+      const std::array<int4, 4> in = util::Xor(std::span<const int4, 4>(pi), std::span<const int4, 4>(pt));
+      const std::array<int4, 2> out = h.Hash(std::span<const int4, 4>(in));
+      pi[0] = util::Xor(pi[0], out[0]);
+      pi[1] = util::Xor(pi[1], out[1]);
+    }
+  }
+  // vdpf.cuh:287: accept when the two parties' proofs agree
+  __host__ __device__ static bool Verify(std::span<const int4, 4> pi0, std::span<const int4, 4> pi1) {
+    bool same = true;
+    for (int i = 0; i < 4; ++i)
+      same = same && pi0[i].x == pi1[i].x && pi0[i].y == pi1[i].y && pi0[i].z == pi1[i].z && pi0[i].w == pi1[i].w;
+    return same;
+  }
+  static bool Verify(const int4 pi0[4], const int4 pi1[4]) { return Verify(std::span<const int4, 4>(pi0, 4), std::span<const int4, 4>(pi1, 4)); }
+  // vdpf.cuh:313: every x of the domain in index order, and the proof over all of them
+  void EvalAll(bool b, int4 s0, std::span<const Cw> cws, std::span<const int4, 4> cs, int4 ocw, std::span<int4> ys, std::array<int4, 4>& pi) const {
+    static_assert(in_bits <= 26, "a full-domain VDPF evaluation keeps 80 B per leaf on the device");
+    const size_t n = size_t(1) << in_bits;
+    if (cws.size() < static_cast<size_t>(kSlots) || ys.size() < n) throw Error("fss::Vdpf::EvalAll: cws / ys too small", FSS_AMD_EINVAL);
+    std::vector<In> xs(n);
+    for (size_t i = 0; i < n; ++i) xs[i] = static_cast<In>(i);
+    const bool direct = detail::DeviceView(ys.data()) != nullptr;
+    detail::Stage st(StageCtx(), 32 + sizeof(Cw) * kSlots + 64 + 32 + n * sizeof(In) + 32 + n * 64 + (direct ? 0 : n * 16) + 64);
+    const int4* d_s0 = st.Value(s0);
+    const Cw* d_cws = st.Load(cws.data(), kSlots);
+    const int4* d_cs = st.Load(cs.data(), 4);
+    const int4* d_ocw = st.Value(ocw);
+    const In* d_xs = st.Load(xs.data(), n);
+    int4* d_ys = st.Out(ys.data(), n);
+    int4* d_pt = static_cast<int4*>(st.Take(n * 64));
+    EvalPoints(b, d_s0, d_cws, d_cs, d_ocw, d_xs, d_ys, d_pt, static_cast<int64_t>(n));
+    if constexpr (kEngine) {
+      int4* d_pi = static_cast<int4*>(st.Take(64));
+      ProveChain(d_pt, static_cast<int64_t>(n), d_cs, d_pi);
+      st.Back(pi.data(), static_cast<const int4*>(d_pi), 4);
+    } else {
+      std::vector<std::array<int4, 4>> pts(n);
+      CheckHip(hipMemcpy(pts.data(), d_pt, n * 64, hipMemcpyDeviceToHost), "hipMemcpy (per-point hashes)");
+      Prove(std::span<const std::array<int4, 4>>(pts), cs, pi);
+    }
+    st.Back(ys.data(), static_cast<const int4*>(d_ys), n);
+  }
+
+  // ---- batched device forms (every pointer a device pointer; asynchronous on `stream`) --------------------------------
+  // Vdpf::Gen for nkeys keys; d_retry[k] = its return value (may be null).  d_cs: 4 int4 per key.
+  void GenBatch(Cw* d_cws, int4* d_cs, int4* d_ocws, const int4* d_s0s, const In* d_alphas, const int4* d_betas, int64_t nkeys,
+                int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
+    if constexpr (kEngine)
+      Check(fss_amd_vdpf_gen(handle(), in_bits, Group::kId, d_s0s, d_alphas, detail::XBytes<In>(), d_betas, nkeys, d_cws, d_cs, d_ocws,
+                             d_retry, stream), "fss_amd_vdpf_gen");
+    else
+      detail::LaunchThreads(detail::ThreadVdpfGenKernel<Vdpf, In>, nkeys, stream, *this, d_cws, reinterpret_cast<std::array<int4, 4>*>(d_cs),
+                            d_ocws, d_s0s, d_alphas, d_betas, nkeys, d_retry);
   }
   void GenLevelMajor(int4* cw_s, uint64_t* tr_bits, int4* d_cs, int4* d_ocws, const int4* d_s0s, const In* d_alphas,
                      const int4* d_betas, int64_t nkeys, int32_t* d_retry = nullptr, hipStream_t stream = 0) const {
@@ -1330,22 +1511,24 @@ class Vdpf {
                                        nkeys, cw_s, tr_bits, d_cs, d_ocws, d_retry, stream),
           "fss_amd_vdpf_gen_level_major");
   }
-  // Vdpf::Eval (vdpf.cuh:204-257) of one key at n points: ys[i], pi_tildes[4i..4i+3]
+  // Vdpf::Eval of one key at n points: ys[i], pi_tildes[4i..4i+3]
   void EvalPoints(bool b, const int4* d_s0, const Cw* d_cws, const int4* d_cs, const int4* d_ocw, const In* d_xs,
                   int4* d_ys, int4* d_pi_tildes, int64_t n, hipStream_t stream = 0) const {
-    Check(fss_amd_vdpf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_cs, d_ocw, d_xs,
-                                   detail::XBytes<In>(), n, d_ys, d_pi_tildes, stream), "fss_amd_vdpf_eval_points");
+    if constexpr (kEngine)
+      Check(fss_amd_vdpf_eval_points(handle(), in_bits, Group::kId, b, d_s0, d_cws, d_cs, d_ocw, d_xs, detail::XBytes<In>(), n, d_ys,
+                                     d_pi_tildes, stream), "fss_amd_vdpf_eval_points");
+    else
+      detail::LaunchThreads(detail::ThreadVdpfEvalKernel<Vdpf, In>, n, stream, *this, b, d_s0, d_cws, d_cs, d_ocw, d_xs, d_ys,
+                            reinterpret_cast<std::array<int4, 4>*>(d_pi_tildes), n);
   }
-  // Vdpf::Prove (vdpf.cuh:268-278) over the n hashes of one key (a sequential chain)
-  void Prove(const int4* d_pi_tildes, int64_t n, const int4* d_cs, int4* d_pi, hipStream_t stream = 0) const {
+  // Vdpf::Prove over the n hashes of one key, on the device (a sequential chain run by a single lane)
+  void ProveChain(const int4* d_pi_tildes, int64_t n, const int4* d_cs, int4* d_pi, hipStream_t stream = 0) const {
     Check(fss_amd_vdpf_prove(handle(), d_pi_tildes, n, d_cs, d_pi, stream), "fss_amd_vdpf_prove");
   }
   // ... and for nkeys keys with one evaluation each
   void ProveKeys(const int4* d_pi_tildes, const int4* d_cs, int64_t nkeys, int4* d_pis, hipStream_t stream = 0) const {
     Check(fss_amd_vdpf_prove_keys(handle(), d_pi_tildes, d_cs, nkeys, d_pis, stream), "fss_amd_vdpf_prove_keys");
   }
-  // Vdpf::Verify (vdpf.cuh:287-292), host copies of the two proofs
-  static bool Verify(const int4 pi0[4], const int4 pi1[4]) { return std::memcmp(pi0, pi1, 4 * sizeof(int4)) == 0; }
 };
 
 // ---------------------------------------------------------------- fss::gpu launchers
@@ -1468,16 +1651,33 @@ void DcfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const int4* cw
                           cw_s, cw_v, out_cw, xs, ys, nkeys);
 }
 
-// include/fss/vdpf point launchers (point_eval_gpu.cuh:389-396, :514-526), 64 tr bits per key
-template <int in_bits, typename Group, typename Prg, typename In>
-void VdpfRelayoutGpu(const typename Vdpf<in_bits, Group, Prg, In>::Cw* cws, int64_t nkeys, int4* cw_s, uint64_t* tr_bits,
+// The VDPF point launchers in the reference's own form (point_eval_gpu.cuh:389-396, :514-526): template arguments
+// <in_bits, Group, Prg, XorHash, Hash, In>, `uint32_t* extra` tr bits (in_bits <= 32), `const uint32_t* xs`,
+// `const std::array<int4, 4>* cs`, `int nkeys`.
+template <int in_bits, typename Group, typename Prg, typename XorHash, typename Hash, typename In>
+void VdpfRelayoutGpu(const typename Vdpf<in_bits, Group, Prg, XorHash, Hash, In>::Cw* cws, int nkeys, int4* cw_s, uint32_t* extra,
+                     hipStream_t stream = 0) {
+  static_assert(in_bits <= 32, "uint32_t extra holds 32 tr bits (as in the reference); use the uint64_t* tr_bits form");
+  Check(fss_amd_vdpf_relayout_u32(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, extra, stream), "fss_amd_vdpf_relayout_u32");
+}
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename XorHash, typename Hash, typename In, int pd>
+void VdpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint32_t* extra, const std::array<int4, 4>* cs, const int4* ocws,
+                      const uint32_t* xs, int4* ys, int4* pi, int nkeys, const Vdpf<in_bits, Group, Prg, XorHash, Hash, In, pd>& vdpf,
+                      hipStream_t stream = 0) {
+  static_assert(in_bits <= 32, "uint32_t extra / xs (as in the reference); use the uint64_t* tr_bits form for wider keys");
+  Check(fss_amd_vdpf_eval_keys_u32(vdpf.handle(), in_bits, Group::kId, b, seeds, cw_s, extra, cs, ocws, xs, 4, nkeys, ys, pi, stream),
+        "fss_amd_vdpf_eval_keys_u32");
+}
+// ... and the wide forms: 64 tr bits per key (two planes above 64), xs of the scheme's own In, 64-bit key counts
+template <int in_bits, typename Group, typename Prg, typename XorHash, typename Hash, typename In>
+void VdpfRelayoutGpu(const typename Vdpf<in_bits, Group, Prg, XorHash, Hash, In>::Cw* cws, int64_t nkeys, int4* cw_s, uint64_t* tr_bits,
                      hipStream_t stream = 0) {
   Check(fss_amd_vdpf_relayout(detail_gpu::AnyCtx(), in_bits, cws, nkeys, cw_s, tr_bits, stream), "fss_amd_vdpf_relayout");
 }
-template <int unroll = 4, int in_bits, typename Group, typename Prg, typename In>
+template <int unroll = 4, int in_bits, typename Group, typename Prg, typename XorHash, typename Hash, typename In, int pd>
 void VdpfEvalPointGpu(bool b, const int4* seeds, const int4* cw_s, const uint64_t* tr_bits, const int4* cs,
                       const int4* ocws, const In* xs, int4* ys, int4* pi, int64_t nkeys,
-                      const Vdpf<in_bits, Group, Prg, In>& vdpf, hipStream_t stream = 0) {
+                      const Vdpf<in_bits, Group, Prg, XorHash, Hash, In, pd>& vdpf, hipStream_t stream = 0) {
   Check(fss_amd_vdpf_eval_keys(vdpf.handle(), in_bits, Group::kId, b, seeds, cw_s, tr_bits, cs, ocws, xs,
                                detail::XBytes<In>(), nkeys, ys, pi, stream), "fss_amd_vdpf_eval_keys");
 }

@@ -84,6 +84,7 @@ class DeviceSet {
         Check(fss_amd_ctx_create(&m->ctx, d, spec.aes, spec.hash_key), "fss_amd_ctx_create");
         if (spec.prg == FSS_AMD_PRG_CHACHA) Check(fss_amd_ctx_set_prg(m->ctx, spec.prg, spec.nonce, spec.rounds), "fss_amd_ctx_set_prg");
         if (spec.mod) Check(fss_amd_ctx_set_uint_modulus(m->ctx, spec.mod), "fss_amd_ctx_set_uint_modulus");
+        Check(fss_amd_ctx_set_points_plan(m->ctx, FSS_AMD_POINTS_AUTO), "fss_amd_ctx_set_points_plan");  // as the value types' contexts
         CheckHip(hipStreamCreate(&m->stream), "hipStreamCreate");
         CheckHip(hipEventCreate(&m->ev0), "hipEventCreate");
         CheckHip(hipEventCreate(&m->ev1), "hipEventCreate");

@@ -17,8 +17,164 @@
 
 #include <array>
 #include <cstdint>
+#include <span>
+#include <tuple>
 
 namespace fss {
+
+// ---------------------------------------------------------------- the VDPF hashes (hash.cuh:15-30, hash/blake3.cuh, hash/sha256.cuh)
+// Hashable:    hash.Hash(span<const int4, 4>)        -> array<int4, 2>   (the paper's H': 64 B -> 32 B)
+// XorHashable: hash.Hash(tuple<int4, const int4>)    -> array<int4, 4>   (the paper's H: two digests, the first word's
+//              control bit 0 / 1 as domain separation)
+// Both hash types are written from the published algorithms (BLAKE3 spec section 2; FIPS 180-4), callable on host and
+// device.  The engine's kernels hash by themselves (fss_amd/csrc/fss_dev.hpp) from the same key material: the objects
+// here are what a caller constructs (`fss::hash::Blake3 h{iv}`), what Vdpf's per-thread device forms call, and what the
+// host side folds a proof with.
+namespace hash {
+namespace detail {
+__host__ __device__ constexpr uint32_t Rotr(uint32_t v, int n) { return v >> n | v << (32 - n); }
+// message word used at position i of round r: the spec's permutation applied r times
+struct Blake3Schedule {
+  uint8_t at[7][16];
+};
+constexpr Blake3Schedule BuildBlake3Schedule() {
+  constexpr uint8_t perm[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
+  Blake3Schedule s{};
+  for (int i = 0; i < 16; ++i) s.at[0][i] = static_cast<uint8_t>(i);
+  for (int r = 1; r < 7; ++r)
+    for (int i = 0; i < 16; ++i) s.at[r][i] = s.at[r - 1][perm[i]];
+  return s;
+}
+inline constexpr Blake3Schedule kBlake3Schedule = BuildBlake3Schedule();
+// The first eight output words of ONE keyed-hash compression of a single-block message (flags CHUNK_START | CHUNK_END |
+// ROOT | KEYED_HASH, counter 0): all either Hash needs.
+__host__ __device__ inline void Blake3Block(const uint32_t key[8], const uint32_t m[16], uint32_t block_len, uint32_t out[8]) {
+  uint32_t v[16] = {key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                    0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0u, 0u, block_len, 1u | 2u | 8u | 16u};
+  auto mix = [&v](int a, int b, int c, int d, uint32_t x, uint32_t y) {
+    v[a] += v[b] + x; v[d] = Rotr(v[d] ^ v[a], 16);
+    v[c] += v[d];     v[b] = Rotr(v[b] ^ v[c], 12);
+    v[a] += v[b] + y; v[d] = Rotr(v[d] ^ v[a], 8);
+    v[c] += v[d];     v[b] = Rotr(v[b] ^ v[c], 7);
+  };
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint8_t* w = kBlake3Schedule.at[r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mix(j, 4 + j, 8 + j, 12 + j, m[w[2 * j]], m[w[2 * j + 1]]);                                   // columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mix(j, 4 + (j + 1) % 4, 8 + (j + 2) % 4, 12 + (j + 3) % 4, m[w[8 + 2 * j]], m[w[9 + 2 * j]]);  // diagonals
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = v[i] ^ v[8 + i];
+}
+__host__ __device__ inline void Words(int4 v, uint32_t* w) {
+  w[0] = static_cast<uint32_t>(v.x); w[1] = static_cast<uint32_t>(v.y); w[2] = static_cast<uint32_t>(v.z); w[3] = static_cast<uint32_t>(v.w);
+}
+__host__ __device__ inline int4 Int4(const uint32_t* w) {
+  return int4{static_cast<int>(w[0]), static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[3])};
+}
+// SHA-256 compression of one 64-byte block given as sixteen big-endian words
+__host__ __device__ inline void Sha256Block(uint32_t h[8], const uint32_t block[16]) {
+  constexpr uint32_t k[64] = {
+      0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u,
+      0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu,
+      0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u,
+      0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+      0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u,
+      0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+      0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+  uint32_t w[64];
+  for (int i = 0; i < 16; ++i) w[i] = block[i];
+  for (int i = 16; i < 64; ++i)
+    w[i] = w[i - 16] + (Rotr(w[i - 15], 7) ^ Rotr(w[i - 15], 18) ^ w[i - 15] >> 3) + w[i - 7] + (Rotr(w[i - 2], 17) ^ Rotr(w[i - 2], 19) ^ w[i - 2] >> 10);
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+  for (int i = 0; i < 64; ++i) {
+    const uint32_t t1 = hh + (Rotr(e, 6) ^ Rotr(e, 11) ^ Rotr(e, 25)) + ((e & f) ^ (~e & g)) + k[i] + w[i];
+    const uint32_t t2 = (Rotr(a, 2) ^ Rotr(a, 13) ^ Rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+// SHA-256 of `nwords` little-endian words of message bytes (48 or 80 bytes here), digest as little-endian words of its bytes
+__host__ __device__ inline void Sha256Words(const uint32_t* msg, int nwords, uint32_t out[8]) {
+  uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+  const int blocks = (nwords * 4 + 9 + 63) / 64;
+  for (int bk = 0; bk < blocks; ++bk) {
+    uint32_t blk[16];
+    for (int i = 0; i < 16; ++i) {
+      const int wi = 16 * bk + i;
+      blk[i] = wi < nwords ? __builtin_bswap32(msg[wi]) : (wi == nwords ? 0x80000000u : 0u);
+    }
+    if (bk == blocks - 1) blk[15] = static_cast<uint32_t>(nwords) * 32u;  // the length in bits (below 2^32)
+    Sha256Block(h, blk);
+  }
+  for (int i = 0; i < 8; ++i) out[i] = __builtin_bswap32(h[i]);
+}
+}  // namespace detail
+
+// fss::hash::Blake3 (hash/blake3.cuh:24-172): keyed BLAKE3, the caller's 32-byte IV as the key.
+class Blake3 {
+ public:
+  int32_t iv[8];  // public: the engine's contexts are keyed by it
+  static constexpr int kEngineHashKind = 0;
+  __host__ __device__ explicit Blake3(std::span<const int4, 2> iv2) : iv{iv2[0].x, iv2[0].y, iv2[0].z, iv2[0].w, iv2[1].x, iv2[1].y, iv2[1].z, iv2[1].w} {}
+  __host__ __device__ explicit Blake3(const int4 iv2[2]) : Blake3(std::span<const int4, 2>(iv2, 2)) {}
+  // H': one compression of the 64-byte message, the first 32 bytes of its output (blake3.cuh:145-149)
+  __host__ __device__ std::array<int4, 2> Hash(std::span<const int4, 4> msg) const {
+    uint32_t k[8], m[16], o[8];
+    for (int i = 0; i < 8; ++i) k[i] = static_cast<uint32_t>(iv[i]);
+    for (int i = 0; i < 4; ++i) detail::Words(msg[i], m + 4 * i);
+    detail::Blake3Block(k, m, 64, o);
+    return {detail::Int4(o), detail::Int4(o + 4)};
+  }
+  // H: (a with control bit 0 | b) and (a with control bit 1 | b), 32-byte messages, 32 bytes each (blake3.cuh:160-171)
+  __host__ __device__ std::array<int4, 4> Hash(std::tuple<int4, const int4> msg) const {
+    uint32_t k[8], m[16] = {}, o0[8], o1[8];
+    for (int i = 0; i < 8; ++i) k[i] = static_cast<uint32_t>(iv[i]);
+    detail::Words(std::get<0>(msg), m);
+    detail::Words(std::get<1>(msg), m + 4);
+    m[3] &= ~1u;
+    detail::Blake3Block(k, m, 32, o0);
+    m[3] |= 1u;
+    detail::Blake3Block(k, m, 32, o1);
+    return {detail::Int4(o0), detail::Int4(o0 + 4), detail::Int4(o1), detail::Int4(o1 + 4)};
+  }
+  __host__ __device__ bool SameKey(const Blake3& o) const {
+    bool same = true;
+    for (int i = 0; i < 8; ++i) same = same && iv[i] == o.iv[i];
+    return same;
+  }
+};
+// fss::hash::Sha256 (hash/sha256.cuh:25-99): SHA-256 of the 16-byte key followed by the message.  Host-only in the
+// reference (OpenSSL EVP_Digest); plain code here, callable on the device as well.
+class Sha256 {
+ public:
+  int4 key;
+  static constexpr int kEngineHashKind = 1;
+  __host__ __device__ explicit Sha256(int4 key_) : key(key_) {}
+  __host__ __device__ std::array<int4, 2> Hash(std::span<const int4, 4> msg) const {  // sha256.cuh:43-60: 80 bytes
+    uint32_t m[20], o[8];
+    detail::Words(key, m);
+    for (int i = 0; i < 4; ++i) detail::Words(msg[i], m + 4 + 4 * i);
+    detail::Sha256Words(m, 20, o);
+    return {detail::Int4(o), detail::Int4(o + 4)};
+  }
+  __host__ __device__ std::array<int4, 4> Hash(std::tuple<int4, const int4> msg) const {  // sha256.cuh:69-90: two 48-byte messages
+    uint32_t m[12], o0[8], o1[8];
+    detail::Words(key, m);
+    detail::Words(std::get<0>(msg), m + 4);
+    detail::Words(std::get<1>(msg), m + 8);
+    m[7] &= ~1u;
+    detail::Sha256Words(m, 12, o0);
+    m[7] |= 1u;
+    detail::Sha256Words(m, 12, o1);
+    return {detail::Int4(o0), detail::Int4(o0 + 4), detail::Int4(o1), detail::Int4(o1 + 4)};
+  }
+  __host__ __device__ bool SameKey(const Sha256& o) const { return key.x == o.key.x && key.y == o.key.y && key.z == o.key.z && key.w == o.key.w; }
+};
+}  // namespace hash
+
 namespace thread {
 
 __host__ __device__ inline int4 X4(int4 a, int4 b) { return int4{a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
@@ -544,12 +700,17 @@ struct AesSchedules {
     for (int j = 0; j < 4; ++j) s->tag[j] = t[j];
     WaveLdsSync();
   }
-  // This wave's copy of the schedules, re-derived from the key bytes first if the slot holds something else.
+  // This wave's copy of the schedules, re-derived from the key bytes first if the slot holds something else.  nullptr
+  // when the lanes active NOW do not all hold the same key set -- `uniform` was decided when the objects were built
+  // (always true on the host), but lanes may since have picked between two objects (`odd ? sch_b : sch_a`), or objects
+  // built in divergent branches may meet after reconvergence: one slot cannot serve two key sets at once, and the
+  // callers then take the per-lane expansion.
   template <typename Tab>
   __device__ LdsWords SlotKeys(const Tab& tab) const {
     WaveKeySlot<mul>* s = MyKeySlot<mul>();
     uint32_t t[4];
     Tag(t);
+    if (!SameInAllLanes(t, 4)) return nullptr;
     const bool stale = !slot_ready || ((s->tag[0] ^ t[0]) | (s->tag[1] ^ t[1]) | (s->tag[2] ^ t[2]) | (s->tag[3] ^ t[3])) != 0;
     if (__ballot(stale) != 0) FillSlot([&tab](uint32_t b) { return tab.S(b); });
     slot_ready = true;
@@ -595,10 +756,11 @@ struct AesSchedules {
     uint32_t in[4], o[4];
     Words(seed, in);
     (void)ready;
-    if (uniform) {
+    bool shared_keys = uniform;  // one key set for the whole wave (else: every lane expands its own)
 #if defined(__HIP_DEVICE_COMPILE__)
-      if constexpr (kSlotted) {
-        const LdsWords k = ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab);
+    if constexpr (kSlotted) {
+      const LdsWords k = !uniform ? nullptr : (ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab));
+      if (k) {
 #pragma unroll
         for (int i = 0; i < mul; i += 2) {
           uint32_t o2[4];
@@ -608,7 +770,10 @@ struct AesSchedules {
         }
         return out;
       }
+      shared_keys = false;  // (slotted objects keep no schedules of their own)
+    }
 #endif
+    if (shared_keys) {
       if constexpr (mul == 2) {  // both children side by side (Gen of a DPF level)
         uint32_t o2[4];
         AesEncrypt2<BE>(tab, AesKeyWords{rk[0]}, KeyXor{rk[0], rk[1]}, in, o, o2);
@@ -642,23 +807,29 @@ struct AesSchedules {
     uint32_t in[4], o[4];
     Words(seed, in);
     (void)ready;
-    if (uniform) {
-      const uint32_t mask = right ? ~0u : 0u;
+    bool shared_keys = uniform;
 #if defined(__HIP_DEVICE_COMPILE__)
-      if constexpr (mul == 4) {
-        const LdsWords k = (ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab)) + (right ? 88 : 0);  // [sl, vl | sr, vr]: this lane's side, keys 0, 1 or 2, 3
-        uint32_t o2[4];
-        AesEncrypt2<BE>(tab, LdsKeyPerLane{k}, LdsKeyPerLane{k + 44}, in, o, o2);  // seed and value block side by side
-        out[0] = Mmo(o, seed);
-        out[1] = Mmo(o2, seed);
-        return out;
-      } else if constexpr (kSlotted) {
-        const LdsWords k = (ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab)) + (right ? 44 : 0);  // [left | right]: this lane's child
-        AesEncrypt<BE>(tab, LdsKeyPerLane{k}, in, o);
-        out[0] = Mmo(o, seed);
+    if constexpr (kSlotted) {
+      const LdsWords base = !uniform ? nullptr : (ready ? (LdsWords)(uintptr_t)ready : SlotKeys(tab));
+      if (base) {
+        if constexpr (mul == 4) {
+          const LdsWords k = base + (right ? 88 : 0);  // [sl, vl | sr, vr]: this lane's side, keys 0, 1 or 2, 3
+          uint32_t o2[4];
+          AesEncrypt2<BE>(tab, LdsKeyPerLane{k}, LdsKeyPerLane{k + 44}, in, o, o2);  // seed and value block side by side
+          out[0] = Mmo(o, seed);
+          out[1] = Mmo(o2, seed);
+        } else {
+          const LdsWords k = base + (right ? 44 : 0);  // [left | right]: this lane's child
+          AesEncrypt<BE>(tab, LdsKeyPerLane{k}, in, o);
+          out[0] = Mmo(o, seed);
+        }
         return out;
       }
+      shared_keys = false;
+    }
 #endif
+    if (shared_keys) {
+      const uint32_t mask = right ? ~0u : 0u;
 #pragma unroll
       for (int i = 0; i < half; ++i) {
         AesEncrypt<BE>(tab, AesKeySelect{rk[i], rk[half + i], mask}, in, o);
@@ -793,10 +964,13 @@ struct HtLevelMajorView {
 // ---------------------------------------------------------------- DPF (dpf.cuh:93-214)
 // Gen: both parties' paths towards alpha are walked together; per level the correction word cancels the seeds of
 // the child OFF the path and leaves the control bits differing exactly ON it.
-template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In a, int4 beta) {
-  int4 seed[2] = {WithCtl(s0s[0], false), WithCtl(s0s[1], false)};
-  bool t[2] = {false, true};
+// The in_bits levels (slots 0 .. in_bits - 1); on return seed[p] / t[p] are the parties' states at the leaf alpha.
+template <int in_bits, typename In, typename Prg>
+__device__ inline void DpfGenLevels(const Prg& prg, int4* slots, const int4 s0s[2], In a, int4 seed[2], bool t[2]) {
+  seed[0] = WithCtl(s0s[0], false);
+  seed[1] = WithCtl(s0s[1], false);
+  t[0] = false;
+  t[1] = true;
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
     const std::array<int4, 2> g[2] = {prg.Gen(seed[0]), prg.Gen(seed[1])};
@@ -817,6 +991,12 @@ __device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
     slots[2 * i] = WithCtl(s_cw, t_cw[0]);
     slots[2 * i + 1] = int4{t_cw[1], 0, 0, 0};  // whole slot written (dpf.cuh:147-153)
   }
+}
+template <int in_bits, typename Group, typename In, typename Prg>
+__device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In a, int4 beta) {
+  int4 seed[2];
+  bool t[2];
+  DpfGenLevels<in_bits, In>(prg, slots, s0s, a, seed, t);
   Group v = Group::From(WithCtl(beta, false)) + (-Group::From(seed[0])) + Group::From(seed[1]);
   if (t[1]) v = -v;
   slots[2 * in_bits] = v.Into();
@@ -826,8 +1006,11 @@ __device__ inline void DpfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
 // The walks below ask for the NEXT level's correction word before they start this level's cipher and apply it without a
 // branch: a thread's key is its own cache lines (key-major: 32 bytes per level), and a load issued where it is used
 // -- inside `if (t)` -- stalls the wave for a memory round trip per level with nothing of its own left to issue.
-template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 DpfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x) {
+// The walk down to the leaf x: on return s / t are the leaf's seed (control bit cleared) and control bit, `last` the word
+// of slot in_bits (the output correction word), requested a level ahead like every other slot.
+template <int in_bits, typename In, typename Prg, typename Key>
+__device__ __attribute__((always_inline)) inline void DpfWalkOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x, int4& s_out, bool& t_out,
+                                                                int4& last) {
   auto&& prg = PreparedPrg(prg_);
   int4 s = WithCtl(s0, false);
   bool t = b;
@@ -847,6 +1030,15 @@ __device__ inline int4 DpfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& ke
     cw = cw_next;
     flag = flag_next;
   }
+  s_out = s;
+  t_out = t;
+  last = cw;
+}
+template <int in_bits, typename Group, typename In, typename Prg, typename Key>
+__device__ inline int4 DpfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
+  int4 s, cw;
+  bool t;
+  DpfWalkOn<in_bits, In>(prg, b, s0, key, x, s, t, cw);
   Group y = Group::From(s);
   if (t) y = y + Group::From(cw);
   if (b) y = -y;
@@ -942,6 +1134,57 @@ __device__ inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& ke
 template <int in_bits, typename Group, typename In, typename Prg>
 __device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
   return DcfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
+}
+
+// ---------------------------------------------------------------- verifiable DPF (vdpf.cuh:103-257)
+// The DPF's levels with no output slot (a key is in_bits slots), then: cs = H(Pack(a), s0) ^ H(Pack(a), s1) over the two
+// parties' leaf seeds, the output correction word from the same seeds, and "retry" when the leaf control bits agree.
+// Eval is the DPF walk plus one H per point, corrected by cs where the control bit is set.
+template <typename In>
+__host__ __device__ inline int4 PackIn(In val) {  // util::Pack (util.cuh:47-64)
+  const unsigned __int128 v = static_cast<unsigned __int128>(val);
+  return int4{static_cast<int>(static_cast<uint32_t>(v)), sizeof(In) > 4 ? static_cast<int>(static_cast<uint32_t>(v >> 32)) : 0,
+              sizeof(In) > 8 ? static_cast<int>(static_cast<uint32_t>(v >> 64)) : 0,
+              sizeof(In) > 8 ? static_cast<int>(static_cast<uint32_t>(v >> 96)) : 0};
+}
+struct VdpfKeyView {  // in_bits slots; "slot in_bits" is the key's separate output correction word
+  const int4* slots;
+  int4 ocw;
+  int in_bits;
+  __device__ int4 S(int i) const { return i == in_bits ? ocw : slots[2 * i]; }
+  __device__ bool Flag(int i) const { return (slots[2 * i + 1].x & 0xff) != 0; }
+};
+template <int in_bits, typename Group, typename In, typename Prg, typename XorHash>
+__device__ inline int VdpfGen(const Prg& prg, XorHash xor_hash, int4* slots, std::array<int4, 4>& cs, int4& ocw, const int4 s0s[2], In a,
+                              int4 beta) {
+  int4 seed[2];
+  bool t[2];
+  DpfGenLevels<in_bits, In>(prg, slots, s0s, a, seed, t);
+  const int4 a_buf = PackIn(a);
+  const std::array<int4, 4> h0 = xor_hash.Hash(std::tuple<int4, const int4>{a_buf, seed[0]});
+  const std::array<int4, 4> h1 = xor_hash.Hash(std::tuple<int4, const int4>{a_buf, seed[1]});
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = X4(h0[j], h1[j]);
+  if (t[0] == t[1]) return 1;  // the caller resamples the seeds (vdpf.cuh:171-172); ocw is left as it was
+  Group v = Group::From(WithCtl(beta, false)) + (-Group::From(seed[0])) + Group::From(seed[1]);
+  if (t[1]) v = -v;
+  ocw = v.Into();
+  return 0;
+}
+template <int in_bits, typename Group, typename In, typename Prg, typename XorHash>
+__device__ inline std::array<int4, 4> VdpfEval(const Prg& prg, XorHash xor_hash, bool b, int4 s0, const int4* slots, const int4* cs, int4 ocw,
+                                               In x, int4& y) {
+  int4 s, cw;
+  bool t;
+  DpfWalkOn<in_bits, In>(prg, b, s0, VdpfKeyView{slots, ocw, in_bits}, x, s, t, cw);
+  Group g = Group::From(s);
+  if (t) g = g + Group::From(cw);
+  if (b) g = -g;
+  y = g.Into();
+  std::array<int4, 4> pi = xor_hash.Hash(std::tuple<int4, const int4>{PackIn(x), s});
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pi[j] = X4(pi[j], If(t, cs[j]));
+  return pi;
 }
 
 // ---------------------------------------------------------------- Half-Tree DPF (half_tree_dpf.cuh:68-231)

@@ -183,11 +183,11 @@ int main() {
     {  // ---- VDPF (ChaCha + BLAKE3): shares reconstruct, the two parties' proofs agree, a forged key is caught
       int before = errors;
       using VPrg = fss::prg::ChaCha<2>;
-      using VT = fss::Vdpf<kInBits, Group, VPrg, In>;
+      using VT = fss::Vdpf<kInBits, Group, VPrg, fss::hash::Blake3, fss::hash::Blake3, In>;
       const int nonce[2] = {0x12345678, (int)0x9abcdef0};
       const int4 iv[2] = {{0x11223344, 0x55667788, (int)0x99aabbccu, (int)0xddeeff00u},
                           {0x00112233, 0x44556677, (int)0x8899aabbu, (int)0xccddeeffu}};
-      VT vdpf{VPrg(nonce), fss::hash::Blake3(iv)};
+      VT vdpf{VPrg(nonce), fss::hash::Blake3(iv), fss::hash::Blake3(iv)};
       int4 *d_cs, *d_ocws, *d_pi0, *d_pi1, *d_pr0, *d_pr1;
       HIP_OK(hipMalloc(&d_cs, 4 * kN * sizeof(int4)));
       HIP_OK(hipMalloc(&d_ocws, kN * sizeof(int4)));

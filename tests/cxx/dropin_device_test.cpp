@@ -464,6 +464,35 @@ __global__ void AlternatingKeySetKernel(S sch_a, S sch_b, int4* ys /* [3][n] */,
   ys[n + tid] = sch_b.Eval(party, seeds[tid], cws_b + size_t(tid) * S::kSlots, xs[tid]);
   ys[2 * n + tid] = sch_a.Eval(party, seeds[tid], cws_a + size_t(tid) * S::kSlots, xs[tid]);
 }
+// Two HOST-constructed schemes (each `uniform` by construction) and a per-lane choice between them: the lanes of one wave
+// then hold different key sets although every object says its keys are wave-uniform -- one LDS key slot cannot serve both,
+// the cipher has to notice (the tag is not the same in all active lanes) and expand per lane.  Also: the objects built in
+// divergent branches on the device and used after the branches have met again.
+template <typename S, typename In>
+__global__ void ChooseSchemePerLaneKernel(S sch_a, S sch_b, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws_a,
+                                          const typename S::Cw* cws_b, const In* xs, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  const bool odd = tid & 1;
+  const S& sch = odd ? sch_b : sch_a;
+  ys[tid] = sch.Eval(party, seeds[tid], (odd ? cws_b : cws_a) + size_t(tid) * S::kSlots, xs[tid]);
+}
+template <typename S, typename Prg, typename In>
+__global__ void BuiltInBranchesKernel(int4* ys, bool party, const int4* seeds, const typename S::Cw* cws_a, const typename S::Cw* cws_b,
+                                      const In* xs, int n) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  const bool odd = tid & 1;
+  const unsigned char* keys[Prg::kMul];
+  for (int i = 0; i < Prg::kMul; ++i) keys[i] = kSetA[i];
+  Prg prg(keys);
+  if (odd) {  // each branch sees only lanes with ONE key set: both constructions find their keys "uniform"
+    for (int i = 0; i < Prg::kMul; ++i) keys[i] = kSetB[i];
+    prg = Prg(keys);
+  }
+  S sch{prg};
+  ys[tid] = sch.Eval(party, seeds[tid], (odd ? cws_b : cws_a) + size_t(tid) * S::kSlots, xs[tid]);
+}
 template <typename S, typename Prg>
 static void KeySetCase(const char* name) {
   const int before = g_fail;
@@ -491,25 +520,34 @@ static void KeySetCase(const char* name) {
   int4* d_yb = DeviceBuf<int4>(kN);
   int4* d_mixed = DeviceBuf<int4>(kN);
   int4* d_turns = DeviceBuf<int4>(3 * kN);
+  int4* d_chosen = DeviceBuf<int4>(kN);
+  int4* d_branch = DeviceBuf<int4>(kN);
   sch_a.GenBatch(d_ca, d_seeds, d_alphas, d_betas, kN);  // the engine's keys and (uniform-key kernels) reference shares
   sch_b.GenBatch(d_cb, d_seeds, d_alphas, d_betas, kN);
   EvalKeysKernel<S, uint16_t><<<kN / 128, 128>>>(sch_a, d_ya, false, d_seeds0, d_ca, d_xs, kN);
   EvalKeysKernel<S, uint16_t><<<kN / 128, 128>>>(sch_b, d_yb, false, d_seeds0, d_cb, d_xs, kN);
   PerLaneKeySetKernel<S, Prg, uint16_t><<<kN / 128, 128>>>(d_mixed, false, d_seeds0, d_ca, d_cb, d_xs, kN);
   AlternatingKeySetKernel<S, uint16_t><<<kN / 128, 128>>>(sch_a, sch_b, d_turns, false, d_seeds0, d_ca, d_cb, d_xs, kN);
+  ChooseSchemePerLaneKernel<S, uint16_t><<<kN / 128, 128>>>(sch_a, sch_b, d_chosen, false, d_seeds0, d_ca, d_cb, d_xs, kN);
+  BuiltInBranchesKernel<S, Prg, uint16_t><<<kN / 128, 128>>>(d_branch, false, d_seeds0, d_ca, d_cb, d_xs, kN);
   HIP_OK(hipDeviceSynchronize());
   auto ya = ToHost(d_ya, kN), yb = ToHost(d_yb, kN), mixed = ToHost(d_mixed, kN), turns = ToHost(d_turns, 3 * kN);
-  int differ = 0, bad_mixed = 0, bad_turns = 0;
+  auto chosen = ToHost(d_chosen, kN), branch = ToHost(d_branch, kN);
+  int differ = 0, bad_mixed = 0, bad_turns = 0, bad_chosen = 0, bad_branch = 0;
   for (int i = 0; i < kN; ++i) {
     differ += !Same(ya[i], yb[i]);
+    bad_chosen += !Same(chosen[i], i & 1 ? yb[i] : ya[i]);
+    bad_branch += !Same(branch[i], i & 1 ? yb[i] : ya[i]);
     bad_mixed += !Same(mixed[i], i & 1 ? yb[i] : ya[i]);
     bad_turns += !Same(turns[i], ya[i]) || !Same(turns[kN + i], yb[i]) || !Same(turns[2 * kN + i], ya[i]);
   }
   EXPECT(differ > kN / 2);  // the two key sets really give different shares
   EXPECT(bad_mixed == 0);
   EXPECT(bad_turns == 0);
+  EXPECT(bad_chosen == 0);  // two host-built schemes, one picked per lane
+  EXPECT(bad_branch == 0);  // PRGs built in divergent branches, used after they met again
   for (void* q : {(void*)d_seeds, (void*)d_seeds0, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_ca, (void*)d_cb, (void*)d_ya,
-                  (void*)d_yb, (void*)d_mixed, (void*)d_turns})
+                  (void*)d_yb, (void*)d_mixed, (void*)d_turns, (void*)d_chosen, (void*)d_branch})
     HIP_OK(hipFree(q));
   std::printf("AES-128-MMO  %s: key sets differing per lane, and alternating in one thread == the uniform-key kernels: %s\n", name,
               g_fail == before ? "ok" : "FAILED");

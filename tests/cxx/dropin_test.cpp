@@ -10,7 +10,11 @@
 //           :618 (DpfRelayoutGpu<in_bits, Group, Prg, uint> with uint32_t extra), :625 (DpfEvalPointGpu<1, ...>
 //           with uint32_t xs), :653-661 (Dcf), :688-697 (HalfTree), plus DpfEvalAllGpu<16> as
 //           check_evalall_gpu.cu:64-91 uses it, each compared with the host-signature methods and reconstructed.
+//   part 4  the verifiable DPF: fss::Vdpf<in_bits, Group, Prg, XorHash, Hash, In> {prg, xor_hash, hash} with Gen / Eval /
+//           Prove / Verify / EvalAll as src/vdpf_test.cu and samples/vdpf_cpu.cu call them, the per-thread device forms and
+//           VdpfRelayoutGpu / VdpfEvalPointGpu as src/bench_gpu.cu:170-205,704-735; fss::util::ResolveParDepth.
 // Exit code 0 and a final "OK" line on success.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -677,6 +681,241 @@ static void LaunchVersusRelease() {
   std::printf("launch loop against ReleaseStreamScratch on one stream: %s\n", g_fail == before ? "ok" : "FAILED");
 }
 
+
+// ---------------------------------------------------------------------------------------------- part 4: the verifiable DPF
+// Caller code in the reference's own syntax: the class with its seven template parameters and three public members,
+// Gen / Eval / Prove / Verify / EvalAll as src/vdpf_test.cu:28-110 and samples/vdpf_cpu.cu:22-80 call them, the per-thread
+// device forms as src/bench_gpu.cu:170-205 (VdpfGenKernel / VdpfEvalKernel), the launchers with their six explicit template
+// arguments, `uint32_t* extra`, `const uint32_t* xs` and `const array<int4, 4>* cs` as src/bench_gpu.cu:704-735.
+template <int in_bits, typename Group>
+using VdpfType = fss::Vdpf<in_bits, Group, fss::prg::ChaCha<2>, fss::hash::Blake3, fss::hash::Blake3, uint>;
+static const int4 kBlake3Iv[2] = {{0x11111111, 0x22222222, 0x33333333, 0x44444444},
+                                  {0x55555555, 0x66666666, 0x77777777, static_cast<int>(0x88888888u)}};
+__constant__ int kNonceDev[2] = {0x12345678, static_cast<int>(0x9abcdef0u)};
+__constant__ int4 kBlake3IvDev[2] = {{0x11111111, 0x22222222, 0x33333333, 0x44444444},
+                                     {0x55555555, 0x66666666, 0x77777777, static_cast<int>(0x88888888u)}};
+
+template <int in_bits, typename Group>
+__global__ void VdpfGenKernel(typename VdpfType<in_bits, Group>::Cw* cws, std::array<int4, 4>* cs, int4* ocws, const int4* seeds,
+                              const uint* alphas, const int4* betas, int* rets) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= kN) return;
+  fss::prg::ChaCha<2> prg(kNonceDev);
+  fss::hash::Blake3 xor_hash{std::span<const int4, 2>(kBlake3IvDev)};
+  fss::hash::Blake3 hash{std::span<const int4, 2>(kBlake3IvDev)};
+  VdpfType<in_bits, Group> vdpf{prg, xor_hash, hash};
+  int4 s0s_arr[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  std::span<const int4, 2> s0s(s0s_arr);
+  rets[tid] = vdpf.Gen(cws + tid * in_bits, cs[tid], ocws[tid], s0s, alphas[tid], betas[tid]);
+}
+template <int in_bits, typename Group>
+__global__ void VdpfEvalKernel(int4* ys, std::array<int4, 4>* pis, bool party, const int4* seeds, const typename VdpfType<in_bits, Group>::Cw* cws,
+                               const std::array<int4, 4>* cs, const int4* ocws, const uint* xs) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= kN) return;
+  fss::prg::ChaCha<2> prg(kNonceDev);
+  fss::hash::Blake3 xor_hash{std::span<const int4, 2>(kBlake3IvDev)};
+  fss::hash::Blake3 hash{std::span<const int4, 2>(kBlake3IvDev)};
+  VdpfType<in_bits, Group> vdpf{prg, xor_hash, hash};
+  int4 y;
+  std::span<const typename VdpfType<in_bits, Group>::Cw> cws_span(cws + tid * in_bits, in_bits);
+  std::span<const int4, 4> cs_span(cs[tid].data(), 4);
+  pis[tid] = vdpf.Eval(party, seeds[tid], cws_span, cs_span, ocws[tid], xs[tid], y);
+  ys[tid] = y;
+}
+
+template <typename V, typename In>
+static void VdpfHostFlow(V vdpf, In alpha, const char* tag) {  // src/vdpf_test.cu:59-110, samples/vdpf_cpu.cu:55-80
+  const int before = g_fail;
+  using Group = typename V::GroupType;
+  constexpr int n = V::kSlots;
+  int4 s0s[2];
+  typename V::Cw cws[n];
+  std::array<int4, 4> cs;
+  int4 ocw = kZero;
+  const int4 b_buf = I4(604, 0, 0, 0);
+  int ret, tries = 0;
+  srand(7);
+  do {
+    s0s[0] = {rand(), rand(), rand(), rand() & ~1};
+    s0s[1] = {rand(), rand(), rand(), rand() & ~1};
+    ret = vdpf.Gen(cws, cs, ocw, std::span<const int4, 2>(s0s, 2), alpha, b_buf);
+  } while (ret != 0 && ++tries < 64);
+  EXPECT(ret == 0);
+  std::vector<std::array<int4, 4>> pt0, pt1;
+  const In mask = static_cast<In>(n >= (int)sizeof(In) * 8 ? ~In(0) : (In(1) << n) - 1);
+  for (int i = 0; i < 24; ++i) {
+    const In x = i == 0 ? alpha : static_cast<In>((alpha + In(i) * 2654435761u) & mask);
+    int4 y0, y1;
+    pt0.push_back(vdpf.Eval(false, s0s[0], std::span<const typename V::Cw>(cws, n), std::span<const int4, 4>(cs), ocw, x, y0));
+    pt1.push_back(vdpf.Eval(true, s0s[1], std::span<const typename V::Cw>(cws, n), std::span<const int4, 4>(cs), ocw, x, y1));
+    EXPECT(Same(Recon<Group>(y0, y1), x == alpha ? Group::From(b_buf).Into() : kZero));
+    EXPECT(std::memcmp(pt0.back().data(), pt1.back().data(), 64) == 0);  // an honest key: the corrected hashes agree point by point
+  }
+  std::array<int4, 4> pi0, pi1;
+  vdpf.Prove(std::span<const std::array<int4, 4>>(pt0), std::span<const int4, 4>(cs), pi0);
+  vdpf.Prove(std::span<const std::array<int4, 4>>(pt1), std::span<const int4, 4>(cs), pi1);
+  EXPECT(V::Verify(std::span<const int4, 4>(pi0), std::span<const int4, 4>(pi1)));
+  if constexpr (V::kEngine) {  // the same fold on the device, the hashes left where a batched evaluation writes them
+    std::array<int4, 4>* d_pt = ToDevice(pt0.data(), pt0.size());
+    std::array<int4, 4> pid;
+    vdpf.Prove(std::span<const std::array<int4, 4>>(d_pt, pt0.size()), std::span<const int4, 4>(cs), pid);
+    EXPECT(std::memcmp(pid.data(), pi0.data(), 64) == 0);  // header hash on the host == engine hash on the device
+    HIP_OK(hipFree(d_pt));
+  }
+  {  // a forged key (one bit of a correction word): party 1's proof no longer matches
+    typename V::Cw bad[n];
+    std::memcpy(bad, cws, sizeof bad);
+    bad[n / 2].s.y ^= 0x100;
+    std::vector<std::array<int4, 4>> ptb;
+    for (int i = 0; i < 24; ++i) {
+      const In x = i == 0 ? alpha : static_cast<In>((alpha + In(i) * 2654435761u) & mask);
+      int4 y1;
+      ptb.push_back(vdpf.Eval(true, s0s[1], std::span<const typename V::Cw>(bad, n), std::span<const int4, 4>(cs), ocw, x, y1));
+    }
+    std::array<int4, 4> pib;
+    vdpf.Prove(std::span<const std::array<int4, 4>>(ptb), std::span<const int4, 4>(cs), pib);
+    EXPECT(!V::Verify(std::span<const int4, 4>(pi0), std::span<const int4, 4>(pib)));
+  }
+  if constexpr (n <= 12) {  // EvalAll (vdpf.cuh:313-361): every x in index order, and the proof over all of them
+    std::vector<int4> ys0(size_t(1) << n), ys1(size_t(1) << n);
+    std::array<int4, 4> pa0, pa1;
+    vdpf.EvalAll(false, s0s[0], std::span<const typename V::Cw>(cws, n), std::span<const int4, 4>(cs), ocw, std::span<int4>(ys0), pa0);
+    vdpf.EvalAll(true, s0s[1], std::span<const typename V::Cw>(cws, n), std::span<const int4, 4>(cs), ocw, std::span<int4>(ys1), pa1);
+    int bad = 0;
+    for (size_t x = 0; x < ys0.size(); ++x) bad += !Same(Recon<Group>(ys0[x], ys1[x]), x == alpha ? Group::From(b_buf).Into() : kZero);
+    EXPECT(bad == 0);
+    EXPECT(V::Verify(std::span<const int4, 4>(pa0), std::span<const int4, 4>(pa1)));
+    std::vector<std::array<int4, 4>> all;  // == Eval at every x, then Prove
+    for (size_t x = 0; x < ys0.size(); ++x) {
+      int4 y;
+      all.push_back(vdpf.Eval(false, s0s[0], std::span<const typename V::Cw>(cws, n), std::span<const int4, 4>(cs), ocw, static_cast<In>(x), y));
+      bad += !Same(y, ys0[x]);
+    }
+    std::array<int4, 4> pe;
+    vdpf.Prove(std::span<const std::array<int4, 4>>(all), std::span<const int4, 4>(cs), pe);
+    EXPECT(bad == 0 && std::memcmp(pe.data(), pa0.data(), 64) == 0);
+  }
+  std::printf("VDPF %s  Gen / Eval / Prove / Verify%s, host signatures: %s\n", tag, n <= 12 ? " / EvalAll" : "", g_fail == before ? "ok" : "FAILED");
+}
+
+template <int in_bits, typename Group>
+static void VdpfLaunchers() {  // src/bench_gpu.cu:704-735
+  const int before = g_fail;
+  using Vdpf = VdpfType<in_bits, Group>;
+  GpuData data(in_bits);
+  typename Vdpf::Cw* d_cws;
+  int4 *d_cw_s, *d_pi, *d_ys1;
+  uint32_t* d_extra;
+  std::array<int4, 4>* d_cs;
+  std::array<int4, 4>* d_pit;
+  int4* d_ocws;
+  int* d_rets;
+  HIP_OK(hipMalloc(&d_cws, sizeof(typename Vdpf::Cw) * in_bits * kN));
+  HIP_OK(hipMalloc(&d_cw_s, sizeof(int4) * in_bits * kN));
+  HIP_OK(hipMalloc(&d_extra, sizeof(uint32_t) * kN));
+  HIP_OK(hipMalloc(&d_pi, sizeof(int4) * kN * 4));
+  HIP_OK(hipMalloc(&d_pit, sizeof(int4) * kN * 4));
+  HIP_OK(hipMalloc(&d_cs, sizeof(std::array<int4, 4>) * kN));
+  HIP_OK(hipMalloc(&d_ocws, sizeof(int4) * kN));
+  HIP_OK(hipMalloc(&d_ys1, sizeof(int4) * kN));
+  HIP_OK(hipMalloc(&d_rets, sizeof(int) * kN));
+  HIP_OK(hipMemset(d_ocws, 0, sizeof(int4) * kN));
+  VdpfGenKernel<in_bits, Group><<<kN / 256, 256>>>(d_cws, d_cs, d_ocws, data.d_seeds, data.d_alphas, data.d_betas, d_rets);
+  HIP_OK(hipDeviceSynchronize());
+  fss::gpu::VdpfRelayoutGpu<in_bits, Group, fss::prg::ChaCha<2>, fss::hash::Blake3, fss::hash::Blake3, uint>(d_cws, kN, d_cw_s, d_extra);
+  HIP_OK(hipDeviceSynchronize());
+
+  fss::prg::ChaCha<2> prg(kNonce);
+  fss::hash::Blake3 xor_hash{std::span<const int4, 2>(kBlake3Iv)};
+  Vdpf vdpf{prg, xor_hash, xor_hash};
+  fss::gpu::VdpfEvalPointGpu<1, in_bits, Group, fss::prg::ChaCha<2>, fss::hash::Blake3, fss::hash::Blake3, uint>(
+      false, data.d_seeds0, d_cw_s, d_extra, d_cs, d_ocws, data.d_xs, data.d_ys, d_pi, kN, vdpf);
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<int4> y0(kN), y1(kN), yk(kN), pi0(4 * kN), pi1(4 * kN), pik(4 * kN), ocws(kN);
+  std::vector<int> rets(kN);
+  ToHost(y0.data(), data.d_ys, kN);
+  ToHost(pi0.data(), d_pi, 4 * kN);
+  ToHost(rets.data(), d_rets, kN);
+  ToHost(ocws.data(), d_ocws, kN);
+  fss::gpu::VdpfEvalPointGpu(true, data.d_seeds1, d_cw_s, d_extra, d_cs, d_ocws, data.d_xs, d_ys1, d_pi, kN, vdpf);  // arguments deduced
+  HIP_OK(hipDeviceSynchronize());
+  ToHost(y1.data(), d_ys1, kN);
+  ToHost(pi1.data(), d_pi, 4 * kN);
+  // the caller's own kernel with the per-thread Eval (src/bench_gpu.cu:188-205) on the key-major keys
+  VdpfEvalKernel<in_bits, Group><<<kN / 256, 256>>>(d_ys1, d_pit, false, data.d_seeds0, d_cws, d_cs, d_ocws, data.d_xs);
+  HIP_OK(hipDeviceSynchronize());
+  ToHost(yk.data(), d_ys1, kN);
+  ToHost(pik.data(), reinterpret_cast<const int4*>(d_pit), 4 * kN);
+  int bad = 0, retries = 0, bad_thread = 0;
+  for (int i = 0; i < kN; ++i) {
+    if (rets[i]) { ++retries; continue; }  // (t0 == t1 at the leaf: the caller would resample; 2^-1 of random keys never: Gen forces t0 != t1 off alpha only)
+    const int4 want = data.h_xs[i] == data.h_alphas[i] ? Group::From(data.h_betas[i]).Into() : kZero;
+    int4 wb = want;
+    wb.w &= ~1;
+    bad += !Same(Recon<Group>(y0[i], y1[i]), Group::From(wb).Into());
+    bad += std::memcmp(&pi0[4 * i], &pi1[4 * i], 64) != 0;
+    bad_thread += !Same(yk[i], y0[i]) || std::memcmp(&pik[4 * i], &pi0[4 * i], 64) != 0;
+  }
+  EXPECT(bad == 0);
+  EXPECT(bad_thread == 0);  // header BLAKE3 + per-thread walk on the device == the engine's kernel
+  EXPECT(retries < kN / 2);
+  {  // the host-signature Gen / Eval on key 0's inputs give the device's bytes
+    typename Vdpf::Cw cws[in_bits];
+    std::array<int4, 4> cs;
+    int4 ocw = kZero;
+    const int ret = vdpf.Gen(cws, cs, ocw, std::span<const int4, 2>(&data.h_seeds[0], 2), data.h_alphas[0], data.h_betas[0]);
+    std::vector<typename Vdpf::Cw> dev_cws(in_bits);
+    ToHost(dev_cws.data(), d_cws, in_bits);
+    std::array<int4, 4> dev_cs;
+    ToHost(&dev_cs, d_cs, 1);
+    EXPECT(ret == rets[0] && std::memcmp(cws, dev_cws.data(), sizeof cws) == 0 && std::memcmp(&cs, &dev_cs, 64) == 0);
+    if (ret == 0) {
+      EXPECT(Same(ocw, ocws[0]));
+      int4 y;
+      const std::array<int4, 4> pi = vdpf.Eval(false, data.h_seeds0[0], std::span<const typename Vdpf::Cw>(cws, in_bits), std::span<const int4, 4>(cs), ocw,
+                                               data.h_xs[0], y);
+      EXPECT(Same(y, y0[0]) && std::memcmp(pi.data(), &pi0[0], 64) == 0);
+    }
+  }
+  HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_cw_s)); HIP_OK(hipFree(d_extra)); HIP_OK(hipFree(d_pi)); HIP_OK(hipFree(d_pit)); HIP_OK(hipFree(d_cs));
+  HIP_OK(hipFree(d_ocws)); HIP_OK(hipFree(d_ys1)); HIP_OK(hipFree(d_rets));
+  std::printf("VDPF n=%d ChaCha<2> + Blake3  VdpfRelayoutGpu / VdpfEvalPointGpu in the reference's syntax, per-thread Gen / Eval kernels (%d retries): %s\n",
+              in_bits, retries, g_fail == before ? "ok" : "FAILED");
+}
+
+static void VdpfAll() {
+  EXPECT(fss::util::ResolveParDepth(3) == 3 && fss::util::ResolveParDepth(0) == 0);  // util.cuh:40-45
+  const int d = fss::util::ResolveParDepth(-1);
+  EXPECT(d >= 0 && d <= 12 && (1u << d) >= std::max(1u, std::thread::hardware_concurrency()));
+  {  // src/vdpf_test.cu:24-44: ChaCha<2> + Blake3 for both hashes, uint16_t inputs, the 127-bit group
+    using Uint127Group = fss::group::Uint<__uint128_t, (static_cast<__uint128_t>(1) << 127)>;
+    fss::prg::ChaCha<2> prg(kNonce);
+    fss::hash::Blake3 xor_hash(std::span<const int4, 2>(kBlake3Iv, 2)), hash_(std::span<const int4, 2>(kBlake3Iv, 2));
+    using V16 = fss::Vdpf<16, fss::group::Bytes, fss::prg::ChaCha<2>, fss::hash::Blake3, fss::hash::Blake3, uint16_t>;
+    VdpfHostFlow(V16{prg, xor_hash, hash_}, (uint16_t)107, "n=16 ChaCha<2> + Blake3, Bytes      ");
+    using V16u = fss::Vdpf<16, Uint127Group, fss::prg::ChaCha<2>, fss::hash::Blake3, fss::hash::Blake3, uint16_t>;
+    VdpfHostFlow(V16u{prg, xor_hash, hash_}, (uint16_t)107, "n=16 ChaCha<2> + Blake3, Uint<u128> ");
+    using V10 = fss::Vdpf<10, UintGroup, fss::prg::ChaCha<2>, fss::hash::Blake3, fss::hash::Blake3, uint16_t>;
+    VdpfHostFlow(V10{prg, xor_hash, hash_}, (uint16_t)599, "n=10 ChaCha<2> + Blake3, Uint<u64>  ");
+    // two different keys for H and H': one engine context cannot hold both -- refused, not silently hashed with one of them
+    const int4 other[2] = {{1, 2, 3, 4}, {5, 6, 7, 8}};
+    V10 two{prg, xor_hash, fss::hash::Blake3(std::span<const int4, 2>(other, 2))};
+    bool refused = false;
+    try { (void)two.handle(); } catch (const fss::Error& e) { refused = e.code == FSS_AMD_EINVAL; }
+    EXPECT(refused);
+  }
+  {  // samples/vdpf_cpu.cu:22: AES-128-MMO + Sha256 for both hashes
+    const unsigned char* keys2[2] = {k0, k1};
+    fss::prg::Aes128Mmo<2> prg(keys2);
+    const int4 hkey = I4(0x01234567, 0x89abcdef, 0x0f1e2d3c, 0x4b5a6978);
+    fss::hash::Sha256 xor_hash(hkey), hash_(hkey);
+    using VS = fss::Vdpf<12, fss::group::Bytes, fss::prg::Aes128Mmo<2>, fss::hash::Sha256, fss::hash::Sha256, uint16_t>;
+    VdpfHostFlow(VS{prg, xor_hash, hash_}, (uint16_t)2049, "n=12 Aes128Mmo<2> + Sha256, Bytes   ");
+  }
+  VdpfLaunchers<20, UintGroup>();
+  VdpfLaunchers<32, fss::group::Bytes>();
+}
 int main() {
   try {
     HostSignatureDpf();
@@ -696,6 +935,7 @@ int main() {
     OnAStream();
     PinnedHostBuffers();
     LaunchVersusRelease();
+    VdpfAll();
     fss::ReleaseEngines();
   } catch (const fss::Error& e) {
     std::fprintf(stderr, "fss::Error: %s\n", e.what());

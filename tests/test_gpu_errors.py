@@ -269,3 +269,38 @@ def test_grotto_pathwalk_reconstructs_only_with_itself():
     assert ((table[0] ^ table[1]) == want).all()
     mixed = walk[0] ^ table[1]
     assert (mixed != want).any(), "walk and table shares are documented as incompatible"
+
+
+def test_a_fresh_context_walks_plainly_and_auto_is_opt_in():
+    """The C ABI's own default is FSS_AMD_POINTS_PLAIN -- an eval call allocates nothing and waits for nothing, as the
+    reference's launchers (include/fss/point_eval_gpu.cuh:448-460) -- and FSS_AMD_POINTS_AUTO is an explicit choice of
+    the context (fss_amd_ctx_set_points_plan); the Python Engine makes it at creation.  Same outputs either way."""
+    import fss_amd
+    from fss_amd import _lib
+    L = _lib.lib()
+    L.fss_amd_last_kernel.restype = C.c_char_p
+    h = C.c_void_p()
+    keys = b"".join(bytes(k) for k in fss_amd.engine.DEFAULT_AES_KEYS)
+    assert L.fss_amd_ctx_create(C.byref(h), 0, C.c_char_p(keys), None) == 0
+    try:
+        n = 1 << 19
+        gen = torch.Generator(device="cuda").manual_seed(60)
+        xs = torch.randint(-2**31, 2**31, (n,), dtype=torch.int32, device="cuda", generator=gen)
+        seed = torch.randint(-2**31, 2**31, (4,), dtype=torch.int32, device="cuda", generator=gen)
+        cws = torch.randint(-2**31, 2**31, (33, 8), dtype=torch.int32, device="cuda", generator=gen)
+        ys = [torch.empty((n, 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+        P = lambda t: C.c_void_p(t.data_ptr())
+        free0 = torch.cuda.mem_get_info()[0]
+        g, b = C.c_int(0), C.c_int(0)
+        assert L.fss_amd_dpf_eval_points(h, 32, 4, 0, P(seed), P(cws), P(xs), 4, n, P(ys[0]), None) == 0
+        assert L.fss_amd_last_kernel(h, C.byref(g), C.byref(b)) == b"dpf_eval_points"
+        torch.cuda.synchronize()
+        assert free0 - torch.cuda.mem_get_info()[0] < (1 << 20)  # nothing allocated by the call
+        assert L.fss_amd_ctx_set_points_plan(h, 0) == 0  # FSS_AMD_POINTS_AUTO
+        assert L.fss_amd_dpf_eval_points(h, 32, 4, 0, P(seed), P(cws), P(xs), 4, n, P(ys[1]), None) == 0
+        assert L.fss_amd_last_kernel(h, C.byref(g), C.byref(b)) == b"dpf_eval_points_shared"
+        torch.cuda.synchronize()
+        assert torch.equal(ys[0], ys[1])
+        assert fss_amd.Engine(0).points_plan == "auto"
+    finally:
+        L.fss_amd_ctx_destroy(h)

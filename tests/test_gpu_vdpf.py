@@ -121,3 +121,39 @@ def test_vdpf_python_surface(veng, O):
     bad[5, 1] ^= 4
     pb = v.eval_points(1, s0s[1], bad, cs, ocw, xs)[1]
     assert not v.verify(v.prove(out[0][1], cs), v.prove(pb, cs))
+
+
+@pytest.mark.parametrize("n", [1, 20, 32])
+def test_vdpf_u32_extra_entry_points_vs_u64(veng, n):
+    """fss_amd_vdpf_relayout_u32 / fss_amd_vdpf_eval_keys_u32: the reference's own `uint32_t* extra` packing of the tr bits
+    (VdpfRelayoutGpu / VdpfEvalPointGpu, point_eval_gpu.cuh:389-396, :514-526; in_bits <= 32) gives the outputs and hashes
+    of the 64-bit form; in_bits = 33 is refused."""
+    import ctypes as C
+    from fss_amd import _lib
+    L, h = _lib.lib(), veng._h
+    rng = SplitMix64(4400 + n)
+    nkeys, g = 333, G.U64
+    s0s = np.stack([np.stack([rng.i4(clear_lsb=False), rng.i4(clear_lsb=False)]) for _ in range(nkeys)])
+    alphas = [rand_below(rng, n) for _ in range(nkeys)]
+    xs = [alphas[i] if i % 2 else rand_below(rng, n) for i in range(nkeys)]
+    betas = np.stack([rng.i4(clear_lsb=False) for _ in range(nkeys)])
+    cws, cs, ocws, _ = veng.vdpf_gen(n, g, T(s0s), xs_tensor(alphas, n), T(betas))
+    keys = veng.vdpf_relayout(n, cws)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    cw_s = torch.empty_like(keys.cw_s)
+    extra = torch.empty((nkeys,), dtype=torch.int32, device="cuda")
+    _lib.check(L.fss_amd_vdpf_relayout_u32(h, n, P(cws), nkeys, P(cw_s), P(extra), None), "vdpf_relayout_u32")
+    torch.cuda.synchronize()
+    assert torch.equal(cw_s, keys.cw_s)
+    assert (extra.cpu().numpy().view(np.uint32).astype(np.uint64) == keys.tr_bits.cpu().numpy().view(np.uint64)).all()
+    xt = xs_tensor(xs, n).cuda()
+    for b in (0, 1):
+        seeds = T(np.ascontiguousarray(s0s[:, b])).cuda()
+        ys, pis = veng.vdpf_eval_keys(keys, g, b, seeds, cs, ocws, xt)
+        ys2, pis2 = torch.empty_like(ys), torch.empty_like(pis)
+        _lib.check(L.fss_amd_vdpf_eval_keys_u32(h, n, g, b, P(seeds), P(cw_s), P(extra), P(cs), P(ocws), P(xt), 4, nkeys, P(ys2), P(pis2),
+                                                None), "vdpf_eval_keys_u32")
+        torch.cuda.synchronize()
+        assert torch.equal(ys, ys2) and torch.equal(pis, pis2)
+    assert L.fss_amd_vdpf_relayout_u32(h, 33, P(cws), 1, P(cw_s), P(extra), None) == -1
+    assert L.fss_amd_vdpf_eval_keys_u32(h, 33, g, 0, P(cw_s), P(cw_s), P(extra), P(cs), P(ocws), P(xt), 8, 1, P(cw_s), P(cw_s), None) == -1
