@@ -19,11 +19,23 @@ __global__ __launch_bounds__(1024) void prg_gen_kernel(const DevCtx K, const uin
     if (i >= n) continue;
     uint4 s = seeds[i];
     uint32_t in[4] = {s.x, s.y, s.z, s.w};
-    uint32_t o[4][4];
-    prg_raw(L, c, mul, in, o);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < mul) out[i * mul + j] = make_uint4(o[j][0], o[j][1], o[j][2], o[j][3]);
+    // one path per mul (wave-uniform), each with its own named outputs: a shared o[4][4] that the three paths fill to
+    // different depths stayed a stack object (16 B of scratch per lane with AES, 40 B with ChaCha)
+    auto put = [&](int j, const uint32_t o[4]) { out[i * mul + j] = make_uint4(o[0], o[1], o[2], o[3]); };
+    if (mul == 1) {
+      uint32_t o0[4];
+      if constexpr (std::is_same_v<LT, Lds>) aes_mmo<false>(L, c->rk[0], 0, in, o0);
+      else prg_hash(L, c, in, o0);
+      put(0, o0);
+    } else if (mul == 2) {
+      uint32_t o0[4], o1[4];
+      prg_gen2(L, c, in, o0, o1);
+      put(0, o0); put(1, o1);
+    } else {
+      uint32_t o0[4], o1[4], o2[4], o3[4];
+      prg_gen4(L, c, in, o0, o1, o2, o3);
+      put(0, o0); put(1, o1); put(2, o2); put(3, o3);
+    }
   }
 }
 

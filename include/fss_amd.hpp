@@ -544,6 +544,113 @@ class Aes128Mmo {
   }
 };
 
+// fss::prg::Aes128MmoWide<mul>: the opt-in wide form of Aes128Mmo for callers who write their own kernels -- the engine's
+// own four-table, rotate-free LDS layout (128 KiB, fss_amd_thread.hpp: WideAesTables) behind the same Gen(int4) /
+// GenSide, the same outputs bit for bit, 1.3 - 1.45 x the rate of the default 32 KiB one-table form on key-major keys
+// (DPF n = 32, 2^21 keys: 2.5 G evals/s one key per thread, 2.6 G in a grid-stride loop, against 1.9 G; DCF 1.45 - 1.5 G
+// against 1.0 G; profiles/r6/dropin_device_test.txt).  The default types stay what they are because this one dictates the
+// caller's launch:
+//   * workgroups of exactly 1024 threads (128 KiB of LDS = one workgroup per CU; anything else is refused at run time:
+//     the kernel traps);
+//   * the kernel calls  fss::prg::Aes128MmoWide<mul>::InitWorkgroup();  once, from EVERY thread, in uniform control flow,
+//     before the first Gen / Eval: the tables are filled cooperatively behind one workgroup barrier (a Gen that does
+//     not find them traps);
+//   * the object is built on the HOST and reaches the kernel by value, as a kernel argument (alone or inside its scheme:
+//     `kernel<<<n / 1024, 1024>>>(dpf, ...)` with `dpf.Eval(...)` called on the parameter itself): its round keys are
+//     read with scalar loads from where the object lives, a round at a time.  A copy in a local variable still works but
+//     reads them from the copy's memory with vector loads.
+// Its walks also read a key-major key a 128-byte line at a time (thread::KeyMajorLines: every line fetched once instead of
+// 1.8 times), which takes 20 - 32 more registers.  Best shape: as many workgroups as the chip has CUs and a grid-stride
+// loop over the keys (the tables are filled once per workgroup and no CU waits for a workgroup's last wave before the next
+// workgroup may start).
+// Pick it when the kernel is yours to shape (block size 1024, 110 registers per thread to spare); keep Aes128Mmo when the
+// PRG has to work inside kernels with other block sizes, their own LDS, or divergent first calls.
+// Call-site shape: src/bench_gpu.cu:100-138 (tables prepared by the block, then one Eval per thread).
+template <int mul>
+class Aes128MmoWide {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+  static constexpr int kPairs = mul == 4 ? 2 : 1;
+  static constexpr int kPerRound = mul == 1 ? 4 : 8;
+  uint32_t keyw_[mul][4];                 // the raw keys (little-endian words), for Describe
+  uint32_t sel_[kPairs][11 * kPerRound];  // per round A[4] (, D[4] = (A ^ B)[4]): mul 2: {k0, k0^k1}; mul 4: {k0, k0^k2}, {k1, k1^k3}
+  // (no mutable members: the object is read in place from the kernel-argument segment, which a written-to copy would end)
+
+  void SetKeys(const unsigned char* const* keys) {
+    uint32_t rk[mul][44];
+    for (int i = 0; i < mul; ++i) {
+      for (int j = 0; j < 4; ++j)
+        keyw_[i][j] = static_cast<uint32_t>(keys[i][4 * j]) | static_cast<uint32_t>(keys[i][4 * j + 1]) << 8 |
+                      static_cast<uint32_t>(keys[i][4 * j + 2]) << 16 | static_cast<uint32_t>(keys[i][4 * j + 3]) << 24;
+      thread::AesExpandKeyWords<false>(keys[i], rk[i], [](uint32_t b) { return static_cast<uint32_t>(thread::kAes.sbox[b]); });
+    }
+    for (int r = 0; r < 11; ++r)
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (mul == 1) {
+          sel_[0][4 * r + j] = rk[0][4 * r + j];
+        } else if constexpr (mul == 2) {
+          sel_[0][8 * r + j] = rk[0][4 * r + j];
+          sel_[0][8 * r + 4 + j] = rk[0][4 * r + j] ^ rk[1][4 * r + j];
+        } else {
+          sel_[0][8 * r + j] = rk[0][4 * r + j];
+          sel_[0][8 * r + 4 + j] = rk[0][4 * r + j] ^ rk[2][4 * r + j];
+          sel_[1][8 * r + j] = rk[1][4 * r + j];
+          sel_[1][8 * r + 4 + j] = rk[1][4 * r + j] ^ rk[3][4 * r + j];
+        }
+      }
+  }
+
+ public:
+  Aes128MmoWide(std::span<AesKeyCtx*, mul> ctxs) {
+    const unsigned char* keys[mul];
+    for (int i = 0; i < mul; ++i) keys[i] = ctxs[i]->key;
+    SetKeys(keys);
+  }
+  explicit Aes128MmoWide(const unsigned char* const keys[mul]) { SetKeys(keys); }
+  static std::array<AesKeyCtx*, mul> CreateCtxs(const unsigned char* keys[mul]) { return Aes128Mmo<mul>::CreateCtxs(keys); }
+  static void FreeCtxs(std::span<AesKeyCtx*, mul> ctxs) { Aes128Mmo<mul>::FreeCtxs(ctxs); }
+
+  // Device, every thread of the 1024-thread workgroup, uniform control flow, once per kernel before the first Gen / Eval.
+  __device__ static void InitWorkgroup() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    thread::WideTablesInit();
+#endif
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  __device__ __attribute__((always_inline)) thread::PreparedWide<mul> Prepared() const {
+    return thread::PreparedWide<mul>{thread::WideTab::Make(), sel_[0], sel_[kPairs - 1], thread::PreparedWide<mul>::PublishedLevels()};
+  }
+#endif
+  __device__ __attribute__((always_inline)) std::array<int4, mul> Gen(int4 seed) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return Prepared().Gen(seed);
+#else
+    (void)seed;
+    return {};
+#endif
+  }
+  __host__ std::array<int4, mul> Gen(int4 seed) const { return detail::GenOne(*this, seed); }
+  __device__ __attribute__((always_inline)) std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return Prepared().GenSide(seed, right);
+#else
+    (void)seed;
+    (void)right;
+    return {};
+#endif
+  }
+  // the per-thread walks read key-major keys a cache line at a time with this PRG (thread::KeyMajorLines)
+  static constexpr bool kKeyMajorLines = true;
+  // The engine runs the same function with these keys: schemes over it take the batched entry points and launchers too.
+  static constexpr int kMul = mul;
+  void Describe(detail::Spec& s) const {
+    s.prg = FSS_AMD_PRG_AES128_MMO;
+    for (int i = 0; i < mul; ++i)
+      for (int j = 0; j < 16; ++j) s.aes[16 * i + j] = static_cast<uint8_t>(keyw_[i][j >> 2] >> (8 * (j & 3)));
+  }
+};
+
 // fss::prg::Aes128MmoRaw<mul>(const uint8_t keys[][16]) (include/fss/prg/aes128_mmo_raw.cuh:39-110): the reference's
 // host-only AES-NI form of the same function, constructed from the key bytes directly.  Here it IS Aes128Mmo with that
 // constructor: Gen on the host goes to the engine, schemes over it are engine schemes, and on the device it works too.
@@ -787,6 +894,7 @@ namespace prg {
 static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Aes128Mmo<4>, 4>);
 static_assert(Prgable<Aes128Soft<1>, 1> && Prgable<Aes128Soft<2>, 2> && Prgable<Aes128Soft<4>, 4>);
 static_assert(Prgable<Aes128MmoRaw<1>, 1> && Prgable<Aes128MmoRaw<2>, 2> && Prgable<Aes128MmoRaw<4>, 4>);
+static_assert(Prgable<Aes128MmoWide<1>, 1> && Prgable<Aes128MmoWide<2>, 2> && Prgable<Aes128MmoWide<4>, 4>);
 static_assert(Prgable<Aes128SoftBanked<1>, 1> && Prgable<Aes128SoftBanked<2>, 2> && Prgable<Aes128SoftBanked<4>, 4>);
 static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
 }  // namespace prg

@@ -878,7 +878,317 @@ struct PreparedAes {
     return ks.GenSide(tab, seed, right, keys);
   }
 };
+// ---------------------------------------------------------------- the engine's table layout for per-thread callers (opt-in)
+// fss::prg::Aes128MmoWide (include/fss_amd.hpp): the four-table, rotate-free layout of the engine's own kernels
+// (fss_amd/csrc/fss_dev.hpp) behind the per-thread Gen / GenSide.  T_t = Te0 rotated left by 8 t bits, every entry
+// repeated once per LDS bank:
+//   words [0, 16384):      row i (64 words) = [T0[i] x 32 | T1[i] x 32]
+//   words [16384, 32768):  row i            = [T2[i] x 32 | T3[i] x 32]
+// so the byte address of a lookup is  region << 16 | index << 8 | half << 7 | (lane & 31) << 2  -- formed by ONE v_perm
+// (or one v_bitop3 for byte 1) that drops the state byte into bits 8..15 of a per-lane constant -- no bank conflicts, and
+// no rotate instructions in the round (twelve per round in the one-table form above: what bounds that form is VALU
+// issue, include/fss_amd_thread.hpp's own counters in profiles/r5/dropin_device_pmc.txt).  The price is what makes it
+// opt-in: 128 KiB of LDS, i.e. ONE workgroup per CU, which pays only with 1024-thread workgroups; the table sits at LDS
+// address 0 (the byte insertion needs the base's low 17 bits clear) and is filled cooperatively behind a workgroup
+// barrier -- the caller's kernel says so explicitly (WideTablesInit, every thread, uniform control flow).
+// Round keys: scalar loads straight from where the PRG object lives -- the kernel-argument segment for an object passed
+// to the kernel by value -- one round at a time (the load's address carries a dependency on a value of the round, or
+// the compiler hoists all 88 / 176 words out of the level loop and spills them).
+constexpr int kWideTeWords = 32768;
+struct alignas(131072) WideAesTables {
+  uint32_t te[kWideTeWords];
+};
+struct WideAesMarker {
+  uint32_t w[4];
+};
+__device__ inline WideAesTables* WorkgroupWideTables() {
+  __shared__ WideAesTables tab;
+  return &tab;
+}
+__device__ inline WideAesMarker* WorkgroupWideMarker() {
+  __shared__ WideAesMarker m;
+  return &m;
+}
+// levels walked by each of the workgroup's sixteen waves (PreparedWide::LevelDone), zeroed by WideTablesInit
+__device__ inline uint32_t* WorkgroupWideProgress() {
+  __shared__ __attribute__((aligned(16))) uint32_t prog[16];
+  return prog;
+}
+__device__ inline void WideMarkerWant(uint32_t want[4]) {
+  uint32_t nonce[2];
+  LaunchNonce(nonce);
+  want[0] = 0x66737377u; want[1] = 0x69646554u; want[2] = nonce[0]; want[3] = nonce[1];
+}
+// Every thread of the workgroup, once, in uniform control flow, before the first Gen / Eval of a wide PRG.
+__device__ inline void WideTablesInit() {
+  WideAesTables* t = WorkgroupWideTables();
+  const unsigned tid = LinearTid(), n = blockDim.x * blockDim.y * blockDim.z;
+  // refused, loudly: a workgroup of another size (128 KiB of LDS per workgroup = one per CU: 256 threads would leave
+  // three quarters of the CU's wave slots empty), or a table that the linker did not place at LDS address 0
+  if (n != 1024 || static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) uint32_t*)(t->te))) != 0u)
+    __builtin_trap();
+  // word tid + 1024 k holds entry ((tid >> 6) + 16 k) & 255 of table ((k >> 4) << 1) | ((tid >> 5) & 1): sixteen distinct
+  // entries per lane, requested together
+  const int odd = (tid >> 5) & 1;
+  uint32_t e[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) e[k] = kAes.te0[((tid >> 6) + 16 * k) & 255];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int tbl = ((k >> 4) << 1) | odd;
+    t->te[tid + 1024 * k] = RotL(e[k & 15], (8 * tbl) & 31);
+  }
+  if (tid == 0) {
+    uint32_t want[4];
+    WideMarkerWant(want);
+    WideAesMarker* m = WorkgroupWideMarker();
+    m->w[0] = want[0]; m->w[1] = want[1]; m->w[2] = want[2]; m->w[3] = want[3];
+  }
+  if (tid < 16) WorkgroupWideProgress()[tid] = 0;
+  __syncthreads();
+}
+// a constant the compiler must keep in a vector register (a literal or scalar operand puts the consuming instruction
+// in the slow issue class)
+__device__ inline uint32_t InVgpr(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+// zero in a scalar register that the compiler must treat as depending on `dep`
+__device__ inline uint32_t ZeroAfter(uint32_t dep) {
+  uint32_t z = 0;
+  asm volatile("" : "+s"(z) : "v"(dep));
+  return z;
+}
+struct WideTab {
+  uint32_t lo[4];  // per table: region << 16 | half << 7 | (lane & 31) << 2
+  uint32_t m_ff00, m_00ff, m_ff0000, m_ffff;
+  // Refuses (traps) unless WideTablesInit ran in this launch for this workgroup.  (No per-object "already checked" flag:
+  // a PRG object that is written to stops being readable in place from the kernel-argument segment.)
+  __device__ static WideTab Make() {
+    {
+      uint32_t want[4];
+      WideMarkerWant(want);
+      const WideAesMarker* m = WorkgroupWideMarker();
+      if (((m->w[0] ^ want[0]) | (m->w[1] ^ want[1]) | (m->w[2] ^ want[2]) | (m->w[3] ^ want[3])) != 0) __builtin_trap();  // WideTablesInit() was not called
+    }
+    WideTab L;
+    const uint32_t l4 = (__lane_id() & 31u) << 2;
+    L.lo[0] = l4; L.lo[1] = l4 | 0x80u; L.lo[2] = l4 | 0x10000u; L.lo[3] = l4 | 0x10080u;
+    L.m_ff00 = InVgpr(0xff00u); L.m_00ff = InVgpr(0xffu); L.m_ff0000 = InVgpr(0xff0000u); L.m_ffff = InVgpr(0xffffu);
+    return L;
+  }
+  // address of T_T[byte K of w]
+  template <int K, int T>
+  __device__ uint32_t Addr(uint32_t w) const {
+    if constexpr (K == 1) return __builtin_amdgcn_bitop3_b32(w, m_ff00, lo[T], 0xEA);  // (w & 0xff00) | lo: byte 1 already sits at index << 8
+    else return __builtin_amdgcn_perm(w, lo[T], 0x0c020000u | ((4u + K) << 8));       // bytes: lo[0], byte K of w, lo[2], 0
+  }
+  __device__ static uint32_t At(uint32_t addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(static_cast<uintptr_t>(addr));
+  }
+  template <int K, int T>
+  __device__ uint32_t Lk(uint32_t w) const { return At(Addr<K, T>(w)); }
+};
+// Round keys of ONE schedule (44 words) or of a per-lane choice between two (per round: A[4] then D[4] = (A ^ B)[4]; the
+// lane's key is A ^ (mask & D)), read a round at a time through a pointer the compiler sees as depending on the round.
+template <bool SEL>
+struct WideKeys {
+  static constexpr int kPerRound = SEL ? 8 : 4;
+  const uint32_t* base;
+  __device__ const uint32_t* Round(int r, uint32_t dep) const { return base + kPerRound * r + ZeroAfter(dep); }
+};
+__device__ inline uint32_t Select(uint32_t m, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA); }  // m ? a : b, bitwise
+
+// out = AES_k(in) ^ in  on the wide tables; SEL: k = A ^ (mask & D) per lane.
+template <bool SEL>
+__device__ __attribute__((always_inline)) inline void WideAesMmo(const WideTab& L, WideKeys<SEL> key, uint32_t mask, const uint32_t in[4],
+                                                                 uint32_t out[4]) {
+  constexpr int RS = WideKeys<SEL>::kPerRound;
+  uint32_t s[4], kc[RS];
+  {
+    const uint32_t* k0 = key.Round(0, in[0]);
+    const uint32_t* k1 = key.Round(1, in[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = SEL ? Xor3(in[j], k0[j], mask & k0[4 + j]) : (in[j] ^ k0[j]);
+#pragma unroll
+    for (int j = 0; j < RS; ++j) kc[j] = k1[j];
+  }
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    uint32_t a[4], b[4], c[4], d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = L.Lk<0, 0>(s[j]);
+      b[j] = L.Lk<1, 1>(s[(j + 1) & 3]);
+      c[j] = L.Lk<2, 2>(s[(j + 2) & 3]);
+      d[j] = L.Lk<3, 3>(s[(j + 3) & 3]);
+    }
+    const uint32_t* kn = key.Round(r + 1, a[0]);  // the next round's keys: requested after this round's lookups, used a round later
+    uint32_t knx[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) knx[j] = kn[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t x = Xor3(a[j], b[j], c[j]);
+      s[j] = SEL ? Xor3(x, AndXor(mask, kc[4 + j], d[j]), kc[j]) : Xor3(x, d[j], kc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RS; ++j) kc[j] = knx[j];
+  }
+  // last round: T2 has S in byte 0, T3 in byte 1, T0 in byte 2, T1 in byte 3 -- every lookup holds its S-box byte in
+  // place, three bitwise selects assemble the column
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t a = L.Lk<0, 2>(s[j]), b = L.Lk<1, 3>(s[(j + 1) & 3]), c = L.Lk<2, 0>(s[(j + 2) & 3]), d = L.Lk<3, 1>(s[(j + 3) & 3]);
+    const uint32_t p = Select(L.m_ffff, Select(L.m_00ff, a, b), Select(L.m_ff0000, c, d));
+    out[j] = SEL ? Xor3(AndXor(mask, kc[4 + j], p), in[j], kc[j]) : Xor3(p, in[j], kc[j]);
+  }
+}
+// Two blocks of the SAME plaintext under two key sets, round by round side by side (a DCF level's seed and value block;
+// both children of a DPF level in Gen): 32 lookups in flight per lane.
+template <bool SEL>
+__device__ __attribute__((always_inline)) inline void WideAesMmo2(const WideTab& L, WideKeys<SEL> keyA, WideKeys<SEL> keyB, uint32_t maskA,
+                                                                  uint32_t maskB, const uint32_t in[4], uint32_t outA[4], uint32_t outB[4]) {
+  constexpr int RS = WideKeys<SEL>::kPerRound;
+  uint32_t sa[4], sb[4], ka[RS], kb[RS];
+  {
+    const uint32_t* a0 = keyA.Round(0, in[0]);
+    const uint32_t* b0 = keyB.Round(0, in[1]);
+    const uint32_t* a1 = keyA.Round(1, in[2]);
+    const uint32_t* b1 = keyB.Round(1, in[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sa[j] = SEL ? Xor3(in[j], a0[j], maskA & a0[4 + j]) : (in[j] ^ a0[j]);
+      sb[j] = SEL ? Xor3(in[j], b0[j], maskB & b0[4 + j]) : (in[j] ^ b0[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RS; ++j) { ka[j] = a1[j]; kb[j] = b1[j]; }
+  }
+#pragma unroll
+  for (int r = 1; r < 10; ++r) {
+    uint32_t ta[16], tb[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ta[j] = L.Lk<0, 0>(sa[j]); ta[4 + j] = L.Lk<1, 1>(sa[(j + 1) & 3]); ta[8 + j] = L.Lk<2, 2>(sa[(j + 2) & 3]); ta[12 + j] = L.Lk<3, 3>(sa[(j + 3) & 3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tb[j] = L.Lk<0, 0>(sb[j]); tb[4 + j] = L.Lk<1, 1>(sb[(j + 1) & 3]); tb[8 + j] = L.Lk<2, 2>(sb[(j + 2) & 3]); tb[12 + j] = L.Lk<3, 3>(sb[(j + 3) & 3]);
+    }
+    const uint32_t* na = keyA.Round(r + 1, ta[0]);
+    const uint32_t* nb = keyB.Round(r + 1, tb[0]);
+    uint32_t nxa[RS], nxb[RS];
+#pragma unroll
+    for (int j = 0; j < RS; ++j) { nxa[j] = na[j]; nxb[j] = nb[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t xa = Xor3(ta[j], ta[4 + j], ta[8 + j]), xb = Xor3(tb[j], tb[4 + j], tb[8 + j]);
+      sa[j] = SEL ? Xor3(xa, AndXor(maskA, ka[4 + j], ta[12 + j]), ka[j]) : Xor3(xa, ta[12 + j], ka[j]);
+      sb[j] = SEL ? Xor3(xb, AndXor(maskB, kb[4 + j], tb[12 + j]), kb[j]) : Xor3(xb, tb[12 + j], kb[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RS; ++j) { ka[j] = nxa[j]; kb[j] = nxb[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t a = L.Lk<0, 2>(sa[j]), b = L.Lk<1, 3>(sa[(j + 1) & 3]), c = L.Lk<2, 0>(sa[(j + 2) & 3]), d = L.Lk<3, 1>(sa[(j + 3) & 3]);
+    const uint32_t pa = Select(L.m_ffff, Select(L.m_00ff, a, b), Select(L.m_ff0000, c, d));
+    const uint32_t a2 = L.Lk<0, 2>(sb[j]), b2 = L.Lk<1, 3>(sb[(j + 1) & 3]), c2 = L.Lk<2, 0>(sb[(j + 2) & 3]), d2 = L.Lk<3, 1>(sb[(j + 3) & 3]);
+    const uint32_t pb = Select(L.m_ffff, Select(L.m_00ff, a2, b2), Select(L.m_ff0000, c2, d2));
+    outA[j] = SEL ? Xor3(AndXor(maskA, ka[4 + j], pa), in[j], ka[j]) : Xor3(pa, in[j], ka[j]);
+    outB[j] = SEL ? Xor3(AndXor(maskB, kb[4 + j], pb), in[j], kb[j]) : Xor3(pb, in[j], kb[j]);
+  }
+}
+
+// What a wide PRG hands a walk (and what its own Gen / GenSide run on): the per-lane table constants and pointers to the
+// object's key words.  sel[p]: the A / D schedules of pair p -- mul = 2: {k0, k0 ^ k1};  mul = 4: {k0, k0 ^ k2}, {k1, k1 ^ k3};
+// mul = 1: one plain schedule.
+template <int mul>
+struct PreparedWide {
+  WideTab tab;
+  const uint32_t* sel0;
+  const uint32_t* sel1;
+  mutable uint32_t levels_done = 0;  // (Prepared() starts it from what this wave has published: a thread may walk key after key)
+  // Called by the walks once per level.  The sixteen waves of the workgroup start together and share one LDS pipe; the
+  // instruction arbiter prefers the oldest wave of a SIMD, so without help the four waves of a SIMD finish one after
+  // the other and the last ones run on a pipe they cannot fill alone -- and a workgroup that owns the CU's whole LDS
+  // cannot be followed by the next one until its last wave has left.  Every fourth level a wave publishes how far it
+  // is (one single-lane LDS write) and reads the three waves it shares its SIMD with (one four-lane read): its
+  // priority is the number of them that are ahead (the engine's own closed loop, fss_amd/csrc/fss_dev.hpp: rank_prio).
+  __device__ void LevelDone() const {
+    ++levels_done;
+    if (levels_done & 3u) return;
+    uint32_t* prog = WorkgroupWideProgress();
+    const unsigned w = (LinearTid() >> 6) & 15u, simd = w & 3u, age = w >> 2;  // waves w, w + 4, w + 8, w + 12 share a SIMD
+    const unsigned lane = __lane_id();
+    uint32_t other = 0;
+    if (lane < 4) {
+      if (lane == age) prog[simd * 4 + age] = levels_done;
+      other = *reinterpret_cast<const volatile uint32_t*>(prog + simd * 4 + lane);
+    }
+    switch (__popcll(__ballot(other > levels_done))) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+  // A walk has ended: the wave's count is published (a thread that walks key after key -- a grid-stride loop -- carries on
+  // from it), its priority is the default again for whatever the caller's kernel does next.
+  __device__ void WalkDone() const {
+    uint32_t* prog = WorkgroupWideProgress();
+    const unsigned w = (LinearTid() >> 6) & 15u;
+    if (__lane_id() == 0) prog[(w & 3u) * 4 + (w >> 2)] = levels_done;
+    __builtin_amdgcn_s_setprio(0);
+  }
+  __device__ static uint32_t PublishedLevels() {
+    const unsigned w = (LinearTid() >> 6) & 15u;
+    return Uniform(WorkgroupWideProgress()[(w & 3u) * 4 + (w >> 2)]);
+  }
+  __device__ static void Words(int4 v, uint32_t w[4]) {
+    w[0] = static_cast<uint32_t>(v.x); w[1] = static_cast<uint32_t>(v.y); w[2] = static_cast<uint32_t>(v.z); w[3] = static_cast<uint32_t>(v.w);
+  }
+  __device__ static int4 Int4(const uint32_t w[4]) {
+    return int4{static_cast<int>(w[0]), static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[3])};
+  }
+  __device__ __attribute__((always_inline)) std::array<int4, mul> Gen(int4 seed) const {
+    std::array<int4, mul> out;
+    uint32_t in[4], o[4], o2[4];
+    Words(seed, in);
+    if constexpr (mul == 1) {
+      WideAesMmo<false>(tab, WideKeys<false>{sel0}, 0u, in, o);
+      out[0] = Int4(o);
+    } else if constexpr (mul == 2) {
+      WideAesMmo2<true>(tab, WideKeys<true>{sel0}, WideKeys<true>{sel0}, 0u, ~0u, in, o, o2);
+      out[0] = Int4(o); out[1] = Int4(o2);
+    } else {
+      WideAesMmo2<true>(tab, WideKeys<true>{sel0}, WideKeys<true>{sel1}, 0u, 0u, in, o, o2);   // k0, k1
+      out[0] = Int4(o); out[1] = Int4(o2);
+      WideAesMmo2<true>(tab, WideKeys<true>{sel0}, WideKeys<true>{sel1}, ~0u, ~0u, in, o, o2);  // k2, k3
+      out[2] = Int4(o); out[3] = Int4(o2);
+    }
+    return out;
+  }
+  __device__ __attribute__((always_inline)) std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+    std::array<int4, mul / 2> out;
+    uint32_t in[4], o[4];
+    Words(seed, in);
+    const uint32_t mask = right ? ~0u : 0u;
+    if constexpr (mul == 2) {
+      WideAesMmo<true>(tab, WideKeys<true>{sel0}, mask, in, o);
+      out[0] = Int4(o);
+    } else {
+      uint32_t o2[4];
+      WideAesMmo2<true>(tab, WideKeys<true>{sel0}, WideKeys<true>{sel1}, mask, mask, in, o, o2);
+      out[0] = Int4(o); out[1] = Int4(o2);
+    }
+    return out;
+  }
+};
 #endif
+
 // The PRG a walk calls level after level: its prepared form where the type has one, the PRG itself otherwise.
 template <typename Prg>
 __device__ inline decltype(auto) PreparedPrg(const Prg& prg) {
@@ -935,6 +1245,98 @@ struct KeyMajorView {
   __device__ int4 V(int i) const { return slots[2 * i + 1]; }
   __device__ bool Flag(int i) const { return (slots[2 * i + 1].x & 0xff) != 0; }
 };
+// A key-major key read a cache line at a time.  A thread's key is its own memory: with one slot per level every 128-byte
+// line (four slots) is touched on four levels, several microseconds apart -- and with a whole chip of threads streaming
+// their keys (32 CUs x 1024 threads x one line = the XCD's entire 4 MiB L2) the line has been evicted in between: the
+// per-thread walks fetched 1.8 x their keys from the fabric, 4.9 TB/s at 2.4 G evals/s, and stalled on it
+// (profiles/r6/dropin_device_wide_pmc.txt).  Here a thread requests ALL the slots of a line when it reaches the line's
+// first slot (one level ahead of their first use, so the loads land under a cipher) and keeps them in registers: every
+// line is fetched once.  Slot j lives in buffer position j & 3 -- the same position for every lane, whatever the lane's
+// own line phase (keys are 1056 bytes apart: four phases) -- so reads are by a wave-uniform index: no per-lane selects.
+// kFullV: the slot's second word is a value (DCF) rather than a flag byte (DPF, Half-Tree): 32 instead of 20 registers.
+template <bool kFullV>
+struct KeyMajorLines {
+  const int4* slots;
+  int nslots;
+  // The buffer is a shift register of named values: position q holds slot (next to be consumed) + q.  A line's loads
+  // go to positions 0 .. 3 in order -- a line is requested exactly when its first slot is the next one to be consumed --
+  // and Pop hands out position 0 and moves the rest down.  No runtime index anywhere: an indexed (or selected) read of
+  // buffer members is turned into an indexed load by the compiler, and the buffer into a stack object.
+  mutable int4 s0_, s1_, s2_, s3_;
+  mutable int4 v0_, v1_, v2_, v3_;  // kFullV: the slots' second words; otherwise only .x (the flag byte's word) is kept
+  // A line's loads land in staging registers first and move into the buffer after the cipher (Land): loads issued in a
+  // conditional block straight into registers that the other lanes keep live are waited for by the compiler at the end of
+  // that block -- a memory round trip BEFORE the cipher they were meant to land under, on every level.
+  mutable int4 ts0_, ts1_, ts2_, ts3_;
+  mutable int4 tv0_, tv1_, tv2_, tv3_;
+  mutable bool fresh_ = false;
+  mutable int room_ = 0;
+  __device__ __attribute__((always_inline)) void Take(int slot, bool want, int4& s, int4& v) const {
+    if (want && slot < nslots) {
+      s = slots[2 * slot];
+      if constexpr (kFullV) v = slots[2 * slot + 1];
+      else v.x = slots[2 * slot + 1].x;
+    }
+  }
+  // Called before the cipher under which slot j's loads are to land (j = the next slot Pop will hand out): requests slot
+  // j's line if j is the first slot of one (or the key's first slot).
+  __device__ __attribute__((always_inline)) void Ahead(int j) const {
+    fresh_ = false;
+    if (j >= nslots) return;  // wave-uniform
+    const uintptr_t a = reinterpret_cast<uintptr_t>(slots + 2 * j);
+    fresh_ = j == 0 || (a & 127u) == 0;
+    room_ = 4 - static_cast<int>((a >> 5) & 3u);  // slots from here to the end of the line
+    if (fresh_) {
+      Take(j, true, ts0_, tv0_);
+      Take(j + 1, room_ > 1, ts1_, tv1_);
+      Take(j + 2, room_ > 2, ts2_, tv2_);
+      Take(j + 3, room_ > 3, ts3_, tv3_);
+    }
+  }
+  // After the cipher: the next slot's two words (for !kFullV only v.x is meaningful: the word that holds the flag byte), and
+  // the buffer moved down by one -- for the lanes that requested a line before the cipher, out of the staging registers
+  // (one select per register: "land, then shift" as two steps would be two moves).
+  __device__ __attribute__((always_inline)) void Pop(int4& s, int4& v) const {
+    // (the predicate reaches the selects through an opaque copy: selects that the compiler can prove to be governed by the
+    // very condition of the loads' block are folded back into that block -- and the loads are waited for there again)
+    uint64_t m = __ballot(fresh_);
+    asm volatile("" : "+s"(m));
+    const bool f = (m >> __lane_id()) & 1u;
+    auto pick = [f](const int4& t, const int4& o) { return int4{f ? t.x : o.x, f ? t.y : o.y, f ? t.z : o.z, f ? t.w : o.w}; };
+    auto pick_v = [f](const int4& t, const int4& o) {
+      if constexpr (kFullV) return int4{f ? t.x : o.x, f ? t.y : o.y, f ? t.z : o.z, f ? t.w : o.w};
+      else return int4{f ? t.x : o.x, 0, 0, 0};
+    };
+    s = pick(ts0_, s0_); v = pick_v(tv0_, v0_);
+    s0_ = pick(ts1_, s1_); v0_ = pick_v(tv1_, v1_);
+    s1_ = pick(ts2_, s2_); v1_ = pick_v(tv2_, v2_);
+    s2_ = pick(ts3_, s3_); v2_ = pick_v(tv3_, v3_);
+  }
+};
+// A walk in lines mode calls this on its point before the level loop: a use the compiler must satisfy HERE.  The point
+// was typically loaded just before the walk (`xs[tid]`); left pending into the loop, its wait is repeated by the compiler
+// on every iteration as a full `s_waitcnt vmcnt(0)` -- which would also wait for the line loads the cursor has in flight.
+template <typename In>
+__device__ __attribute__((always_inline)) inline void SettleBeforeLoop(const In& x) {
+  const uint32_t lo = static_cast<uint32_t>(x);
+  asm volatile("" : : "v"(lo));
+  if constexpr (sizeof(In) > 4) {
+    const uint32_t hi = static_cast<uint32_t>(x >> 32);
+    asm volatile("" : : "v"(hi));
+  }
+  if constexpr (sizeof(In) > 8) {
+    const uint32_t h2 = static_cast<uint32_t>(x >> 64), h3 = static_cast<uint32_t>(x >> 96);
+    asm volatile("" : : "v"(h2), "v"(h3));
+  }
+}
+__device__ __attribute__((always_inline)) inline void SettleBeforeLoop(const int4& v) {  // ... and the party's seed
+  asm volatile("" : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+}
+// PRG types whose walks read key-major keys a line at a time (the wide form: its walks are bound by the LDS pipe and the
+// memory system, with registers to spare; the default form is bound by VALU issue and keeps the two loads per level)
+template <typename Prg>
+concept LineWalkPrg = requires { Prg::kKeyMajorLines; };
+
 struct DpfLevelMajorView {
   const int4* cw_s;
   const int4* out_cw;
@@ -1012,14 +1414,32 @@ template <int in_bits, typename In, typename Prg, typename Key>
 __device__ __attribute__((always_inline)) inline void DpfWalkOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x, int4& s_out, bool& t_out,
                                                                 int4& last) {
   auto&& prg = PreparedPrg(prg_);
+  constexpr bool kLines = requires { key.Ahead(0); };  // KeyMajorLines: slots arrive a cache line at a time
   int4 s = WithCtl(s0, false);
   bool t = b;
-  int4 cw = key.S(0);
-  bool flag = key.Flag(0);
+  int4 cw;
+  bool flag;
+  if constexpr (kLines) {
+    int4 w;
+    key.Ahead(0);
+    key.Pop(cw, w);
+    flag = (w.x & 0xff) != 0;
+    SettleBeforeLoop(x);
+    SettleBeforeLoop(s);
+  } else {
+    cw = key.S(0);
+    flag = key.Flag(0);
+  }
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
-    const int4 cw_next = key.S(i + 1);  // slot in_bits: the output correction word
-    const bool flag_next = key.Flag(i + 1 < in_bits ? i + 1 : i);  // (no branch around the load: it would be waited for at once)
+    int4 cw_next;  // slot i + 1 (slot in_bits: the output correction word)
+    bool flag_next;
+    if constexpr (kLines) {
+      key.Ahead(i + 1);  // requests the line of slot i + 1 if that slot starts one; taken from the buffer after the cipher
+    } else {
+      cw_next = key.S(i + 1);
+      flag_next = key.Flag(i + 1 < in_bits ? i + 1 : i);  // (no branch around the load: it would be waited for at once)
+    }
     const int side = BitAt(x, in_bits - 1 - i);
     int4 taken;  // Gen(s)[side]; a PRG that can compute one side alone is asked for just that
     if constexpr (requires { prg.GenSide(s, true); }) taken = prg.GenSide(s, side != 0)[0];
@@ -1027,15 +1447,22 @@ __device__ __attribute__((always_inline)) inline void DpfWalkOn(const Prg& prg_,
     const bool side_cw = side ? flag : Ctl(cw);
     s = X4(WithCtl(taken, false), If(t, WithCtl(cw, false)));
     t = Ctl(taken) ^ (t && side_cw);
+    if constexpr (kLines) {
+      int4 w;
+      key.Pop(cw_next, w);
+      flag_next = (w.x & 0xff) != 0;  // (slot in_bits has no flag: unused after the last level)
+    }
     cw = cw_next;
     flag = flag_next;
+    if constexpr (requires { prg.LevelDone(); }) prg.LevelDone();
   }
+  if constexpr (requires { prg.WalkDone(); }) prg.WalkDone();
   s_out = s;
   t_out = t;
   last = cw;
 }
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 DpfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
+__device__ __attribute__((always_inline)) inline int4 DpfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key, In x) {
   int4 s, cw;
   bool t;
   DpfWalkOn<in_bits, In>(prg, b, s0, key, x, s, t, cw);
@@ -1045,8 +1472,9 @@ __device__ inline int4 DpfEvalOn(const Prg& prg, bool b, int4 s0, const Key& key
   return y.Into();
 }
 template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
-  return DpfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
+__device__ __attribute__((always_inline)) inline int4 DpfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
+  if constexpr (LineWalkPrg<Prg>) return DpfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorLines<false>{slots, in_bits + 1}, x);
+  else return DpfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
 }
 
 // ---------------------------------------------------------------- DCF (dcf.cuh:108-276); PRG output [sl, vl, sr, vr]
@@ -1096,16 +1524,22 @@ __device__ inline void DcfGen(const Prg& prg, int4* slots, const int4 s0s[2], In
 }
 
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x) {
+__device__ __attribute__((always_inline)) inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& key, In x) {
   auto&& prg = PreparedPrg(prg_);
+  constexpr bool kLines = requires { key.Ahead(0); };  // KeyMajorLines: slots arrive a cache line at a time
   int4 s = WithCtl(s0, false);
   bool t = b;
+  if constexpr (kLines) {
+    SettleBeforeLoop(x);
+    SettleBeforeLoop(s);
+  }
   Group acc;
   auto add = [b](Group sum, Group term) { return b ? sum + (-term) : sum + term; };  // party 1 subtracts
   // (no request-ahead of the correction words here: a level is two ciphers side by side, the loads measured as hidden,
   // and eight more live registers put a caller's kernel without launch bounds over its 128)
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits; ++i) {
+    if constexpr (kLines) key.Ahead(i);  // slot i's line, if it starts one: lands under this level's ciphers
     const int side = BitAt(x, in_bits - 1 - i);
     int4 ts, tv;  // Gen(s)[2 side], Gen(s)[2 side + 1]
     if constexpr (requires { prg.GenSide(s, true); }) {
@@ -1115,7 +1549,13 @@ __device__ inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& ke
       const std::array<int4, 4> g = prg.Gen(s);
       ts = g[2 * side]; tv = g[2 * side + 1];
     }
-    const int4 cw_s = key.S(i), cw_v = key.V(i);
+    int4 cw_s, cw_v;
+    if constexpr (kLines) {
+      key.Pop(cw_s, cw_v);
+    } else {
+      cw_s = key.S(i);
+      cw_v = key.V(i);
+    }
     acc = add(acc, Group::From(WithCtl(tv, false)));
     if (t) acc = add(acc, Group::From(WithCtl(cw_v, false)));
     int4 child = WithCtl(ts, false);
@@ -1126,14 +1566,25 @@ __device__ inline int4 DcfEvalOn(const Prg& prg_, bool b, int4 s0, const Key& ke
     }
     s = child;
     t = ct;
+    if constexpr (requires { prg.LevelDone(); }) prg.LevelDone();
+  }
+  if constexpr (requires { prg.WalkDone(); }) prg.WalkDone();
+  int4 last_v;
+  if constexpr (kLines) {
+    int4 unused;
+    key.Ahead(in_bits);
+    key.Pop(unused, last_v);
+  } else {
+    last_v = key.V(in_bits);
   }
   acc = add(acc, Group::From(s));
-  if (t) acc = add(acc, Group::From(key.V(in_bits)));
+  if (t) acc = add(acc, Group::From(last_v));
   return acc.Into();
 }
 template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
-  return DcfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
+__device__ __attribute__((always_inline)) inline int4 DcfEval(const Prg& prg, bool b, int4 s0, const int4* slots, In x) {
+  if constexpr (LineWalkPrg<Prg>) return DcfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorLines<true>{slots, in_bits + 1}, x);
+  else return DcfEvalOn<in_bits, Group, In>(prg, b, s0, KeyMajorView{slots}, x);
 }
 
 // ---------------------------------------------------------------- verifiable DPF (vdpf.cuh:103-257)
@@ -1225,20 +1676,37 @@ __device__ inline void HtGen(const Prg& prg, int4 hash_key, int4* slots, int4& o
 }
 
 template <int in_bits, typename Group, typename In, typename Prg, typename Key>
-__device__ inline int4 HtEvalOn(const Prg& prg_, int4 hash_key, bool b, int4 s0, const Key& key, int4 ocw, In x) {
+__device__ __attribute__((always_inline)) inline int4 HtEvalOn(const Prg& prg_, int4 hash_key, bool b, int4 s0, const Key& key, int4 ocw, In x) {
   auto&& prg = PreparedPrg(prg_);
+  constexpr bool kLines = requires { key.Ahead(0); };
   int4 node = WithCtl(s0, b);
-  int4 cw = key.S(0);
+  int4 cw, cw_word1;  // the current level's slot: its seed word, and (lines mode) the word that holds its flag byte
+  if constexpr (kLines) {
+    key.Ahead(0);
+    key.Pop(cw, cw_word1);
+    SettleBeforeLoop(x);
+    SettleBeforeLoop(node);
+  } else {
+    cw = key.S(0);
+  }
 #pragma unroll 1  // one level per iteration: a level is one to four whole ciphers of straight-line code
   for (int i = 0; i < in_bits - 1; ++i) {
-    const int4 cw_next = key.S(i + 1);  // (see DpfEvalOn)
+    int4 cw_next;  // (see DpfEvalOn)
+    if constexpr (kLines) key.Ahead(i + 1);
+    else cw_next = key.S(i + 1);
     const int4 h = HtHash(prg, hash_key, node);
     node = X4(X4(h, If(BitAt(x, in_bits - 1 - i), node)), If(Ctl(node), cw));
+    if constexpr (kLines) key.Pop(cw_next, cw_word1);
     cw = cw_next;
+    if constexpr (requires { prg.LevelDone(); }) prg.LevelDone();
   }
+  if constexpr (requires { prg.WalkDone(); }) prg.WalkDone();
   const bool sigma = BitAt(x, 0), t = Ctl(node);
   const int4 last = cw;  // key.S(in_bits - 1)
-  const bool lcw = sigma ? key.Flag(in_bits - 1) : Ctl(last);
+  bool last_flag;
+  if constexpr (kLines) last_flag = (cw_word1.x & 0xff) != 0;
+  else last_flag = key.Flag(in_bits - 1);
+  const bool lcw = sigma ? last_flag : Ctl(last);
   const int4 h = HtHash(prg, hash_key, WithCtl(node, sigma));
   const int4 high = X4(WithCtl(h, false), If(t, WithCtl(last, false)));
   const bool low = Ctl(h) ^ (t && lcw);
@@ -1248,8 +1716,9 @@ __device__ inline int4 HtEvalOn(const Prg& prg_, int4 hash_key, bool b, int4 s0,
   return y.Into();
 }
 template <int in_bits, typename Group, typename In, typename Prg>
-__device__ inline int4 HtEval(const Prg& prg, int4 hash_key, bool b, int4 s0, const int4* slots, int4 ocw, In x) {
-  return HtEvalOn<in_bits, Group, In>(prg, hash_key, b, s0, KeyMajorView{slots}, ocw, x);
+__device__ __attribute__((always_inline)) inline int4 HtEval(const Prg& prg, int4 hash_key, bool b, int4 s0, const int4* slots, int4 ocw, In x) {
+  if constexpr (LineWalkPrg<Prg>) return HtEvalOn<in_bits, Group, In>(prg, hash_key, b, s0, KeyMajorLines<false>{slots, in_bits}, ocw, x);
+  else return HtEvalOn<in_bits, Group, In>(prg, hash_key, b, s0, KeyMajorView{slots}, ocw, x);
 }
 
 }  // namespace thread

@@ -760,6 +760,40 @@ static void Groups() {
   GroupCase<fss::group::Uint<uint64_t, 18446744073709551557ull>>("Uint<u64, 2^64 - 59>");
 }
 
+
+// Milliseconds per launch at steady clocks: the chip needs tens of milliseconds of continuous work to reach the clock it
+// sustains (a 1 ms kernel timed cold runs 10 - 15 % below it), so `launch` runs back to back for `warm_ms` first, then the
+// median of `reps` event-timed launches is taken.  quick: one warm-up, one timed launch (the correctness-only passes).
+template <typename F>
+static float SteadyMs(F&& launch, bool quick = false, float warm_ms = 60.f, int reps = 21) {
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  auto once = [&] {
+    float ms = 0;
+    HIP_OK(hipEventRecord(e0));
+    launch();
+    HIP_OK(hipEventRecord(e1));
+    HIP_OK(hipEventSynchronize(e1));
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+  };
+  float est = once();
+  float out = est;
+  if (!quick) {
+    est = std::max(once(), 1e-3f);
+    const int warm = std::min(2000, static_cast<int>(warm_ms / est) + 1);
+    for (int i = 0; i < warm; ++i) launch();
+    std::vector<float> t(static_cast<size_t>(reps));
+    for (auto& v : t) v = once();
+    std::sort(t.begin(), t.end());
+    out = t[t.size() / 2];
+  }
+  HIP_OK(hipEventDestroy(e0));
+  HIP_OK(hipEventDestroy(e1));
+  return out;
+}
+
 // what the compatibility form costs next to the engine: DPF / DCF n=32, 2^kLog independent keys, one evaluation each
 // (2^18: 1024 workgroups, ONE residency of the chip -- start-up and the ragged end are in the figure; 2^21: eight)
 template <int kLog>
@@ -796,19 +830,10 @@ static void Timing() {
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
-  float ms_thread = 0, ms_engine = 0;
-  for (int rep = 0; rep < 2; ++rep) {  // the second pass is the timed one
-    HIP_OK(hipEventRecord(e0));
-    EvalKeysKernel<Dpf, uint32_t><<<kN / 256, 256>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN);
-    HIP_OK(hipEventRecord(e1));
-    HIP_OK(hipEventSynchronize(e1));
-    HIP_OK(hipEventElapsedTime(&ms_thread, e0, e1));
-    HIP_OK(hipEventRecord(e0));
-    fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, cw_s, extra, out_cw, d_xs, d_ye, kN, dpf);
-    HIP_OK(hipEventRecord(e1));
-    HIP_OK(hipEventSynchronize(e1));
-    HIP_OK(hipEventElapsedTime(&ms_engine, e0, e1));
-  }
+  // 2^18 keys: one cold-ish launch each (one residency of the chip: what a single small call costs); 2^21: steady clocks
+  constexpr bool kQuick = kLog <= 18;
+  const float ms_thread = SteadyMs([&] { EvalKeysKernel<Dpf, uint32_t><<<kN / 256, 256>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN); }, kQuick);
+  const float ms_engine = SteadyMs([&] { fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, cw_s, extra, out_cw, d_xs, d_ye, kN, dpf); }, kQuick);
   auto yt = ToHost(d_yt, kN), ye = ToHost(d_ye, kN);
   int bad = 0;
   for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
@@ -833,19 +858,8 @@ static void Timing() {
     int4* cw_v = DeviceBuf<int4>(size_t(32) * kN);
     dcf.GenBatch(d_dc, d_seeds, d_alphas, d_betas, kN);
     fss::gpu::DcfRelayoutGpu<32, G, PrgD, uint32_t>(d_dc, kN, cw_s, cw_v, out_cw);
-    float ms_t = 0, ms_e = 0;
-    for (int rep = 0; rep < 2; ++rep) {
-      HIP_OK(hipEventRecord(e0));
-      EvalKeysKernel<Dcf, uint32_t><<<kN / 256, 256>>>(dcf, d_yt, false, d_seeds0, d_dc, d_xs, kN);
-      HIP_OK(hipEventRecord(e1));
-      HIP_OK(hipEventSynchronize(e1));
-      HIP_OK(hipEventElapsedTime(&ms_t, e0, e1));
-      HIP_OK(hipEventRecord(e0));
-      fss::gpu::DcfEvalPointGpu<4>(false, d_seeds0, cw_s, cw_v, out_cw, d_xs, d_ye, kN, dcf);
-      HIP_OK(hipEventRecord(e1));
-      HIP_OK(hipEventSynchronize(e1));
-      HIP_OK(hipEventElapsedTime(&ms_e, e0, e1));
-    }
+    const float ms_t = SteadyMs([&] { EvalKeysKernel<Dcf, uint32_t><<<kN / 256, 256>>>(dcf, d_yt, false, d_seeds0, d_dc, d_xs, kN); }, kQuick);
+    const float ms_e = SteadyMs([&] { fss::gpu::DcfEvalPointGpu<4>(false, d_seeds0, cw_s, cw_v, out_cw, d_xs, d_ye, kN, dcf); }, kQuick);
     auto dt = ToHost(d_yt, kN), de = ToHost(d_ye, kN);
     int badd = 0;
     for (int i = 0; i < kN; ++i) badd += !Same(dt[i], de[i]);
@@ -872,19 +886,8 @@ static void Timing() {
     int4* h_s = DeviceBuf<int4>(size_t(64) * kN);
     ht.GenBatch(d_hc, d_ho, d_seeds, d_ha, d_betas, kN);
     fss::gpu::HalfTreeDpfRelayoutGpu<64, G, PrgH, uint64_t>(d_hc, kN, h_s, extra);
-    float ms_t = 0, ms_e = 0;
-    for (int rep = 0; rep < 2; ++rep) {
-      HIP_OK(hipEventRecord(e0));
-      HtEvalKeysKernel<Ht, uint64_t><<<kN / 256, 256>>>(ht, d_yt, false, d_seeds0, d_hc, d_ho, d_hx, kN);
-      HIP_OK(hipEventRecord(e1));
-      HIP_OK(hipEventSynchronize(e1));
-      HIP_OK(hipEventElapsedTime(&ms_t, e0, e1));
-      HIP_OK(hipEventRecord(e0));
-      fss::gpu::HalfTreeDpfEvalPointGpu<4>(false, d_seeds0, h_s, extra, d_ho, d_hx, d_ye, kN, ht);
-      HIP_OK(hipEventRecord(e1));
-      HIP_OK(hipEventSynchronize(e1));
-      HIP_OK(hipEventElapsedTime(&ms_e, e0, e1));
-    }
+    const float ms_t = SteadyMs([&] { HtEvalKeysKernel<Ht, uint64_t><<<kN / 256, 256>>>(ht, d_yt, false, d_seeds0, d_hc, d_ho, d_hx, kN); }, kQuick);
+    const float ms_e = SteadyMs([&] { fss::gpu::HalfTreeDpfEvalPointGpu<4>(false, d_seeds0, h_s, extra, d_ho, d_hx, d_ye, kN, ht); }, kQuick);
     auto ht_t = ToHost(d_yt, kN), ht_e = ToHost(d_ye, kN);
     int badh = 0;
     for (int i = 0; i < kN; ++i) badh += !Same(ht_t[i], ht_e[i]);
@@ -897,6 +900,202 @@ static void Timing() {
   for (void* q : {(void*)d_seeds, (void*)d_seeds0, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_cws, (void*)d_yt, (void*)d_ye,
                   (void*)cw_s, (void*)extra, (void*)out_cw})
     HIP_OK(hipFree(q));
+}
+// ---- fss::prg::Aes128MmoWide: the opt-in wide form (the engine's four-table layout, 128 KiB of LDS) in the caller's own
+// kernels -- workgroups of 1024, InitWorkgroup() by every thread first, the scheme used in place as the kernel's argument.
+// Shape of src/bench_gpu.cu:100-138: the block prepares the tables, then one Eval per thread.
+template <typename S, typename In>
+__global__ __launch_bounds__(1024) void WideEvalKeysKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws,
+                                                           const In* xs, int n) {
+  decltype(sch.prg)::InitWorkgroup();  // every thread, before any of them leaves
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
+}
+// ... and the same with a grid-stride loop: as many workgroups as the chip has CUs, every thread walks key after key.  The
+// tables are filled once per workgroup and a CU is never left waiting for the last wave of one workgroup before the next
+// may start (with 128 KiB of LDS per workgroup, workgroups cannot overlap on a CU).
+template <typename S, typename In>
+__global__ __launch_bounds__(1024) void WideEvalKeysStrideKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws,
+                                                                 const In* xs, int n) {
+  decltype(sch.prg)::InitWorkgroup();
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+    ys[k] = sch.Eval(party, seeds[k], cws + size_t(k) * S::kSlots, xs[k]);
+}
+template <typename S, typename In>
+__global__ __launch_bounds__(1024) void WideHtEvalKeysKernel(S sch, int4* ys, bool party, const int4* seeds, const typename S::Cw* cws,
+                                                             const int4* ocws, const In* xs, int n) {
+  decltype(sch.prg)::InitWorkgroup();
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, ocws[tid], xs[tid]);
+}
+template <typename S, typename In>
+__global__ __launch_bounds__(1024) void WideGenKeysKernel(S sch, typename S::Cw* cws, const int4* seeds, const In* alphas, const int4* betas,
+                                                          int n) {
+  decltype(sch.prg)::InitWorkgroup();
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  int4 s[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  sch.Gen(cws + size_t(tid) * S::kSlots, s, alphas[tid], betas[tid]);
+}
+template <int mul>
+__global__ __launch_bounds__(1024) void WidePrgKernel(fss::prg::Aes128MmoWide<mul> prg, const int4* seeds, int4* out, int n) {
+  fss::prg::Aes128MmoWide<mul>::InitWorkgroup();
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  const auto g = prg.Gen(seeds[tid]);
+  for (int i = 0; i < mul; ++i) out[size_t(tid) * mul + i] = g[i];
+}
+
+template <int kLog>
+static void Wide(bool timing) {
+  const int before = g_fail;
+  constexpr int kN = 1 << kLog;
+  using G = fss::group::Uint<uint64_t>;
+  const unsigned char* keys1[1] = {k0};
+  const unsigned char* keys2[2] = {k0, k1};
+  const unsigned char* keys4[4] = {k0, k1, k2, k3};
+  std::vector<int4> seeds(2 * kN), seeds0(kN), betas(kN);
+  std::vector<uint32_t> alphas(kN), xs(kN);
+  for (int i = 0; i < kN; ++i) {
+    seeds0[i] = seeds[2 * i] = RandSeed();
+    seeds[2 * i + 1] = RandSeed();
+    betas[i] = RandSeed();
+    alphas[i] = static_cast<uint32_t>(Next());
+    xs[i] = i % 2 ? alphas[i] : static_cast<uint32_t>(Next());
+  }
+  int4* d_seeds = ToDevice(seeds.data(), 2 * kN);
+  int4* d_seeds0 = ToDevice(seeds0.data(), kN);
+  int4* d_betas = ToDevice(betas.data(), kN);
+  uint32_t* d_alphas = ToDevice(alphas.data(), kN);
+  uint32_t* d_xs = ToDevice(xs.data(), kN);
+  int4* d_yt = DeviceBuf<int4>(kN);
+  int4* d_ye = DeviceBuf<int4>(kN);
+  int4* cw_s = DeviceBuf<int4>(size_t(32) * kN);
+  int4* cw_v = DeviceBuf<int4>(size_t(32) * kN);
+  uint32_t* extra = DeviceBuf<uint32_t>(kN);
+  int4* out_cw = DeviceBuf<int4>(kN);
+  auto timed = [&](auto&& launch) { return SteadyMs(launch, !timing); };
+  int num_cu = 256;
+  {
+    hipDeviceProp_t prop;
+    HIP_OK(hipGetDeviceProperties(&prop, 0));
+    num_cu = prop.multiProcessorCount;
+  }
+  {  // the PRG itself: every output of Gen for one, two and four keys against the engine's fss_amd_prg_gen
+    int4* d_out = DeviceBuf<int4>(size_t(4) * 4096);
+    auto check = [&](auto prg, auto engine_prg, int mul) {
+      WidePrgKernel<<<4, 1024>>>(prg, d_seeds0, d_out, 4096);
+      HIP_OK(hipDeviceSynchronize());
+      auto got = ToHost(d_out, size_t(mul) * 4096);
+      int bad = 0;
+      for (int i = 0; i < 64; ++i) {
+        const auto want = engine_prg.Gen(seeds0[i * 61 % 4096]);  // host Gen: a batch of one on the engine
+        for (int j = 0; j < mul; ++j) bad += !Same(got[size_t(i * 61 % 4096) * mul + j], want[j]);
+      }
+      EXPECT(bad == 0);
+    };
+    check(fss::prg::Aes128MmoWide<1>(keys1), fss::prg::Aes128Mmo<1>(keys1), 1);
+    check(fss::prg::Aes128MmoWide<2>(keys2), fss::prg::Aes128Mmo<2>(keys2), 2);
+    check(fss::prg::Aes128MmoWide<4>(keys4), fss::prg::Aes128Mmo<4>(keys4), 4);
+    HIP_OK(hipFree(d_out));
+  }
+  {  // DPF n = 32: Gen per thread == the engine's Gen; Eval per thread == DpfEvalPointGpu
+    using Prg = fss::prg::Aes128MmoWide<2>;
+    using Dpf = fss::Dpf<32, G, Prg, uint32_t>;
+    Dpf dpf{Prg(keys2)};
+    Dpf::Cw* d_cws = DeviceBuf<Dpf::Cw>(size_t(33) * kN);
+    Dpf::Cw* d_cws_e = DeviceBuf<Dpf::Cw>(size_t(33) * kN);
+    WideGenKeysKernel<Dpf, uint32_t><<<kN / 1024, 1024>>>(dpf, d_cws, d_seeds, d_alphas, d_betas, kN);
+    dpf.GenBatch(d_cws_e, d_seeds, d_alphas, d_betas, kN);
+    HIP_OK(hipDeviceSynchronize());
+    {
+      auto a = ToHost(d_cws, size_t(33) * kN), e = ToHost(d_cws_e, size_t(33) * kN);
+      int bad = 0;
+      for (size_t i = 0; i < a.size(); ++i) bad += !Same(a[i].s, e[i].s) || (i % 33 != 32 && a[i].tr != e[i].tr);
+      EXPECT(bad == 0);
+    }
+    fss::gpu::DpfRelayoutGpu<32, G, Prg, uint32_t>(d_cws, kN, cw_s, extra, out_cw);
+    const float ms_t = timed([&] { WideEvalKeysKernel<Dpf, uint32_t><<<kN / 1024, 1024>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN); });
+    const float ms_e = timed([&] { fss::gpu::DpfEvalPointGpu<4>(false, d_seeds0, cw_s, extra, out_cw, d_xs, d_ye, kN, dpf); });
+    auto yt = ToHost(d_yt, kN), ye = ToHost(d_ye, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+    EXPECT(bad == 0);
+    HIP_OK(hipMemset(d_yt, 0xff, sizeof(int4) * kN));
+    const float ms_s = timed([&] { WideEvalKeysStrideKernel<Dpf, uint32_t><<<std::min(kN / 1024, num_cu), 1024>>>(dpf, d_yt, false, d_seeds0, d_cws, d_xs, kN); });
+    yt = ToHost(d_yt, kN);
+    for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+    EXPECT(bad == 0);
+    std::printf("     (WIDE DPF n=32, 2^%d keys, grid-stride loop, %d workgroups of 1024: %.3f ms = %.1f M evals/s)\n", kLog, std::min(kN / 1024, num_cu), ms_s,
+                kN / ms_s / 1e3);
+    std::printf("     (WIDE DPF n=32, 2^%d keys, Aes128MmoWide<2>, 1024 threads per block: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+                "DpfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n", kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, bad ? "NO" : "yes");
+    HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_cws_e));
+  }
+  {  // DCF n = 32
+    using Prg = fss::prg::Aes128MmoWide<4>;
+    using Dcf = fss::Dcf<32, G, Prg, uint32_t>;
+    Dcf dcf{Prg(keys4)};
+    Dcf::Cw* d_dc = DeviceBuf<Dcf::Cw>(size_t(33) * kN);
+    Dcf::Cw* d_dc_e = DeviceBuf<Dcf::Cw>(size_t(33) * kN);
+    WideGenKeysKernel<Dcf, uint32_t><<<kN / 1024, 1024>>>(dcf, d_dc, d_seeds, d_alphas, d_betas, kN);
+    dcf.GenBatch(d_dc_e, d_seeds, d_alphas, d_betas, kN);
+    HIP_OK(hipDeviceSynchronize());
+    {
+      auto a = ToHost(d_dc, size_t(33) * kN), e = ToHost(d_dc_e, size_t(33) * kN);
+      EXPECT(std::memcmp(a.data(), e.data(), a.size() * sizeof(a[0])) == 0);
+    }
+    fss::gpu::DcfRelayoutGpu<32, G, Prg, uint32_t>(d_dc, kN, cw_s, cw_v, out_cw);
+    const float ms_t = timed([&] { WideEvalKeysKernel<Dcf, uint32_t><<<kN / 1024, 1024>>>(dcf, d_yt, false, d_seeds0, d_dc, d_xs, kN); });
+    const float ms_e = timed([&] { fss::gpu::DcfEvalPointGpu<4>(false, d_seeds0, cw_s, cw_v, out_cw, d_xs, d_ye, kN, dcf); });
+    auto yt = ToHost(d_yt, kN), ye = ToHost(d_ye, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+    EXPECT(bad == 0);
+    HIP_OK(hipMemset(d_yt, 0xff, sizeof(int4) * kN));
+    const float ms_s = timed([&] { WideEvalKeysStrideKernel<Dcf, uint32_t><<<std::min(kN / 1024, num_cu), 1024>>>(dcf, d_yt, false, d_seeds0, d_dc, d_xs, kN); });
+    yt = ToHost(d_yt, kN);
+    for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+    EXPECT(bad == 0);
+    std::printf("     (WIDE DCF n=32, 2^%d keys, grid-stride loop, %d workgroups of 1024: %.3f ms = %.1f M evals/s)\n", kLog, std::min(kN / 1024, num_cu), ms_s,
+                kN / ms_s / 1e3);
+    std::printf("     (WIDE DCF n=32, 2^%d keys, Aes128MmoWide<4>, 1024 threads per block: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
+                "DcfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n", kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, bad ? "NO" : "yes");
+    HIP_OK(hipFree(d_dc)); HIP_OK(hipFree(d_dc_e));
+  }
+  if constexpr (kLog <= 18) {  // Half-Tree n = 64 (one key: a plain schedule)
+    using Prg = fss::prg::Aes128MmoWide<1>;
+    using Ht = fss::HalfTreeDpf<64, G, Prg, uint64_t>;
+    Ht ht{Prg(keys1), int4{0x12345678, static_cast<int>(0x9abcdef0u), 0x13572468, 0x2468ace0}};
+    std::vector<uint64_t> ha(kN), hx(kN);
+    for (int i = 0; i < kN; ++i) {
+      ha[i] = Next();
+      hx[i] = i % 2 ? ha[i] : Next();
+    }
+    uint64_t* d_ha = ToDevice(ha.data(), kN);
+    uint64_t* d_hx = ToDevice(hx.data(), kN);
+    typename Ht::Cw* d_hc = DeviceBuf<typename Ht::Cw>(size_t(64) * kN);
+    int4* d_ho = DeviceBuf<int4>(kN);
+    int4* h_s = DeviceBuf<int4>(size_t(64) * kN);
+    ht.GenBatch(d_hc, d_ho, d_seeds, d_ha, d_betas, kN);
+    fss::gpu::HalfTreeDpfRelayoutGpu<64, G, Prg, uint64_t>(d_hc, kN, h_s, extra);
+    const float ms_t = timed([&] { WideHtEvalKeysKernel<Ht, uint64_t><<<kN / 1024, 1024>>>(ht, d_yt, false, d_seeds0, d_hc, d_ho, d_hx, kN); });
+    const float ms_e = timed([&] { fss::gpu::HalfTreeDpfEvalPointGpu<4>(false, d_seeds0, h_s, extra, d_ho, d_hx, d_ye, kN, ht); });
+    auto yt = ToHost(d_yt, kN), ye = ToHost(d_ye, kN);
+    int bad = 0;
+    for (int i = 0; i < kN; ++i) bad += !Same(yt[i], ye[i]);
+    EXPECT(bad == 0);
+    std::printf("     (WIDE Half-Tree n=64, 2^%d keys, Aes128MmoWide<1>: per-thread Eval %.3f ms = %.1f M evals/s; HalfTreeDpfEvalPointGpu %.3f ms = "
+                "%.1f M evals/s; same shares: %s)\n", kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, bad ? "NO" : "yes");
+    for (void* q : {(void*)d_ha, (void*)d_hx, (void*)d_hc, (void*)d_ho, (void*)h_s}) HIP_OK(hipFree(q));
+  }
+  for (void* q : {(void*)d_seeds, (void*)d_seeds0, (void*)d_betas, (void*)d_alphas, (void*)d_xs, (void*)d_yt, (void*)d_ye, (void*)cw_s, (void*)cw_v,
+                  (void*)extra, (void*)out_cw})
+    HIP_OK(hipFree(q));
+  std::printf("AES-128-MMO  wide per-thread PRG (Aes128MmoWide<1|2|4>), 2^%d keys: Gen / Eval per thread == engine: %s\n", kLog,
+              g_fail == before ? "ok" : "FAILED");
 }
 }  // namespace p2
 
@@ -1494,6 +1693,8 @@ int main(int argc, char** argv) {
     p2::KeySets();
     p2::Timing<18>();
     if (timing) p2::Timing<21>();
+    p2::Wide<18>(false);
+    if (timing) p2::Wide<21>(true);
     p3::Run();
     p4::Run();
     fss::ReleaseEngines();

@@ -17,6 +17,6 @@ def demangle(n):
         return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().split("(")[0]
     except Exception:
         return n
-print(f"{'kernel':70s} {'vgpr':>5s} {'sgpr':>5s} {'scr':>5s} {'occ':>4s} {'lds':>6s}")
+print(f"{'kernel':160s} {'vgpr':>5s} {'sgpr':>5s} {'scr':>5s} {'occ':>4s} {'lds':>6s}")
 for r in rows:
-    print(f"{demangle(r['name'])[:70]:70s} {r.get('VGPRs','?'):>5s} {r.get('TotalSGPRs','?'):>5s} {r.get('ScratchSize','?'):>5s} {r.get('Occupancy','?'):>4s} {r.get('LDS','?'):>6s}")
+    print(f"{demangle(r['name'])[:160]:160s} {r.get('VGPRs','?'):>5s} {r.get('TotalSGPRs','?'):>5s} {r.get('ScratchSize','?'):>5s} {r.get('Occupancy','?'):>4s} {r.get('LDS','?'):>6s}")
