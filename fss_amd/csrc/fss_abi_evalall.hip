@@ -123,7 +123,9 @@ inline void fused_room(const Plan& pl, int64_t walks, int64_t* room_a, int64_t* 
 
 // nodes: the plan of a node table (shared-prefix point walks): every one of the r levels is an expansion -- a Half-Tree
 // tree's last level too, which for leaves is the conversion (ConvertLastLevel) and not part of `top` / the stages.
-bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl, bool nodes = false) {
+// deep: rolled levels of the leaf stage beyond leaf_extra's (deep_leaf_levels: DPF leaves of a narrow output group in the
+// one-launch form only -- the plan then differs from the group-agnostic one, whose workspace also covers it).
+bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nleaves, Plan* pl, bool nodes = false, int deep = 0) {
   if (in_bits < 1 || in_bits > 62 || nleaves < 1 || first_leaf < 0) return false;
   if (nleaves & (nleaves - 1)) return false;
   int r = 0;
@@ -147,7 +149,12 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
   if (rem == 0) {
     pl->D[pl->nstages++] = 0;  // leaf conversion only
   } else {
-    const int le = leaf_extra(scheme, r);
+    int le = leaf_extra(scheme, r);
+    if (deep > 0 && le == 2) {  // (only on top of the full two rolled levels; the same "a chunk for every wave" rule as leaf_extra)
+      const int room = r - dm - 18;
+      le += deep;
+      if (le > room) le = room < 2 ? 2 : room;
+    }
     const int leaf = rem < dm + le ? rem : dm + le;
     rem -= leaf;
     const int mid = dm + mid_extra(scheme);  // shallowest stage first: it runs on the fewest nodes
@@ -180,6 +187,20 @@ inline bool fused_on() {
   static const bool v = [] { const char* e = tune_env("FSS_AMD_FUSED"); return !(e && atoi(e) == 0); }();
   return v;
 }
+constexpr int kDeepLeafDefault = 2;
+// Two more rolled levels in the leaf stage of a DPF tree whose output group reads only the low 8 bytes of a leaf (OW = 2:
+// the narrow leaf blocks leave twelve registers free, a rolled level takes four): the leaf stage then starts from
+// 2^(r - 6) nodes instead of 2^(r - 4) and the frontier nodes written to and read back from the workspace shrink
+// fourfold -- HBM counter traffic of the 2^28-leaf domain 1.163 x -> 1.04 x its leaves (profiles/r6/evalall_deep_leaf_ab.txt).
+// FSS_AMD_LEAF_DEEP = 0 .. 2.
+constexpr int kDeepLeafMax = 2;
+inline int deep_leaf_levels(const fss_amd_ctx* ctx, int scheme, int group) {
+  static const int v = [] { const char* e = tune_env("FSS_AMD_LEAF_DEEP"); const int t = e ? atoi(e) : kDeepLeafDefault; return t < 0 ? 0 : (t > kDeepLeafMax ? kDeepLeafMax : t); }();
+  static const bool narrow_on = [] { const char* e = tune_env("FSS_AMD_LEAF_NARROW"); return !(e && atoi(e) == 0); }();
+  if (scheme != S_DPF || ctx->prg == FSS_AMD_PRG_CHACHA || !narrow_on || !fused_on()) return 0;
+  return (group >= G_U8 && group <= G_U64) ? v : 0;
+}
+
 // One workgroup per CU (the AES tables leave room for one), fewer only when there are fewer walks than CUs: a small
 // domain is spread as wide as it goes (2^14 leaves on 256 workgroups 14.5 us, on 64 17, on 16 50: the stages below
 // the walks are what more CUs shorten).  FSS_AMD_FUSED_GRID overrides, for tests of uneven shares.
@@ -202,14 +223,14 @@ inline void fused_slices(const Plan& pl, int64_t nkeys, int grid, uint4* const b
   static const int rank = [] { const char* e = tune_env("FSS_AMD_FUSED_RANK"); return e ? (atoi(e) != 0) : 1; }();
   f->rank = rank;
 }
-bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys) {
+bool fused_ok(const fss_amd_ctx* ctx, int scheme, const Plan& pl, int64_t nkeys, int deep = 0) {
   static const bool chacha_too = [] { const char* e = tune_env("FSS_AMD_FUSED_CHACHA"); return !(e && atoi(e) == 0); }();
   if (!fused_on() || !quad_frontier() || (ctx->prg == FSS_AMD_PRG_CHACHA && !chacha_too)) return false;
   if (scheme != S_DPF && scheme != S_GROTTO && scheme != S_HT && scheme != S_DCF) return false;
   if (pl.nstages < 1 || pl.nstages > 7) return false;
   (void)nkeys;
   const int leaf = pl.D[pl.nstages - 1], dm = dmax_for(scheme);
-  if (leaf < 0 || leaf > dm + 2 || (scheme == S_HT && leaf < 1)) return false;
+  if (leaf < 0 || leaf > dm + 2 + deep || (scheme == S_HT && leaf < 1)) return false;
   for (int s = 0; s + 1 < pl.nstages; ++s)
     if (pl.D[s] < 1 || pl.D[s] > 3) return false;
   return true;
@@ -322,6 +343,22 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   if (!workspace || ws_bytes < need) return FSS_AMD_EINVAL;
   if (!aligned16(seed, cws, ocw, ys, workspace)) return FSS_AMD_EINVAL;
   FSS_ON_DEVICE(ctx);
+  // narrow DPF leaves in the one-launch form: a deeper leaf stage where the plan has room for one (deep_leaf_levels);
+  // anything that keeps that plan from running as one launch falls back to the group-agnostic plan above
+  int deep = deep_leaf_levels(ctx, SCHEME, group);
+  if (deep > 0) {
+    Plan dp;
+    bool take = make_plan(SCHEME, true, in_bits, first_leaf, nleaves, &dp, false, deep) && plan_workspace(SCHEME, dp, nleaves) <= ws_bytes &&
+                dp.D[dp.nstages - 1] > pl.D[pl.nstages - 1] && fused_ok(ctx, SCHEME, dp, 1, deep);
+    if (take) {
+      const int grid = fused_grid(ctx, (int64_t)1 << (dp.top - dp.tail));
+      int64_t ra, rb;
+      fused_room(dp, ((((int64_t)1 << (dp.top - dp.tail)) + grid - 1) / grid), &ra, &rb);
+      take = ra * grid <= dp.cap_a && rb * grid <= dp.cap_b;
+    }
+    if (take) pl = dp;
+    else deep = 0;
+  }
 
   const size_t per = (SCHEME == S_DCF) ? 32 : 16;
   uint8_t* w = reinterpret_cast<uint8_t*>(workspace);
@@ -338,7 +375,7 @@ int eval_all_impl(fss_amd_ctx* ctx, int in_bits, int group, int party, const voi
   a.ys = ys;
 
   bool fused = false;
-  if (fused_ok(ctx, SCHEME, pl, 1)) {
+  if (fused_ok(ctx, SCHEME, pl, 1, deep)) {
     FusedArgs f{};
     f.a = a;
 #if FSS_DIAG_STAMPS
@@ -739,6 +776,12 @@ size_t fss_amd_eval_all_workspace(int scheme, int in_bits, int64_t nleaves) {
     const size_t b = plan_workspace(scheme, pl, nleaves);
     if (b > need) need = b;
   }
+  if (scheme == S_DPF)  // the deeper leaf stage narrow output groups may take (deep_leaf_levels)
+    for (int deep = 1; deep <= kDeepLeafMax; ++deep)
+      if (make_plan(scheme, true, in_bits, 0, nleaves, &pl, false, deep)) {
+        const size_t b = plan_workspace(scheme, pl, nleaves);
+        if (b > need) need = b;
+      }
   return need;
 }
 

@@ -884,20 +884,6 @@ __device__ __forceinline__ void prg_tbits2(const ChaChaL& L, const DevCtx* __res
   prg_gen2(L, c, s, l, r);
   tl = l[3]; tr = r[3];
 }
-// Raw PRG outputs for fss_amd_prg_gen: out[j] for j < mul.
-__device__ __forceinline__ void prg_raw(const Lds& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],
-                                        uint32_t out[4][4]) {
-  if (mul == 1) aes_mmo<false>(L, c->rk[0], 0, s, out[0]);
-  else if (mul == 2) prg_gen2(L, c, s, out[0], out[1]);  // two interleaved blocks
-  else prg_gen4(L, c, s, out[0], out[1], out[2], out[3]);
-}
-__device__ __forceinline__ void prg_raw(const ChaChaL& L, const DevCtx* __restrict__ c, int mul, const uint32_t s[4],
-                                        uint32_t out[4][4]) {
-  if (mul == 1) prg_hash(L, c, s, out[0]);
-  else if (mul == 2) prg_gen2(L, c, s, out[0], out[1]);
-  else prg_gen4(L, c, s, out[0], out[1], out[2], out[3]);
-}
-
 // ------------------------------------------------------------------ output groups
 // fss::group::Bytes (include/fss/group/bytes.cuh:19-43) and fss::group::Uint<T, mod>
 // (include/fss/group/uint.cuh:27-88).  The group is a wave-uniform runtime value.

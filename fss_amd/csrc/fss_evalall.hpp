@@ -333,13 +333,17 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
 // code and the register count of a deep stage close to those of a D-level one.  LEAF: the outputs are
 // the tree's leaves and are converted (dpf.cuh:255-263, dcf.cuh:318-329, half_tree_dpf.cuh
 // ConvertLastLevel, grotto_dcf.cuh:194-198) instead of stored as nodes.
-template <class LT, int SCHEME, int E>
+// kLdsLevel: the rolled level (counted like E: the outermost of a stage is E = the stage's rolled depth) whose right child
+// waits in LDS (`park`, this lane's 16 bytes) instead of in four registers while the left subtree is walked -- the fourth
+// rolled level of a DPF leaf stage, which otherwise spills (128 registers, 36 B of scratch per lane): one 16-byte LDS
+// write and read per 64 AES blocks.
+template <class LT, int SCHEME, int E, int kLdsLevel = 0>
 struct OuterLevels {
   template <class Body>
   static __device__ __forceinline__ void run(const LT& L, const DevCtx* __restrict__ c, const Grp& g,
                                              const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
                                              int lvl, const uint32_t node[4], const Acc& v, int64_t ob, int sub_log2,
-                                             Body& body, int half = -1) {
+                                             Body& body, int half = -1, uint4* park = nullptr) {
     // half: which child of the innermost rolled level this subtree is (0 / 1), -1 with no rolled level above the body
     if constexpr (E == 0) {
       body(k_cws, k_ocw, node, v, lvl, ob, half);
@@ -350,17 +354,26 @@ struct OuterLevels {
       if constexpr (SCHEME == S_DCF) dcf_expand(L, c, g, cw, node, v, l, vl, r, vr);
       else if constexpr (SCHEME == S_HT) ht_expand(L, c, cw, node, l, r);
       else dpf_expand(L, c, cw, node, l, r);
+      if constexpr (E == kLdsLevel && SCHEME != S_DCF) {
+        *park = make_uint4(r[0], r[1], r[2], r[3]);
+        OuterLevels<LT, SCHEME, E - 1, kLdsLevel>::run(L, c, g, k_cws, k_ocw, lvl + 1, l, v, ob, sub_log2 - 1, body, 0, park);
+        const uint4 t = *park;
+        const uint32_t rr[4] = {t.x, t.y, t.z, t.w};
+        OuterLevels<LT, SCHEME, E - 1, kLdsLevel>::run(L, c, g, k_cws, k_ocw, lvl + 1, rr, v, ob + ((int64_t)1 << (sub_log2 - 1)), sub_log2 - 1,
+                                                       body, 1, park);
+      } else {
 #pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        uint32_t ch[4];
-        Acc cv;
+        for (int h = 0; h < 2; ++h) {
+          uint32_t ch[4];
+          Acc cv;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          ch[q] = h ? r[q] : l[q];
-          if constexpr (SCHEME == S_DCF) cv.v[q] = h ? vr.v[q] : vl.v[q];
+          for (int q = 0; q < 4; ++q) {
+            ch[q] = h ? r[q] : l[q];
+            if constexpr (SCHEME == S_DCF) cv.v[q] = h ? vr.v[q] : vl.v[q];
+          }
+          OuterLevels<LT, SCHEME, E - 1, kLdsLevel>::run(L, c, g, k_cws, k_ocw, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
+                                                         sub_log2 - 1, body, h, park);
         }
-        OuterLevels<LT, SCHEME, E - 1>::run(L, c, g, k_cws, k_ocw, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
-                                            sub_log2 - 1, body, h);
       }
     }
   }
@@ -524,7 +537,8 @@ struct StageBody {
 template <class LT, int SCHEME, int D, bool LEAF, int E, bool BATCH, int OW, bool UNI = false, class Queue>
 __device__ __forceinline__ void run_stage(const LT& L, const DevCtx* __restrict__ c, const Grp& g, const ExpandArgs& a,
                                           const uint32_t* __restrict__ k_cws, const uint32_t* __restrict__ k_ocw,
-                                          Queue& q, int64_t j_hi, uint32_t* prog = nullptr) {
+                                          Queue& q, int64_t j_hi, uint32_t* prog = nullptr, uint4* park = nullptr) {
+  constexpr int PK = (E >= 4 && SCHEME != S_DCF) ? E : 0;  // a fourth rolled level parks its right child in LDS (OuterLevels)
   StageBody<LT, SCHEME, D, LEAF, OW> body{L, c, g, a, prog, 0u, {}};
   for (int64_t j; q.next(j);) {
     if (j >= j_hi) continue;  // ragged last chunk
@@ -549,14 +563,14 @@ __device__ __forceinline__ void run_stage(const LT& L, const DevCtx* __restrict_
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)key);
       const uint32_t* kc = k_cws + 8 * key0 * a.key_slots;
       const uint32_t* koc = k_ocw ? k_ocw + 4 * key0 : k_ocw;
-      OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
+      OuterLevels<LT, SCHEME, E, PK>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body, -1, park);
     } else if constexpr (BATCH) {
       const int64_t key = j >> a.level0;
       const uint32_t* kc = k_cws + 8 * key * a.key_slots;
       const uint32_t* koc = k_ocw ? k_ocw + 4 * key : k_ocw;
-      OuterLevels<LT, SCHEME, E>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body);
+      OuterLevels<LT, SCHEME, E, PK>::run(L, c, g, kc, koc, a.level0, n0, v0, j << (E + D), E + D, body, -1, park);
     } else {
-      OuterLevels<LT, SCHEME, E>::run(L, c, g, k_cws, k_ocw, a.level0, n0, v0, j << (E + D), E + D, body);
+      OuterLevels<LT, SCHEME, E, PK>::run(L, c, g, k_cws, k_ocw, a.level0, n0, v0, j << (E + D), E + D, body, -1, park);
     }
   }
 }
@@ -721,6 +735,9 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
       a.out_nodes = f.a.out_nodes;
       a.out_v = f.a.out_v;
       run_stage<LT, SCHEME, LD, false, LE, BATCH, 4, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
+    } else if constexpr (LE >= 4) {
+      __shared__ uint4 park_[1024];  // 16 KiB beside the 128 KiB of tables: one right child per lane (OuterLevels)
+      run_stage<LT, SCHEME, LD, true, LE, BATCH, OW, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog, &park_[threadIdx.x]);
     } else {
       run_stage<LT, SCHEME, LD, true, LE, BATCH, OW, UNI>(L, c, g, a, k_cws, k_ocw, q, hi, prog);
     }

@@ -33,6 +33,11 @@ int by_leaf(fss_amd_ctx* ctx, int leaf_t, const SharedKey& k, const FusedArgs& f
   }
   if (leaf_t == DM + 1) return launch_one<SCHEME, DM, 1, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
   if (leaf_t == DM + 2) return launch_one<SCHEME, DM, 2, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
+  // three and four rolled levels: one DPF tree with narrow leaves only (fss_abi_evalall.hip: deep_leaf_levels)
+  if constexpr (SCHEME == S_DPF && OW == 2 && !BATCH && std::is_same_v<LT, Lds>) {
+    if (leaf_t == DM + 3) return launch_one<SCHEME, DM, 3, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
+    if (leaf_t == DM + 4) return launch_one<SCHEME, DM, 4, OW, BATCH, LT, UNI>(ctx, k, f, grid, st);
+  }
   return FSS_AMD_EINVAL;
 }
 
