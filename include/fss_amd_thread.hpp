@@ -521,11 +521,23 @@ __device__ inline bool SameInAllLanes(const uint32_t* w, int n) {
 // apart; by themselves they repeat -- the ring wraps, argument chunks are recycled) and with the workgroup id.  The
 // guarantee is probabilistic: two launches on different queues with equal counters would have to collide in the other
 // 64 bits as well.
-extern "C" __device__ uint64_t fss_amd_llvm_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");  // no clang builtin for it
+// The dispatch id: a clang builtin where the toolchain has one; on the toolchains this header was written against (ROCm 7.x,
+// clang 19 - 22: no builtin) the LLVM intrinsic reached through an asm-labelled declaration -- which works because clang
+// maps the label onto the intrinsic's name, not because anything documents it; any other compiler takes the fallback: the
+// packet's completion-signal handle (a fresh value per in-flight packet of a queue) in the counter's place.  Define
+// FSS_AMD_NO_DISPATCH_ID_INTRINSIC to force the fallback.
+#if __has_builtin(__builtin_amdgcn_dispatch_id)
+__device__ inline uint64_t DispatchCounter(const uint64_t*) { return __builtin_amdgcn_dispatch_id(); }
+#elif defined(__clang__) && __clang_major__ >= 17 && __clang_major__ <= 22 && !defined(FSS_AMD_NO_DISPATCH_ID_INTRINSIC)
+extern "C" __device__ uint64_t fss_amd_llvm_dispatch_id(void) __asm("llvm.amdgcn.dispatch.id");
+__device__ inline uint64_t DispatchCounter(const uint64_t*) { return fss_amd_llvm_dispatch_id(); }
+#else
+__device__ inline uint64_t DispatchCounter(const uint64_t* pkt) { return pkt[7]; }  // hsa_kernel_dispatch_packet_t::completion_signal
+#endif
 __device__ inline void LaunchNonce(uint32_t n[2]) {
   const uint64_t* pkt = reinterpret_cast<const uint64_t*>(__builtin_amdgcn_dispatch_ptr());
   const uint64_t wg = blockIdx.x + gridDim.x * (blockIdx.y + static_cast<uint64_t>(gridDim.y) * blockIdx.z);
-  uint64_t v = fss_amd_llvm_dispatch_id() * 0x9e3779b97f4a7c15ull;
+  uint64_t v = DispatchCounter(pkt) * 0x9e3779b97f4a7c15ull;
   v ^= reinterpret_cast<uint64_t>(pkt) * 0xc2b2ae3d27d4eb4full ^ pkt[5];  // kernarg_address
   v = (v ^ (v >> 29)) * 0xbf58476d1ce4e5b9ull + wg;
   n[0] = Uniform(static_cast<uint32_t>(v));
