@@ -651,6 +651,67 @@ class Aes128MmoWide {
   }
 };
 
+// fss::prg::Aes128SoftWide<mul>: the wide layout for PRG objects that a kernel constructs PER THREAD from key bytes, the
+// shape of the reference's AES kernels (src/bench_gpu.cu:100-138: the block prepares the tables, every thread builds its
+// `Aes128Soft<2> prg(kKeys, s_te0, s_sbox)` and evaluates):
+//     fss::prg::Aes128SoftWide<2>::InitWorkgroup();          // every thread of the 1024-thread workgroup, before anything else
+//     fss::prg::Aes128SoftWide<2> prg(kKeys);  fss::Dpf<...> dpf{prg};  ys[tid] = dpf.Eval(...);
+// Same tables, same launch rules as Aes128MmoWide; an object built on the device has no memory home for scalar key loads,
+// so its round keys live in the wave's LDS key slot like Aes128Mmo's (44 more LDS reads per block than Aes128MmoWide:
+// about 15 % slower; still the rotate-free rounds).  Host-built objects work too.
+template <int mul>
+class Aes128SoftWide {
+  static_assert(mul == 1 || mul == 2 || mul == 4);
+  using Schedules = thread::AesSchedules<mul, false, true>;
+  Schedules ks_;
+
+ public:
+  __host__ __device__ explicit Aes128SoftWide(const uint8_t keys[][16]) {
+    const unsigned char* kp[mul];
+    for (int i = 0; i < mul; ++i) kp[i] = keys[i];
+    ks_.Set(kp, [](uint32_t b) { return static_cast<uint32_t>(thread::kAes.sbox[b]); });
+  }
+  __device__ static void InitWorkgroup() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    thread::WideTablesInit();
+#endif
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  __device__ __attribute__((always_inline)) thread::PreparedAes<mul, Schedules, thread::WideTab> Prepared() const {
+    const thread::WideTab tab = thread::WideTab::Make();
+    return thread::PreparedAes<mul, Schedules, thread::WideTab>{ks_, tab, ks_.ReadyKeys(tab)};
+  }
+#endif
+  __device__ __attribute__((always_inline)) std::array<int4, mul> Gen(int4 seed) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ks_.Gen(thread::WideTab::Make(), seed);
+#else
+    (void)seed;
+    return {};
+#endif
+  }
+  __host__ std::array<int4, mul> Gen(int4 seed) const { return detail::GenOne(*this, seed); }
+  __device__ __attribute__((always_inline)) std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
+    requires(mul >= 2)
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ks_.GenSide(thread::WideTab::Make(), seed, right);
+#else
+    (void)seed;
+    (void)right;
+    return {};
+#endif
+  }
+  // (key-major keys a line at a time, like Aes128MmoWide -- except with four keys, where the 32 registers of the DCF line
+  // buffer beside two ciphers with keys from LDS spill)
+  static constexpr bool kKeyMajorLines = mul != 4;
+  static constexpr int kMul = mul;
+  void Describe(detail::Spec& s) const {
+    s.prg = FSS_AMD_PRG_AES128_MMO;
+    for (int i = 0; i < mul; ++i) ks_.KeyBytes(i, s.aes + 16 * i);
+  }
+};
+
 // fss::prg::Aes128MmoRaw<mul>(const uint8_t keys[][16]) (include/fss/prg/aes128_mmo_raw.cuh:39-110): the reference's
 // host-only AES-NI form of the same function, constructed from the key bytes directly.  Here it IS Aes128Mmo with that
 // constructor: Gen on the host goes to the engine, schemes over it are engine schemes, and on the device it works too.
@@ -895,6 +956,7 @@ static_assert(Prgable<Aes128Mmo<1>, 1> && Prgable<Aes128Mmo<2>, 2> && Prgable<Ae
 static_assert(Prgable<Aes128Soft<1>, 1> && Prgable<Aes128Soft<2>, 2> && Prgable<Aes128Soft<4>, 4>);
 static_assert(Prgable<Aes128MmoRaw<1>, 1> && Prgable<Aes128MmoRaw<2>, 2> && Prgable<Aes128MmoRaw<4>, 4>);
 static_assert(Prgable<Aes128MmoWide<1>, 1> && Prgable<Aes128MmoWide<2>, 2> && Prgable<Aes128MmoWide<4>, 4>);
+static_assert(Prgable<Aes128SoftWide<1>, 1> && Prgable<Aes128SoftWide<2>, 2> && Prgable<Aes128SoftWide<4>, 4>);
 static_assert(Prgable<Aes128SoftBanked<1>, 1> && Prgable<Aes128SoftBanked<2>, 2> && Prgable<Aes128SoftBanked<4>, 4>);
 static_assert(Prgable<ChaCha<1>, 1> && Prgable<ChaCha<2>, 2> && Prgable<ChaCha<4>, 4>);
 }  // namespace prg

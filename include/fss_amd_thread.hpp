@@ -340,9 +340,25 @@ struct LdsTables {
 #endif
 
 // The sixteen table entries of a round: t[j][k] = T(byte k of state word (j + k) % 4) (ShiftRows in the indices).
+// (tables that hold the entry already rotated for its row -- the wide four-table layout, WideTab -- say kFourTables: the
+// lookup for row k goes to table k and the round applies no rotation)
+template <bool BE, typename Tab>
+__host__ __device__ inline uint32_t AesRowRot(uint32_t v, int k) {
+  if constexpr (requires { Tab::kFourTables; }) return v;
+  else return AesRot<BE>(v, k);
+}
 template <bool BE, typename Tab>
 __host__ __device__ inline void AesLookups(const Tab& tab, const uint32_t c[4], uint32_t t[4][4]) {
-  if constexpr (requires { tab.Split(0u); }) {
+  if constexpr (requires { Tab::kFourTables; }) {
+    static_assert(!BE, "the four-table layout is little-endian");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[j][0] = tab.template Lk<0, 0>(c[j]);
+      t[j][1] = tab.template Lk<1, 1>(c[(j + 1) & 3]);
+      t[j][2] = tab.template Lk<2, 2>(c[(j + 2) & 3]);
+      t[j][3] = tab.template Lk<3, 3>(c[(j + 3) & 3]);
+    }
+  } else if constexpr (requires { tab.Split(0u); }) {
     const typename Tab::Halves h[4] = {tab.Split(c[0]), tab.Split(c[1]), tab.Split(c[2]), tab.Split(c[3])};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -364,7 +380,13 @@ __host__ __device__ inline void AesLookups(const Tab& tab, const uint32_t c[4], 
 // instead of four extractions and three merges).
 template <bool BE, typename Tab, typename Key>
 __host__ __device__ inline void AesLastRound(const Tab& tab, const Key& key, const uint32_t c[4], uint32_t out[4]) {
-  if constexpr (requires { Tab::kSboxInTable; }) {
+  if constexpr (requires { Tab::kFourTables; }) {
+    // T2 has S in byte 0, T3 in byte 1, T0 in byte 2, T1 in byte 3: every lookup holds its S-box byte in place
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      out[j] = FoldKey(key, 10, j, tab.LastColumn(tab.template Lk<0, 2>(c[j]), tab.template Lk<1, 3>(c[(j + 1) & 3]),
+                                                   tab.template Lk<2, 0>(c[(j + 2) & 3]), tab.template Lk<3, 1>(c[(j + 3) & 3])), 0u);
+  } else if constexpr (requires { Tab::kSboxInTable; }) {
     uint32_t t[4][4];
     AesLookups<BE>(tab, c, t);
     // byte 1 of t[j][k] goes to byte AesBytePos(k) / 8 of the word: selector 1 = byte 1 of the second operand, 5 = byte 1
@@ -404,7 +426,7 @@ __host__ __device__ inline void AesEncrypt(const Tab& tab, const Key& key, const
     AesLookups<BE>(tab, c, t);  // 16 lookups in flight
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      c[j] = FoldKey(key, r, j, Xor3(t[j][0], AesRot<BE>(t[j][1], 1), AesRot<BE>(t[j][2], 2)), AesRot<BE>(t[j][3], 3));
+      c[j] = FoldKey(key, r, j, Xor3(t[j][0], AesRowRot<BE, Tab>(t[j][1], 1), AesRowRot<BE, Tab>(t[j][2], 2)), AesRowRot<BE, Tab>(t[j][3], 3));
   };
   if constexpr (Tab::kUnrollRounds) {
 #pragma unroll
@@ -431,8 +453,8 @@ __host__ __device__ inline void AesEncrypt2(const Tab& tab, const KeyA& ka, cons
     AesLookups<BE>(tab, b, tb);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      a[j] = FoldKey(ka, r, j, Xor3(ta[j][0], AesRot<BE>(ta[j][1], 1), AesRot<BE>(ta[j][2], 2)), AesRot<BE>(ta[j][3], 3));
-      b[j] = FoldKey(kb, r, j, Xor3(tb[j][0], AesRot<BE>(tb[j][1], 1), AesRot<BE>(tb[j][2], 2)), AesRot<BE>(tb[j][3], 3));
+      a[j] = FoldKey(ka, r, j, Xor3(ta[j][0], AesRowRot<BE, Tab>(ta[j][1], 1), AesRowRot<BE, Tab>(ta[j][2], 2)), AesRowRot<BE, Tab>(ta[j][3], 3));
+      b[j] = FoldKey(kb, r, j, Xor3(tb[j][0], AesRowRot<BE, Tab>(tb[j][1], 1), AesRowRot<BE, Tab>(tb[j][2], 2)), AesRowRot<BE, Tab>(tb[j][3], 3));
     }
   };
   if constexpr (Tab::kUnrollRounds) {
@@ -1000,6 +1022,14 @@ struct WideTab {
   }
   template <int K, int T>
   __device__ uint32_t Lk(uint32_t w) const { return At(Addr<K, T>(w)); }
+  // ... as a table type of the generic cipher (AesEncrypt / AesEncrypt2 with round keys from the wave's LDS slot: PRG
+  // objects constructed per thread inside a kernel, fss::prg::Aes128SoftWide)
+  static constexpr bool kUnrollRounds = true;
+  static constexpr bool kFourTables = true;
+  __device__ uint32_t S(uint32_t i) const { return At(lo[0] | i << 8) >> 8 & 0xff; }  // byte 1 of the T0 entry (2S, S, S, 3S)
+  __device__ uint32_t LastColumn(uint32_t a, uint32_t b, uint32_t c, uint32_t d) const {
+    return __builtin_amdgcn_bitop3_b32(m_ffff, __builtin_amdgcn_bitop3_b32(m_00ff, a, b, 0xCA), __builtin_amdgcn_bitop3_b32(m_ff0000, c, d, 0xCA), 0xCA);
+  }
 };
 // Round keys of ONE schedule (44 words) or of a per-lane choice between two (per round: A[4] then D[4] = (A ^ B)[4]; the
 // lane's key is A ^ (mask & D)), read a round at a time through a pointer the compiler sees as depending on the round.
@@ -1347,7 +1377,7 @@ __device__ __attribute__((always_inline)) inline void SettleBeforeLoop(const int
 // PRG types whose walks read key-major keys a line at a time (the wide form: its walks are bound by the LDS pipe and the
 // memory system, with registers to spare; the default form is bound by VALU issue and keeps the two loads per level)
 template <typename Prg>
-concept LineWalkPrg = requires { Prg::kKeyMajorLines; };
+concept LineWalkPrg = requires { requires Prg::kKeyMajorLines; };
 
 struct DpfLevelMajorView {
   const int4* cw_s;

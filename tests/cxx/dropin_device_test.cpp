@@ -948,6 +948,33 @@ __global__ __launch_bounds__(1024) void WidePrgKernel(fss::prg::Aes128MmoWide<mu
   for (int i = 0; i < mul; ++i) out[size_t(tid) * mul + i] = g[i];
 }
 
+// ... and fss::prg::Aes128SoftWide: the PRG constructed PER THREAD inside the kernel from key bytes in constant memory (the
+// reference's AES kernel shape, src/bench_gpu.cu:100-138), on the same wide tables.
+__constant__ uint8_t kWideKeys[4][16] = {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16},
+                                         {16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1},
+                                         {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8},
+                                         {8, 8, 7, 7, 6, 6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1}};
+template <typename S, typename Prg, typename In>
+__global__ __launch_bounds__(1024) void SoftWideEvalKeysKernel(int4* ys, bool party, const int4* seeds, const typename S::Cw* cws, const In* xs,
+                                                               int n) {
+  Prg::InitWorkgroup();
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  Prg prg(kWideKeys);
+  S sch{prg};
+  ys[tid] = sch.Eval(party, seeds[tid], cws + size_t(tid) * S::kSlots, xs[tid]);
+}
+template <typename S, typename Prg, typename In>
+__global__ __launch_bounds__(1024) void SoftWideGenKeysKernel(typename S::Cw* cws, const int4* seeds, const In* alphas, const int4* betas, int n) {
+  Prg::InitWorkgroup();
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  Prg prg(kWideKeys);
+  S sch{prg};
+  int4 s[2] = {seeds[tid * 2], seeds[tid * 2 + 1]};
+  sch.Gen(cws + size_t(tid) * S::kSlots, s, alphas[tid], betas[tid]);
+}
+
 template <int kLog>
 static void Wide(bool timing) {
   const int before = g_fail;
@@ -1030,6 +1057,29 @@ static void Wide(bool timing) {
     EXPECT(bad == 0);
     std::printf("     (WIDE DPF n=32, 2^%d keys, grid-stride loop, %d workgroups of 1024: %.3f ms = %.1f M evals/s)\n", kLog, std::min(kN / 1024, num_cu), ms_s,
                 kN / ms_s / 1e3);
+    {  // Aes128SoftWide<2>: per-thread construction; Gen and Eval against the same engine results (same keys k0, k1)
+      using PrgS = fss::prg::Aes128SoftWide<2>;
+      using DpfS = fss::Dpf<32, G, PrgS, uint32_t>;
+      DpfS::Cw* d_cws_s = DeviceBuf<DpfS::Cw>(size_t(33) * kN);
+      SoftWideGenKeysKernel<DpfS, PrgS, uint32_t><<<kN / 1024, 1024>>>(d_cws_s, d_seeds, d_alphas, d_betas, kN);
+      HIP_OK(hipDeviceSynchronize());
+      {
+        auto a = ToHost(d_cws_s, size_t(33) * kN);
+        auto e = ToHost(reinterpret_cast<const DpfS::Cw*>(d_cws), size_t(33) * kN);
+        int badg = 0;
+        for (size_t i = 0; i < a.size(); ++i) badg += !Same(a[i].s, e[i].s) || (i % 33 != 32 && a[i].tr != e[i].tr);
+        EXPECT(badg == 0);
+      }
+      HIP_OK(hipMemset(d_yt, 0xff, sizeof(int4) * kN));
+      const float ms_w = timed([&] { SoftWideEvalKeysKernel<DpfS, PrgS, uint32_t><<<kN / 1024, 1024>>>(d_yt, false, d_seeds0, d_cws_s, d_xs, kN); });
+      yt = ToHost(d_yt, kN);
+      int bads = 0;
+      for (int i = 0; i < kN; ++i) bads += !Same(yt[i], ye[i]);
+      EXPECT(bads == 0);
+      std::printf("     (WIDE DPF n=32, 2^%d keys, Aes128SoftWide<2> constructed per thread: %.3f ms = %.1f M evals/s; same shares: %s)\n", kLog, ms_w,
+                  kN / ms_w / 1e3, bads ? "NO" : "yes");
+      HIP_OK(hipFree(d_cws_s));
+    }
     std::printf("     (WIDE DPF n=32, 2^%d keys, Aes128MmoWide<2>, 1024 threads per block: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
                 "DpfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n", kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, bad ? "NO" : "yes");
     HIP_OK(hipFree(d_cws)); HIP_OK(hipFree(d_cws_e));
@@ -1061,6 +1111,20 @@ static void Wide(bool timing) {
     EXPECT(bad == 0);
     std::printf("     (WIDE DCF n=32, 2^%d keys, grid-stride loop, %d workgroups of 1024: %.3f ms = %.1f M evals/s)\n", kLog, std::min(kN / 1024, num_cu), ms_s,
                 kN / ms_s / 1e3);
+    {  // Aes128SoftWide<4>
+      using PrgS = fss::prg::Aes128SoftWide<4>;
+      using DcfS = fss::Dcf<32, G, PrgS, uint32_t>;
+      HIP_OK(hipMemset(d_yt, 0xff, sizeof(int4) * kN));
+      const float ms_w = timed([&] {
+        SoftWideEvalKeysKernel<DcfS, PrgS, uint32_t><<<kN / 1024, 1024>>>(d_yt, false, d_seeds0, reinterpret_cast<const DcfS::Cw*>(d_dc), d_xs, kN);
+      });
+      yt = ToHost(d_yt, kN);
+      int bads = 0;
+      for (int i = 0; i < kN; ++i) bads += !Same(yt[i], ye[i]);
+      EXPECT(bads == 0);
+      std::printf("     (WIDE DCF n=32, 2^%d keys, Aes128SoftWide<4> constructed per thread: %.3f ms = %.1f M evals/s; same shares: %s)\n", kLog, ms_w,
+                  kN / ms_w / 1e3, bads ? "NO" : "yes");
+    }
     std::printf("     (WIDE DCF n=32, 2^%d keys, Aes128MmoWide<4>, 1024 threads per block: per-thread Eval in a caller kernel %.3f ms = %.1f M evals/s; "
                 "DcfEvalPointGpu %.3f ms = %.1f M evals/s; same shares: %s)\n", kLog, ms_t, kN / ms_t / 1e3, ms_e, kN / ms_e / 1e3, bad ? "NO" : "yes");
     HIP_OK(hipFree(d_dc)); HIP_OK(hipFree(d_dc_e));
