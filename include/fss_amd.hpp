@@ -642,6 +642,7 @@ class Aes128MmoWide {
   }
   // the per-thread walks read key-major keys a cache line at a time with this PRG (thread::KeyMajorLines)
   static constexpr bool kKeyMajorLines = true;
+  static constexpr bool kWideTables = true;  // needs the caller's own kernel shape: refused by this header's generic kernels
   // The engine runs the same function with these keys: schemes over it take the batched entry points and launchers too.
   static constexpr int kMul = mul;
   void Describe(detail::Spec& s) const {
@@ -705,6 +706,7 @@ class Aes128SoftWide {
   // (key-major keys a line at a time, like Aes128MmoWide -- except with four keys, where the 32 registers of the DCF line
   // buffer beside two ciphers with keys from LDS spill)
   static constexpr bool kKeyMajorLines = mul != 4;
+  static constexpr bool kWideTables = true;
   static constexpr int kMul = mul;
   void Describe(detail::Spec& s) const {
     s.prg = FSS_AMD_PRG_AES128_MMO;
@@ -1030,8 +1032,18 @@ __global__ void ThreadEvalAllBatchKernel(S sch, bool b, const int4* s0s, const t
   if constexpr (requires { sch.hash_key; }) ys[i] = sch.Eval(b, s0s[k], cws + k * S::kSlots, ocws[k], x);
   else ys[i] = sch.Eval(b, s0s[k], cws + k * S::kSlots, x);
 }
+// a wide PRG (Aes128MmoWide / Aes128SoftWide), alone or as a scheme's `prg`: only for kernels the caller shapes himself
+template <typename T>
+constexpr bool UsesWideTables() {
+  if constexpr (requires { T::kWideTables; }) return true;
+  else if constexpr (requires(const T& t) { t.prg; }) return requires { std::remove_cvref_t<decltype(std::declval<const T&>().prg)>::kWideTables; };
+  else return false;
+}
 template <typename K, typename... Args>
 void LaunchThreads(K kernel, int64_t n, hipStream_t stream, Args... args) {
+  static_assert(!(UsesWideTables<Args>() || ...), "fss::prg::Aes128MmoWide / Aes128SoftWide need 1024-thread workgroups and InitWorkgroup(): they "
+                                                  "work in the caller's own kernels and through the engine (built-in groups), not in this header's "
+                                                  "generic 128-thread kernels for caller-defined groups");
   if (n <= 0) return;
   static_assert((std::is_trivially_copyable_v<Args> && ...), "scheme, PRG and group objects are passed to kernels by "
                                                               "value: they must be trivially copyable");
