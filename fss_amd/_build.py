@@ -193,6 +193,12 @@ def build_dropin_device_test(force=False):
     return _build_cxx_test("dropin_device_test", force)
 
 
+def build_reference_cases_test(force=False):
+    """Compile tests/cxx/reference_cases_test.cpp: the reference's own gtest case list (group axioms, DPF / DCF / Half-Tree /
+    Grotto / VDPF properties) under its suite and case names, through the <fss/...cuh> include lines."""
+    return _build_cxx_test("reference_cases_test", force)
+
+
 def build_multi_gpu_test(force=False):
     """Compile tests/cxx/multi_gpu_test.cpp: fss::gpu::DeviceSet, eight members on one GPU against one launch."""
     return _build_cxx_test("multi_gpu_test", force)

@@ -1,0 +1,5 @@
+// <fss/hash/sha256.cuh>: the include line a caller of myl7/fss writes for fss::hash::Sha256.
+// Kept so that such a caller's #include lines compile unchanged against this library ("include lines");
+// nothing is defined here -- the declarations live in fss_amd.hpp.
+#pragma once
+#include "../../fss_amd.hpp"

@@ -1,0 +1,5 @@
+// <fss/prg/aes128_mmo_soft.cuh>: the include line a caller of myl7/fss writes for fss::prg::Aes128Soft<mul>, fss::prg::aes_detail.
+// Kept so that such a caller's #include lines compile unchanged against this library ("include lines");
+// nothing is defined here -- the declarations live in fss_amd.hpp.
+#pragma once
+#include "../../fss_amd.hpp"

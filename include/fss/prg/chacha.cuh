@@ -1,0 +1,5 @@
+// <fss/prg/chacha.cuh>: the include line a caller of myl7/fss writes for fss::prg::ChaCha<mul, rounds>.
+// Kept so that such a caller's #include lines compile unchanged against this library ("include lines");
+// nothing is defined here -- the declarations live in fss_amd.hpp.
+#pragma once
+#include "../../fss_amd.hpp"

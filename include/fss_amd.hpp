@@ -158,10 +158,26 @@ struct Bytes {
 
 // include/fss/group/uint.cuh:27-88: the low sizeof(T) bytes of the buffer as an integer, wrapping or modulo `mod`;
 // T = __uint128_t keeps 127 bits (bit 0 of w is the clamped bit, so the top word is stored shifted left by one).
+// The engine's name for a Uint group -- enum fss_amd_group + the context's modulus (fss_amd_ctx_set_uint_modulus) -- for the
+// groups its prebuilt kernels compute in: every T up to 64 bits with any modulus, and __uint128_t modulo 2^127.  A 128-bit
+// group with another modulus (the reference allows 0 < mod <= 2^127, group/uint.cuh:28-30; src/group_test.cu:18 uses 2^126)
+// is a complete value type without that name: schemes over it run the per-thread code in the generic kernels, like a
+// caller-defined Groupable.
+template <typename T, T mod, bool kKnown = (sizeof(T) < 16 || mod == (static_cast<T>(1) << 127))>
+struct UintEngineName {};
+template <typename T, T mod>
+struct UintEngineName<T, mod, true> {
+  static constexpr int kId = sizeof(T) == 1   ? FSS_AMD_GROUP_U8
+                             : sizeof(T) == 2 ? FSS_AMD_GROUP_U16
+                             : sizeof(T) == 4 ? FSS_AMD_GROUP_U32
+                             : sizeof(T) == 8 ? FSS_AMD_GROUP_U64
+                                              : FSS_AMD_GROUP_U128_M127;
+  static constexpr uint64_t kMod = sizeof(T) == 16 ? 0 : static_cast<uint64_t>(mod);
+};
 template <typename T, T mod = 0>
   requires((std::is_unsigned_v<T> || std::is_same_v<T, unsigned __int128>) && sizeof(T) <= 16 &&
            (sizeof(T) < 16 || (mod > 0 && mod <= static_cast<T>(1) << 127)))
-struct Uint {
+struct Uint : UintEngineName<T, mod> {
   T val;
   __host__ __device__ Uint() : val(0) {}
   __host__ __device__ Uint operator+(Uint o) const {
@@ -197,14 +213,6 @@ struct Uint {
     }
     return r;
   }
-  // the engine's name for this group: enum fss_amd_group + the context's modulus (fss_amd_ctx_set_uint_modulus)
-  static_assert(sizeof(T) < 16 || mod == (static_cast<T>(1) << 127), "Uint<__uint128_t> is built for mod = 2^127 only");
-  static constexpr int kId = sizeof(T) == 1   ? FSS_AMD_GROUP_U8
-                             : sizeof(T) == 2 ? FSS_AMD_GROUP_U16
-                             : sizeof(T) == 4 ? FSS_AMD_GROUP_U32
-                             : sizeof(T) == 8 ? FSS_AMD_GROUP_U64
-                                              : FSS_AMD_GROUP_U128_M127;
-  static constexpr uint64_t kMod = sizeof(T) == 16 ? 0 : static_cast<uint64_t>(mod);
 
  private:
   __host__ __device__ explicit Uint(T v) : val(v) {}

@@ -194,6 +194,43 @@ static void HostSignatureDcf() {
   std::printf("DCF  n=8  Bytes, n=16 Uint<u32> kGt   host-signature: %s\n", g_fail == before ? "ok" : "FAILED");
 }
 
+// Uint<__uint128_t, mod> with a modulus other than 2^127 (group/uint.cuh:28-30 allows 0 < mod <= 2^127; src/group_test.cu:18
+// uses 2^126): a value type without an engine name, so the scheme's host methods take the generic per-thread kernels.  The
+// correction words of levels 0 .. n - 1 do not depend on the group: they must equal those of the 2^127 group, which the engine computes.
+static void HostSignatureOddModulus() {
+  int before = g_fail;
+  using G126 = fss::group::Uint<__uint128_t, (static_cast<__uint128_t>(1) << 126)>;
+  using G127 = fss::group::Uint<__uint128_t, (static_cast<__uint128_t>(1) << 127)>;
+  using Prg = fss::prg::ChaCha<2>;
+  using D126 = fss::Dpf<16, G126, Prg, uint16_t>;
+  using D127 = fss::Dpf<16, G127, Prg, uint16_t>;
+  static_assert(!D126::kEngine && D127::kEngine);
+  static int nonce[2] = {0x12345678, static_cast<int>(0x9abcdef0u)};
+  Prg prg(nonce);
+  D126 d126{prg};
+  D127 d127{prg};
+  int4 seeds[2] = {kSeeds[0], kSeeds[1]};
+  const int4 beta = I4(0xdeadbeef, 0x01234567, 0x89abcdef, 0xfffffffe);  // bit 126 set: reduced modulo 2^126 by From
+  D126::Cw c126[17];
+  D127::Cw c127[17];
+  d126.Gen(c126, seeds, (uint16_t)4242, beta);
+  d127.Gen(c127, seeds, (uint16_t)4242, beta);
+  int same = 0;
+  for (int i = 0; i < 16; ++i) same += Same(c126[i].s, c127[i].s) && c126[i].tr == c127[i].tr;
+  EXPECT(same == 16);
+  const int4 want = G126::From(beta).Into();
+  EXPECT(!Same(want, G127::From(beta).Into()));
+  for (uint16_t xx : {(uint16_t)0, (uint16_t)4241, (uint16_t)4242, (uint16_t)4243, (uint16_t)65535})
+    EXPECT(Same(Recon<G126>(d126.Eval(false, seeds[0], c126, xx), d126.Eval(true, seeds[1], c126, xx)), xx == 4242 ? want : kZero));
+  std::vector<int4> ys0(1 << 16), ys1(1 << 16);
+  d126.EvalAll(false, seeds[0], c126, ys0.data());
+  d126.EvalAll(true, seeds[1], c126, ys1.data());
+  int bad = 0;
+  for (int i = 0; i < (1 << 16); ++i) bad += !Same(Recon<G126>(ys0[i], ys1[i]), i == 4242 ? want : kZero);
+  EXPECT(bad == 0);
+  std::printf("DPF  n=16 Uint<u128, 2^126> (no engine name: generic kernels)   host-signature: %s\n", g_fail == before ? "ok" : "FAILED");
+}
+
 static void HostSignatureWide() {
   int before = g_fail;
   {  // DPF n = 32 over Uint<uint64_t> (the bench group, src/bench_gpu.cu:23)
@@ -920,6 +957,7 @@ int main() {
   try {
     HostSignatureDpf();
     HostSignatureDcf();
+    HostSignatureOddModulus();
     HostSignatureWide();
     const unsigned char* keys2[2] = {k0, k1};
     const unsigned char* keys4[4] = {k0, k1, k2, k3};

@@ -89,6 +89,17 @@ def test_cxx_dropin_device_test_compiles():
     assert os.path.exists(_build.build_dropin_device_test())
 
 
+def test_cxx_reference_test_list_compiles_and_its_group_axioms_hold():
+    """tests/cxx/reference_cases_test.cpp (the reference's own gtest list through its <fss/...cuh> include lines) compiles; the 33
+    group-axiom cases of src/group_test.cu -- eleven group types, Uint<__uint128_t, 2^126> among them -- are host arithmetic
+    and run here; the scheme cases run under -m gpu (tests/test_gpu_parity.py::test_cxx_reference_test_list)."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_reference_cases_test()
+    r = subprocess.run([exe, "--filter", "GroupAxiomTest"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "33 cases, 0 failed" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 def test_cxx_host_side_aes_known_answers():
     """The software AES of include/fss_amd.hpp on the HOST (tests/cxx/host_kat_test.cpp: aes_detail helpers, FIPS-197 C.1,
     the reference's PRG known answers through Aes128Soft / Aes128SoftBanked Gen and GenSide) -- the cipher code the per-thread

@@ -944,6 +944,21 @@ def test_cxx_dropin_device_side():
     assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout
 
 
+def test_cxx_reference_test_list():
+    """tests/cxx/reference_cases_test.cpp: the reference's own gtest list (src/{group,dpf,dcf,half_tree_dpf,grotto_dcf,vdpf}_test.cu:
+    91 cases) under its suite and case names, written against the reference's include lines and host signatures; the schemes'
+    host forms stage onto the GPU.  Seeds are random per run as in the reference (the seed is printed); a second run pins one."""
+    import subprocess
+    from fss_amd import _build
+    exe = _build.build_reference_cases_test()
+    names = subprocess.run([exe, "--list"], capture_output=True, text=True, timeout=60).stdout.split()
+    assert len(names) == 91 and "GrottoDcfChaChaTest.EdgeAlphaMax" in names and "GroupAxiomTest/10.Inverses" in names
+    for extra in ([], ["--seed", "20261003"]):
+        r = subprocess.run([exe] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+        assert r.stdout.strip().endswith("OK") and "FAILED" not in r.stdout and "91 cases, 0 failed" in r.stdout
+
+
 def test_cxx_multi_gpu_device_set():
     """tests/cxx/multi_gpu_test.cpp: fss::gpu::DeviceSet (include/fss_amd_multi.hpp) with eight members sharing device 0
     -- the headline batch, configs[3] in eight blocks, configs[4]'s schemes on independent keys, Grotto's carries -- gives
