@@ -7,8 +7,8 @@
 //   fss::util::Xor/SetLsb/GetLsb/Pack      <- include/fss/util.cuh:16-64
 //   fss::group::Bytes / Uint<T, mod>       <- include/fss/group/bytes.cuh:19-43, group/uint.cuh:27-88
 //   fss::prg::Aes128Mmo<mul>               <- include/fss/prg/aes128_mmo.cuh:27-95: span constructor, CreateCtxs,
-//                                             FreeCtxs, Gen(int4) -> array<int4, mul>; the "cipher contexts" carry
-//                                             the AES key bytes (AesKeyCtx) instead of OpenSSL EVP state
+//                                             FreeCtxs, Gen(int4) -> array<int4, mul>; behind the EVP_CIPHER_CTX* handles
+//                                             are the AES key bytes (AesKeyCtx), not OpenSSL state
 //   fss::prg::ChaCha<mul, rounds>          <- include/fss/prg/chacha.cuh:24-128 (constructor from the nonce pointer)
 //   fss::Dpf / Dcf / HalfTreeDpf / GrottoDcf
 //                                          <- include/fss/dpf.cuh:61-303, dcf.cuh:74-385, half_tree_dpf.cuh:39-354,
@@ -88,6 +88,15 @@ concept Groupable = std::is_default_constructible_v<Group> && requires(Group lhs
   { Group::From(buf) } -> std::same_as<Group>;
   { lhs.Into() } -> std::same_as<int4>;
 };
+
+// The reference's Aes128Mmo hands out OpenSSL cipher contexts and its callers spell their type (`cuda::std::array<
+// EVP_CIPHER_CTX*, 2> ctxs` in src/dpf_test.cu:164, src/bench_cpu.cu:27).  OpenSSL declares that type as an opaque struct, and
+// so does this header -- the identical declaration, should <openssl/evp.h> be included as well -- so that such call sites
+// compile as they stand.  No OpenSSL is included, linked or called: behind the pointers CreateCtxs hands out are
+// fss::prg::AesKeyCtx objects (the key bytes), and a pointer that is not one of them is refused (fss::Error).
+extern "C" {
+typedef struct evp_cipher_ctx_st EVP_CIPHER_CTX;
+}
 
 namespace fss {
 
@@ -468,9 +477,20 @@ auto GenOne(const P& prg, int4 seed) -> std::array<int4, P::kMul>;  // one PRG c
 
 // ---------------------------------------------------------------- PRG hook
 namespace prg {
-// What CreateCtxs hands out where the reference hands out EVP_CIPHER_CTX* (aes128_mmo.cuh:49-64): the key itself.
+// What stands behind the EVP_CIPHER_CTX* that CreateCtxs hands out (the reference's are OpenSSL contexts holding a key
+// schedule, aes128_mmo.cuh:49-64): the key itself, and a tag by which a pointer that did not come from CreateCtxs -- a real
+// OpenSSL context, whose key cannot be read back -- is told apart.
 struct AesKeyCtx {
+  static constexpr uint64_t kTag = 0x7874634b73656141ull;  // "AesKctx"
+  uint64_t tag;
   unsigned char key[16];
+  static EVP_CIPHER_CTX* Handle(AesKeyCtx* c) { return reinterpret_cast<EVP_CIPHER_CTX*>(c); }
+  static AesKeyCtx* Of(EVP_CIPHER_CTX* h) {
+    AesKeyCtx* c = reinterpret_cast<AesKeyCtx*>(h);
+    if (h == nullptr || c->tag != kTag)
+      throw Error("Aes128Mmo: not a context from CreateCtxs (the key of an OpenSSL context cannot be read back)", FSS_AMD_EINVAL);
+    return c;
+  }
 };
 
 // AES-128 in Matyas-Meyer-Oseas mode as the PRG: out[i] = AES_{key i}(seed) ^ seed (aes128_mmo.cuh:72-93).
@@ -488,23 +508,29 @@ class Aes128Mmo {
 
  public:
   // ctxs: from CreateCtxs(); only read here, the caller frees them with FreeCtxs()  (aes128_mmo.cuh:40-42)
-  Aes128Mmo(std::span<AesKeyCtx*, mul> ctxs) {
+  Aes128Mmo(std::span<EVP_CIPHER_CTX*, mul> ctxs) {
     const unsigned char* keys[mul];
-    for (int i = 0; i < mul; ++i) keys[i] = ctxs[i]->key;
+    for (int i = 0; i < mul; ++i) keys[i] = AesKeyCtx::Of(ctxs[i])->key;
     SetKeys(keys);
   }
   // the key bytes directly (no context objects to manage); also constructible inside a kernel
   __host__ __device__ explicit Aes128Mmo(const unsigned char* const keys[mul]) { SetKeys(keys); }
-  static std::array<AesKeyCtx*, mul> CreateCtxs(const unsigned char* keys[mul]) {
-    std::array<AesKeyCtx*, mul> ctxs;
+  static std::array<EVP_CIPHER_CTX*, mul> CreateCtxs(const unsigned char* keys[mul]) {  // aes128_mmo.cuh:49
+    std::array<EVP_CIPHER_CTX*, mul> ctxs;
     for (int i = 0; i < mul; ++i) {
-      ctxs[i] = new AesKeyCtx;
-      std::memcpy(ctxs[i]->key, keys[i], 16);
+      AesKeyCtx* c = new AesKeyCtx;
+      c->tag = AesKeyCtx::kTag;
+      std::memcpy(c->key, keys[i], 16);
+      ctxs[i] = AesKeyCtx::Handle(c);
     }
     return ctxs;
   }
-  static void FreeCtxs(std::span<AesKeyCtx*, mul> ctxs) {
-    for (AesKeyCtx* c : ctxs) delete c;
+  static void FreeCtxs(std::span<EVP_CIPHER_CTX*, mul> ctxs) {  // aes128_mmo.cuh:66
+    for (EVP_CIPHER_CTX* h : ctxs) {
+      AesKeyCtx* c = AesKeyCtx::Of(h);
+      c->tag = 0;
+      delete c;
+    }
   }
   // Host: one seed through the engine (a batch of one on the GPU; fss_amd_prg_gen is the batched form).
   // Device: computed by the calling thread (the reference's OpenSSL-backed Gen traps there, aes128_mmo.cuh:75-77)
@@ -608,14 +634,14 @@ class Aes128MmoWide {
   }
 
  public:
-  Aes128MmoWide(std::span<AesKeyCtx*, mul> ctxs) {
+  Aes128MmoWide(std::span<EVP_CIPHER_CTX*, mul> ctxs) {
     const unsigned char* keys[mul];
-    for (int i = 0; i < mul; ++i) keys[i] = ctxs[i]->key;
+    for (int i = 0; i < mul; ++i) keys[i] = AesKeyCtx::Of(ctxs[i])->key;
     SetKeys(keys);
   }
   explicit Aes128MmoWide(const unsigned char* const keys[mul]) { SetKeys(keys); }
-  static std::array<AesKeyCtx*, mul> CreateCtxs(const unsigned char* keys[mul]) { return Aes128Mmo<mul>::CreateCtxs(keys); }
-  static void FreeCtxs(std::span<AesKeyCtx*, mul> ctxs) { Aes128Mmo<mul>::FreeCtxs(ctxs); }
+  static std::array<EVP_CIPHER_CTX*, mul> CreateCtxs(const unsigned char* keys[mul]) { return Aes128Mmo<mul>::CreateCtxs(keys); }
+  static void FreeCtxs(std::span<EVP_CIPHER_CTX*, mul> ctxs) { Aes128Mmo<mul>::FreeCtxs(ctxs); }
 
   // Device, every thread of the 1024-thread workgroup, uniform control flow, once per kernel before the first Gen / Eval.
   __device__ static void InitWorkgroup() {

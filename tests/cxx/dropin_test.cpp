@@ -190,6 +190,18 @@ static void HostSignatureDcf() {
     int4 s = Recon<fss::group::Uint<uint32_t>>(gt.Eval(false, seeds[0], gcws, xx), gt.Eval(true, seeds[1], gcws, xx));
     EXPECT(Same(s, xx > 30000 ? b32 : kZero));
   }
+  {  // the handles are spelled EVP_CIPHER_CTX* as in the reference; a pointer that CreateCtxs did not hand out is refused
+    std::array<EVP_CIPHER_CTX*, 4> same_type = ctxs;
+    static unsigned char not_ours[64] = {};
+    same_type[2] = reinterpret_cast<EVP_CIPHER_CTX*>(not_ours);
+    bool refused = false;
+    try {
+      DcfPrg bad(same_type);
+    } catch (const fss::Error& e) {
+      refused = e.code == FSS_AMD_EINVAL;
+    }
+    EXPECT(refused);
+  }
   DcfPrg::FreeCtxs(ctxs);
   std::printf("DCF  n=8  Bytes, n=16 Uint<u32> kGt   host-signature: %s\n", g_fail == before ? "ok" : "FAILED");
 }

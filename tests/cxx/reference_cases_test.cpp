@@ -202,7 +202,7 @@ template <typename Fn>
 void WithAes2(Fn fn) {
   using P = fss::prg::Aes128Mmo<2>;
   const unsigned char* keys[2] = {kAesKey0, kAesKey1};
-  auto ctxs = P::CreateCtxs(keys);
+  std::array<EVP_CIPHER_CTX*, 2> ctxs = P::CreateCtxs(keys);  // the fixture's member, spelled as src/dpf_test.cu:164 spells it
   {
     P prg(ctxs);
     fn(prg);
@@ -266,7 +266,7 @@ const int dcf_added = [] {
   Cases().push_back({"DcfBytesAesTest.EvalLt", [] {  // four keys: src/dcf_test.cu:166-171
                        using P = fss::prg::Aes128Mmo<4>;
                        const unsigned char* keys[4] = {kAesKey0, kAesKey1, kAesKey2, kAesKey3};
-                       auto ctxs = P::CreateCtxs(keys);
+                       std::array<EVP_CIPHER_CTX*, 4> ctxs = P::CreateCtxs(keys);
                        {
                          P prg(ctxs);
                          DcfCases<BytesGroup, P>(prg).EvalLt();

@@ -47,3 +47,101 @@ def test_reference_binding_surface(scheme, prg, s0s, beta):
     assert torch.equal(ys[0] ^ ys[1], want)
     for x in (0, 106, 107, 108, 65535):
         assert torch.equal(f.eval(0, s0s[0], cws, x) ^ f.eval(1, s0s[1], cws, x), want[x])
+
+
+# The same checks under the reference's own class and test names (test/test_dpf_integration.py:21-65,
+# test/test_dcf_integration.py:21-74), so that the two lists can be read side by side; written here, fixtures as there
+# (in_bits = 16, group "bytes", the default PRG "chacha", alpha = 107).
+@pytest.fixture
+def dpf():
+    import fss_crypto
+    return fss_crypto.Dpf(in_bits=16, group="bytes", prg="chacha")
+
+
+@pytest.fixture
+def dcf():
+    import fss_crypto
+    return fss_crypto.Dcf(in_bits=16, group="bytes", prg="chacha", pred="lt")
+
+
+def _is_int32(t, shape, device):
+    return tuple(t.shape) == shape and t.dtype == torch.int32 and t.device.type == device
+
+
+class _GenShape:
+    def test_cws_shape(self, f, s0s, beta):
+        assert _is_int32(f.gen(s0s, alpha=107, beta=beta), (17, 8), "cpu")
+
+    def test_cws_device_is_cpu(self, f, s0s, beta):
+        assert f.gen(s0s, alpha=107, beta=beta).device.type == "cpu"
+
+
+class _EvalShape:
+    def test_output_shape_cpu(self, f, s0s, beta):
+        cws = f.gen(s0s, alpha=107, beta=beta)
+        assert _is_int32(f.eval(party=0, s0=s0s[0], cws=cws, x=50), (4,), "cpu")
+
+    def test_rejects_out_of_domain_x(self, f, s0s, beta):
+        cws = f.gen(s0s, alpha=107, beta=beta)
+        with pytest.raises(ValueError, match="x must be"):
+            f.eval(party=0, s0=s0s[0], cws=cws, x=2**16)
+
+    def test_output_shape_cuda(self, f, s0s, beta):
+        cws = f.gen(s0s, alpha=107, beta=beta)
+        assert _is_int32(f.eval(party=0, s0=s0s[0].to("cuda"), cws=cws.to("cuda"), x=50), (4,), "cuda")
+
+
+class _EvalAllShape:
+    def test_output_shape(self, f, s0s, beta):
+        cws = f.gen(s0s, alpha=107, beta=beta)
+        assert _is_int32(f.eval_all(party=0, s0=s0s[0], cws=cws), (2**16, 4), "cpu")
+
+
+class _OnDpf:
+    @pytest.fixture
+    def f(self, dpf):
+        return dpf
+
+
+class _OnDcf:
+    @pytest.fixture
+    def f(self, dcf):
+        return dcf
+
+
+class TestDpfGenShape(_OnDpf, _GenShape):
+    pass
+
+
+class TestDpfEvalShape(_OnDpf, _EvalShape):
+    pass
+
+
+class TestDpfEvalAllShape(_OnDpf, _EvalAllShape):
+    pass
+
+
+class TestDcfGenShape(_OnDcf, _GenShape):
+    pass
+
+
+class TestDcfEvalShape(_OnDcf, _EvalShape):
+    pass
+
+
+class TestDcfEvalAllShape(_OnDcf, _EvalAllShape):
+    pass
+
+
+class TestDcfPredVariant:
+    def test_gt_variant(self, s0s, beta):
+        import fss_crypto
+        dcf_gt = fss_crypto.Dcf(in_bits=16, group="bytes", prg="chacha", pred="gt")
+        cws = dcf_gt.gen(s0s, alpha=107, beta=beta)
+        assert _is_int32(cws, (17, 8), "cpu")
+        # ... and it is the other predicate: beta above alpha, nothing at or below it
+        want = beta.clone()
+        want[3] &= ~1
+        for x, hit in ((50, False), (107, False), (108, True), (65535, True)):
+            got = dcf_gt.eval(0, s0s[0], cws, x) ^ dcf_gt.eval(1, s0s[1], cws, x)
+            assert torch.equal(got, want if hit else torch.zeros(4, dtype=torch.int32))

@@ -126,3 +126,18 @@ def test_contract_covers_every_validator():
     public = {n for n in dir(_validate) if n.startswith("validate_")}
     assert public <= fns, public - fns
     assert "split_uint128" in fns
+
+
+def test_reference_module_layout():
+    """The reference's module names resolve (its own tests import `fss_crypto._validate`, test/test_validation.py:3-17; callers
+    may import `fss_crypto.dpf.Dpf` / `fss_crypto.dcf.Dcf`, fss_crypto/__init__.py:3-4) and are this package's objects."""
+    import importlib
+    import fss_amd._validate as ours
+    ref = importlib.import_module("fss_crypto._validate")
+    for name in ("validate_alpha", "validate_beta", "validate_cpu_only", "validate_cws", "validate_device_match", "validate_domain_value",
+                 "validate_group", "validate_in_bits", "validate_party", "validate_pred", "validate_prg", "validate_s0", "validate_s0s"):
+        assert getattr(ref, name) is getattr(ours, name)
+    assert importlib.import_module("fss_crypto._int").split_uint128((1 << 64) + 5) == (5, 1)
+    import fss_crypto
+    assert importlib.import_module("fss_crypto.dpf").Dpf is fss_crypto.Dpf
+    assert importlib.import_module("fss_crypto.dcf").Dcf is fss_crypto.Dcf
