@@ -827,14 +827,22 @@ __host__ __device__ inline void InitTe0Banked(uint32_t* dst, int tid, int nthrea
 template <int mul>
 class Aes128Soft {
   static_assert(mul == 1 || mul == 2 || mul == 4);
-  thread::AesSchedules<mul, true> ks_;
+  using Schedules = thread::AesSchedules<mul, true, true>;
+  Schedules ks_;
   const uint32_t* te0_;
   const uint8_t* sbox_;
+  mutable bool wave_tables_ready_ = false;  // device: this thread has seen its wave's LDS copy of the round table filled
 
  public:
   // keys: mul 16-byte AES-128 keys; te0: the 256-entry round table (InitTe0 / ComputeTe0); sbox: the S-box (InitSbox /
   // Sbox).  On the device both tables belong in __shared__ memory, filled by the workgroup before any thread
   // constructs its PRG (aes128_mmo_soft.cuh:191-207); on the host, arrays of the caller.
+  // Device: the constructor expands the keys through the caller's S-box; the cipher itself does NOT read the caller's 1 KiB
+  // table -- 64 random lookups of a wave instruction into 256 words share banks four or five deep, which is what bounded
+  // the reference-shaped kernel (src/bench_gpu.cu:100-138) at 1.96 G evals/s -- but the workgroup's bank-replicated copy of
+  // the same table (thread::WaveTablesT<true>: 32 KiB of static LDS, every wave fills it itself at its first call, no
+  // barrier; the S-box is byte 1 of its entries), as Aes128Mmo's device side does.  Same function, same bytes; the
+  // caller's kernel is unchanged.  (A caller who wants to own the banked table: Aes128SoftBanked below.)
   __host__ __device__ Aes128Soft(const uint8_t keys[][16], const uint32_t* te0, const uint8_t* sbox)
       : te0_(te0), sbox_(sbox) {
     const unsigned char* kp[mul];
@@ -844,23 +852,28 @@ class Aes128Soft {
 
   __host__ __device__ std::array<int4, mul> Gen(int4 seed) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_is_shared(te0_) && __builtin_amdgcn_is_shared(sbox_))
-      return ks_.Gen(thread::LdsTables{(const __attribute__((address_space(3))) uint32_t*)te0_,
-                                       (const __attribute__((address_space(3))) uint8_t*)sbox_}, seed);
-#endif
+    return ks_.Gen(thread::WaveTablesT<true>(wave_tables_ready_), seed);
+#else
     return ks_.Gen(thread::PlainTables{te0_, sbox_}, seed);
+#endif
   }
   // the outputs of one side of a tree level (see Aes128Mmo::GenSide)
   __host__ __device__ std::array<int4, (mul + 1) / 2> GenSide(int4 seed, bool right) const
     requires(mul >= 2)
   {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_is_shared(te0_) && __builtin_amdgcn_is_shared(sbox_))
-      return ks_.GenSide(thread::LdsTables{(const __attribute__((address_space(3))) uint32_t*)te0_,
-                                           (const __attribute__((address_space(3))) uint8_t*)sbox_}, seed, right);
-#endif
+    return ks_.GenSide(thread::WaveTablesT<true>(wave_tables_ready_), seed, right);
+#else
     return ks_.GenSide(thread::PlainTables{te0_, sbox_}, seed, right);
+#endif
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  // Device only: this PRG with its per-call checks made once, for a walk that calls it level after level (see Aes128Mmo)
+  __device__ thread::PreparedAes<mul, Schedules, thread::BankedLdsRoundTable> Prepared() const {
+    const thread::BankedLdsRoundTable tab = thread::WaveTablesT<true>(wave_tables_ready_);
+    return thread::PreparedAes<mul, Schedules, thread::BankedLdsRoundTable>{ks_, tab, ks_.ReadyKeys(tab)};
+  }
+#endif
 
   // The engine runs the same function (AES-128-MMO with these keys): schemes over Aes128Soft take the batched entry
   // points and the fss::gpu launchers like schemes over Aes128Mmo.

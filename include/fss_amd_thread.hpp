@@ -582,12 +582,16 @@ struct WorkgroupAesTable {
   uint32_t te0[256 * 32];
   uint32_t marker[16][4];
 };
-__device__ inline BankedLdsRoundTable WaveTables(bool& ready) {
+// BE: the table in the reference's big-endian word order (Te0[i] = 2S << 24 | S << 16 | S << 8 | 3S, aes128_mmo_soft.cuh:55-60)
+// for fss::prg::Aes128Soft, whose schedules and state words are big-endian; a copy of its own (a kernel that uses both PRG
+// types on the device holds both, 64 KiB).  S(x) is byte 1 of an entry in either order.
+template <bool BE>
+__device__ inline BankedLdsRoundTable WaveTablesT(bool& ready) {
   __shared__ __attribute__((aligned(16))) WorkgroupAesTable tab;
   uint32_t* mark = tab.marker[(LinearTid() >> 6) & 15];
   uint32_t nonce[2];
   LaunchNonce(nonce);
-  const uint32_t want[4] = {0x66737361u, 0x6d645f74u, nonce[0], nonce[1]};
+  const uint32_t want[4] = {BE ? 0x66737362u : 0x66737361u, 0x6d645f74u, nonce[0], nonce[1]};
   const bool missing = !ready || ((mark[0] ^ want[0]) | (mark[1] ^ want[1]) | (mark[2] ^ want[2]) | (mark[3] ^ want[3])) != 0;
   if (__ballot(missing) != 0) {
     const uint64_t act = __ballot(1);
@@ -595,7 +599,7 @@ __device__ inline BankedLdsRoundTable WaveTables(bool& ready) {
     const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(act >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(act), 0u));
     uint4* rows = reinterpret_cast<uint4*>(tab.te0);  // 2048 groups of four copies
     for (int i = rank; i < 2048; i += cnt) {
-      const uint32_t v = kAes.te0[i >> 3];
+      const uint32_t v = BE ? ByteSwap(kAes.te0[i >> 3]) : kAes.te0[i >> 3];
       rows[i] = make_uint4(v, v, v, v);
     }
     WaveLdsSync();  // the table first, then the marker that says this wave has written it
@@ -605,6 +609,7 @@ __device__ inline BankedLdsRoundTable WaveTables(bool& ready) {
   ready = true;
   return BankedLdsRoundTable((const __attribute__((address_space(3))) uint32_t*)(tab.te0) + (__lane_id() & 31));
 }
+__device__ inline BankedLdsRoundTable WaveTables(bool& ready) { return WaveTablesT<false>(ready); }
 
 // The LDS home of a two- or four-key PRG's round keys (DPF: 2 x 44 words, DCF: 4 x 44).  176 wave-uniform words do not
 // fit the scalar register file next to a walk's own state -- the compiler would park them in VGPR lanes and from there
