@@ -769,8 +769,8 @@ class Aes128MmoRaw : public Aes128Mmo<mul> {
 //     __shared__ uint32_t s_te0[256]; __shared__ uint8_t s_sbox[256];   // filled with ComputeTe0 / Sbox
 //     fss::prg::Aes128Soft<2> prg(keys, s_te0, s_sbox);  fss::Dpf<...> dpf{prg};  ys[tid] = dpf.Eval(...);
 // (src/bench_gpu.cu:100-138).  Same names, same arguments, same table contents (big-endian Te0, te0[0] = c66363a5).
-// Behind them: ds_read lookups on the caller's LDS tables, wave-uniform round keys in scalar registers instead of a
-// 176-byte-per-key array per thread, all nine table rounds unrolled, and -- through GenSide, which Dpf / Dcf::Eval use
+// Behind them: ds_read lookups on a bank-replicated LDS copy of the round table (the host side reads the caller's tables),
+// wave-uniform round keys (scalar registers or the wave's LDS slot) instead of a 176-byte-per-key array per thread, all nine table rounds unrolled, and -- through GenSide, which Dpf / Dcf::Eval use
 // -- only the child a level takes.
 namespace aes_detail {
 constexpr int kNb = 4;
