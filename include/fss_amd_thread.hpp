@@ -1317,6 +1317,9 @@ struct KeyMajorLines {
   mutable int4 ts0_, ts1_, ts2_, ts3_;
   mutable int4 tv0_, tv1_, tv2_, tv3_;
   mutable bool fresh_ = false;
+  // (the buffer starts as zeros, as the aggregate form `{slots, n}` left it: spelled out, so that -Wextra has nothing to say)
+  __device__ KeyMajorLines(const int4* key_slots, int n)
+      : slots(key_slots), nslots(n), s0_{}, s1_{}, s2_{}, s3_{}, v0_{}, v1_{}, v2_{}, v3_{}, ts0_{}, ts1_{}, ts2_{}, ts3_{}, tv0_{}, tv1_{}, tv2_{}, tv3_{} {}
   __device__ __attribute__((always_inline)) void Take(const int4* p, bool want, int4& s, int4& v) const {
     if (want) {
       s = p[0];

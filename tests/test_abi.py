@@ -100,6 +100,20 @@ def test_cxx_reference_test_list_compiles_and_its_group_axioms_hold():
     assert r.returncode == 0 and "33 cases, 0 failed" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+def test_public_cxx_headers_are_warning_free_under_wall_wextra():
+    """include/fss_amd.hpp, fss_amd_thread.hpp and fss_amd_multi.hpp (through the <fss/...cuh> include lines) with the templates the
+    drop-in tests instantiate -- host signatures, launchers, per-thread walks in kernels, DeviceSet, the reference's test list -- compile for host and gfx950 under
+    -Wall -Wextra -Werror: a caller who builds with warnings as errors can include them."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    for src in ("reference_cases_test.cpp", "dropin_test.cpp", "dropin_device_test.cpp", "multi_gpu_test.cpp"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++20", "-Wall", "-Wextra", "-Werror", "-Wno-unused-command-line-argument",
+                            "-I" + os.path.join(root, "include"), "-fsyntax-only", os.path.join(root, "tests", "cxx", src)],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+
 def test_cxx_host_side_aes_known_answers():
     """The software AES of include/fss_amd.hpp on the HOST (tests/cxx/host_kat_test.cpp: aes_detail helpers, FIPS-197 C.1,
     the reference's PRG known answers through Aes128Soft / Aes128SoftBanked Gen and GenSide) -- the cipher code the per-thread
