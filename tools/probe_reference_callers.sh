@@ -22,7 +22,7 @@ mkdir -p "$T/cuda/std" "$T/gtest" "$T/benchmark"
   echo '#include <hip/hip_runtime.h>'
   for n in Error_t:hipError_t Success GetErrorString Malloc Free Memcpy MemcpyAsync Memset MemcpyHostToDevice MemcpyDeviceToHost \
            MemcpyDeviceToDevice Memcpy2D MemcpyToSymbol DeviceSynchronize GetLastError PeekAtLastError Stream_t:hipStream_t StreamCreate \
-           StreamDestroy StreamSynchronize Event_t:hipEvent_t EventCreate EventRecord EventSynchronize EventElapsedTime EventDestroy; do
+           StreamDestroy StreamSynchronize GetDeviceCount SetDevice Event_t:hipEvent_t EventCreate EventRecord EventSynchronize EventElapsedTime EventDestroy; do
     c=${n%%:*}; h=${n#*:}; [ "$h" = "$n" ] && h="hip$n"; echo "#define cuda$c $h"
   done
 } > "$T/cuda_runtime.h"
@@ -59,6 +59,10 @@ struct State {
 template <class T> inline void DoNotOptimize(T&& v) { asm volatile("" : : "g"(&v) : "memory"); }
 struct Bench { Bench* Name(const std::string&) { return this; } Bench* UseManualTime() { return this; } };
 inline Bench* Register(void (*)(State&)) { static Bench b; return &b; }
+template <class F> inline Bench* RegisterBenchmark(const char*, F) { static Bench b; return &b; }
+inline void Initialize(int*, char**) {}
+inline void RunSpecifiedBenchmarks() {}
+inline void Shutdown() {}
 }
 #define BM_CAT2(a, b) a##b
 #define BM_CAT(a, b) BM_CAT2(a, b)
@@ -68,7 +72,7 @@ B
 fail=0
 for f in samples/dpf_dcf_cpu.cu samples/half_tree_dpf_cpu.cu samples/grotto_dcf_cpu.cu samples/dpf_dcf_gpu.cu samples/vdpf_cpu.cu \
          check_evalall_gpu.cu src/dpf_test.cu src/dcf_test.cu src/half_tree_dpf_test.cu src/grotto_dcf_test.cu src/vdpf_test.cu \
-         src/group_test.cu src/bench_cpu.cu src/bench_gpu.cu; do
+         src/group_test.cu src/bench_cpu.cu src/bench_gpu.cu third_party/fss/bench.cu; do
   if /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -std=c++20 -x hip -Wno-c++11-narrowing -Wno-unused-value -include "$T/pre.h" \
        -I "$T" -I "$ROOT/include" -c "$REF/$f" -o "$T/o.o" > "$T/log" 2>&1; then
     echo "ok      $f"
