@@ -1451,6 +1451,13 @@ __global__ void EvalKernel(int4* ys, bool party, const int4* seeds, const Dpf::C
   Dpf dpf{prg};
   ys[tid] = dpf.Eval(party, seeds[tid], cws + size_t(tid) * (kBits + 1), xs[tid]);
 }
+// A scheme built on the HOST (its PRG's table pointers are host arrays) and passed to the kernel by value, no tables of the
+// kernel's own: the device side of Aes128Soft reads the workgroup's bank-replicated copy, never the caller's pointers.
+__global__ void HostBuiltEvalKernel(Dpf dpf, int4* ys, bool party, const int4* seeds, const Dpf::Cw* cws, const uint32_t* xs, int n) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  ys[tid] = dpf.Eval(party, seeds[tid], cws + size_t(tid) * (kBits + 1), xs[tid]);
+}
 // the same kernel on the bank-replicated table (fss::prg::Aes128SoftBanked): 32 KiB + 256 B of LDS per workgroup
 using SoftB2 = fss::prg::Aes128SoftBanked<2>;
 using DpfB = fss::Dpf<kBits, G, SoftB2, uint32_t>;
@@ -1619,6 +1626,11 @@ static void Run() {
     HIP_OK(hipDeviceSynchronize());
     auto ye = ToHost(d_ye, kN);
     EXPECT(std::memcmp(ye.data(), y0.data(), sizeof(int4) * kN) == 0);
+    // ... and the same host-built object inside a kernel, per thread (party 1)
+    HostBuiltEvalKernel<<<kN / kThreads, kThreads>>>(hdpf, d_ye, true, d_seeds1, d_cws, d_xs, kN);
+    HIP_OK(hipDeviceSynchronize());
+    ye = ToHost(d_ye, kN);
+    EXPECT(std::memcmp(ye.data(), y1.data(), sizeof(int4) * kN) == 0);
   }
   // ---- DCF over Aes128Soft<4> (GenSide takes {s, v} of one side): 4096 keys of n = 16 against the engine
   {
