@@ -406,49 +406,66 @@ __global__ __launch_bounds__(1024) void gen_kernel(const DevCtx K, const uint32_
       const uint32_t am = bit_mask(alpha, n - 1 - i);  // ~0 when a_bit
       uint32_t scw[4], vcw_buf[4], tl_cw, tr_cw;
       if constexpr (SCHEME == S_DCF && std::is_same<LT, Lds>::value) {
-        // AES: evaluate by side (lose pair, fold, keep pair) with the per-lane key choice, so at most 16
-        // PRG output words are live across an AES call instead of 32 (the all-children order spilled 2 KiB).
-        uint32_t ls0[4], lv0[4], ls1[4], lv1[4];
-        prg_take4(L, c, ~am, s0, ls0, lv0);
-        prg_take4(L, c, ~am, s1, ls1, lv1);
-        const uint32_t lose_cw = (ls0[3] ^ ls1[3]) & 1u;
+        // AES: four cipher pairs per level, each the SAME block of both parties side by side (seed blocks of the lose side,
+        // value blocks of the lose side, value blocks of the keep side, seed blocks of the keep side), every pair folded
+        // into the level's state before the next one starts: between two pairs only the two seeds, the seed correction
+        // word, the value correction word and the running value are live -- 17 words, no output words of a cipher among them.  (By party instead -- seed and value block of one party, then
+        // of the other -- one party's eight output words waited through the other party's pair: 16 - 17 words, and the
+        // kernel kept 27 of its words in scratch; all children at once spilled 2 KiB, round 1.)
+        uint32_t lose_cw, vcw[4];
+        {
+          uint32_t ls0[4], ls1[4];
+          aes_mmo2<true>(L, &c->sel02[0][0], &c->sel02[0][0], ~am, ~am, s0, s1, ls0, ls1);
+          lose_cw = (ls0[3] ^ ls1[3]) & 1u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) scw[q] = ls0[q] ^ ls1[q];
-        scw[3] &= ~1u;
-        lv0[3] &= ~1u; lv1[3] &= ~1u;
-        // v_cw = -v + (v1_lose - v0_lose) [+ beta]   (dcf.cuh:146-154); negated when t1
-        Acc vc;
-        vc.add(g, lv1); vc.sub(g, lv0);
-        const bool add_beta = am ? (a.pred == 0) : (a.pred == 1);
-        if (add_beta) {  // reloaded per level (an L2 hit) rather than held across the AES calls
-          uint32_t bb[4];
-          ld4(bb, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));
-          bb[3] &= ~1u;
-          vc.add(g, bb);
+          for (int q = 0; q < 4; ++q) scw[q] = ls0[q] ^ ls1[q];
+          scw[3] &= ~1u;
         }
         {
-          uint4 vb = v.finish(g, false);
-          uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
-          vc.sub(g, vbuf);
+          uint32_t lv0[4], lv1[4];
+          aes_mmo2<true>(L, &c->sel13[0][0], &c->sel13[0][0], ~am, ~am, s0, s1, lv0, lv1);
+          lv0[3] &= ~1u; lv1[3] &= ~1u;
+          // v_cw = -v + (v1_lose - v0_lose) [+ beta]   (dcf.cuh:146-154); negated when t1
+          Acc vc;
+          vc.add(g, lv1); vc.sub(g, lv0);
+          const bool add_beta = am ? (a.pred == 0) : (a.pred == 1);
+          if (add_beta) {  // reloaded per level (an L2 hit) rather than held across the AES calls
+            uint32_t bb[4];
+            ld4(bb, a.betas ? a.betas[k] : make_uint4(0, 0, 0, 0));
+            bb[3] &= ~1u;
+            vc.add(g, bb);
+          }
+          {
+            uint4 vb = v.finish(g, false);
+            uint32_t vbuf[4] = {vb.x, vb.y, vb.z, vb.w};
+            vc.sub(g, vbuf);
+          }
+          // v = v - v1_keep + v0_keep + (t1 ? -v_cw : v_cw)   (dcf.cuh:156-159): the last term now (the group's addition commutes)
+          const uint4 vcw4 = vc.finish(g, t1 != 0u);
+          vcw[0] = vcw4.x; vcw[1] = vcw4.y; vcw[2] = vcw4.z; vcw[3] = vcw4.w;
+          if (t1) v.sub(g, vcw); else v.add(g, vcw);
         }
-        uint4 vcw4 = vc.finish(g, t1 != 0u);
-        uint32_t vcw[4] = {vcw4.x, vcw4.y, vcw4.z, vcw4.w};
-        uint32_t ks0[4], kv0[4], ks1[4], kv1[4];
-        prg_take4(L, c, am, s0, ks0, kv0);
-        prg_take4(L, c, am, s1, ks1, kv1);
-        const uint32_t kt0 = ks0[3] & 1u, kt1 = ks1[3] & 1u;
-        const uint32_t keep_cw = (kt0 ^ kt1 ^ 1u) & 1u;
-        ks0[3] &= ~1u; ks1[3] &= ~1u; kv0[3] &= ~1u; kv1[3] &= ~1u;
-        // v = v - v1_keep + v0_keep + (t1 ? -v_cw : v_cw)   (dcf.cuh:156-159)
-        v.sub(g, kv1); v.add(g, kv0);
-        if (t1) v.sub(g, vcw); else v.add(g, vcw);
+        {
+          uint32_t kv0[4], kv1[4];
+          aes_mmo2<true>(L, &c->sel13[0][0], &c->sel13[0][0], am, am, s0, s1, kv0, kv1);
+          kv0[3] &= ~1u; kv1[3] &= ~1u;
+          v.sub(g, kv1); v.add(g, kv0);
+        }
+        uint32_t keep_cw;
+        {
+          uint32_t ks0[4], ks1[4];
+          aes_mmo2<true>(L, &c->sel02[0][0], &c->sel02[0][0], am, am, s0, s1, ks0, ks1);
+          const uint32_t kt0 = ks0[3] & 1u, kt1 = ks1[3] & 1u;
+          keep_cw = (kt0 ^ kt1 ^ 1u) & 1u;
+          ks0[3] &= ~1u; ks1[3] &= ~1u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          s0[q] = ks0[q] ^ (t0 & scw[q]);
-          s1[q] = ks1[q] ^ (t1 & scw[q]);
+          for (int q = 0; q < 4; ++q) {
+            s0[q] = ks0[q] ^ (t0 & scw[q]);
+            s1[q] = ks1[q] ^ (t1 & scw[q]);
+          }
+          t0 = 0u - ((kt0 ^ ((t0 & 1u) & keep_cw)) & 1u);
+          t1 = 0u - ((kt1 ^ ((t1 & 1u) & keep_cw)) & 1u);
         }
-        t0 = 0u - ((kt0 ^ ((t0 & 1u) & keep_cw)) & 1u);
-        t1 = 0u - ((kt1 ^ ((t1 & 1u) & keep_cw)) & 1u);
         tl_cw = am ? lose_cw : keep_cw;
         tr_cw = am ? keep_cw : lose_cw;
         vcw_buf[0] = vcw[0]; vcw_buf[1] = vcw[1]; vcw_buf[2] = vcw[2]; vcw_buf[3] = (vcw[3] & ~1u) | tr_cw;
