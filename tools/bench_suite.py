@@ -232,13 +232,13 @@ def run_suite(args):
             del yb
 
     # full domain
-    for scheme, n in (("dpf", 24), ("dpf", 26), ("ht", 24)):
+    for scheme, n in (("dpf", 24), ("dpf", 26), ("ht", 24), ("dcf", 24), ("dcf", 26)):
         sid, s0s, cws, ocw, _, _ = make_key(eng, scheme, n, G, 7 + n)
         sd, cd = s0s[0].cuda(), cws.cuda()
         od = None if ocw is None else ocw.cuda()
         ys = torch.empty((1 << n, 4), dtype=torch.int32, device="cuda")
         record(f"{scheme} EvalAll n={n}", 1 << n, lambda: eng.eval_all(sid, n, G, 0, sd, cd, ocw=od, out=ys),
-               2.0 if scheme == "dpf" else 1.5, 16, steps=5)
+               {"dpf": 2.0, "ht": 1.5, "dcf": 4.0}[scheme], 16, steps=5)  # AES blocks per leaf (DCF: seed and value block of both children)
         del ys
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_suite.json"), "w") as f:
