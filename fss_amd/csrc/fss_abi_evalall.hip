@@ -89,7 +89,7 @@ inline int leaf_extra(int scheme, int log2_leaves) {
 
 // Extra rolled levels of the stages between the frontier and the leaf stage (FSS_AMD_MID_E = 0 .. 2): fewer,
 // deeper launches above the leaf stage.
-inline int mid_extra(int scheme) {
+inline int mid_extra(int scheme, int log2_leaves) {
   static int v = [] {
     const char* e = tune_env("FSS_AMD_MID_E");
     int t = e ? atoi(e) : -1;
@@ -97,7 +97,11 @@ inline int mid_extra(int scheme) {
   }();
   if (v >= 0) return v;
   // DPF / Grotto: one rolled level per intermediate stage -- the 2^25-leaf block goes 2^18 -> 2^21 in one launch
-  // instead of two (0.647 -> 0.639 ms); Half-Tree and DCF measured flat
+  // instead of two (0.647 -> 0.639 ms); Half-Tree measured flat.  DCF (one level in registers): from 2^25 leaves on -- with
+  // single-level stages a 2^26-leaf tree has eight of them, one more than the one-launch form takes, and falls back to the
+  // chain of launches: 2.68 -> 2.48 ms with two levels per stage (2^28: 9.74 -> 9.69; 2^20 - 2^24 are 1 - 4 % faster
+  // without; round 6, profiles/r6/dcf_evalall_stores.txt)
+  if (scheme == S_DCF) return log2_leaves >= 25 ? 1 : 0;
   return (scheme == S_DPF || scheme == S_GROTTO) ? 1 : 0;
 }
 
@@ -157,7 +161,7 @@ bool make_plan(int scheme, bool aes, int in_bits, int64_t first_leaf, int64_t nl
     }
     const int leaf = rem < dm + le ? rem : dm + le;
     rem -= leaf;
-    const int mid = dm + mid_extra(scheme);  // shallowest stage first: it runs on the fewest nodes
+    const int mid = dm + mid_extra(scheme, r);  // shallowest stage first: it runs on the fewest nodes
     if (rem % mid) pl->D[pl->nstages++] = rem % mid;
     for (int i = 0; i < rem / mid; ++i) pl->D[pl->nstages++] = mid;
     pl->D[pl->nstages++] = leaf;

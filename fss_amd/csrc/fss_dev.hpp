@@ -789,6 +789,11 @@ __device__ __forceinline__ void prg_take4(const Lds& L, const DevCtx* __restrict
                                           uint32_t os[4], uint32_t ov[4]) {
   aes_mmo2<true>(L, &c->sel02[0][0], &c->sel13[0][0], m, m, s, s, os, ov);
 }
+// half of prg_gen4: the seed and value block of ONE side, the same for every lane (`right` uniform: plain schedules)
+__device__ __forceinline__ void prg_gen4_side(const Lds& L, const DevCtx* __restrict__ c, const uint32_t s[4], bool right,
+                                              uint32_t os[4], uint32_t ov[4]) {
+  aes_mmo2<false>(L, c->rk[right ? 2 : 0], c->rk[right ? 3 : 1], 0, 0, s, s, os, ov);
+}
 __device__ __forceinline__ void prg_hash(const Lds& L, const DevCtx* __restrict__ c, const uint32_t in[4], uint32_t h[4]) {
   aes_mmo<false>(L, c->rk[0], 0, in, h);
 }

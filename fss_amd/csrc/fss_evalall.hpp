@@ -115,6 +115,29 @@ __device__ __forceinline__ void dcf_expand(const LT& L, const DevCtx* __restrict
   left[3] = and_xor(tm, wl, left[3]);      right[3] = and_xor(tm, wr, right[3]);
 }
 
+// One child of a DCF node: its seed and value block as ONE cipher pair (keys 0, 1 for the left child, 2, 3 for the right:
+// [sl, vl, sr, vr], dcf.cuh:223), corrected and accumulated as dcf_expand does.  `right` is uniform.  The stages take
+// the children one at a time -- a child's eight words are consumed (stored, converted or walked into) before the other
+// child's pair runs, so a pair never runs with the other child's outputs waiting: with both children expanded at once
+// (dcf_expand) the leaf kernels kept 7 - 13 words per lane in scratch.
+template <class LT>
+__device__ __forceinline__ void dcf_child(const LT& L, const DevCtx* __restrict__ c, const Grp& g,
+                                          const uint32_t* __restrict__ cw, const uint32_t st[4], const Acc& v, bool right,
+                                          uint32_t child[4], Acc& vc) {
+  const uint32_t in[4] = {st[0], st[1], st[2], st[3] & ~1u};
+  const uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(st[3], 0, 1);
+  uint32_t b[4];
+  prg_gen4_side(L, c, in, right, child, b);
+  b[3] &= ~1u;
+  const uint32_t vcw[4] = {cw[4], cw[5], cw[6], cw[7] & ~1u};
+  vc = v; vc.add(g, b); vc.add_if(g, tm, vcw);
+  const uint32_t w3 = right ? ((cw[3] & ~1u) | (cw[7] & 1u)) : cw[3];
+  child[0] = and_xor(tm, cw[0], child[0]);
+  child[1] = and_xor(tm, cw[1], child[1]);
+  child[2] = and_xor(tm, cw[2], child[2]);
+  child[3] = and_xor(tm, w3, child[3]);
+}
+
 // Half-Tree inner node (half_tree_dpf.cuh:293-302): one hash, right = left ^ parent.
 template <class LT>
 __device__ __forceinline__ void ht_expand(const LT& L, const DevCtx* __restrict__ c, const uint32_t* __restrict__ cw,
@@ -348,9 +371,23 @@ struct OuterLevels {
     if constexpr (E == 0) {
       body(k_cws, k_ocw, node, v, lvl, ob, half);
     } else {
+      const uint32_t* cw = k_cws + 8 * lvl;
+      if constexpr (SCHEME == S_DCF && std::is_same<LT, Lds>::value) {  // AES: a child at a time -- the parent (node, running value)
+                                                                          // waits, not the sibling's outputs (ChaCha: one permutation
+                                                                          // yields all four blocks, so both children at once below)
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          uint32_t ch[4];
+          Acc cv;
+          dcf_child(L, c, g, cw, node, v, h != 0, ch, cv);
+          // (`half` here: the subtree's index among those of the rolled levels walked so far, 0 .. 2^levels - 1)
+          OuterLevels<LT, SCHEME, E - 1, kLdsLevel>::run(L, c, g, k_cws, k_ocw, lvl + 1, ch, cv, ob + ((int64_t)h << (sub_log2 - 1)),
+                                                         sub_log2 - 1, body, (half < 0 ? 0 : 2 * half) + h, park);
+        }
+        return;
+      }
       uint32_t l[4], r[4];
       Acc vl, vr;
-      const uint32_t* cw = k_cws + 8 * lvl;
       if constexpr (SCHEME == S_DCF) dcf_expand(L, c, g, cw, node, v, l, vl, r, vr);
       else if constexpr (SCHEME == S_HT) ht_expand(L, c, cw, node, l, r);
       else dpf_expand(L, c, cw, node, l, r);
@@ -398,12 +435,59 @@ struct StageBody {
   // a line now and half after six more AES blocks (FSS_LEAF_PAIR_LINES, A/B).  The same for DCF (two leaves per
   // half) measured flat to slightly worse and is not taken.
   static constexpr bool kHold = FSS_LEAF_PAIR_LINES && LEAF && (SCHEME == S_DPF || (SCHEME == S_HT && FSS_HT_PAIR && FSS_HT_HOLD)) && D == 2;
-  uint4 held[kHold ? 4 : 1];
+  // DCF on the AES tables (one level in registers, a child at a time): the two leaves of the innermost rolled level's first
+  // half wait for the two of its second half, and a lane stores 64 contiguous bytes at once.  With 32 bytes per body the
+  // 2^28-leaf domain wrote 14.3 GiB for its 4 GiB of leaves and ran at 2.07 GHz under that traffic; 64 bytes: 7.5 GiB,
+  // 10.65 -> 9.7 ms.  All eight leaves of a lane held for whole 128-byte lines (a shift register of six more) wrote
+  // 6.7 GiB but cost more in moves and spills than it saved: 10.0 ms (profiles/r6/dcf_evalall_stores.txt).
+  static constexpr bool kHoldDcf = FSS_LEAF_PAIR_LINES && LEAF && SCHEME == S_DCF && D == 1 && std::is_same<LT, Lds>::value;
+  uint4 held[kHold ? 4 : (kHoldDcf ? 3 : 1)];
   __device__ __forceinline__ void operator()(const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc,
                                              const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob, int half) {
     constexpr int NN = 1 << D;
     const int party = a.party;
     if (prog != nullptr) rank_prio(prog, mine, 0u, 0u);  // a step = one body: the last D levels of one subtree
+    if constexpr (SCHEME == S_DCF && D == 1 && std::is_same<LT, Lds>::value) {
+      // DCF on the AES tables expands one level in registers: the two children one after the other, each stored (a node and
+      // its running value) or converted (a leaf) before the other's cipher pair runs
+      const uint32_t* cw = kc + 8 * lvl;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint32_t ch[4];
+        Acc cv;
+        dcf_child(L, c, g, cw, nin, vin, h != 0, ch, cv);
+        if constexpr (!LEAF) {
+          a.out_nodes[ob + h] = make_uint4(ch[0], ch[1], ch[2], ch[3]);
+          a.out_v[ob + h] = make_uint4(cv.v[0], cv.v[1], cv.v[2], cv.v[3]);
+        } else {
+          const uint32_t* ocp = kc + 8 * a.in_bits + 4;
+          const uint32_t oc[4] = {ocp[0], ocp[1], ocp[2], ocp[3]};
+          const uint32_t sl[4] = {ch[0], ch[1], ch[2], ch[3] & ~1u};
+          const uint32_t tm = (uint32_t)__builtin_amdgcn_sbfe(ch[3], 0, 1);
+          Acc y = cv;
+          y.add(g, sl);
+          y.add_if(g, tm, oc);
+          const uint4 yy = y.finish(g, party != 0);
+          uint4* ys = reinterpret_cast<uint4*>(a.ys);
+          if constexpr (kHoldDcf) {
+            // `half` counts the subtrees of the rolled levels; its low bit is the innermost level's side
+            const int side = half < 0 ? -1 : (half & 1);
+            if (side == 0) {
+              held[h] = yy;
+            } else if (h == 0) {
+              held[2] = yy;
+            } else {  // the last of the four (or, with no rolled level above, of the two): everything out together
+              if (side == 1) { ys[ob - 2] = held[0]; ys[ob - 1] = held[1]; }
+              ys[ob] = held[2];
+              ys[ob + 1] = yy;
+            }
+          } else {
+            ys[ob + h] = yy;
+          }
+        }
+      }
+      return;
+    }
     uint32_t nodes[NN][4];
     Acc vs[SCHEME == S_DCF ? NN : 1];
     nodes[0][0] = nin[0]; nodes[0][1] = nin[1]; nodes[0][2] = nin[2]; nodes[0][3] = nin[3];
