@@ -31,6 +31,9 @@
 #ifndef FSS_HT_PAIR
 #define FSS_HT_PAIR 1
 #endif
+#ifndef FSS_DCF_HOLD_NODES
+#define FSS_DCF_HOLD_NODES 1
+#endif
 #ifndef FSS_LEAF_PAIR_LINES
 #define FSS_LEAF_PAIR_LINES 1
 #endif
@@ -442,6 +445,8 @@ struct StageBody {
   // 6.7 GiB but cost more in moves and spills than it saved: 10.0 ms (profiles/r6/dcf_evalall_stores.txt).
   static constexpr bool kHoldDcf = FSS_LEAF_PAIR_LINES && LEAF && SCHEME == S_DCF && D == 1 && std::is_same<LT, Lds>::value;
   uint4 held[kHold ? 4 : (kHoldDcf ? 3 : 1)];
+  static constexpr bool kHoldDcfNodes = FSS_DCF_HOLD_NODES && !LEAF && SCHEME == S_DCF && D == 1 && std::is_same<LT, Lds>::value;
+  uint4 heldn[kHoldDcfNodes ? 3 : 1], heldv[kHoldDcfNodes ? 3 : 1];
   __device__ __forceinline__ void operator()(const uint32_t* __restrict__ kc, const uint32_t* __restrict__ koc,
                                              const uint32_t nin[4], const Acc& vin, int lvl, int64_t ob, int half) {
     constexpr int NN = 1 << D;
@@ -457,8 +462,33 @@ struct StageBody {
         Acc cv;
         dcf_child(L, c, g, cw, nin, vin, h != 0, ch, cv);
         if constexpr (!LEAF) {
-          a.out_nodes[ob + h] = make_uint4(ch[0], ch[1], ch[2], ch[3]);
-          a.out_v[ob + h] = make_uint4(cv.v[0], cv.v[1], cv.v[2], cv.v[3]);
+          const uint4 nn = make_uint4(ch[0], ch[1], ch[2], ch[3]), vv = make_uint4(cv.v[0], cv.v[1], cv.v[2], cv.v[3]);
+          if constexpr (kHoldDcfNodes) {  // as the leaves below: the first half's two nodes (and values) wait for the second half's,
+                                          // 64 contiguous bytes per array at once.  Costs the one-launch kernel its spill-free
+                                          // state (116 registers -> 128 + 124 B of scratch, outside the leaf stage's loop) and
+                                          // measures ahead all the same: the DCF node table of 2^23 nodes 0.45 -> 0.42 ms, the
+                                          // 2^28-leaf domain 10.0 -> 9.85 ms (same lease; FSS_DCF_HOLD_NODES=0 for the A/B)
+            const int side = half < 0 ? -1 : (half & 1);
+            if (side == 0) {
+              heldn[h] = nn; heldv[h] = vv;
+            } else if (h == 0) {
+              heldn[2] = nn; heldv[2] = vv;
+            } else {
+              if (side == 1) {
+                a.out_nodes[ob - 2] = heldn[0]; a.out_nodes[ob - 1] = heldn[1];
+              }
+              a.out_nodes[ob] = heldn[2];
+              a.out_nodes[ob + 1] = nn;
+              if (side == 1) {
+                a.out_v[ob - 2] = heldv[0]; a.out_v[ob - 1] = heldv[1];
+              }
+              a.out_v[ob] = heldv[2];
+              a.out_v[ob + 1] = vv;
+            }
+          } else {
+            a.out_nodes[ob + h] = nn;
+            a.out_v[ob + h] = vv;
+          }
         } else {
           const uint32_t* ocp = kc + 8 * a.in_bits + 4;
           const uint32_t oc[4] = {ocp[0], ocp[1], ocp[2], ocp[3]};
