@@ -573,10 +573,12 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
   FSS_PRG_PROLOGUE(LT, te0);
   const int n = a.in_bits;
   const Grp g = make_grp(a.group, c);
-  auto hash = [&](const uint32_t node[4], uint32_t h[4]) {
-    uint32_t in[4] = {node[0] ^ c->hash_key[0], node[1] ^ c->hash_key[1], node[2] ^ c->hash_key[2],
-                      node[3] ^ c->hash_key[3]};
-    prg_hash(L, c, in, h);
+  // the two parties' hashes of a level side by side: two interleaved cipher streams (aes_mmo2) keep the LDS pipe busy
+  // through each other's arithmetic (one block at a time: 20.1 ms for 2^24 keys of n = 64; paired: 19.8)
+  auto hash2 = [&](const uint32_t na[4], const uint32_t nb[4], uint32_t ha[4], uint32_t hb[4]) {
+    uint32_t ia[4] = {na[0] ^ c->hash_key[0], na[1] ^ c->hash_key[1], na[2] ^ c->hash_key[2], na[3] ^ c->hash_key[3]};
+    uint32_t ib[4] = {nb[0] ^ c->hash_key[0], nb[1] ^ c->hash_key[1], nb[2] ^ c->hash_key[2], nb[3] ^ c->hash_key[3]};
+    prg_hash2(L, c, ia, ib, ha, hb);
   };
   WaveQ q(a.dyn, &waveq_ctr_, a.nkeys, 1);
   for (int64_t k; q.next(k);) {
@@ -591,7 +593,7 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
     for (int i = 0; i < n - 1; ++i) {
       const uint32_t am = bit_mask(alpha, n - 1 - i);
       uint32_t h0[4], h1[4], cw[4];
-      hash(n0, h0); hash(n1, h1);
+      hash2(n0, n1, h0, h1);
       const uint32_t t0 = lsb_mask(n0[3]), t1 = lsb_mask(n1[3]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -610,13 +612,14 @@ __global__ __launch_bounds__(1024) void ht_gen_kernel(const DevCtx K, const uint
     {
       const uint32_t an = (uint32_t)alpha.lo & 1u;
       const uint32_t t0 = lsb_mask(n0[3]), t1 = lsb_mask(n1[3]);
-      uint32_t p[4], h00[4], h01[4], h10[4], h11[4];
-      p[0] = n0[0]; p[1] = n0[1]; p[2] = n0[2];
-      p[3] = n0[3] & ~1u; hash(p, h00);
-      p[3] = n0[3] | 1u; hash(p, h01);
-      p[0] = n1[0]; p[1] = n1[1]; p[2] = n1[2];
-      p[3] = n1[3] & ~1u; hash(p, h10);
-      p[3] = n1[3] | 1u; hash(p, h11);
+      uint32_t h00[4], h01[4], h10[4], h11[4];
+      uint32_t pz[4], po[4];  // the node with its control bit cleared / set (half_tree_dpf.cuh:108-121)
+      pz[0] = po[0] = n0[0]; pz[1] = po[1] = n0[1]; pz[2] = po[2] = n0[2];
+      pz[3] = n0[3] & ~1u; po[3] = n0[3] | 1u;
+      hash2(pz, po, h00, h01);
+      pz[0] = po[0] = n1[0]; pz[1] = po[1] = n1[1]; pz[2] = po[2] = n1[2];
+      pz[3] = n1[3] & ~1u; po[3] = n1[3] | 1u;
+      hash2(pz, po, h10, h11);
       const uint32_t l00 = h00[3] & 1u, l01 = h01[3] & 1u, l10 = h10[3] & 1u, l11 = h11[3] & 1u;
       h00[3] &= ~1u; h01[3] &= ~1u; h10[3] &= ~1u; h11[3] &= ~1u;
       uint32_t hcw[4];
