@@ -31,8 +31,13 @@
 #ifndef FSS_HT_PAIR
 #define FSS_HT_PAIR 1
 #endif
+// DCF stages that store NODES (intermediate stages, the node table of the shared-prefix plan) holding a half's two nodes and
+// running values for 64-byte stores, as the leaf stage does with its leaves: OFF.  It pays on big trees (node table of 2^23
+// nodes 0.45 -> 0.42 ms, 2^28 leaves 10.0 -> 9.85 ms) and costs on small ones -- its 24 registers put the one-launch kernel
+// back at 128 + 124 B of scratch, some of it in the frontier walk (2^24 leaves: walks 27 -> 34 us, 0.649 -> 0.669 ms; 2^20
+// leaves 0.089 -> 0.093 ms), which is where configs[2]'s 2^19-node table lives (profiles/r6/dcf_evalall_stores.txt).
 #ifndef FSS_DCF_HOLD_NODES
-#define FSS_DCF_HOLD_NODES 1
+#define FSS_DCF_HOLD_NODES 0
 #endif
 #ifndef FSS_LEAF_PAIR_LINES
 #define FSS_LEAF_PAIR_LINES 1
@@ -463,11 +468,8 @@ struct StageBody {
         dcf_child(L, c, g, cw, nin, vin, h != 0, ch, cv);
         if constexpr (!LEAF) {
           const uint4 nn = make_uint4(ch[0], ch[1], ch[2], ch[3]), vv = make_uint4(cv.v[0], cv.v[1], cv.v[2], cv.v[3]);
-          if constexpr (kHoldDcfNodes) {  // as the leaves below: the first half's two nodes (and values) wait for the second half's,
-                                          // 64 contiguous bytes per array at once.  Costs the one-launch kernel its spill-free
-                                          // state (116 registers -> 128 + 124 B of scratch, outside the leaf stage's loop) and
-                                          // measures ahead all the same: the DCF node table of 2^23 nodes 0.45 -> 0.42 ms, the
-                                          // 2^28-leaf domain 10.0 -> 9.85 ms (same lease; FSS_DCF_HOLD_NODES=0 for the A/B)
+          if constexpr (kHoldDcfNodes) {  // (FSS_DCF_HOLD_NODES, off) as the leaves below: the first half's two nodes and values
+                                          // wait for the second half's, 64 contiguous bytes per array at once
             const int side = half < 0 ? -1 : (half & 1);
             if (side == 0) {
               heldn[h] = nn; heldv[h] = vv;
