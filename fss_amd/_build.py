@@ -106,6 +106,11 @@ def remove_stale_variants():
             continue
         os.remove(f)
         gone.append(f)
+    # ... and their objects (csrc/build/<unit>.<tag>.o; the product's are <unit>.o, the diagnostic build's <unit>.diag.o)
+    for f in glob.glob(os.path.join(CSRC, "build", "*.*.o")):
+        if not f.endswith(".diag.o"):
+            os.remove(f)
+            gone.append(f)
     return gone
 
 
