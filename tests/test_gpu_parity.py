@@ -682,6 +682,33 @@ def test_full_size_eval_all_properties(engine, O):
         assert (y0[x] == O.dpf_eval(p, n, g, 0, s[0], cws, x)).all()
 
 
+def test_big_dcf_eval_all_properties(engine, O):
+    """DCF full domains from 2^25 leaves on take two levels per intermediate stage (fss_abi_evalall.hip: mid_extra) and, like
+    every DCF tree on the AES tables, expand a node's children one at a time with 64-byte leaf stores (fss_evalall.hpp:
+    dcf_child): n = 26 whole and its second 2^25-leaf half as a block -- the two parties' leaves add up to beta below alpha
+    and to zero from alpha on, over the WHOLE domain; leaves at and around alpha, at the ends and at random places equal
+    the oracle's Eval; the block equals the same leaves of the whole."""
+    n, g = 26, G.U64
+    rng = SplitMix64(0x5EED0D26)
+    p = O.Prg(4)
+    s = [rng.i4(), rng.i4()]
+    alpha, beta = rng.below(n), rng.i4()
+    cws = O.dcf_gen(p, n, g, 0, s, alpha, beta)
+    y = [engine.eval_all(DCF, n, g, b, T(s[b]), T(cws)) for b in (0, 1)]
+    v = [(t[:, 0].to(torch.int64) & 0xFFFFFFFF) | (t[:, 1].to(torch.int64) << 32) for t in y]
+    total = v[0] + v[1]
+    bv = (int(beta[0]) & 0xFFFFFFFF) | ((int(beta[1]) & 0xFFFFFFFF) << 32)
+    bv = bv - (1 << 64) if bv >= (1 << 63) else bv
+    assert bool((total[:alpha] == bv).all()) and bool((total[alpha:] == 0).all())
+    y0 = y[0].cpu().numpy()
+    xs = sorted({0, 1, (1 << n) - 1, max(alpha - 1, 0), alpha, min(alpha + 1, (1 << n) - 1)} | {rng.below(n) for _ in range(40)})
+    want = O.eval_points(p, DCF, n, g, 0, s[0], cws, np.array(xs, dtype=np.uint64), nthreads=4)
+    assert (y0[xs] == want).all()
+    half = 1 << (n - 1)
+    blk = engine.eval_all(DCF, n, g, 0, T(s[0]), T(cws), first_leaf=half, nleaves=half)
+    assert torch.equal(blk, y[0][half:])
+
+
 def test_full_size_half_tree_keys_reconstruct(engine, O):
     """configs[4] shape (Half-Tree n=64, independent keys) at 2^18 keys generated on the
     device: shares reconstruct beta at alpha and 0 elsewhere; a sample equals the oracle."""
