@@ -594,13 +594,17 @@ static int keys_common(fss_amd_ctx* ctx, int scheme, int in_bits, int group, int
   a.out_cw = reinterpret_cast<const uint4*>(out_cw);
   a.extra = reinterpret_cast<const uint32_t*>(extra);
   if (n <= quad_points_max()) {  // small batch: a quad of lanes per key (points_common)
-    const int64_t lanes = n * 4;
+    const bool oct = quad_octets_pay(ctx, scheme, n);  // DCF / AES, few keys: an octet of lanes per key (fss_quad.hpp)
+    const int64_t lanes = n * (oct ? 8 : 4);
     const int bs = lanes >= 65536 ? 1024 : 256;
     const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
     const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
     switch (scheme) {
       case S_DPF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_DPF>), grid, block, 0, S(stream), ctx->host, ctx->te0, a)); break;
-      case S_DCF: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_DCF>), grid, block, 0, S(stream), ctx->host, ctx->te0, a)); break;
+      case S_DCF:
+        if (oct) FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_DCF, true>), grid, block, 0, S(stream), ctx->host, ctx->te0, a));
+        else FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_DCF>), grid, block, 0, S(stream), ctx->host, ctx->te0, a));
+        break;
       default: FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((keys_quad_kernel<LT, S_HT>), grid, block, 0, S(stream), ctx->host, ctx->te0, a)); break;
     }
     HIP_TRY(hipGetLastError());

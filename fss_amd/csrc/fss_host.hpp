@@ -405,13 +405,22 @@ inline int64_t quad_points_max() {
   }();
   return v;
 }
+// DCF with the AES tables, a batch small enough that eight lanes per walk still fit the chip in one pass: the octet form of
+// the quad kernels (QuadPrg<Lds, SCHEME>; 1 .. 2^15 walks: 58 -> 37 - 42 us at n = 32).  FSS_AMD_QUAD_OCT=0 turns it off (A/B).
+inline bool quad_octets_pay(const fss_amd_ctx* ctx, int scheme, int64_t walks) {
+  static const bool on = [] { const char* e = tune_env("FSS_AMD_QUAD_OCT"); return !(e && atoi(e) == 0); }();
+  return on && scheme == S_DCF && ctx->prg != FSS_AMD_PRG_CHACHA && walks * 8 <= (int64_t)ctx->num_cu * 1024;
+}
 template <int SCHEME>
 int launch_points_quad(fss_amd_ctx* ctx, const char* name, const SharedKey& k, const EvalArgs& a, hipStream_t st) {
-  const int64_t lanes = a.n * 4;
+  // a quad of lanes per walk; DCF on the AES tables: an octet while the octets fit the chip's lanes in one pass (fss_quad.hpp)
+  const bool oct = quad_octets_pay(ctx, SCHEME, a.n);
+  const int64_t lanes = a.n * (oct ? 8 : 4);
   const int bs = lanes >= 65536 ? 1024 : 256;
   const int64_t want = (lanes + bs - 1) / bs, cap = ctx->num_cu;
   const dim3 grid((unsigned)(want < cap ? want : cap)), block(bs);
-  FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, SCHEME>), grid, block, 0, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a));
+  if (oct) FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, SCHEME, true>), grid, block, 0, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a));
+  else FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((points_quad_kernel<LT, SCHEME>), grid, block, 0, st, ctx->host, ctx->te0, k.seed, k.cws, k.ocw, a));
   HIP_TRY(hipGetLastError());
   ctx->last_kernel = name;
   ctx->last_grid = (int)grid.x;

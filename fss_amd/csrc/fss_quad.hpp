@@ -3,6 +3,7 @@
 // fss_evalall.hpp) and small batches of points or keys (points_quad_kernel, keys_quad_kernel, below).
 #pragma once
 #include <cstddef>
+#include <type_traits>
 #include "fss_dev.hpp"
 #include "fss_point.hpp"
 
@@ -73,6 +74,20 @@ __device__ __forceinline__ void quad_aes_pair(const Lds& L, uint32_t in, uint32_
 template <class LT, int SCHEME>
 struct QuadPrg;
 
+// DCF on the AES tables, few walks (a batch of at most an eighth of the chip's lanes: points_quad_kernel / keys_quad_kernel
+// <.., OCT = true>, chosen by the host): EIGHT lanes per walk.  A level costs a seed block and a value block of the same input; one quad
+// interleaving both (quad_aes_pair) issues twice the instructions, and a lone wave's level is bound by the instructions it
+// issues (1.8 us per level against the DPF walk's 0.95).  In an octet the four lanes after the walk's quad compute the value
+// block while the quad computes the seed block -- the same instructions, other keys (is_v) -- and only the seed quad's result
+// feeds the next level; the value quad fetches the level's node from it (one DPP row shift) and keeps the running value.
+// DCF n = 32, 1 .. 2^15 points: 58 -> 37 - 42 us per call.  Where every lane has work anyway (the 2^15 walks of an EvalAll
+// frontier, 2^16 points and more) the pair form stays: octets there only double the waves that contend for a SIMD
+// (frontier walks 26 -> 32 us, 2^16 points 58 -> 77 us; profiles/r6/dcf_octet_walks.txt).
+// lane i <- lane i - 4 of its row of sixteen: the value quad of an octet reads its seed quad
+__device__ __forceinline__ uint32_t quad_from_seed_quad(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+}
+
 template <int SCHEME>
 struct QuadPrg<Lds, SCHEME> {
   const Lds* L;
@@ -80,9 +95,13 @@ struct QuadPrg<Lds, SCHEME> {
   // DCF: the value block's keys 1 / 3; DPF: key 1 alone, for both-children expansions
   uint32_t kb[SCHEME == S_HT ? 1 : 11], ke[SCHEME == S_DCF ? 11 : 1];
   uint32_t hk;  // Half-Tree: this lane's word of hash_key
-  __device__ __forceinline__ void init(const Lds& l, const DevCtx* __restrict__ c, int q) {
+  bool oct = false, is_v = false;  // DCF: a walk per octet; this lane belongs to the octet's value quad (keys 1 / 3 in ka / kd)
+  __device__ __forceinline__ void init(const Lds& l, const DevCtx* __restrict__ c, int q, bool octets = false) {
     L = &l;
-    const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01) : (SCHEME == S_DCF ? offsetof(DevCtx, sel02) : offsetof(DevCtx, rk))) / 4;
+    oct = SCHEME == S_DCF && octets;
+    is_v = oct && ((threadIdx.x >> 2) & 1) != 0;
+    const uint32_t* gk = c->self_dev + (SCHEME == S_DPF ? offsetof(DevCtx, sel01)
+                                        : (SCHEME == S_DCF ? (is_v ? offsetof(DevCtx, sel13) : offsetof(DevCtx, sel02)) : offsetof(DevCtx, rk))) / 4;
     const uint32_t* gv = c->self_dev + offsetof(DevCtx, sel13) / 4;
 #pragma unroll
     for (int r = 0; r < 11; ++r) {
@@ -172,6 +191,25 @@ __device__ __forceinline__ void quad_level_cw(const QuadPrg<LT, SCHEME>& P, cons
     const uint32_t cwq = w ^ (is3 & m & ((w ^ aux) & 1u));
     st = and_xor(tm, cwq, o);
   } else if constexpr (SCHEME == S_DCF) {  // DcfWalk::level
+    if constexpr (std::is_same<LT, Lds>::value) {
+      if (P.oct) {  // (wave-uniform) an octet per walk: see QuadPrg<Lds, SCHEME>
+        // both quads start from the level's node (the value quad takes it from the seed quad) and run ONE block each: the
+        // seed quad's result is the next node, the value quad's is added to the running value it keeps.  What the other
+        // quad computes in the same registers (a value out of seed blocks, a node out of value blocks) is never read.
+        const uint32_t from_seed_quad = quad_from_seed_quad(st);  // every lane executes the shift: a DPP read of a masked-off lane is no read
+        const uint32_t node = P.is_v ? from_seed_quad : st;
+        const uint32_t tmn = lsb_mask(quad_get<FSS_QP(3, 3, 3, 3)>(node));
+        const uint32_t o = P.take(node & ~(is3 & 1u), m);
+        uint32_t ovo[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(o), quad_get<FSS_QP(1, 1, 1, 1)>(o), quad_get<FSS_QP(2, 2, 2, 2)>(o),
+                           quad_get<FSS_QP(3, 3, 3, 3)>(o) & ~1u};
+        v.add(g, ovo);
+        uint32_t vcwo[4] = {vcw_in[0], vcw_in[1], vcw_in[2], aux & ~1u};
+        v.add_if(g, tmn, vcwo);
+        const uint32_t cwo = w ^ (is3 & m & ((w ^ aux) & 1u));  // word 3: tl_cw in s.w, tr_cw in v.w
+        st = and_xor(tmn, cwo, o);
+        return;
+      }
+    }
     uint32_t os, ovq;
     P.take_sv(st & ~(is3 & 1u), m, os, ovq);
     uint32_t ov[4] = {quad_get<FSS_QP(0, 0, 0, 0)>(ovq), quad_get<FSS_QP(1, 1, 1, 1)>(ovq), quad_get<FSS_QP(2, 2, 2, 2)>(ovq),
@@ -229,7 +267,7 @@ __device__ __forceinline__ uint32_t quad_finish(const LT& L, const DevCtx* __res
 // Below ~2^17 points a point evaluation is the frontier's situation: a chain of in_bits PRG calls run by lone
 // waves.  One walk per quad of lanes runs a level in ~0.9 us instead of 2.2 - 3.  Shared key; launched by
 // the *_eval_points entry points for batches that leave most of the chip idle.
-template <class LT, int SCHEME>
+template <class LT, int SCHEME, bool OCT = false>  // OCT: DCF / AES, an octet of lanes per walk (ignored for every other pair)
 __global__ __launch_bounds__(1024) void points_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0,
                                                           const uint32_t* __restrict__ k_seed,
                                                           const uint32_t* __restrict__ k_cws,
@@ -240,18 +278,25 @@ __global__ __launch_bounds__(1024) void points_quad_kernel(const DevCtx K, const
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
   QuadPrg<LT, SCHEME> P;
-  P.init(L, c, q);
+  constexpr bool oct = OCT && SCHEME == S_DCF && std::is_same<LT, Lds>::value;  // eight lanes per walk (QuadPrg<Lds, SCHEME>)
+  if constexpr (std::is_same<LT, Lds>::value) P.init(L, c, q, oct);
+  else P.init(L, c, q);
   const Grp g = make_grp(a.group, c);
   const int n = a.in_bits, depth = SCHEME == S_HT ? n - 1 : n;  // Half-Tree: the last level is the conversion
-  const int64_t nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
+  constexpr int sh = oct ? 3 : 2;
+  const int64_t nquads = ((int64_t)gridDim.x * blockDim.x) >> sh;
   uint32_t* __restrict__ ys = reinterpret_cast<uint32_t*>(a.ys);
-  for (int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; j < a.n; j += nquads) {
+  for (int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> sh; j < a.n; j += nquads) {
     const X128 x = load_x(a.xs, a.x_bytes, j);
     uint32_t st = k_seed[q];
     st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);
     Acc v;
 #pragma unroll 1
     for (int i = 0; i < depth; ++i) quad_level(P, g, k_cws, i, bit_mask(x, n - 1 - i), q, is3, st, v);
+    if constexpr (oct) {  // the value quad holds the running value: it takes the leaf node too, and finishes alone
+      st = quad_from_seed_quad(st);
+      if (((threadIdx.x >> 2) & 1) == 0) continue;
+    }
     const uint32_t* p = k_cws + 8 * (SCHEME == S_HT ? n - 1 : n) + (SCHEME == S_DCF ? 4 : 0);
     const uint32_t cwl[4] = {p[0], p[1], p[2], p[3]};  // DPF / DCF: the output correction word; Half-Tree: the last level's
     if constexpr (SCHEME == S_HT) {
@@ -264,7 +309,7 @@ __global__ __launch_bounds__(1024) void points_quad_kernel(const DevCtx K, const
 }
 
 // Small batches of independent level-major keys (fss::gpu::*EvalPointGpu's inputs): a quad per key.
-template <class LT, int SCHEME>
+template <class LT, int SCHEME, bool OCT = false>
 __global__ __launch_bounds__(1024) void keys_quad_kernel(const DevCtx K, const uint32_t* __restrict__ te0, EvalArgs a) {
   static_assert(SCHEME == S_DPF || SCHEME == S_DCF || SCHEME == S_HT, "quad key walk: DPF / DCF / Half-Tree");
   const DevCtx* c = first_kernarg(K);
@@ -272,12 +317,15 @@ __global__ __launch_bounds__(1024) void keys_quad_kernel(const DevCtx K, const u
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
   QuadPrg<LT, SCHEME> P;
-  P.init(L, c, q);
+  constexpr bool oct = OCT && SCHEME == S_DCF && std::is_same<LT, Lds>::value;
+  if constexpr (std::is_same<LT, Lds>::value) P.init(L, c, q, oct);
+  else P.init(L, c, q);
   const Grp g = make_grp(a.group, c);
   const int n = a.in_bits, depth = SCHEME == S_HT ? n - 1 : n;
-  const int64_t nk = a.n, nquads = ((int64_t)gridDim.x * blockDim.x) >> 2;
+  constexpr int sh = oct ? 3 : 2;
+  const int64_t nk = a.n, nquads = ((int64_t)gridDim.x * blockDim.x) >> sh;
   uint32_t* __restrict__ ys = reinterpret_cast<uint32_t*>(a.ys);
-  for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; k < nk; k += nquads) {
+  for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> sh; k < nk; k += nquads) {
     const X128 x = load_x(a.xs, a.x_bytes, k);
     uint32_t st = reinterpret_cast<const uint32_t*>(a.seeds + k)[q];
     st = (st & ~(is3 & 1u)) | (is3 & (uint32_t)a.party);
@@ -296,6 +344,10 @@ __global__ __launch_bounds__(1024) void keys_quad_kernel(const DevCtx K, const u
         const uint32_t tr = SCHEME == S_DPF ? (uint32_t)(((i < 64 ? trb : trbh) >> (i & 63)) & 1ull) : 0u;
         quad_level_cw(P, g, w, tr, nullptr, m, is3, st, v);
       }
+    }
+    if constexpr (oct) {
+      st = quad_from_seed_quad(st);
+      if (((threadIdx.x >> 2) & 1) == 0) continue;
     }
     const uint4 u = a.out_cw[k];  // DPF / DCF: cws[in_bits]; Half-Tree: the key's ocw
     const uint32_t oc[4] = {u.x, u.y, u.z, u.w};
