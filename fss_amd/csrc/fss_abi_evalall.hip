@@ -40,6 +40,9 @@ inline int top_max(int scheme, bool aes, bool single_key = false) {
     return (t < 0 || t > 20) ? -1 : t;
   }();
   if (v >= 0) return v;
+  // DCF on the AES tables walks an octet of lanes per walk (fss_quad.hpp): one level less, so that the 2^14 octets of a single
+  // tree still occupy half of every workgroup's waves, as the 2^15 quads of the other schemes do
+  if (quad_frontier() && aes && frontier_octets<Lds, S_DCF>() && scheme == S_DCF) return single_key ? 14 : 15;
   if (quad_frontier()) return (single_key && aes) ? 15 : 16;
   if (aes && (scheme == S_DPF || scheme == S_GROTTO)) return 18;
   return 15;
@@ -97,11 +100,11 @@ inline int mid_extra(int scheme, int log2_leaves) {
   }();
   if (v >= 0) return v;
   // DPF / Grotto: one rolled level per intermediate stage -- the 2^25-leaf block goes 2^18 -> 2^21 in one launch
-  // instead of two (0.647 -> 0.639 ms); Half-Tree measured flat.  DCF (one level in registers): from 2^25 leaves on -- with
-  // single-level stages a 2^26-leaf tree has eight of them, one more than the one-launch form takes, and falls back to the
-  // chain of launches: 2.68 -> 2.48 ms with two levels per stage (2^28: 9.74 -> 9.69; 2^20 - 2^24 are 1 - 4 % faster
-  // without; round 6, profiles/r6/dcf_evalall_stores.txt)
-  if (scheme == S_DCF) return log2_leaves >= 25 ? 1 : 0;
+  // instead of two (0.647 -> 0.639 ms); Half-Tree measured flat.  DCF (one level in registers): from 2^24 leaves on -- with
+  // single-level stages a 2^24-leaf tree (14 levels walked, a three-level leaf stage) has eight stages, one more than the
+  // one-launch form takes, and falls back to the chain of launches: 2^26 leaves 2.68 -> 2.48 ms with two levels per stage
+  // (2^28: 9.74 -> 9.69; 2^20 - 2^22 are 1 - 4 % faster without; round 6, profiles/r6/dcf_evalall_stores.txt)
+  if (scheme == S_DCF) return log2_leaves >= 24 ? 1 : 0;
   return (scheme == S_DPF || scheme == S_GROTTO) ? 1 : 0;
 }
 
@@ -316,7 +319,7 @@ int launch_frontier(fss_amd_ctx* ctx, hipStream_t st, int64_t nout, const uint32
                     const ExpandArgs& a, int top, int tail) {
   constexpr int WS = SCHEME == S_GROTTO ? S_DPF : SCHEME;
   if (quad_frontier()) {
-    const int64_t lanes = (nout >> tail) * 4;  // a quad per walk
+    const int64_t lanes = (nout >> tail) << ((ctx->prg != FSS_AMD_PRG_CHACHA && frontier_octets<Lds, WS>()) ? 3 : 2);  // a quad per walk (DCF / AES: an octet)
     const int fbs = lanes >= 65536 ? 1024 : (lanes >= 256 ? 256 : 64);
     const int64_t want = (lanes + fbs - 1) / fbs, cap = (int64_t)ctx->num_cu * (1024 / fbs);
     FSS_BY_PRG_DO(ctx, hipLaunchKernelGGL((frontier_quad_kernel<LT, WS, BATCH>), dim3((unsigned)(want < cap ? want : cap)), dim3(fbs),

@@ -36,6 +36,9 @@
 // nodes 0.45 -> 0.42 ms, 2^28 leaves 10.0 -> 9.85 ms) and costs on small ones -- its 24 registers put the one-launch kernel
 // back at 128 + 124 B of scratch, some of it in the frontier walk (2^24 leaves: walks 27 -> 34 us, 0.649 -> 0.669 ms; 2^20
 // leaves 0.089 -> 0.093 ms), which is where configs[2]'s 2^19-node table lives (profiles/r6/dcf_evalall_stores.txt).
+#ifndef FSS_DCF_FRONTIER_OCTETS
+#define FSS_DCF_FRONTIER_OCTETS 1
+#endif
 #ifndef FSS_DCF_HOLD_NODES
 #define FSS_DCF_HOLD_NODES 0
 #endif
@@ -283,6 +286,15 @@ __global__ __launch_bounds__(1024) void frontier_kernel(const DevCtx K, const ui
 }
 
 // -- frontier with the AES tables: one walk per quad of lanes (fss_quad.hpp) ---------------------------------
+// Lanes per frontier walk: a quad; DCF on the AES tables an octet (QuadPrg<Lds, SCHEME>).
+template <class LT, int SCHEME>
+__host__ __device__ constexpr bool frontier_octets() {
+  return FSS_DCF_FRONTIER_OCTETS && SCHEME == S_DCF && std::is_same<LT, Lds>::value;
+}
+template <class LT, int SCHEME>
+__host__ __device__ constexpr int frontier_lanes_log2() {
+  return frontier_octets<LT, SCHEME>() ? 3 : 2;
+}
 // The walks j_first, j_first + j_stride, ... < j_end of this lane's quad (j counts walks: quads of lanes).
 template <class LT, int SCHEME, bool BATCH>  // SCHEME: S_DPF (also Grotto), S_DCF or S_HT
 __device__ __forceinline__ void quad_frontier_walks(const LT& L, const DevCtx* __restrict__ c,
@@ -296,7 +308,12 @@ __device__ __forceinline__ void quad_frontier_walks(const LT& L, const DevCtx* _
   const int q = threadIdx.x & 3;
   const uint32_t is3 = q == 3 ? ~0u : 0u;
   QuadPrg<LT, SCHEME> P;
-  P.init(L, c, q);
+  // DCF on the AES tables: an octet of lanes per walk (fss_quad.hpp, QuadPrg<Lds, SCHEME>; the callers count walks per
+  // eight lanes, kFrontierLanesLog2, and the planner walks one level less so that the octets still take only half of a
+  // workgroup's waves -- with all sixteen walking, the waves of a SIMD queue for its issue slot and the walk gets slower)
+  constexpr bool kOct = frontier_octets<LT, SCHEME>();
+  if constexpr (std::is_same<LT, Lds>::value) P.init(L, c, q, kOct);
+  else P.init(L, c, q);
   const Grp g = make_grp(a.group, c);
   const int depth = a.level0 - tail;  // levels walked: p + top - tail
   top -= tail;
@@ -338,8 +355,13 @@ __device__ __forceinline__ void quad_frontier_walks(const LT& L, const DevCtx* _
         out[4 * ((j << 2) + 2 * h + 1) + q] = g1;
       }
     } else {
-      out[4 * j + q] = st;
-      if constexpr (SCHEME == S_DCF) reinterpret_cast<uint32_t*>(a.out_v)[4 * j + q] = v.v[q];
+      if constexpr (kOct) {  // the node is the seed quad's, the running value the value quad's
+        if (P.is_v) reinterpret_cast<uint32_t*>(a.out_v)[4 * j + q] = v.v[q];
+        else out[4 * j + q] = st;
+      } else {
+        out[4 * j + q] = st;
+        if constexpr (SCHEME == S_DCF) reinterpret_cast<uint32_t*>(a.out_v)[4 * j + q] = v.v[q];
+      }
     }
   }
 }
@@ -353,8 +375,8 @@ __global__ __launch_bounds__(1024) void frontier_quad_kernel(const DevCtx K, con
   FSS_PRG_PROLOGUE(LT, te0);
   const int64_t nout = (BATCH ? a.nkeys : (int64_t)1) << (top - tail);  // walks
   quad_frontier_walks<LT, SCHEME, BATCH>(L, c, k_seed, k_cws, a, top, tail,
-                                         ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2, nout,
-                                         ((int64_t)gridDim.x * blockDim.x) >> 2);
+                                         ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> frontier_lanes_log2<LT, SCHEME>(), nout,
+                                         ((int64_t)gridDim.x * blockDim.x) >> frontier_lanes_log2<LT, SCHEME>());
 }
 
 // -- expansion stage ------------------------------------------------------------
@@ -812,8 +834,8 @@ __global__ __launch_bounds__(1024) void evalall_fused_kernel(const DevCtx K, con
     a.level0 = level;
     a.out_nodes = mine[0] - lo;
     a.out_v = minev[0] - lo;
-    quad_frontier_walks<LT, WS, BATCH>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> 2), w_hi,
-                                       blockDim.x >> 2);
+    quad_frontier_walks<LT, WS, BATCH>(L, c, k_seed, k_cws, a, f.top, f.tail, w_lo + (threadIdx.x >> frontier_lanes_log2<LT, WS>()), w_hi,
+                                       blockDim.x >> frontier_lanes_log2<LT, WS>());
   }
   FSS_FUSED_STAMP();
   int cur = 0;
